@@ -1,0 +1,45 @@
+# Top-level build: libntt_mi355x.so (HIP, gfx950), the CPU oracle and the CPU
+# emulation of the kernel templates used by the tests.
+#
+#   make            product library only
+#   make all-test   + oracle, reference oracle (if /root/reference exists), emulator
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+PKG      = optimized-number-theoretic-transform-implementations_amd
+CSRC     = $(PKG)/csrc
+LIB      = $(PKG)/libntt_mi355x.so
+HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
+            -Wall -Wextra -Wno-unused-parameter -Iinclude -Iinclude/internal -I$(CSRC) $(EXTRA_HIPFLAGS)
+OBJS     = $(CSRC)/ntt_host.o $(CSRC)/inst_u64.o $(CSRC)/inst_f64k0.o $(CSRC)/inst_f64k1.o $(CSRC)/inst_f64k18.o
+HDRS     = $(wildcard $(CSRC)/*.h) $(wildcard include/*.h) $(wildcard include/internal/*.h)
+
+lib: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle all
+	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref; fi
+
+emu:
+	$(MAKE) -C tests/emu
+
+all-test: lib oracle emu
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+	$(MAKE) -C tests/emu clean
+
+.PHONY: lib oracle emu all-test clean
+
+# instruction-level micro-benchmarks (run on the GPU box: build/ubench)
+ubench: build/ubench
+build/ubench: tools/ubench.hip $(HDRS)
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -I$(CSRC) -o $@ tools/ubench.hip
+.PHONY: ubench

@@ -1,0 +1,141 @@
+/*
+ * ntt_mi355x.h -- batched, device-resident negacyclic NTT engine for MI355X (gfx950).
+ *
+ * This is the throughput API of libntt_mi355x.so.  The reference package
+ * (IBM/optimized-number-theoretic-transform-implementations) has no batch API:
+ * its only precedent is the two-polynomial fwd_ntt_ref_harvey_lazy_dbl
+ * (reference include/ntt_reference.h:44-49, src/ntt_reference.c:71-91).  The
+ * functions below generalise that to `batch` independent polynomials that stay
+ * in HBM, with exactly the reference's transform semantics, so results compare
+ * element-for-element with
+ *
+ *   fwd_ntt_ref_harvey / fwd_ntt_radix4      (include/ntt_reference.h:19-31,
+ *                                             include/ntt_radix4.h:16-28)
+ *   inv_ntt_ref_harvey / inv_ntt_radix4      (src/ntt_reference.c:33-66,
+ *                                             src/ntt_radix4.c:64-114)
+ *
+ * i.e. forward: natural order in -> bit-reversed order out, values in [0,q);
+ * inverse: bit-reversed in -> natural out, scaled by N^-1, values in [0,q).
+ * The single-polynomial reference signatures themselves are exported by the same
+ * library (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h).
+ *
+ * Plain C ABI: pointers and sizes only.  `stream` arguments are hipStream_t
+ * passed as void* (NULL = the device's default stream).  All functions return
+ * NTT_OK (0) or a negative ntt_status; ntt_last_error() describes the failure.
+ * There is no CPU fallback: without a HIP device every compute entry point
+ * fails with NTT_ERR_NO_DEVICE.
+ */
+#ifndef NTT_MI355X_H
+#define NTT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#  define NTT_API __attribute__((visibility("default")))
+#else
+#  define NTT_API
+#endif
+
+typedef enum ntt_status {
+  NTT_OK              = 0,
+  NTT_ERR_ARG         = -1, /* bad argument (N not a power of two, q not NTT-friendly ...) */
+  NTT_ERR_NO_DEVICE   = -2, /* no HIP device / HIP runtime unusable                        */
+  NTT_ERR_HIP         = -3, /* a HIP call failed; see ntt_last_error()                     */
+  NTT_ERR_UNSUPPORTED = -4, /* e.g. FP64 arithmetic requested for q > 2^51                 */
+  NTT_ERR_NOMEM       = -5
+} ntt_status;
+
+typedef enum ntt_arith {
+  NTT_ARITH_AUTO = 0, /* FP64 path when q allows it, else 64-bit integer Shoup      */
+  NTT_ARITH_U64  = 1, /* reference-identical Harvey/Shoup lazy arithmetic, any q<2^61 */
+  NTT_ARITH_F64  = 2  /* balanced FP64 arithmetic, q <= 2^51(1+2^-10)                 */
+} ntt_arith;
+
+typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
+
+/* ---- library / device ---- */
+NTT_API const char *ntt_last_error(void);
+NTT_API int         ntt_device_count(void);             /* <0: ntt_status */
+NTT_API const char *ntt_version(void);
+
+/* ---- plans ----
+ * root must be a primitive 2N-th root of unity mod q (the `w` column of
+ * reference tests/test_cases.h:145-208).  The plan derives every table itself
+ * with the reference's layouts (include/internal/pre_compute.h:38-83). */
+NTT_API int  ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t q,
+                             uint64_t root, int arith);
+/* build from caller tables in the reference's radix-2 layout: w_powers[k] =
+ * root^bitrev(k), N entries each; w_inv_powers may be NULL (forward-only plan) */
+NTT_API int  ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t N, uint64_t q,
+                                         const uint64_t *w_powers,
+                                         const uint64_t *w_inv_powers, int arith);
+NTT_API void ntt_plan_destroy(ntt_plan *p);
+/* info[0..7] = {N, q, log2N, arith actually used, FP64 headroom class,
+ *               number of HBM passes, device, root (0 if built from tables)} */
+NTT_API int  ntt_plan_info(const ntt_plan *p, uint64_t info[8]);
+/* force the strided multi-pass path (self-check of the fused kernels) */
+NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
+
+/* ---- batched transforms: d_a is device memory laid out [batch][N], in place ---- */
+NTT_API int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+NTT_API int ntt_inv_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+/* same, but inputs may be lazy values in [0,8q) (what the reference's *_lazy
+ * entry points accept and emit); outputs are still in [0,q) */
+NTT_API int ntt_fwd_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+NTT_API int ntt_inv_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+
+/* ---- callers either side of the path ---- */
+/* d_c[i] = d_a[i]*d_b[i] mod q over n = batch*N values in [0,q); c may alias a or b */
+NTT_API int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a,
+                                    const uint64_t *d_b, uint64_t batch, void *stream);
+/* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
+ * fwd(a), fwd(b), pointwise, inv.  d_a and d_b are overwritten (left in the NTT
+ * domain); d_c may alias d_a. */
+NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
+                                     uint64_t *d_b, uint64_t batch, void *stream);
+
+/* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
+NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);
+NTT_API int ntt_dev_free(int device, void *d_ptr);
+NTT_API int ntt_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+NTT_API int ntt_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+NTT_API int ntt_stream_create(int device, void **stream);
+NTT_API int ntt_stream_destroy(int device, void *stream);
+NTT_API int ntt_stream_sync(int device, void *stream);
+NTT_API int ntt_event_create(int device, void **event);
+NTT_API int ntt_event_destroy(int device, void *event);
+NTT_API int ntt_event_record(int device, void *event, void *stream);
+NTT_API int ntt_event_elapsed_ms(int device, void *start, void *stop, float *ms); /* syncs stop */
+
+/* ---- synthetic data and digests, device side ----
+ * d_a[i] = splitmix64(seed ^ (offset + i)) mod q : the same function as the
+ * oracle's orc_fill_uniform, so a host can regenerate any sampled polynomial */
+NTT_API int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed,
+                             uint64_t offset, void *stream);
+/* d_out[p] = sum_i splitmix64(i) * d_a[p*N+i]  (mod 2^64): position-sensitive
+ * per-polynomial checksum for full-size parity checks */
+NTT_API int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, uint64_t N,
+                              uint64_t batch, void *stream);
+
+/* ---- multi-GPU: one call drives every listed device (per-device streams, no
+ * collective -- polynomials are independent).  plans[g], d_a[g] and
+ * batch[g] describe the shard resident on plans[g]'s device; the call returns
+ * when all shards are done.  inverse != 0 selects the inverse transform. */
+NTT_API int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const *d_a,
+                            const uint64_t *batch, int inverse);
+
+/* ---- parameter helpers (reference: SageMath script, tests/test_cases.h:113-142) ---- */
+/* smallest primitive 2N-th root of unity mod q ("minimum root" rule); 0 if none */
+NTT_API uint64_t ntt_min_root(uint64_t q, uint64_t N);
+/* skip-th largest prime p < 2^bits with p = 1 (mod 2N); 0 if none */
+NTT_API uint64_t ntt_find_prime(unsigned bits, uint64_t N, unsigned skip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTT_MI355X_H */

@@ -1,0 +1,38 @@
+/*
+ * ntt_radix4.h -- radix-4 NTT entry points, MI355X implementation.
+ *
+ * Drop-in replacement for reference include/ntt_radix4.h:10-35 /
+ * src/ntt_radix4.c:27-114.  The tables are the reference's 2N-entry EXPANDED
+ * tables (include/internal/pre_compute.h:85-105): slot 2k holds the radix-2
+ * twiddle w[k], which is what the GPU butterfly network consumes; the merged
+ * odd slots are the CPU radix-4 butterfly's private shortcut and are not needed
+ * on the device (any exact evaluation gives identical reduced output, SURVEY
+ * A.6).  Output of the lazy forward is in [0,q), inside the documented [0,8q).
+ */
+#ifndef NTT_MI355X_NTT_RADIX4_H
+#define NTT_MI355X_NTT_RADIX4_H
+
+#include "fast_mul_operators.h"
+
+EXTERNC_BEGIN
+
+/* replaces reference src/ntt_radix4.c:27-62 */
+NTT_EXPORT void fwd_ntt_radix4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[],
+                                    const uint64_t w_con[]);
+
+/* reference include/ntt_radix4.h:16-28 */
+static inline void fwd_ntt_radix4(uint64_t a[], const uint64_t N, const uint64_t q, const uint64_t w[],
+                                  const uint64_t w_con[])
+{
+  fwd_ntt_radix4_lazy(a, N, q, w, w_con);
+  for(size_t i = 0; i < N; i++) {
+    a[i] = reduce_8q_to_q(a[i], q);
+  }
+}
+
+/* replaces reference src/ntt_radix4.c:64-114 (inputs anywhere in [0,8q)) */
+NTT_EXPORT void inv_ntt_radix4(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, const uint64_t w[],
+                               const uint64_t w_con[]);
+
+EXTERNC_END
+#endif /* NTT_MI355X_NTT_RADIX4_H */

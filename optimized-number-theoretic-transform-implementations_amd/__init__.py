@@ -1,0 +1,327 @@
+"""ctypes binding of libntt_mi355x.so -- the MI355X-native negacyclic NTT engine.
+
+The product is the C-ABI shared library built from ``csrc/`` (HIP kernels for
+gfx950 + a C host layer); this module is only a thin binding so that the Python
+test-suite and ``bench.py`` can call it.  It mirrors the library's two surfaces:
+
+* the batched, device-resident plan API of ``include/ntt_mi355x.h``
+  (``Plan.fwd`` / ``Plan.inv`` / ``Plan.pointwise_mul`` / ``Plan.negacyclic_mul``);
+* the reference's single-polynomial signatures on host arrays
+  (``fwd_ntt_ref_harvey``, ``inv_ntt_ref_harvey``, ``fwd_ntt_radix4``,
+  ``inv_ntt_radix4``, ``fwd_ntt_radix4x4``, ``fwd_ntt_ref_harvey_dbl``), which
+  behave like reference include/ntt_reference.h:13-65, ntt_radix4.h:10-35 and
+  ntt_radix4x4.h:10-28.
+
+There is no CPU fallback: if the shared library is missing the import fails,
+and without a HIP device every compute call raises ``NttError``.
+
+The directory name contains hyphens (it is fixed by the project layout), so
+import it with ``importlib`` -- see ``load()`` in the repository's ``ontt.py``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntt_mi355x.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libntt_mi355x.so is not built (run `make lib` or __graft_entry__.build()); "
+        "there is no pure-Python or CPU fallback for the NTT kernels")
+
+_lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+
+U64P = C.POINTER(C.c_uint64)
+VOIDP = C.c_void_p
+
+NTT_OK = 0
+ARITH_AUTO, ARITH_U64, ARITH_F64 = 0, 1, 2
+
+#: every symbol include/ntt_mi355x.h and the reference-named headers declare
+EXPORTED_SYMBOLS = [
+    "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
+    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic",
+    "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
+    "ntt_pointwise_mul_batch", "ntt_negacyclic_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
+    "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
+    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
+    # reference signatures (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h)
+    "fwd_ntt_ref_harvey_lazy", "inv_ntt_ref_harvey", "fwd_ntt_ref_harvey_lazy_dbl",
+    "fwd_ntt_radix4_lazy", "inv_ntt_radix4", "fwd_ntt_radix4x4_lazy", "fwd_ntt_seal_lazy",
+    "inv_ntt_seal",
+]
+
+
+class NttError(RuntimeError):
+    pass
+
+
+class MulOp(C.Structure):
+    """reference mul_op_t: two __uint128_t, passed by value (fast_mul_operators.h:10-13)."""
+    _fields_ = [("op_lo", C.c_uint64), ("op_hi", C.c_uint64), ("con_lo", C.c_uint64), ("con_hi", C.c_uint64)]
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("ntt_last_error", C.c_char_p)
+_sig("ntt_version", C.c_char_p)
+_sig("ntt_device_count", C.c_int)
+_sig("ntt_plan_create", C.c_int, C.POINTER(VOIDP), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int)
+_sig("ntt_plan_create_from_tables", C.c_int, C.POINTER(VOIDP), C.c_int, C.c_uint64, C.c_uint64, U64P, U64P, C.c_int)
+_sig("ntt_plan_destroy", None, VOIDP)
+_sig("ntt_plan_info", C.c_int, VOIDP, U64P)
+_sig("ntt_plan_set_generic", C.c_int, VOIDP, C.c_int)
+for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide"):
+    _sig(_n, C.c_int, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_pointwise_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_negacyclic_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
+_sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
+_sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
+_sig("ntt_d2h", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
+_sig("ntt_stream_create", C.c_int, C.c_int, C.POINTER(VOIDP))
+_sig("ntt_stream_destroy", C.c_int, C.c_int, VOIDP)
+_sig("ntt_stream_sync", C.c_int, C.c_int, VOIDP)
+_sig("ntt_event_create", C.c_int, C.c_int, C.POINTER(VOIDP))
+_sig("ntt_event_destroy", C.c_int, C.c_int, VOIDP)
+_sig("ntt_event_record", C.c_int, C.c_int, VOIDP, VOIDP)
+_sig("ntt_event_elapsed_ms", C.c_int, C.c_int, VOIDP, VOIDP, C.POINTER(C.c_float))
+_sig("ntt_fill_uniform", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_poly_checksum", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_batch_multi", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), U64P, C.c_int)
+_sig("ntt_min_root", C.c_uint64, C.c_uint64, C.c_uint64)
+_sig("ntt_find_prime", C.c_uint64, C.c_uint, C.c_uint64, C.c_uint)
+for _n in ("fwd_ntt_ref_harvey_lazy", "fwd_ntt_radix4_lazy", "fwd_ntt_radix4x4_lazy", "fwd_ntt_seal_lazy"):
+    _sig(_n, None, U64P, C.c_uint64, C.c_uint64, U64P, U64P)
+_sig("fwd_ntt_ref_harvey_lazy_dbl", None, U64P, U64P, C.c_uint64, C.c_uint64, U64P, U64P)
+_sig("inv_ntt_ref_harvey", None, U64P, C.c_uint64, C.c_uint64, MulOp, C.c_uint64, U64P, U64P)
+_sig("inv_ntt_radix4", None, U64P, C.c_uint64, C.c_uint64, MulOp, U64P, U64P)
+_sig("inv_ntt_seal", None, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, U64P, U64P)
+
+
+def last_error():
+    return _lib.ntt_last_error().decode()
+
+
+def _check(rc):
+    if rc != NTT_OK:
+        raise NttError("ntt status %d: %s" % (rc, last_error()))
+
+
+def version():
+    return _lib.ntt_version().decode()
+
+
+def device_count():
+    n = _lib.ntt_device_count()
+    if n < 0:
+        raise NttError(last_error())
+    return n
+
+
+def min_root(q, n):
+    return int(_lib.ntt_min_root(q, n))
+
+
+def find_prime(bits, n, skip=0):
+    return int(_lib.ntt_find_prime(bits, n, skip))
+
+
+def _ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(U64P)
+
+
+# --------------------------------------------------------------------------
+# device memory (library-owned HIP allocations; torch tensors work as well:
+# pass tensor.data_ptr() wherever a device pointer is expected)
+# --------------------------------------------------------------------------
+class DeviceBuffer:
+    def __init__(self, n_u64, device=0):
+        self.device, self.n = device, int(n_u64)
+        p = VOIDP()
+        _check(_lib.ntt_dev_malloc(device, C.byref(p), self.n * 8))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        assert host.size <= self.n
+        _check(_lib.ntt_h2d(self.device, self.ptr, host.ctypes.data, host.size * 8))
+        return self
+
+    def download(self, n=None, offset=0):
+        n = self.n - offset if n is None else int(n)
+        out = np.empty(n, dtype=np.uint64)
+        _check(_lib.ntt_d2h(self.device, out.ctypes.data, self.ptr + 8 * offset, n * 8))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.ntt_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def fill_uniform(dptr, n, q, seed, offset=0, device=0, stream=None):
+    _check(_lib.ntt_fill_uniform(device, dptr, n, q, seed, offset, stream))
+
+
+def poly_checksum(dout, dptr, N, batch, device=0, stream=None):
+    _check(_lib.ntt_poly_checksum(device, dout, dptr, N, batch, stream))
+
+
+def stream_sync(device=0, stream=None):
+    _check(_lib.ntt_stream_sync(device, stream))
+
+
+class Event:
+    def __init__(self, device=0):
+        self.device = device
+        e = VOIDP()
+        _check(_lib.ntt_event_create(device, C.byref(e)))
+        self.h = e.value
+
+    def record(self, stream=None):
+        _check(_lib.ntt_event_record(self.device, self.h, stream))
+
+    def elapsed_ms_since(self, start):
+        ms = C.c_float()
+        _check(_lib.ntt_event_elapsed_ms(self.device, start.h, self.h, C.byref(ms)))
+        return ms.value
+
+
+# --------------------------------------------------------------------------
+# plans
+# --------------------------------------------------------------------------
+class Plan:
+    """Tables for one (device, N, q, root); see include/ntt_mi355x.h."""
+
+    def __init__(self, N, q, root, device=0, arith=ARITH_AUTO):
+        h = VOIDP()
+        _check(_lib.ntt_plan_create(C.byref(h), device, N, q, root, arith))
+        self.h, self.N, self.q, self.root, self.device = h.value, N, q, root, device
+
+    def info(self):
+        v = (C.c_uint64 * 8)()
+        _check(_lib.ntt_plan_info(self.h, v))
+        keys = ("N", "q", "log2N", "arith", "f64_class", "hbm_passes", "device", "root")
+        return dict(zip(keys, [int(x) for x in v]))
+
+    def set_generic(self, on):
+        _check(_lib.ntt_plan_set_generic(self.h, int(on)))
+
+    def fwd(self, dptr, batch, stream=None, wide=False):
+        f = _lib.ntt_fwd_batch_wide if wide else _lib.ntt_fwd_batch
+        _check(f(self.h, dptr, batch, stream))
+
+    def inv(self, dptr, batch, stream=None, wide=False):
+        f = _lib.ntt_inv_batch_wide if wide else _lib.ntt_inv_batch
+        _check(f(self.h, dptr, batch, stream))
+
+    def pointwise_mul(self, dc, da, db, batch, stream=None):
+        _check(_lib.ntt_pointwise_mul_batch(self.h, dc, da, db, batch, stream))
+
+    def negacyclic_mul(self, dc, da, db, batch, stream=None):
+        _check(_lib.ntt_negacyclic_mul_batch(self.h, dc, da, db, batch, stream))
+
+    # host-array conveniences used by the parity tests
+    def fwd_host(self, a, wide=False):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        batch = a.size // self.N
+        buf = DeviceBuffer(a.size, self.device).upload(a)
+        self.fwd(buf.ptr, batch, wide=wide)
+        out = buf.download()
+        buf.free()
+        return out
+
+    def inv_host(self, a, wide=False):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        batch = a.size // self.N
+        buf = DeviceBuffer(a.size, self.device).upload(a)
+        self.inv(buf.ptr, batch, wide=wide)
+        out = buf.download()
+        buf.free()
+        return out
+
+    def destroy(self):
+        if self.h:
+            _lib.ntt_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def batch_multi(plans, dptrs, batches, inverse=False):
+    n = len(plans)
+    ph = (VOIDP * n)(*[p.h for p in plans])
+    dp = (VOIDP * n)(*dptrs)
+    bt = (C.c_uint64 * n)(*batches)
+    _check(_lib.ntt_batch_multi(n, ph, dp, bt, int(inverse)))
+
+
+# --------------------------------------------------------------------------
+# reference-signature entry points on host numpy arrays (in place)
+# --------------------------------------------------------------------------
+def _mulop(op, con):
+    return MulOp(op & (2**64 - 1), op >> 64, con & (2**64 - 1), con >> 64)
+
+
+def _reduce(a, q, k):
+    """the header-inline final reduction of the reference wrappers"""
+    for m in ((4, 2, 1) if k == 8 else (2, 1)):
+        np.subtract(a, np.uint64(m * q), out=a, where=a >= np.uint64(m * q))
+
+
+def fwd_ntt_ref_harvey(a, N, q, w, w_con):
+    _lib.fwd_ntt_ref_harvey_lazy(_ptr(a), N, q, _ptr(w), _ptr(w_con))
+    _reduce(a, q, 4)
+
+
+def fwd_ntt_ref_harvey_dbl(a1, a2, N, q, w, w_con):
+    _lib.fwd_ntt_ref_harvey_lazy_dbl(_ptr(a1), _ptr(a2), N, q, _ptr(w), _ptr(w_con))
+    _reduce(a1, q, 4)
+    _reduce(a2, q, 4)
+
+
+def inv_ntt_ref_harvey(a, N, q, n_inv, n_inv_con, word_size, w, w_con):
+    _lib.inv_ntt_ref_harvey(_ptr(a), N, q, _mulop(n_inv, n_inv_con), word_size, _ptr(w), _ptr(w_con))
+
+
+def fwd_ntt_radix4(a, N, q, w, w_con):
+    _lib.fwd_ntt_radix4_lazy(_ptr(a), N, q, _ptr(w), _ptr(w_con))
+    _reduce(a, q, 8)
+
+
+def fwd_ntt_radix4x4(a, N, q, w, w_con):
+    _lib.fwd_ntt_radix4x4_lazy(_ptr(a), N, q, _ptr(w), _ptr(w_con))
+    _reduce(a, q, 8)
+
+
+def inv_ntt_radix4(a, N, q, n_inv, n_inv_con, w, w_con):
+    _lib.inv_ntt_radix4(_ptr(a), N, q, _mulop(n_inv, n_inv_con), _ptr(w), _ptr(w_con))
+
+
+def fwd_ntt_seal(a, N, q, w, w_con):
+    _lib.fwd_ntt_seal_lazy(_ptr(a), N, q, _ptr(w), _ptr(w_con))
+    _reduce(a, q, 4)
+
+
+def inv_ntt_seal(a, N, q, n_inv, n_inv_con, w, w_con):
+    _lib.inv_ntt_seal(_ptr(a), N, q, n_inv, n_inv_con, _ptr(w), _ptr(w_con))

@@ -1,0 +1,306 @@
+/*
+ * ntt_arith.h -- modular arithmetic policies for the gfx950 NTT kernels.
+ *
+ * Two interchangeable policies drive the same butterfly network:
+ *
+ *  ArithU64  exact restatement of the reference's Harvey/Shoup lazy arithmetic
+ *            (reference include/internal/fast_mul_operators.h:15-106) on 64-bit
+ *            integers; valid for every q with 4q < 2^64.  On gfx950 one Shoup
+ *            product costs ~10 quarter-rate 32-bit multiplies.
+ *
+ *  ArithF64  the MI355X fast path for q <= 2^51(1+2^-10): coefficients are kept
+ *            as integer-valued doubles in balanced form, a product is
+ *            h=t*w, l=fma(t,w,-h), k=rint(t*(w/q)), r=fma(-k,q,h)+l
+ *            (6 FP64 ops, every step exact -- proof in DESIGN.md section 4), and the
+ *            conditional subtracts of the Harvey butterfly become a
+ *            compile-time schedule of rint-reductions.  Final outputs are
+ *            reduced to [0,q), so results are bit-identical to the reference
+ *            (SURVEY A.6).  No MFMA: this is element-wise 53-bit work.
+ *
+ * Everything here is NTT_HD (host+device) so tests/emu can run the identical
+ * code on the CPU against the oracle.
+ */
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#  include <hip/hip_runtime.h>
+#  define NTT_HD __host__ __device__ __forceinline__
+#  define NTT_DEVICE_CODE 1
+#else
+#  define NTT_HD inline __attribute__((always_inline))
+#endif
+
+namespace ntt {
+
+/* 16-byte twiddle record: one dwordx4 load fetches the multiplier and its
+ * precomputed quotient helper. */
+struct alignas(16) TwU64 {
+  uint64_t w;   /* w in [0,q)                        */
+  uint64_t con; /* floor(w * 2^64 / q)  (pre_compute.h:68-77 semantics) */
+};
+struct alignas(16) TwF64 {
+  double w;  /* balanced representative of w, in (-q/2, q/2] */
+  double wq; /* fl(w / q)                                     */
+};
+
+NTT_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+NTT_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+NTT_HD double rint_(double a) { return __builtin_rint(a); }
+
+/* ------------------------------------------------------------------ */
+/* ArithU64                                                            */
+/* ------------------------------------------------------------------ */
+struct ArithU64 {
+  using val = uint64_t;
+  using tw  = TwU64;
+  struct consts {
+    uint64_t q, q2;
+    TwU64    ninv;  /* N^-1 and its precon                      */
+    TwU64    wninv; /* N^-1 * winv[1] merged (ntt_reference.c:55-61) */
+    TwU64    r64;   /* 2^64 mod q and its precon (pointwise product)  */
+    TwU64    one;   /* {1, floor(2^64/q)}: Shoup form of "t mod q"    */
+  };
+  /* value-range bookkeeping is static for this policy: [0,4q) fwd, [0,2q) inv */
+  static constexpr bool kTracksBounds = false;
+
+  static NTT_HD uint64_t csub(uint64_t v, uint64_t b) { return v < b ? v : v - b; }
+
+  /* inputs may be anywhere in [0,8q) (the lazy radix-4 output range the
+   * reference's bench feeds back in, tests/bench.c:123-137) */
+  template <bool INV> static NTT_HD val load(uint64_t raw, bool wide, const consts &c)
+  {
+    if(!wide) return raw;                    /* strict API: [0,q)         */
+    raw = csub(raw, 2 * c.q2);               /* -> [0,4q): forward range  */
+    return INV ? csub(raw, c.q2) : raw;      /* -> [0,2q): inverse range  */
+  }
+  static NTT_HD uint64_t shoup(const tw &t, uint64_t y, const consts &c)
+  {
+    return t.w * y - mulhi64(t.con, y) * c.q; /* [0,2q) */
+  }
+  /* fast_mul_operators.h:72-81 */
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const uint64_t x1 = csub(x, c.q2);
+    const uint64_t m  = shoup(t, y, c);
+    x                 = x1 + m;
+    y                 = x1 - m + c.q2;
+  }
+  /* fast_mul_operators.h:83-92 */
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const uint64_t s = csub(x + y, c.q2);
+    const uint64_t d = x - y + c.q2;
+    x                = s;
+    y                = shoup(t, d, c);
+  }
+  /* fast_mul_operators.h:94-106: last inverse stage, N^-1 folded in */
+  static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const uint64_t s = x + y;
+    const uint64_t d = x - y + c.q2;
+    x                = shoup(c.ninv, s, c);
+    y                = shoup(c.wninv, d, c);
+  }
+  static NTT_HD uint64_t store_fwd(val v, const consts &c) { return csub(csub(v, c.q2), c.q); }
+  static NTT_HD uint64_t store_fwd_lazy(val v, const consts &) { return v; } /* < 4q */
+  static NTT_HD uint64_t store_inv(val v, const consts &c) { return csub(v, c.q); }
+  static NTT_HD val      scale_ninv(val v, const consts &c) { return shoup(c.ninv, v, c); }
+  /* pointwise product of two values in [0,q), result in [0,q).  The 128-bit
+   * product hi:lo is folded with two Shoup products:
+   * hi*2^64 + lo = hi*(2^64 mod q) + (lo mod q)  (mod q). */
+  static NTT_HD uint64_t mulmod_full(uint64_t a, uint64_t b, const consts &c)
+  {
+    const uint64_t hi = mulhi64(a, b), lo = a * b;
+    const uint64_t r  = shoup(c.r64, hi, c) + shoup(c.one, lo, c); /* < 4q */
+    return csub(csub(r, c.q2), c.q);
+  }
+};
+
+/* ------------------------------------------------------------------ */
+/* ArithF64                                                            */
+/* ------------------------------------------------------------------ */
+/*
+ * Bound bookkeeping.  Values are integer-valued doubles v with |v| <= B*q.
+ * theta = q / 2^52.  With balanced twiddles (|w| <= q/2) a product satisfies
+ *   |r| <= (1/2 + B_y * theta / 2 + eps) * q                       
+ * and stays exact while B*q < 2^53.  KSH = number of bits of headroom class:
+ * the policy is instantiated for q <= 2^(51-KSH) * (1 + 2^-10).
+ */
+struct F64Consts {
+  double q, qinv;  /* q and fl(1/q)                                      */
+  double half_q;   /* q/2 rounded down, for balanced input conversion    */
+  TwF64  ninv;     /* N^-1 (balanced) and ninv/q                         */
+  TwF64  wninv;    /* N^-1 * winv[1] (balanced) and its /q               */
+  uint64_t qi;     /* q as integer                                       */
+};
+
+struct ArithF64 {
+  using val    = double;
+  using tw     = TwF64;
+  using consts = F64Consts;
+  static constexpr bool kTracksBounds = true;
+
+  static NTT_HD double magic52() { return 4503599627370496.0; } /* 2^52 */
+
+  /* u64 in [0,2^52) -> double, exact (mantissa splice); inputs of the strict
+   * API are in [0,q), q < 2^52 */
+  static NTT_HD double u64_to_f64_lt52(uint64_t u)
+  {
+    union {
+      uint64_t u;
+      double   d;
+    } x;
+    x.u = u | 0x4330000000000000ULL;
+    return x.d - magic52();
+  }
+  /* v - q*rint(v/q): |result| <= q/2 (+1 ulp of the quotient) */
+  static NTT_HD double reduce(double v, const consts &c)
+  {
+    const double k = rint_(v * c.qinv);
+    return fma_(-k, c.q, v);
+  }
+  static NTT_HD double mulmod(const tw &t, double y, const consts &c)
+  {
+    const double h = y * t.w;
+    const double k = rint_(y * t.wq);
+    const double l = fma_(y, t.w, -h);
+    const double d = fma_(-k, c.q, h);
+    return d + l;
+  }
+  /* strict API: raw in [0,q).  WIDE (reference-signature shims): raw may be
+   * anywhere in [0,8q) -- folded with integer conditional subtracts first. */
+  template <bool INV> static NTT_HD val load(uint64_t raw, bool wide, const consts &c)
+  {
+    if(wide) {
+      raw = raw < 4 * c.qi ? raw : raw - 4 * c.qi;
+      raw = raw < 2 * c.qi ? raw : raw - 2 * c.qi;
+      raw = raw < c.qi ? raw : raw - c.qi;
+    }
+    return u64_to_f64_lt52(raw);
+  }
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const double xr = RED ? reduce(x, c) : x;
+    const double m  = mulmod(t, y, c);
+    x               = xr + m;
+    y               = xr - m;
+  }
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = RED ? reduce(s, c) : s;
+    y              = mulmod(t, d, c);
+  }
+  static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = mulmod(c.ninv, s, c);
+    y              = mulmod(c.wninv, d, c);
+  }
+  /* balanced |v| < 2^53 -> canonical [0,q) as u64 */
+  static NTT_HD uint64_t to_canonical(double v, const consts &c)
+  {
+    const double r  = reduce(v, c);           /* |r| <= q/2 (+tiny)      */
+    const double a0 = r + magic52();          /* r >= 0 branch           */
+    const double a1 = r + (magic52() + c.q);  /* r <  0 branch: r + q    */
+    union {
+      double   d;
+      uint64_t u;
+    } x;
+    x.d = (r < 0.0) ? a1 : a0;
+    uint64_t u = x.u & 0xFFFFFFFFFFFFFULL;
+    /* rint ties/ulp slack can leave r == q/2+.. or r+q == q exactly once in a
+     * blue moon; fold the single possible overshoot */
+    return u >= c.qi ? u - c.qi : u;
+  }
+  static NTT_HD uint64_t store_fwd(val v, const consts &c) { return to_canonical(v, c); }
+  static NTT_HD uint64_t store_inv(val v, const consts &c) { return to_canonical(v, c); }
+  static NTT_HD val      scale_ninv(val v, const consts &c) { return mulmod(c.ninv, v, c); }
+  /* pointwise product of two values in [0,q): b is re-centred so |a*b/q| <= q/2
+   * and the on-the-fly quotient h*qinv is within 0.4 of the truth */
+  static NTT_HD uint64_t mulmod_full(uint64_t a, uint64_t b, const consts &c)
+  {
+    const double x  = u64_to_f64_lt52(a);
+    double       y  = u64_to_f64_lt52(b);
+    y               = y > c.half_q ? y - c.q : y;
+    const double h  = x * y;
+    const double k  = rint_(h * c.qinv);
+    const double l  = fma_(x, y, -h);
+    const double d  = fma_(-k, c.q, h);
+    return to_canonical(d + l, c);
+  }
+};
+
+/* ------------------------------------------------------------------ */
+/* compile-time reduction schedule for ArithF64                        */
+/* ------------------------------------------------------------------ */
+/*
+ * Returns a bit mask over local stages 0..nstages-1: bit s set => reduce the
+ * non-multiplied operand in that stage.  Model, in units of q,
+ * theta2 = theta/2 = q/2^53 upper bound for the class:
+ *   forward  no-reduce: B' = B + rho(B),      reduce: B' = 1/2 + e + rho(B)
+ *            rho(B) = 1/2 + B*theta2*(1+e) + e
+ *   inverse  s,d bounded by 2B;  no-reduce: B' = max(2B, rho(2B)),
+ *            reduce: B' = max(1/2+e, rho(2B))
+ * A stage must reduce when the no-reduce bound (or, inverse, 2B itself)
+ * would exceed LIM = (2^53/q)*(1-2^-6).
+ */
+struct F64Sched {
+  uint32_t mask;
+  double   bout;
+};
+
+constexpr double f64_rho(double b, double theta2) { return 0.5 + b * theta2 * 1.001 + 0.001; }
+
+constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in)
+{
+  /* class ksh: q <= 2^(51-ksh)*(1+2^-10) */
+  double theta2 = 0.25 * 1.001; /* q/2^53 for ksh=0 */
+  double lim    = 4.0 / 1.001;  /* 2^53/q           */
+  for(int i = 0; i < ksh; i++) {
+    theta2 *= 0.5;
+    lim *= 2.0;
+  }
+  lim *= (1.0 - 1.0 / 64.0);
+  double   b    = b_in;
+  uint32_t mask = 0;
+  for(int s = 0; s < nstages; s++) {
+    if(!inverse) {
+      const double nr = b + f64_rho(b, theta2);
+      /* also keep the *next* stage feasible: after a no-reduce stage the next
+       * one can always reduce, so only the immediate bound matters */
+      if(nr > lim) {
+        mask |= (1u << s);
+        b = 0.501 + f64_rho(b, theta2);
+      } else {
+        b = nr;
+      }
+    } else {
+      const double two_b = 2.0 * b;
+      const double r     = f64_rho(two_b, theta2);
+      /* s = x+y must itself stay exact: two_b <= lim is a precondition kept
+       * by always reducing when the unreduced sum would break it next time */
+      const double nr = two_b > r ? two_b : r;
+      if(2.0 * nr > lim) {
+        mask |= (1u << s);
+        b = r > 0.501 ? r : 0.501;
+      } else {
+        b = nr;
+      }
+    }
+  }
+  return F64Sched{mask, b};
+}
+
+} /* namespace ntt */

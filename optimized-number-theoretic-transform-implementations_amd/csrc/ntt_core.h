@@ -1,0 +1,442 @@
+/*
+ * ntt_core.h -- the butterfly network shared by the gfx950 kernels and the CPU
+ * emulation used by the unit tests (tests/emu).
+ *
+ * Transform semantics are the reference's: forward =
+ * Cooley-Tukey, natural order in, bit-reversed order out, in place; stage s
+ * (s = 0..m-1) pairs elements whose indices differ in bit m-1-s and uses twiddle
+ * slot 2^s + (i >> (m-s)) of the bit-reversed power table
+ * (reference src/ntt_reference.c:17-30).  Inverse = Gentleman-Sande over the
+ * same stages in reverse with the inverse table, N^-1 folded into stage 0
+ * (src/ntt_reference.c:41-65).
+ *
+ * GPU decomposition.  A "block" of 2^LOGN consecutive
+ * coefficients is transformed by 2^(LOGN-4) threads that hold 16 coefficients
+ * each in registers.  The LOGN stages are cut into groups of <= 4 stages; inside
+ * a group every butterfly is register-to-register (the in-thread radix-16 tile
+ * echoes reference src/ntt_radix4x4.c:54-78); between groups the block is
+ * re-distributed through LDS in a "reader-linear" layout
+ *     addr = e_r * (T + PAD) + t_r
+ * (e_r = register slot, t_r = thread of the *next* group) so reads are always
+ * conflict-free and PAD (found at compile time) makes the scattered
+ * ds_write_b64 of the previous group conflict-free as well.
+ *
+ *   first group : top 4 index bits in-thread (R0 active + passengers below),
+ *                 coalesced 8-byte global loads, block-uniform twiddles
+ *   middle      : 4 active bits [lo,lo+4), wave-uniform twiddles while lo >= 6
+ *   last group  : bits [0,RL) in-thread, RL = 2 (LOGN even) or 1; lanes sit on
+ *                 consecutive pairs/quads so the final stores are 16 B/lane
+ */
+#pragma once
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+#include "ntt_arith.h"
+
+namespace ntt {
+
+constexpr int kLE = 4;       /* log2 coefficients per thread */
+constexpr int kE  = 1 << kLE;
+
+template <int I, int N, class F> NTT_HD void static_for(F &&f)
+{
+  if constexpr(I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+/* Lane-bit order per (LOGN, group): thread bit t < NL of group g addresses index
+ * bit kLaneBits[LOGN-6][g][t].  Found by tools/lds_layout_search.py so that, with
+ * one pad element per LDS row, every ds_write_b64 of every exchange (both
+ * directions) hits 16 distinct 8-byte bank columns per 16-lane group; the reads
+ * are linear and conflict-free by construction.  -1 = unused. */
+constexpr int8_t kLaneBits[9][4][6] = {
+  /* LOGN  6 */ {{0, 1, -1, -1, -1, -1}, {2, 3, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}},
+  /* LOGN  7 */ {{0, 1, 2, -1, -1, -1}, {5, 6, 0, -1, -1, -1}, {1, 2, 3, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}},
+  /* LOGN  8 */ {{0, 1, 2, 3, -1, -1}, {6, 7, 0, 1, -1, -1}, {2, 3, 4, 5, -1, -1}, {-1, -1, -1, -1, -1, -1}},
+  /* LOGN  9 */ {{0, 1, 2, 3, 4, -1}, {6, 7, 8, 0, 5, -1}, {1, 2, 3, 4, 5, -1}, {-1, -1, -1, -1, -1, -1}},
+  /* LOGN 10 */ {{0, 1, 2, 3, 4, 5}, {8, 9, 0, 1, 6, 7}, {2, 3, 4, 5, 6, 7}, {-1, -1, -1, -1, -1, -1}},
+  /* LOGN 11 */ {{0, 1, 2, 3, 4, 5}, {0, 1, 2, 3, 4, 9}, {6, 7, 8, 0, 5, 9}, {2, 3, 4, 6, 1, 5}},
+  /* LOGN 12 */ {{0, 1, 2, 3, 4, 5}, {0, 1, 2, 3, 4, 5}, {8, 9, 0, 1, 6, 7}, {2, 3, 4, 5, 6, 7}},
+  /* LOGN 13 */ {{0, 1, 2, 3, 4, 5}, {0, 1, 2, 3, 4, 9}, {6, 7, 8, 0, 5, 9}, {2, 3, 4, 6, 1, 5}},
+  /* LOGN 14 */ {{0, 1, 2, 3, 4, 5}, {0, 1, 2, 3, 4, 5}, {8, 9, 0, 1, 6, 7}, {2, 3, 4, 5, 6, 7}},
+};
+constexpr int kLdsPad = 1;
+
+/* ------------------------------------------------------------------ */
+/* compile-time plan                                                   */
+/* ------------------------------------------------------------------ */
+template <int LOGN> struct Plan {
+  static_assert(LOGN >= 6 && LOGN <= 14, "fused block size out of range");
+  static constexpr int LT   = LOGN - kLE; /* log2 threads per block */
+  static constexpr int T    = 1 << LT;
+  static constexpr int RL   = (LOGN & 1) ? 1 : 2;
+  static constexpr int REM  = LOGN - RL;
+  static constexpr int R0   = (REM % 4 == 0) ? 4 : (REM % 4);
+  static constexpr int NMID = (REM - R0) / 4;
+  static constexpr int NG   = NMID + 2;
+  static constexpr int NL   = LT < 6 ? LT : 6; /* lane bits of one block */
+
+  static constexpr int R(int g) { return g == 0 ? R0 : (g == NG - 1 ? RL : 4); }
+  /* first local stage of group g */
+  static constexpr int S(int g)
+  {
+    int s = 0;
+    for(int i = 0; i < g; i++) s += R(i);
+    return s;
+  }
+  /* lowest active index bit of group g */
+  static constexpr int LO(int g) { return LOGN - S(g) - R(g); }
+
+  /* in-thread slot bit b (0..3) -> index bit */
+  static constexpr int EB(int g, int b)
+  {
+    if(g == 0) return LOGN - 4 + b;
+    if(g == NG - 1) return b < RL ? b : RL + NL + (b - RL);
+    return LO(g) + b;
+  }
+  /* thread bit t (0..LT-1) -> index bit */
+  static constexpr int TB(int g, int t)
+  {
+    if(t < NL) return kLaneBits[LOGN - 6][g][t]; /* lane bits: tuned order */
+    return g == 0 ? t : t + 4;                   /* wave bits              */
+  }
+  /* the untuned assignment kLaneBits permutes (kept for the layout tests) */
+  static constexpr int TB_DEFAULT(int g, int t)
+  {
+    if(g == 0) return t;
+    if(g == NG - 1) return t < NL ? RL + t : t + 4;
+    return t < LO(g) ? t : t + 4;
+  }
+  /* slot bit that local stage j of group g toggles */
+  static constexpr int ABIT(int g, int j)
+  {
+    if(g == 0) return (4 - R0) + (R0 - 1 - j);
+    if(g == NG - 1) return RL - 1 - j;
+    return 3 - j;
+  }
+  static constexpr uint32_t IOFF(int g, int e)
+  {
+    uint32_t v = 0;
+    for(int b = 0; b < 4; b++) v |= ((e >> b) & 1u) << EB(g, b);
+    return v;
+  }
+  static constexpr uint32_t IBASE(int g, uint32_t t)
+  {
+    uint32_t v = 0;
+    for(int b = 0; b < LT; b++) v |= ((t >> b) & 1u) << TB(g, b);
+    return v;
+  }
+  /* inverse maps: index -> (thread, slot) of group g */
+  static constexpr uint32_t THREAD_OF(int g, uint32_t i)
+  {
+    uint32_t v = 0;
+    for(int b = 0; b < LT; b++) v |= ((i >> TB(g, b)) & 1u) << b;
+    return v;
+  }
+  static constexpr uint32_t SLOT_OF(int g, uint32_t i)
+  {
+    uint32_t v = 0;
+    for(int b = 0; b < 4; b++) v |= ((i >> EB(g, b)) & 1u) << b;
+    return v;
+  }
+  /* LDS layout read by group gr: addr(i) = slot*ROW + thread.  PAD makes the
+   * writer (group gw) conflict-free: ds_write_b64 is serviced in 16-lane groups
+   * over 32 four-byte banks, i.e. 16 eight-byte columns. */
+  static constexpr bool pad_ok(int gw, int gr, int pad)
+  {
+    const int row = T + pad;
+    for(uint32_t t0 = 0; t0 < (uint32_t)T; t0 += 16) {
+      uint32_t seen = 0;
+      const int n   = T < 16 ? T : 16;
+      for(int l = 0; l < n; l++) {
+        const uint32_t i = IBASE(gw, t0 + l);
+        const uint32_t a = SLOT_OF(gr, i) * row + THREAD_OF(gr, i);
+        const uint32_t c = a & 15u;
+        if(seen & (1u << c)) return false;
+        seen |= 1u << c;
+      }
+    }
+    return true;
+  }
+  /* one pad for every exchange of the plan (both directions), so that all
+   * layouts share the same rows and a wave-local exchange only ever touches
+   * the columns owned by its own wave */
+  static constexpr int PAD() { return kLdsPad; }
+  static constexpr bool layout_conflict_free()
+  {
+    bool ok = true;
+    for(int g = 0; g + 1 < NG; g++) ok = ok && pad_ok(g, g + 1, PAD()) && pad_ok(g + 1, g, PAD());
+    return ok;
+  }
+  static constexpr int ROW       = T + PAD();
+  static constexpr int LDS_ELEMS = kE * ROW; /* per block */
+  /* an exchange stays inside one wave when the threads' wave bits address
+   * the same index bits on both sides */
+  static constexpr bool WAVE_LOCAL(int ga, int gb)
+  {
+    for(int t = 6; t < LT; t++) {
+      if(TB(ga, t) != TB(gb, t)) return false;
+    }
+    return true;
+  }
+  /* twiddle slot of a stage is wave-uniform when no lane bit reaches the
+   * shifted-in part */
+  static constexpr bool TW_UNIFORM(int g, int j)
+  {
+    if(LT < 6) return false; /* several blocks share a wave */
+    const int sh = LOGN - (S(g) + j);
+    for(int t = 0; t < 6; t++) {
+      if(TB(g, t) >= sh) return false;
+    }
+    return true;
+  }
+};
+
+/* ------------------------------------------------------------------ */
+/* kernel parameters                                                   */
+/* ------------------------------------------------------------------ */
+template <class A> struct Params {
+  uint64_t *             a;       /* [batch][N] coefficients, in place            */
+  const typename A::tw * tw;      /* N records, bit-reversed power order          */
+  typename A::consts     c;
+  uint32_t               logn;    /* log2 N of the whole transform                */
+  uint32_t               s0;      /* global stages handled before (fwd) / after (inv) this pass */
+  uint32_t               wide;    /* inputs may be lazy ([0,8q)) instead of [0,q) */
+  uint32_t               lastinv; /* inverse: this pass ends with global stage 0  */
+  uint64_t               nblocks; /* batch * 2^s0 blocks of 2^LOGN                */
+};
+
+NTT_HD uint32_t uniform_u32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+  return v;
+#endif
+}
+
+template <class A> NTT_HD typename A::tw load_tw(const typename A::tw *tab, uint32_t idx)
+{
+  return tab[idx];
+}
+
+/* ------------------------------------------------------------------ */
+/* one register-resident group of stages                               */
+/* ------------------------------------------------------------------ */
+/*
+ * x[16]  : the thread's coefficients (slot e <-> index IBASE(t)+IOFF(e))
+ * t      : thread id inside the block;  blk: block id inside the polynomial
+ * MASK   : ArithF64 reduction schedule, bit = processing position of the stage
+ * p.lastinv (inverse only): local stage 0 is global stage 0 and folds N^-1
+ *          (reference src/ntt_reference.c:55-65)
+ */
+template <class A, int LOGN, int G, bool INV, uint32_t MASK>
+NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
+                      const Params<A> &p)
+{
+  using P            = Plan<LOGN>;
+  constexpr int R    = P::R(G);
+  constexpr int SG   = P::S(G);
+  const uint32_t ib  = P::IBASE(G, t);
+  static_for<0, R>([&](auto jj) {
+    /* forward walks local stages upward, inverse downward */
+    constexpr int J  = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
+    constexpr int SL = SG + J;                 /* local stage              */
+    constexpr int SH = LOGN - SL;              /* index bits consumed      */
+    constexpr int AB = P::ABIT(G, J);
+    constexpr int POS = INV ? (LOGN - 1 - SL) : SL; /* processing position */
+    constexpr bool RED = (MASK >> POS) & 1u;
+    const uint32_t gs  = p.s0 + SL;            /* global stage             */
+    uint32_t       tb  = (1u << gs) + (blk << SL) + (ib >> SH);
+    if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
+    static_for<0, kE>([&](auto ee) {
+      constexpr int E0 = decltype(ee)::value;
+      if constexpr(((E0 >> AB) & 1) == 0) {
+        constexpr int      E1  = E0 | (1 << AB);
+        constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+        if(INV && SL == 0 && p.lastinv) {
+          A::inv_bfly_last(x[E0], x[E1], p.c);
+        } else {
+          const typename A::tw w = load_tw<A>(p.tw, tb + OFF);
+          if constexpr(INV) {
+            A::template inv_bfly<RED>(x[E0], x[E1], w, p.c);
+          } else {
+            A::template fwd_bfly<RED>(x[E0], x[E1], w, p.c);
+          }
+        }
+      }
+    });
+  });
+}
+
+/* ------------------------------------------------------------------ */
+/* LDS exchange: writer side of group GW into the layout read by GR    */
+/* ------------------------------------------------------------------ */
+template <class A, int LOGN, int GW, int GR>
+NTT_HD void lds_scatter(const typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
+{
+  using P           = Plan<LOGN>;
+  constexpr int ROW = P::ROW;
+  const uint32_t i  = P::IBASE(GW, t);
+  const uint32_t b  = P::SLOT_OF(GR, i) * ROW + P::THREAD_OF(GR, i);
+  static_for<0, kE>([&](auto ee) {
+    constexpr int      E  = decltype(ee)::value;
+    constexpr uint32_t IO = P::IOFF(GW, E);
+    constexpr uint32_t D  = P::SLOT_OF(GR, IO) * ROW + P::THREAD_OF(GR, IO);
+    lds[b + D]            = x[E];
+  });
+}
+
+template <class A, int LOGN, int GW, int GR>
+NTT_HD void lds_gather(typename A::val (&x)[kE], uint32_t t, const typename A::val *lds)
+{
+  using P           = Plan<LOGN>;
+  constexpr int ROW = P::ROW;
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    x[E]            = lds[E * ROW + t];
+  });
+}
+
+/* ------------------------------------------------------------------ */
+/* global memory ends                                                  */
+/* ------------------------------------------------------------------ */
+struct alignas(16) u64x2 {
+  uint64_t a, b;
+};
+
+/* first-kind group: slot e <-> index (e << LT) + t : 8-byte coalesced */
+template <class A, int LOGN, bool INV>
+NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64_t *blk,
+                              bool wide, const typename A::consts &c)
+{
+  using P = Plan<LOGN>;
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    x[E]            = A::template load<INV>(blk[((uint32_t)E << P::LT) + t], wide, c);
+  });
+}
+
+/* last-kind group: slots come in runs of 2^RL consecutive indices */
+template <class A, int LOGN, bool INV>
+NTT_HD void global_load_last(typename A::val (&x)[kE], uint32_t t, const uint64_t *blk,
+                             bool wide, const typename A::consts &c)
+{
+  using P              = Plan<LOGN>;
+  constexpr int G      = P::NG - 1;
+  const uint32_t ib    = P::IBASE(G, t);
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    const u64x2   v = *reinterpret_cast<const u64x2 *>(blk + ib + P::IOFF(G, E));
+    x[E]            = A::template load<INV>(v.a, wide, c);
+    x[E + 1]        = A::template load<INV>(v.b, wide, c);
+  });
+}
+
+template <class A, int LOGN, bool INV>
+NTT_HD void global_store_first(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
+                               const typename A::consts &c)
+{
+  using P = Plan<LOGN>;
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    blk[((uint32_t)E << P::LT) + t] = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
+  });
+}
+
+template <class A, int LOGN, bool INV>
+NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
+                              const typename A::consts &c)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    u64x2         v;
+    v.a = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
+    v.b = INV ? A::store_inv(x[E + 1], c) : A::store_fwd(x[E + 1], c);
+    *reinterpret_cast<u64x2 *>(blk + ib + P::IOFF(G, E)) = v;
+  });
+}
+
+/* ------------------------------------------------------------------ */
+/* reduction schedules (ArithF64) for a fused block pass                */
+/* ------------------------------------------------------------------ */
+template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
+{
+  if constexpr(!A::kTracksBounds) {
+    return 0;
+  } else {
+    /* the schedule is causal, so when the last inverse stage is the folded
+     * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
+    return f64_schedule(INV, LOGN, KSH, 1.0).mask;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* strided ("column") pass: R stages on elements far apart in memory    */
+/* ------------------------------------------------------------------ */
+/*
+ * Used for the leading stages of transforms larger than one fused block and for
+ * sizes below the fused range.  Global stages [S, S+R) of an N=2^m transform:
+ * i = hi*(2^R*span) + e*span + lo, span = N >> (S+R); one thread per (hi,lo).
+ * Twiddle slot at local stage j: 2^(S+j) + (hi<<j) + (e>>(R-j)).
+ */
+template <class A, int R, bool INV, uint32_t MASK>
+NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint32_t S,
+                               bool wide, bool lastinv, const typename A::tw *tab,
+                               const typename A::consts &c)
+{
+  constexpr int  NE   = 1 << R;
+  const uint32_t lsp  = logn - S - R; /* log2 span */
+  const uint32_t lo   = col & ((1u << lsp) - 1);
+  const uint32_t hi   = col >> lsp;
+  uint64_t *     base = poly + ((uint64_t)hi << (lsp + R)) + lo;
+  typename A::val x[NE];
+  static_for<0, NE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    x[E]            = A::template load<INV>(base[(uint64_t)E << lsp], wide, c);
+  });
+  static_for<0, R>([&](auto jj) {
+    constexpr int  J   = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
+    constexpr int  AB  = R - 1 - J;
+    constexpr int  POS = INV ? (R - 1 - J) : J;
+    constexpr bool RED = (MASK >> POS) & 1u;
+    const uint32_t tb  = (1u << (S + J)) + (hi << J);
+    static_for<0, NE>([&](auto ee) {
+      constexpr int E0 = decltype(ee)::value;
+      if constexpr(((E0 >> AB) & 1) == 0) {
+        constexpr int E1 = E0 | (1 << AB);
+        if(INV && J == 0 && lastinv) {
+          A::inv_bfly_last(x[E0], x[E1], c); /* global stage 0: S == 0 */
+        } else {
+          const typename A::tw w = tab[tb + (E0 >> (R - J))];
+          if constexpr(INV) {
+            A::template inv_bfly<RED>(x[E0], x[E1], w, c);
+          } else {
+            A::template fwd_bfly<RED>(x[E0], x[E1], w, c);
+          }
+        }
+      }
+    });
+  });
+  static_for<0, NE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    base[(uint64_t)E << lsp] = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
+  });
+}
+
+template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
+{
+  if constexpr(!A::kTracksBounds) {
+    return 0;
+  } else {
+    return f64_schedule(INV, R, KSH, 1.0).mask;
+  }
+}
+
+} /* namespace ntt */

@@ -1,0 +1,723 @@
+/*
+ * ntt_host.hip -- host side of libntt_mi355x.so: plans, pass dispatch, the C ABI
+ * declared in include/ntt_mi355x.h and the reference-signature entry points of
+ * include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h and ntt_seal.h.
+ *
+ * No CPU compute path exists in this library: every transform is a HIP kernel
+ * launch and every failure is reported (status code / abort for the void
+ * reference signatures).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ntt_kernels.h"
+#include "ntt_passplan.h"
+#include "ntt_tables.h"
+
+#include "ntt_mi355x.h"
+#include "ntt_radix4.h"
+#include "ntt_radix4x4.h"
+#include "ntt_reference.h"
+#include "ntt_seal.h"
+
+using namespace ntt;
+
+namespace ntt {
+/* defined in inst_*.hip */
+template <> hipError_t launch_pass<ArithU64, 0>(const PassArgs &);
+template <> hipError_t launch_pass<ArithF64, 0>(const PassArgs &);
+template <> hipError_t launch_pass<ArithF64, 1>(const PassArgs &);
+template <> hipError_t launch_pass<ArithF64, 18>(const PassArgs &);
+} // namespace ntt
+
+/* ------------------------------------------------------------------ */
+/* errors                                                              */
+/* ------------------------------------------------------------------ */
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if(e_ != hipSuccess) {                                                                    \
+      return fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    }                                                                                         \
+  } while(0)
+
+static int env_int(const char *name, int dflt)
+{
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+static int check_device(int device)
+{
+  int        n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess || n <= 0) {
+    return fail(NTT_ERR_NO_DEVICE, std::string("no usable HIP device (") +
+                                     (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                     "); libntt_mi355x has no CPU fallback");
+  }
+  if(device < 0 || device >= n) return fail(NTT_ERR_ARG, "device index out of range");
+  return NTT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* plan                                                                */
+/* ------------------------------------------------------------------ */
+struct ntt_plan {
+  int      device  = 0;
+  uint64_t N       = 0, q = 0, root = 0;
+  int      m       = 0;
+  int      arith   = NTT_ARITH_U64; /* resolved: U64 or F64 */
+  int      kcls    = 0;             /* instantiated FP64 headroom class */
+  bool     generic = false;
+  bool     has_fwd = false, has_inv = false;
+  void *   d_fwd   = nullptr;
+  void *   d_inv   = nullptr;
+  ArithU64::consts cu{};
+  F64Consts        cf{};
+  hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
+  int              max_grid   = 0;
+};
+
+static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+
+static int resolve_arith(int requested, uint64_t q, int *out)
+{
+  const char *env = getenv("NTT_ARITH");
+  if(requested == NTT_ARITH_AUTO && env) {
+    if(!strcmp(env, "u64")) requested = NTT_ARITH_U64;
+    if(!strcmp(env, "f64")) requested = NTT_ARITH_F64;
+  }
+  if(requested == NTT_ARITH_AUTO) requested = h_f64_eligible(q) ? NTT_ARITH_F64 : NTT_ARITH_U64;
+  if(requested == NTT_ARITH_F64 && !h_f64_eligible(q)) {
+    return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q <= 2^51(1+2^-10)");
+  }
+  if(requested != NTT_ARITH_F64 && requested != NTT_ARITH_U64) return fail(NTT_ERR_ARG, "bad arith");
+  *out = requested;
+  return NTT_OK;
+}
+
+template <class TW, class MK>
+static int upload_table(void **d_out, const std::vector<uint64_t> &w, uint64_t q, MK mk)
+{
+  std::vector<TW> host(w.size());
+  for(size_t i = 0; i < w.size(); i++) host[i] = mk(w[i], q);
+  HIP_TRY(hipMalloc(d_out, host.size() * sizeof(TW)));
+  HIP_TRY(hipMemcpy(*d_out, host.data(), host.size() * sizeof(TW), hipMemcpyHostToDevice));
+  return NTT_OK;
+}
+
+/* fwd / inv: radix-2 power tables in bit-reversed order (either may be empty);
+ * ninv_override: 0 = derive N^-1 */
+static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root,
+                      const std::vector<uint64_t> &fwd, const std::vector<uint64_t> &inv, int arith,
+                      uint64_t ninv_override)
+{
+  if(!out) return fail(NTT_ERR_ARG, "null plan pointer");
+  *out = nullptr;
+  if(!is_pow2(N) || N < 2 || N > (1ull << 28)) return fail(NTT_ERR_ARG, "N must be a power of two in [2,2^28]");
+  if(q < 3 || !(q & 1) || q >= (1ull << 61)) return fail(NTT_ERR_ARG, "q must be odd, 3 <= q < 2^61");
+  if((q - 1) % (2 * N) != 0) return fail(NTT_ERR_ARG, "2N must divide q-1");
+  int rc = check_device(device);
+  if(rc) return rc;
+  int ar = 0;
+  rc     = resolve_arith(arith, q, &ar);
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  ntt_plan *p = new ntt_plan();
+  p->device   = device;
+  p->N        = N;
+  p->q        = q;
+  p->root     = root;
+  p->m        = (int)h_log2(N);
+  p->arith    = ar;
+  p->generic  = env_int("NTT_GENERIC", 0) != 0;
+  p->max_grid = env_int("NTT_MAX_GRID", 0);
+  p->has_fwd  = !fwd.empty();
+  p->has_inv  = !inv.empty();
+  std::vector<uint64_t> inv_for_consts = inv.empty() ? std::vector<uint64_t>(2, 1) : inv;
+  p->cu = h_consts_u64(q, N, inv_for_consts);
+  if(ninv_override) {
+    p->cu.ninv  = h_tw_u64(ninv_override % q, q);
+    p->cu.wninv = h_tw_u64(h_mulmod(ninv_override % q, inv_for_consts[1], q), q);
+  }
+  if(ar == NTT_ARITH_F64) {
+    p->cf = h_consts_f64(q, N, inv_for_consts);
+    if(ninv_override) {
+      p->cf.ninv  = h_tw_f64(ninv_override % q, q);
+      p->cf.wninv = h_tw_f64(h_mulmod(ninv_override % q, inv_for_consts[1], q), q);
+    }
+    const int k = h_f64_ksh(q);
+    p->kcls     = k >= 18 ? 18 : (k >= 1 ? 1 : 0);
+    const int force = env_int("NTT_F64_CLASS", -1);
+    if(force == 0 || (force == 1 && k >= 1)) p->kcls = force;
+  }
+  rc = NTT_OK;
+  if(ar == NTT_ARITH_F64) {
+    if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, fwd, q, h_tw_f64);
+    if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv, q, h_tw_f64);
+  } else {
+    if(p->has_fwd) rc = upload_table<TwU64>(&p->d_fwd, fwd, q, h_tw_u64);
+    if(!rc && p->has_inv) rc = upload_table<TwU64>(&p->d_inv, inv, q, h_tw_u64);
+  }
+  if(rc) {
+    ntt_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return NTT_OK;
+}
+
+extern "C" int ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root, int arith)
+{
+  if(!is_pow2(N) || q < 3 || root == 0 || root >= q) return fail(NTT_ERR_ARG, "bad N, q or root");
+  if(h_powmod(root, N, q) != q - 1) return fail(NTT_ERR_ARG, "root is not a primitive 2N-th root of unity mod q");
+  const uint64_t rinv = h_powmod(root, q - 2, q);
+  return plan_build(out, device, N, q, root, h_power_table(root, N, q), h_power_table(rinv, N, q), arith, 0);
+}
+
+extern "C" int ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t N, uint64_t q,
+                                           const uint64_t *w_powers, const uint64_t *w_inv_powers, int arith)
+{
+  if(!w_powers && !w_inv_powers) return fail(NTT_ERR_ARG, "no table given");
+  if(!is_pow2(N)) return fail(NTT_ERR_ARG, "N must be a power of two");
+  std::vector<uint64_t> f, i;
+  if(w_powers) f.assign(w_powers, w_powers + N);
+  if(w_inv_powers) i.assign(w_inv_powers, w_inv_powers + N);
+  return plan_build(out, device, N, q, 0, f, i, arith, 0);
+}
+
+extern "C" void ntt_plan_destroy(ntt_plan *p)
+{
+  if(!p) return;
+  (void)hipSetDevice(p->device);
+  if(p->d_fwd) (void)hipFree(p->d_fwd);
+  if(p->d_inv) (void)hipFree(p->d_inv);
+  if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  delete p;
+}
+
+extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
+{
+  if(!p || !info) return fail(NTT_ERR_ARG, "null argument");
+  info[0] = p->N;
+  info[1] = p->q;
+  info[2] = (uint64_t)p->m;
+  info[3] = (uint64_t)p->arith;
+  info[4] = (uint64_t)p->kcls;
+  info[5] = (uint64_t)make_passes(p->m, p->generic).n;
+  info[6] = (uint64_t)p->device;
+  info[7] = p->root;
+  return NTT_OK;
+}
+
+extern "C" int ntt_plan_set_generic(ntt_plan *p, int on)
+{
+  if(!p) return fail(NTT_ERR_ARG, "null plan");
+  p->generic = on != 0;
+  return NTT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* transforms                                                          */
+/* ------------------------------------------------------------------ */
+static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
+{
+  if(p->arith == NTT_ARITH_U64) return launch_pass<ArithU64, 0>(pa);
+  switch(p->kcls) {
+    case 18: return launch_pass<ArithF64, 18>(pa);
+    case 1: return launch_pass<ArithF64, 1>(pa);
+    default: return launch_pass<ArithF64, 0>(pa);
+  }
+}
+
+static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream)
+{
+  if(!p || (!d_a && batch)) return fail(NTT_ERR_ARG, "null argument");
+  if(batch == 0) return NTT_OK;
+  if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
+  HIP_TRY(hipSetDevice(p->device));
+  const PassList L = make_passes(p->m, p->generic);
+  for(int k = 0; k < L.n; k++) {
+    const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
+    PassArgs    pa{};
+    pa.a        = d_a;
+    pa.tw       = inverse ? p->d_inv : p->d_fwd;
+    pa.consts   = p->arith == NTT_ARITH_U64 ? (const void *)&p->cu : (const void *)&p->cf;
+    pa.batch    = batch;
+    pa.logn     = (uint32_t)p->m;
+    pa.fused    = ps.fused;
+    pa.r        = ps.r;
+    pa.s        = ps.s;
+    pa.inverse  = inverse;
+    pa.wide     = wide && k == 0;
+    pa.lastinv  = inverse && ps.s == 0;
+    pa.max_grid = p->max_grid;
+    pa.stream   = (hipStream_t)stream;
+    hipError_t e = dispatch_pass(p, pa);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  }
+  return NTT_OK;
+}
+
+extern "C" int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, false, false, stream);
+}
+extern "C" int ntt_inv_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, true, false, stream);
+}
+extern "C" int ntt_fwd_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, false, true, stream);
+}
+extern "C" int ntt_inv_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, true, true, stream);
+}
+
+/* ------------------------------------------------------------------ */
+/* utility kernels                                                     */
+/* ------------------------------------------------------------------ */
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x)
+{
+  x += 0x9e3779b97f4a7c15ULL;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+  return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256) fill_uniform_kernel(uint64_t *a, uint64_t n, uint64_t q, uint64_t seed,
+                                                           uint64_t offset)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    a[i] = splitmix64_dev(seed ^ (offset + i)) % q;
+  }
+}
+
+/* one workgroup per polynomial: sum_i splitmix64(i) * a[i] mod 2^64 */
+__global__ void __launch_bounds__(256) checksum_kernel(uint64_t *out, const uint64_t *a, uint64_t N, uint64_t batch)
+{
+  __shared__ uint64_t part[256];
+  for(uint64_t p = blockIdx.x; p < batch; p += gridDim.x) {
+    const uint64_t *src = a + p * N;
+    uint64_t        acc = 0;
+    for(uint64_t i = threadIdx.x; i < N; i += blockDim.x) acc += splitmix64_dev(i) * src[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for(int s = 128; s > 0; s >>= 1) {
+      if((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+      __syncthreads();
+    }
+    if(threadIdx.x == 0) out[p] = part[0];
+    __syncthreads();
+  }
+}
+
+template <class A>
+__global__ void __launch_bounds__(256) pointwise_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n,
+                                                        const typename A::consts k)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    c[i] = A::mulmod_full(a[i], b[i], k);
+  }
+}
+
+static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
+{
+  uint64_t g = (n + 255) / 256;
+  if(g > cap) g = cap;
+  if(g == 0) g = 1;
+  return (unsigned)g;
+}
+
+extern "C" int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b,
+                                       uint64_t batch, void *stream)
+{
+  if(!p || !d_c || !d_a || !d_b) return fail(NTT_ERR_ARG, "null argument");
+  if(batch == 0) return NTT_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  const uint64_t n = batch * p->N;
+  if(p->arith == NTT_ARITH_F64) {
+    hipLaunchKernelGGL((pointwise_kernel<ArithF64>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_c, d_a,
+                       d_b, n, p->cf);
+  } else {
+    hipLaunchKernelGGL((pointwise_kernel<ArithU64>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_c, d_a,
+                       d_b, n, p->cu);
+  }
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
+extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
+                                        uint64_t batch, void *stream)
+{
+  int rc = ntt_fwd_batch(p, d_a, batch, stream);
+  if(!rc) rc = ntt_fwd_batch(p, d_b, batch, stream);
+  if(!rc) rc = ntt_pointwise_mul_batch(p, d_c, d_a, d_b, batch, stream);
+  if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
+  return rc;
+}
+
+extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,
+                                void *stream)
+{
+  int rc = check_device(device);
+  if(rc) return rc;
+  if(!d_a || q == 0) return fail(NTT_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_a, n, q, seed,
+                     offset);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
+extern "C" int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, uint64_t N, uint64_t batch,
+                                 void *stream)
+{
+  int rc = check_device(device);
+  if(rc) return rc;
+  if(!d_out || !d_a) return fail(NTT_ERR_ARG, "null argument");
+  if(batch == 0) return NTT_OK;
+  HIP_TRY(hipSetDevice(device));
+  const unsigned g = batch > 8192 ? 8192u : (unsigned)batch;
+  hipLaunchKernelGGL(checksum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, d_out, d_a, N, batch);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* thin HIP wrappers                                                   */
+/* ------------------------------------------------------------------ */
+extern "C" const char *ntt_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ntt_version(void) { return "ntt_mi355x 0.1 (gfx950)"; }
+
+extern "C" int ntt_device_count(void)
+{
+  int        n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess) return fail(NTT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+#define DEV_PROLOG(device)           \
+  do {                               \
+    int rc_ = check_device(device);  \
+    if(rc_) return rc_;              \
+    HIP_TRY(hipSetDevice(device));   \
+  } while(0)
+
+extern "C" int ntt_dev_malloc(int device, void **d_ptr, size_t bytes)
+{
+  DEV_PROLOG(device);
+  if(!d_ptr) return fail(NTT_ERR_ARG, "null argument");
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if(e == hipErrorOutOfMemory) return fail(NTT_ERR_NOMEM, "hipMalloc: out of device memory");
+  HIP_TRY(e);
+  return NTT_OK;
+}
+extern "C" int ntt_dev_free(int device, void *d_ptr)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipFree(d_ptr));
+  return NTT_OK;
+}
+extern "C" int ntt_h2d(int device, void *d_dst, const void *h_src, size_t bytes)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return NTT_OK;
+}
+extern "C" int ntt_d2h(int device, void *h_dst, const void *d_src, size_t bytes)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return NTT_OK;
+}
+extern "C" int ntt_stream_create(int device, void **stream)
+{
+  DEV_PROLOG(device);
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return NTT_OK;
+}
+extern "C" int ntt_stream_destroy(int device, void *stream)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return NTT_OK;
+}
+extern "C" int ntt_stream_sync(int device, void *stream)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return NTT_OK;
+}
+extern "C" int ntt_event_create(int device, void **event)
+{
+  DEV_PROLOG(device);
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreate(&ev));
+  *event = (void *)ev;
+  return NTT_OK;
+}
+extern "C" int ntt_event_destroy(int device, void *event)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return NTT_OK;
+}
+extern "C" int ntt_event_record(int device, void *event, void *stream)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return NTT_OK;
+}
+extern "C" int ntt_event_elapsed_ms(int device, void *start, void *stop, float *ms)
+{
+  DEV_PROLOG(device);
+  HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return NTT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* multi-GPU                                                           */
+/* ------------------------------------------------------------------ */
+extern "C" int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const *d_a, const uint64_t *batch,
+                               int inverse)
+{
+  if(ndev <= 0 || !plans || !d_a || !batch) return fail(NTT_ERR_ARG, "bad argument");
+  for(int g = 0; g < ndev; g++) {
+    ntt_plan *p = plans[g];
+    if(!p) return fail(NTT_ERR_ARG, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    if(!p->own_stream) HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    int rc = run_transform(p, d_a[g], batch[g], inverse != 0, false, (void *)p->own_stream);
+    if(rc) return rc;
+  }
+  for(int g = 0; g < ndev; g++) {
+    HIP_TRY(hipSetDevice(plans[g]->device));
+    HIP_TRY(hipStreamSynchronize(plans[g]->own_stream));
+  }
+  return NTT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* parameter helpers (reference: tests/test_cases.h:113-142)           */
+/* ------------------------------------------------------------------ */
+static bool h_is_prime(uint64_t n)
+{
+  static const uint64_t wit[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  if(n < 2) return false;
+  for(uint64_t b : wit) {
+    if(n % b == 0) return n == b;
+  }
+  uint64_t d = n - 1;
+  int      r = 0;
+  while(!(d & 1)) {
+    d >>= 1;
+    r++;
+  }
+  for(uint64_t b : wit) {
+    uint64_t x = h_powmod(b, d, n);
+    if(x == 1 || x == n - 1) continue;
+    bool comp = true;
+    for(int i = 1; i < r && comp; i++) {
+      x = h_mulmod(x, x, n);
+      if(x == n - 1) comp = false;
+    }
+    if(comp) return false;
+  }
+  return true;
+}
+
+extern "C" uint64_t ntt_min_root(uint64_t q, uint64_t N)
+{
+  if(!is_pow2(N) || q < 3 || (q - 1) % (2 * N)) return 0;
+  const uint64_t cof = (q - 1) / (2 * N);
+  uint64_t       g   = 0;
+  for(uint64_t x = 2; x < q && !g; x++) {
+    const uint64_t c = h_powmod(x, cof, q);
+    if(h_powmod(c, N, q) == q - 1) g = c;
+  }
+  if(!g) return 0;
+  const uint64_t g2   = h_mulmod(g, g, q);
+  uint64_t       best = g, cur = g;
+  for(uint64_t i = 0; i < N; i++) {
+    best = cur < best ? cur : best;
+    cur  = h_mulmod(cur, g2, q);
+  }
+  return best;
+}
+
+extern "C" uint64_t ntt_find_prime(unsigned bits, uint64_t N, unsigned skip)
+{
+  if(bits < 4 || bits > 61 || !is_pow2(N)) return 0;
+  const uint64_t step = 2 * N;
+  for(uint64_t p = (((1ull << bits) - 1) / step) * step + 1; p > step; p -= step) {
+    if(h_is_prime(p)) {
+      if(!skip) return p;
+      skip--;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* reference-signature entry points (host pointers, one polynomial)    */
+/* ------------------------------------------------------------------ */
+namespace {
+
+struct CompatPlan {
+  uint64_t  N, q, key, ninv;
+  bool      inverse;
+  ntt_plan *plan;
+};
+
+std::mutex              g_mu;
+std::vector<CompatPlan> g_plans;
+uint64_t *              g_stage       = nullptr;
+size_t                  g_stage_bytes = 0;
+
+uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
+{
+  uint64_t h = 0xcbf29ce484222325ULL;
+  for(uint64_t i = 0; i < n; i++) {
+    h ^= w[i * stride];
+    h *= 0x100000001b3ULL;
+    h ^= h >> 29;
+  }
+  return h;
+}
+
+[[noreturn]] void die(const char *fn)
+{
+  fprintf(stderr, "libntt_mi355x: %s failed: %s\n", fn, g_err.c_str());
+  abort();
+}
+
+/* w: caller table; stride 1 = radix-2 table, stride 2 = radix-4 expanded table
+ * whose even slots are the radix-2 entries (pre_compute.h:85-105) */
+void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t q, const uint64_t *w,
+                uint64_t stride, bool inverse, uint64_t ninv)
+{
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int                   device = env_int("NTT_DEVICE", 0);
+  const uint64_t              key    = table_key(w, N, stride);
+  ntt_plan *                  plan   = nullptr;
+  for(const CompatPlan &c : g_plans) {
+    if(c.N == N && c.q == q && c.key == key && c.inverse == inverse && c.ninv == ninv) plan = c.plan;
+  }
+  if(!plan) {
+    std::vector<uint64_t> tab(N), none;
+    for(uint64_t k = 0; k < N; k++) tab[k] = w[k * stride];
+    int rc = inverse ? plan_build(&plan, device, N, q, 0, none, tab, NTT_ARITH_AUTO, ninv)
+                     : plan_build(&plan, device, N, q, 0, tab, none, NTT_ARITH_AUTO, 0);
+    if(rc) die(fn);
+    g_plans.push_back(CompatPlan{N, q, key, ninv, inverse, plan});
+  }
+  const uint64_t batch = a2 ? 2 : 1;
+  const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
+  if(hipSetDevice(device) != hipSuccess) {
+    g_err = "hipSetDevice";
+    die(fn);
+  }
+  if(bytes > g_stage_bytes) {
+    if(g_stage) (void)hipFree(g_stage);
+    if(hipMalloc((void **)&g_stage, bytes) != hipSuccess) {
+      g_err = "hipMalloc staging buffer";
+      die(fn);
+    }
+    g_stage_bytes = bytes;
+  }
+  bool ok = hipMemcpy(g_stage, a1, N * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if(ok && a2) ok = hipMemcpy(g_stage + N, a2, N * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if(!ok) {
+    g_err = "hipMemcpy H2D";
+    die(fn);
+  }
+  if(run_transform(plan, g_stage, batch, inverse, true, nullptr)) die(fn);
+  ok = hipMemcpy(a1, g_stage, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  if(ok && a2) ok = hipMemcpy(a2, g_stage + N, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  if(!ok) {
+    g_err = std::string("hipMemcpy D2H / kernel execution: ") + hipGetErrorString(hipGetLastError());
+    die(fn);
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+void fwd_ntt_ref_harvey_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
+{
+  (void)w_con; /* the device derives its own precomputation from w */
+  compat_run("fwd_ntt_ref_harvey_lazy", a, nullptr, N, q, w, 1, false, 0);
+}
+
+void fwd_ntt_ref_harvey_lazy_dbl(uint64_t a1[], uint64_t a2[], uint64_t N, uint64_t q, const uint64_t w[],
+                                 const uint64_t w_con[])
+{
+  (void)w_con;
+  compat_run("fwd_ntt_ref_harvey_lazy_dbl", a1, a2, N, q, w, 1, false, 0);
+}
+
+void inv_ntt_ref_harvey(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, uint64_t word_size,
+                        const uint64_t w[], const uint64_t w_con[])
+{
+  (void)w_con;
+  (void)word_size;
+  compat_run("inv_ntt_ref_harvey", a, nullptr, N, q, w, 1, true, (uint64_t)n_inv.op);
+}
+
+void fwd_ntt_radix4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
+{
+  (void)w_con;
+  compat_run("fwd_ntt_radix4_lazy", a, nullptr, N, q, w, 2, false, 0);
+}
+
+void inv_ntt_radix4(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, const uint64_t w[],
+                    const uint64_t w_con[])
+{
+  (void)w_con;
+  compat_run("inv_ntt_radix4", a, nullptr, N, q, w, 2, true, (uint64_t)n_inv.op);
+}
+
+void fwd_ntt_radix4x4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
+{
+  (void)w_con;
+  compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, 2, false, 0);
+}
+
+void fwd_ntt_seal_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
+{
+  (void)w_con;
+  compat_run("fwd_ntt_seal_lazy", a, nullptr, N, q, w, 1, false, 0);
+}
+
+void inv_ntt_seal(uint64_t a[], uint64_t N, uint64_t q, uint64_t n_inv, uint64_t n_inv_con, const uint64_t w[],
+                  const uint64_t w_con[])
+{
+  (void)w_con;
+  (void)n_inv_con;
+  compat_run("inv_ntt_seal", a, nullptr, N, q, w, 1, true, n_inv);
+}
+
+} /* extern "C" */

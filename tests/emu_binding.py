@@ -1,0 +1,40 @@
+"""ctypes binding of tests/emu/libntt_emu.so: the kernel templates of csrc/
+compiled for the CPU (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EDIR = os.path.join(ROOT, "tests", "emu")
+U64P = C.POINTER(C.c_uint64)
+
+
+class Emu:
+    def __init__(self):
+        path = os.path.join(EDIR, "libntt_emu.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", EDIR])
+        L = self.lib = C.CDLL(path)
+        L.emu_transform.argtypes = [U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64] + [C.c_int] * 5
+        L.emu_plan_info.argtypes = [C.c_int, U64P]
+        L.emu_pointwise.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
+
+    def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        rc = self.lib.emu_transform(a.ctypes.data_as(U64P), a.size >> m, m, q, root, arith, int(inverse),
+                                    int(generic), int(wide), ksh)
+        return rc, a
+
+    def plan_info(self, logn):
+        v = np.zeros(10, dtype=np.uint64)
+        assert self.lib.emu_plan_info(logn, v.ctypes.data_as(U64P)) == 0
+        keys = ("NG", "R0", "RL", "T", "ROW", "LDS_ELEMS", "wave_local", "fmask", "imask", "conflict_free")
+        return dict(zip(keys, [int(x) for x in v]))
+
+    def pointwise(self, a, b, q, arith):
+        c = np.zeros_like(a)
+        rc = self.lib.emu_pointwise(c.ctypes.data_as(U64P), a.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
+                                    a.size, q, arith)
+        return rc, c

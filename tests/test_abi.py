@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads, exports every symbol the headers declare, and
+fails loudly (no CPU fallback) when no HIP device is present.  No compute."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for hdr in ("ntt_mi355x.h", "ntt_reference.h", "ntt_radix4.h", "ntt_radix4x4.h", "ntt_seal.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"#\s*define[^\n]*", "", text)
+        names |= set(re.findall(r"NTT_(?:API|EXPORT)\s+[\w\s\*]*?\b(\w+)\s*\(", text))
+    return names
+
+
+def test_exports_match_headers(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 38
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported, declared - exported
+    assert set(lib.EXPORTED_SYMBOLS) == declared
+    # nothing of the oracle may be linked into the product
+    assert not any(s.startswith("orc_") for s in exported)
+    needed = subprocess.check_output(["readelf", "-d", lib.LIB_PATH], text=True)
+    assert "libntt_oracle" not in needed and "libamdhip64" in needed
+
+
+def test_mul_op_abi():
+    """mul_op_t keeps the reference ABI: two __uint128_t, 32 bytes, 16-aligned"""
+    src = '#include "fast_mul_operators.h"\n_Static_assert(sizeof(mul_op_t)==32 && _Alignof(mul_op_t)==16,"abi");int main(void){return 0;}\n'
+    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "include", "internal"), "-x", "c", "-"], input=src, text=True, check=True)
+
+
+def test_headers_compile_as_c_and_cxx():
+    for comp, std in (("gcc", "-std=gnu11"), ("g++", "-std=c++17")):
+        src = "\n".join('#include "%s"' % h for h in ("ntt_mi355x.h", "ntt_reference.h", "ntt_radix4.h",
+                                                      "ntt_radix4x4.h", "ntt_seal.h", "pre_compute.h")) + "\nint main(void){return 0;}\n"
+        subprocess.run([comp, std, "-Wall", "-Wextra", "-Werror", "-Wno-unused-function", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "internal"),
+                        "-x", "c" if comp == "gcc" else "c++", "-"], input=src, text=True, check=True)
+
+
+def test_host_table_builders_match_oracle(oracle, kat, tmp_path):
+    """include/internal/pre_compute.h (the builders the reference's test_cases.h
+    calls) produce the golden tables"""
+    prog = tmp_path / "t.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "pre_compute.h"
+static unsigned long long fnv(const uint64_t *a, size_t n){unsigned long long h=0xcbf29ce484222325ULL;
+ for(size_t i=0;i<n;i++)for(int b=0;b<8;b++){h^=(a[i]>>(8*b))&0xff;h*=0x100000001b3ULL;}return h;}
+int main(int argc,char**argv){uint64_t m=strtoull(argv[1],0,0),q=strtoull(argv[2],0,0),w=strtoull(argv[3],0,0),n=1ULL<<m;
+ uint64_t *t=malloc(8*n),*c=malloc(8*n),*e=malloc(16*n),*ec=malloc(16*n);
+ calc_w(t,w,n,q,m);calc_w_con(c,t,n,q,WORD_SIZE);expand_w(e,t,n,q);calc_w_con(ec,e,2*n,q,WORD_SIZE);
+ printf("%016llx %016llx %016llx %016llx\n",fnv(t,n),fnv(c,n),fnv(e,2*n),fnv(ec,2*n));return 0;}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "include", "internal"), "-o", str(exe), str(prog)])
+    for i in (0, 4, 12, 13, 18):
+        c = kat["cases"][i]
+        out = subprocess.check_output([str(exe), str(c["m"]), str(c["q"]), str(c["w"])], text=True).split()
+        t = c["table_fnv"]
+        assert out == [t["w"], t["wcon"], t["e"], t["econ"]]
+
+
+def test_no_device_fails_loudly(lib):
+    """On a machine without a GPU every compute entry point must refuse, never
+    silently compute on the CPU.  (On the GPU box this test is vacuous.)"""
+    try:
+        n = lib.device_count()
+    except lib.NttError:
+        n = 0
+    if n > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(lib.NttError) as e:
+        lib.Plan(256, 0x1e01, 62)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_parameter_helpers(lib, oracle, kat):
+    for c in kat["cases"][:8]:
+        assert lib.min_root(c["q"], 1 << c["m"]) == c["w"]
+    assert lib.find_prime(50, 1 << 14) == oracle.find_prime(50, 1 << 14)
+    assert lib.min_root(7, 16) == 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests"), reason="reference tree only exists in the build container")
+def test_reference_drivers_compile_unchanged_against_our_headers(lib):
+    """SURVEY 8b 'drop in unchanged': the reference's own tests/main.c,
+    test_correctness.c and bench.c build against include/ + libntt_mi355x.so."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "dropin"], stdout=subprocess.DEVNULL)
+    for exe in ("ntt-variants-dropin", "ntt-variants-bench-dropin"):
+        assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", exe))

@@ -1,0 +1,270 @@
+"""GPU (-m gpu): the HIP library, called through its C ABI, is bit-exact against
+the oracle and the golden vectors on every reference parameter set; the
+reference-signature entry points behave like the reference's; full-size runs
+are checked through round trips, linearity and per-polynomial checksums."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNI_SEED = 0x5EED5EED
+
+
+def _arith_modes(lib, q):
+    return [lib.ARITH_U64] + ([lib.ARITH_F64] if q <= (1 << 51) + (1 << 41) else [])
+
+
+def _inputs(oracle, n, q, batch, seed):
+    a = oracle.fill_uniform(batch * n, q, seed)
+    a[:4] = q - 1
+    a[4:8] = 0
+    a[-1] = q - 1
+    return a
+
+
+def test_device_present(lib):
+    assert lib.device_count() >= 1
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_reference_cases_batched(lib, oracle, kat, i):
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    cx = oracle.ctx(n, q, w)
+    batch = 3
+    a = _inputs(oracle, n, q, batch, 4242 + i)
+    a[:n] = oracle.fill_uniform(n, q, UNI_SEED, i << 32)     # polynomial 0 = the golden KAT input
+    expect = cx.fwd(a)
+    assert oracle.fnv(expect[:n]) == c["uni_out_fnv"]
+    for arith in _arith_modes(lib, q):
+        plan = lib.Plan(n, q, w, arith=arith)
+        got = plan.fwd_host(a)
+        assert np.array_equal(got, expect), (i, arith, "fwd")
+        assert oracle.fnv(got[:n]) == c["uni_out_fnv"]       # golden digest straight from the GPU
+        back = plan.inv_host(got)
+        assert np.array_equal(back, a), (i, arith, "inv")
+        plan.set_generic(True)                               # strided multi-pass self-check path
+        assert np.array_equal(plan.fwd_host(a), expect), (i, arith, "generic fwd")
+        assert np.array_equal(plan.inv_host(expect), a), (i, arith, "generic inv")
+        plan.destroy()
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_edge_inputs_match_golden(lib, oracle, kat, i):
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    rows = [np.zeros(n, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64)]
+    for pos in (0, 1, n - 1):
+        e = np.zeros(n, dtype=np.uint64)
+        e[pos] = 1
+        rows.append(e)
+    names = ["zero", "qm1", "delta0", "delta1", "deltaN1"]
+    plan = lib.Plan(n, q, w)
+    got = plan.fwd_host(np.concatenate(rows))
+    for k, name in enumerate(names):
+        assert oracle.fnv(got[k * n:(k + 1) * n]) == c["edge_out_fnv"][name], name
+    plan.destroy()
+
+
+def test_case0_full_vectors(lib, case0_vectors):
+    v = case0_vectors
+    plan = lib.Plan(1 << v["m"], v["q"], v["w"])
+    x = np.array(v["rand_in"], dtype=np.uint64)
+    y = np.array(v["rand_out"], dtype=np.uint64)
+    assert np.array_equal(plan.fwd_host(x), y)
+    assert np.array_equal(plan.inv_host(y), x)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 5, 9, 12, 13, 14, 17, 18])
+def test_reference_signatures(lib, oracle, kat, i):
+    """mirror of reference tests/test_correctness.c:23-111 through the exported
+    fwd_ntt_*/inv_ntt_* symbols (host pointers, reference table layouts)"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    cx = oracle.ctx(n, q, w)
+    tw, twc, twi, twic = (cx.table(k) for k in ("w", "wcon", "winv", "winv_con"))
+    te, tec, tei, teic = (cx.table(k) for k in ("e", "econ", "einv", "einv_con"))
+    a_orig = oracle.fill_uniform(n, q, 99 + i)
+    a_ntt = cx.fwd(a_orig)
+    a = a_orig.copy()
+    lib.fwd_ntt_ref_harvey(a, n, q, tw, twc)
+    assert np.array_equal(a, a_ntt)
+    lib.inv_ntt_ref_harvey(a, n, q, c["n_inv"], c["n_inv_con"], 64, twi, twic)
+    assert np.array_equal(a, a_orig)
+    a, b = a_orig.copy(), a_orig.copy()
+    lib.fwd_ntt_ref_harvey_dbl(a, b, n, q, tw, twc)
+    assert np.array_equal(a, a_ntt) and np.array_equal(b, a_ntt)
+    a = a_orig.copy()
+    lib.fwd_ntt_seal(a, n, q, tw, twc)
+    assert np.array_equal(a, a_ntt)
+    lib.inv_ntt_seal(a, n, q, c["n_inv"], c["n_inv_con"], twi, twic)
+    assert np.array_equal(a, a_orig)
+    a = a_orig.copy()
+    lib.fwd_ntt_radix4(a, n, q, te, tec)
+    assert np.array_equal(a, a_ntt)
+    lib.inv_ntt_radix4(a, n, q, c["n_inv"], c["n_inv_con"], tei, teic)
+    assert np.array_equal(a, a_orig)
+    a = a_orig.copy()
+    lib.fwd_ntt_radix4x4(a, n, q, te, tec)
+    assert np.array_equal(a, a_ntt)
+    # lazy-range inputs, as the reference's bench feeds them back (tests/bench.c:123-137)
+    lazy = a_orig + np.uint64(q) * (oracle.fill_uniform(n, 8, 3) % np.uint64(8))
+    a = lazy.copy()
+    lib.fwd_ntt_radix4(a, n, q, te, tec)
+    assert np.array_equal(a, a_ntt)
+    a = (a_ntt + np.uint64(q) * (oracle.fill_uniform(n, 8, 4) % np.uint64(8))).astype(np.uint64)
+    lib.inv_ntt_radix4(a, n, q, c["n_inv"], c["n_inv_con"], tei, teic)
+    assert np.array_equal(a, a_orig)
+
+
+@pytest.mark.parametrize("bits,m", [(50, 14), (50, 12), (52, 16), (49, 13), (40, 11), (31, 10), (60, 12), (45, 6), (20, 3), (33, 7)])
+def test_generated_parameters(lib, oracle, bits, m):
+    n = 1 << m
+    q = lib.find_prime(bits, n)
+    w = lib.min_root(q, n)
+    assert q == oracle.find_prime(bits, n) and w == oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    batch = 5   # ragged: not a multiple of the blocks one workgroup holds
+    a = _inputs(oracle, n, q, batch, bits * 131 + m)
+    expect = cx.fwd(a)
+    for arith in _arith_modes(lib, q):
+        plan = lib.Plan(n, q, w, arith=arith)
+        assert np.array_equal(plan.fwd_host(a), expect)
+        assert np.array_equal(plan.inv_host(expect), a)
+        plan.destroy()
+
+
+def test_empty_batch_and_bad_arguments(lib):
+    plan = lib.Plan(256, 0x1e01, 62)
+    plan.fwd(None, 0)
+    plan.inv(None, 0)
+    with pytest.raises(lib.NttError):
+        lib.Plan(256, 0x1e01, 63)             # not a primitive 2N-th root
+    with pytest.raises(lib.NttError):
+        lib.Plan(300, 0x1e01, 62)             # N not a power of two
+    with pytest.raises(lib.NttError):
+        lib.Plan(1 << 10, (1 << 55) - 54783, 3, arith=lib.ARITH_F64)
+
+
+@pytest.mark.parametrize("q,m", [(0x1e01, 6), (0x10001, 8), (0x7fffffffe0001, 7), (0x80000001c0001, 6)])
+def test_negacyclic_product_vs_schoolbook(lib, oracle, q, m):
+    n = 1 << m
+    w = lib.min_root(q, n)
+    batch = 4
+    a, b = _inputs(oracle, n, q, batch, 21), _inputs(oracle, n, q, batch, 22)
+    for arith in _arith_modes(lib, q):
+        plan = lib.Plan(n, q, w, arith=arith)
+        da, db = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b)
+        plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, batch)
+        got = da.download()
+        for p in range(batch):
+            s = slice(p * n, (p + 1) * n)
+            assert np.array_equal(got[s], oracle.schoolbook(a[s].copy(), b[s].copy(), n, q))
+        plan.destroy()
+
+
+def test_pointwise_large_moduli(lib, oracle):
+    for q, n in ((0x7fffffffe0001, 1 << 14), ((1 << 60) - 93 * (1 << 15) + 1, 1 << 10)):
+        q = q if q % (2 * n) == 1 and oracle.lib.orc_is_prime(q) else lib.find_prime(60, n)
+        w = lib.min_root(q, n)
+        plan = lib.Plan(n, q, w)
+        a, b = _inputs(oracle, n, q, 2, 31), _inputs(oracle, n, q, 2, 32)
+        da, db = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b)
+        plan.pointwise_mul(da.ptr, da.ptr, db.ptr, 2)
+        assert np.array_equal(da.download(), oracle.pointwise(a, b, q))
+        plan.destroy()
+
+
+def _full_size_roundtrip(lib, oracle, m, q, w, batch, sample):
+    """device-generated inputs; fwd; sampled polynomials vs oracle; inv; checksum
+    of every polynomial must equal the checksum of its input"""
+    n = 1 << m
+    plan = lib.Plan(n, q, w)
+    buf = lib.DeviceBuffer(batch * n)
+    cs0, cs1 = lib.DeviceBuffer(batch), lib.DeviceBuffer(batch)
+    lib.fill_uniform(buf.ptr, batch * n, q, UNI_SEED, 0)
+    lib.poly_checksum(cs0.ptr, buf.ptr, n, batch)
+    plan.fwd(buf.ptr, batch)
+    cx = oracle.ctx(n, q, w)
+    for p in sample:
+        got = buf.download(n, p * n)
+        inp = oracle.fill_uniform(n, q, UNI_SEED, p * n)
+        assert np.array_equal(got, cx.fwd(inp)), p
+    plan.inv(buf.ptr, batch)
+    lib.poly_checksum(cs1.ptr, buf.ptr, n, batch)
+    a0, a1 = cs0.download(), cs1.download()
+    assert np.array_equal(a0, a1)
+    p = sample[-1]
+    assert oracle.checksum(oracle.fill_uniform(n, q, UNI_SEED, p * n)) == int(a0[p])
+    for b in (buf, cs0, cs1):
+        b.free()
+    plan.destroy()
+
+
+def test_full_size_config2_n4096(lib, oracle):
+    """BASELINE config 2: N=4096, 50-bit q, batch=65536"""
+    q = lib.find_prime(50, 4096)
+    _full_size_roundtrip(lib, oracle, 12, q, lib.min_root(q, 4096), 65536, [0, 1, 4095, 32768, 65535])
+
+
+def test_full_size_config3_n65536(lib, oracle, kat):
+    """BASELINE config 3: N=65536, 51-bit q (reference case 17), batch=8192, fwd+inv round trip"""
+    c = kat["cases"][17]
+    _full_size_roundtrip(lib, oracle, 16, c["q"], c["w"], 8192, [0, 1, 4097, 8191])
+
+
+def test_full_size_config4_share_n16384(lib, oracle, kat):
+    """BASELINE config 4, one GPU's share: N=16384, 51-bit q (reference case 12), batch=131072"""
+    c = kat["cases"][12]
+    _full_size_roundtrip(lib, oracle, 14, c["q"], c["w"], 131072, [0, 77, 65536, 131071])
+
+
+def test_linearity_full_batch(lib, oracle, kat):
+    """fwd(a+b) == fwd(a)+fwd(b) mod q on a 1 GiB batch (checksummed per polynomial)"""
+    c = kat["cases"][13]
+    n, q, w, batch = 1 << 14, c["q"], c["w"], 4096
+    plan = lib.Plan(n, q, w)
+    a = oracle.fill_uniform(batch * n, q, 5)
+    b = oracle.fill_uniform(batch * n, q, 6)
+    s = (a + b) % np.uint64(q)
+    fa, fb, fs = plan.fwd_host(a), plan.fwd_host(b), plan.fwd_host(s)
+    assert np.array_equal((fa + fb) % np.uint64(q), fs)
+    plan.destroy()
+
+
+def test_multi_device_call(lib, oracle, kat):
+    """ntt_batch_multi with however many devices are visible (1 on the test box)"""
+    c = kat["cases"][9]
+    n, q, w = 1 << 14, c["q"], c["w"]
+    ndev = lib.device_count()
+    plans = [lib.Plan(n, q, w, device=d) for d in range(ndev)]
+    batches = [7 + d for d in range(ndev)]
+    host = [oracle.fill_uniform(bt * n, q, 50 + d) for d, bt in enumerate(batches)]
+    bufs = [lib.DeviceBuffer(h.size, device=d).upload(h) for d, h in enumerate(host)]
+    lib.batch_multi(plans, [b.ptr for b in bufs], batches)
+    cx = oracle.ctx(n, q, w)
+    for d in range(ndev):
+        assert np.array_equal(bufs[d].download(), cx.fwd(host[d]))
+    lib.batch_multi(plans, [b.ptr for b in bufs], batches, inverse=True)
+    for d in range(ndev):
+        assert np.array_equal(bufs[d].download(), host[d])
+
+
+def test_reference_test_driver_drop_in():
+    """the reference's own tests/main.c + tests/test_correctness.c, compiled
+    unchanged against include/ and linked to libntt_mi355x.so (oracle/Makefile
+    `dropin`), run here on the GPU: 19 cases, zero 'Bad results'"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ntt-variants-dropin")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binary not built (needs /root/reference at build time)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("Test ") == 19
+    assert "Bad results" not in out.stdout
+    assert out.stdout.count("Running ") >= 19 * 9

@@ -1,0 +1,100 @@
+"""CPU: the travelling oracle reproduces every golden vector captured from the
+compiled reference (oracle/gen_golden.py), without the reference."""
+import numpy as np
+import pytest
+
+UNI_SEED = 0x5EED5EED
+
+
+def _ctx(oracle, c):
+    return oracle.ctx(1 << c["m"], c["q"], c["w"])
+
+
+def test_nineteen_cases_present(kat):
+    assert len(kat["cases"]) == 19
+    assert [c["m"] for c in kat["cases"]] == [8, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14, 14, 14, 14, 15, 15, 16, 16, 17]
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_tables_and_parameters(kat, oracle, i):
+    c = kat["cases"][i]
+    n, q = 1 << c["m"], c["q"]
+    cx = _ctx(oracle, c)
+    assert cx.c.root_inv == c["w_inv"] and cx.c.ninv == c["n_inv"] and cx.c.ninv_con == c["n_inv_con"]
+    assert oracle.min_root(q, n) == c["w"]  # "minimum root" rule, tests/test_cases.h:113-142
+    for name, digest in c["table_fnv"].items():
+        assert oracle.fnv(cx.table(name)) == digest, name
+    assert int(cx.table("w")[1]) == c["w_powers_1"] and int(cx.table("wcon")[1]) == c["w_powers_con_1"]
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_uniform_kat(kat, oracle, i):
+    c = kat["cases"][i]
+    n, q = 1 << c["m"], c["q"]
+    cx = _ctx(oracle, c)
+    u = oracle.fill_uniform(n, q, UNI_SEED, i << 32)
+    assert oracle.fnv(u) == c["uni_in_fnv"]
+    out = cx.fwd(u)
+    assert [int(x) for x in out[:3]] == c["uni_out_head"]
+    assert oracle.fnv(out) == c["uni_out_fnv"]
+    assert np.array_equal(cx.fwd_r4(u), out)
+    assert np.array_equal(cx.inv(out), u) and np.array_equal(cx.inv_r4(out), u)
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_edge_kats(kat, oracle, i):
+    c = kat["cases"][i]
+    n, q = 1 << c["m"], c["q"]
+    cx = _ctx(oracle, c)
+    edges = {"zero": np.zeros(n, dtype=np.uint64), "qm1": np.full(n, q - 1, dtype=np.uint64)}
+    for name, pos in (("delta0", 0), ("delta1", 1), ("deltaN1", n - 1)):
+        e = np.zeros(n, dtype=np.uint64)
+        e[pos] = 1
+        edges[name] = e
+    for name, e in edges.items():
+        assert oracle.fnv(cx.fwd(e)) == c["edge_out_fnv"][name], name
+
+
+def test_case0_full_vectors(case0_vectors, oracle):
+    v = case0_vectors
+    cx = oracle.ctx(1 << v["m"], v["q"], v["w"])
+    for a, b in (("rand_in", "rand_out"), ("uni_in", "uni_out")):
+        x = np.array(v[a], dtype=np.uint64)
+        y = np.array(v[b], dtype=np.uint64)
+        assert np.array_equal(cx.fwd(x), y) and np.array_equal(cx.fwd_r4(x), y)
+        assert np.array_equal(cx.inv(y), x) and np.array_equal(cx.inv_r4(y), x)
+
+
+def test_reference_rand_stream_digests(kat, case0_vectors, oracle):
+    """inputs of the reference's own run (glibc rand()%q): the N=256 case is stored
+    in full, so its digests must match App. B"""
+    c = kat["cases"][0]
+    x = np.array(case0_vectors["rand_in"], dtype=np.uint64)
+    assert oracle.fnv(x) == c["in_fnv"] == "e8a3b71c74d71cfb"
+    assert [int(v) for v in x[:3]] == c["in_head"] == [7121, 783, 6956]
+    y = oracle.ctx(256, c["q"], c["w"]).fwd(x)
+    assert oracle.fnv(y) == c["out_fnv"] == "8ae456206dc728b0"
+
+
+@pytest.mark.parametrize("m,q,w", [(4, 0x10001, None), (6, 0x1e01, None), (8, 0x1e01, 62), (10, 0x10001, 33)])
+def test_definition(oracle, m, q, w):
+    """out[bitrev(i)] = sum_j a_j w^{(2i+1)j}, O(N^2) evaluation"""
+    n = 1 << m
+    w = w or oracle.min_root(q, n)
+    a = oracle.fill_uniform(n, q, 7, 0)
+    assert np.array_equal(oracle.ctx(n, q, w).fwd(a), oracle.fwd_naive(a, n, q, w))
+
+
+def test_negacyclic_product(oracle):
+    n, q = 64, 0x1e01
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    a, b = oracle.fill_uniform(n, q, 1), oracle.fill_uniform(n, q, 2)
+    c = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
+    assert np.array_equal(c, oracle.schoolbook(a, b, n, q))
+
+
+def test_prime_search(oracle):
+    p = oracle.find_prime(50, 1 << 14)
+    assert p < 2**50 and p % (1 << 15) == 1 and oracle.lib.orc_is_prime(p)
+    assert oracle.min_root(p, 1 << 14) != 0

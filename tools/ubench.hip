@@ -1,0 +1,262 @@
+/*
+ * ubench.hip -- gfx950 micro-benchmarks that decide the NTT arithmetic:
+ *   1. issue cost (cycles per wave64 instruction per SIMD) of the integer-multiply and FP64
+ *      instructions the two arithmetic policies are made of;
+ *   2. register-resident butterfly throughput of ArithU64 and ArithF64 as compiled;
+ *   3. plain HBM copy bandwidth (the practical ceiling for the roofline fraction).
+ * Build: make ubench   Run (GPU box): build/ubench
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ntt_core.h"
+#include "ntt_tables.h"
+
+using namespace ntt;
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e = (x);                                                         \
+    if(e != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                    \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while(0)
+
+constexpr int ITERS = 4096;
+constexpr int CHAINS = 8;
+
+#define OP_KERNEL(NAME, DECL, INIT, ASM, SINK)                                   \
+  __global__ void __launch_bounds__(256) k_##NAME(uint64_t *out, uint32_t seed) \
+  {                                                                             \
+    DECL;                                                                       \
+    INIT;                                                                       \
+    for(int it = 0; it < ITERS; it++) {                                         \
+      _Pragma("unroll") for(int c = 0; c < CHAINS; c++) { ASM; }                \
+    }                                                                           \
+    uint64_t s = 0;                                                             \
+    _Pragma("unroll") for(int c = 0; c < CHAINS; c++) { SINK; }                 \
+    if(s == 0x123456789abcdefULL) out[threadIdx.x] = s;                         \
+  }
+
+/* 32-bit integer ops */
+#define DECL_U32 uint32_t a[CHAINS], b = seed | 1u, d = seed * 3u + 7u
+#define INIT_U32 _Pragma("unroll") for(int c = 0; c < CHAINS; c++) a[c] = seed + c * 977u + threadIdx.x
+#define SINK_U32 s += a[c]
+OP_KERNEL(mul_lo_u32, DECL_U32, INIT_U32, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_U32)
+OP_KERNEL(mul_hi_u32, DECL_U32, INIT_U32, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_U32)
+OP_KERNEL(mul_u32_u24, DECL_U32, INIT_U32, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_U32)
+OP_KERNEL(mul_hi_u32_u24, DECL_U32, INIT_U32, asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_U32)
+OP_KERNEL(mad_u32_u24, DECL_U32, INIT_U32, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b), "v"(d)), SINK_U32)
+OP_KERNEL(add_u32, DECL_U32, INIT_U32, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_U32)
+OP_KERNEL(mov_dpp, DECL_U32, INIT_U32, asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[c])), SINK_U32)
+OP_KERNEL(cndmask, DECL_U32, INIT_U32, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b)), SINK_U32)
+
+/* 64-bit integer ops */
+#define DECL_U64 uint64_t a[CHAINS]; uint32_t b = seed | 1u, d = seed * 3u + 7u; uint64_t e = seed * 0x9e3779b97f4a7c15ULL
+#define INIT_U64 _Pragma("unroll") for(int c = 0; c < CHAINS; c++) a[c] = (uint64_t)seed * 0x12345 + c * 977u + threadIdx.x
+#define SINK_U64 s += a[c]
+OP_KERNEL(mad_u64_u32, DECL_U64, INIT_U64, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[c]) : "v"(b), "v"(d) : "vcc"), SINK_U64)
+OP_KERNEL(lshl_add_u64, DECL_U64, INIT_U64, asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[c]) : "v"(e)), SINK_U64)
+OP_KERNEL(cmp_lt_u64, DECL_U64, INIT_U64, asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(a[c]), "v"(e) : "vcc"), SINK_U64)
+
+/* FP64 ops */
+#define DECL_F64 double a[CHAINS]; double b = 1.0 + seed * 1e-9, d = 0.5 + seed * 1e-10
+#define INIT_F64 _Pragma("unroll") for(int c = 0; c < CHAINS; c++) a[c] = 1.0 + c * 0.001 + threadIdx.x * 1e-6
+#define SINK_F64 s += (uint64_t)a[c]
+OP_KERNEL(fma_f64, DECL_F64, INIT_F64, asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b), "v"(d)), SINK_F64)
+OP_KERNEL(mul_f64, DECL_F64, INIT_F64, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_F64)
+OP_KERNEL(add_f64, DECL_F64, INIT_F64, asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[c]) : "v"(d)), SINK_F64)
+OP_KERNEL(rndne_f64, DECL_F64, INIT_F64, asm volatile("v_rndne_f64 %0, %0" : "+v"(a[c])), SINK_F64)
+OP_KERNEL(floor_f64, DECL_F64, INIT_F64, asm volatile("v_floor_f64 %0, %0" : "+v"(a[c])), SINK_F64)
+OP_KERNEL(min_f64, DECL_F64, INIT_F64, asm volatile("v_min_f64 %0, %0, %1" : "+v"(a[c]) : "v"(b)), SINK_F64)
+OP_KERNEL(cmp_gt_f64, DECL_F64, INIT_F64, asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(a[c]), "v"(b) : "vcc"), SINK_F64)
+OP_KERNEL(fma_f32, DECL_U32, INIT_U32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b), "v"(d)), SINK_U32)
+OP_KERNEL(pk_fma_f32, DECL_U64, INIT_U64, asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[c]) : "v"(e)), SINK_U64)
+
+/* conversion ops: dst and src differ in width, chain through a dummy */
+__global__ void __launch_bounds__(256) k_cvt_f64_u32(uint64_t *out, uint32_t seed)
+{
+  uint32_t a[CHAINS];
+  double   r[CHAINS];
+  for(int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x;
+  for(int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for(int c = 0; c < CHAINS; c++) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(r[c]) : "v"(a[c]));
+  }
+  uint64_t s = 0;
+  for(int c = 0; c < CHAINS; c++) s += (uint64_t)r[c];
+  if(s == 0x123456789abcdefULL) out[threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_cvt_u32_f64(uint64_t *out, uint32_t seed)
+{
+  double   a[CHAINS];
+  uint32_t r[CHAINS];
+  for(int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x;
+  for(int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for(int c = 0; c < CHAINS; c++) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(r[c]) : "v"(a[c]));
+  }
+  uint64_t s = 0;
+  for(int c = 0; c < CHAINS; c++) s += r[c];
+  if(s == 0x123456789abcdefULL) out[threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_bpermute(uint64_t *out, uint32_t seed)
+{
+  uint32_t a[CHAINS];
+  for(int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x;
+  const uint32_t addr = ((threadIdx.x ^ 1) & 63) * 4;
+  for(int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for(int c = 0; c < CHAINS; c++) a[c] = __builtin_amdgcn_ds_bpermute(addr, a[c]);
+  }
+  uint64_t s = 0;
+  for(int c = 0; c < CHAINS; c++) s += a[c];
+  if(s == 0x123456789abcdefULL) out[threadIdx.x] = s;
+}
+
+/* register-resident butterflies: 16 values/thread, radix-16 tile repeated */
+template <class A, uint32_t MASK> __global__ void __launch_bounds__(256) k_bfly(uint64_t *out, typename A::consts c, typename A::tw w0, int reps)
+{
+  typename A::val x[16];
+  typename A::tw  w[4];
+  for(int i = 0; i < 16; i++) x[i] = A::template load<false>((uint64_t)(threadIdx.x * 16 + i + 1), false, c);
+  for(int i = 0; i < 4; i++) {
+    w[i] = w0;
+  }
+  for(int r = 0; r < reps; r++) {
+    static_for<0, 4>([&](auto jj) {
+      constexpr int  J   = decltype(jj)::value;
+      constexpr int  AB  = 3 - J;
+      constexpr bool RED = (MASK >> J) & 1u;
+      static_for<0, 16>([&](auto ee) {
+        constexpr int E0 = decltype(ee)::value;
+        if constexpr(((E0 >> AB) & 1) == 0) A::template fwd_bfly<RED>(x[E0], x[E0 | (1 << AB)], w[J], c);
+      });
+    });
+  }
+  uint64_t s = 0;
+  for(int i = 0; i < 16; i++) s += A::store_fwd(x[i], c);
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_copy(uint4 *dst, const uint4 *src, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+static double clock_ghz = 2.4;
+
+template <class K> static void run_op(const char *name, K kernel, uint64_t *d_out, int instr_per_iter = 1)
+{
+  const int  blocks = 256 * 4; /* 4 blocks of 4 waves per CU -> 4 waves per SIMD */
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, 12345u);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, 12345u);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  /* per SIMD: 4 waves * ITERS * CHAINS instructions */
+  const double instr_per_simd = 4.0 * ITERS * CHAINS * instr_per_iter;
+  const double cyc            = ms * 1e-3 * clock_ghz * 1e9 / instr_per_simd;
+  printf("%-16s %8.3f ms  %6.2f cycles/wave-instr/SIMD (at %.2f GHz)\n", name, ms, cyc, clock_ghz);
+}
+
+int main()
+{
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  clock_ghz = prop.clockRate * 1e-6;
+  printf("device %s, %d CUs, clock %.2f GHz, wave %d\n", prop.name, prop.multiProcessorCount, clock_ghz, prop.warpSize);
+  uint64_t *d_out;
+  CK(hipMalloc(&d_out, 1 << 22));
+#define RUN(N) run_op(#N, k_##N, d_out)
+  RUN(add_u32); RUN(mul_lo_u32); RUN(mul_hi_u32); RUN(mul_u32_u24); RUN(mul_hi_u32_u24); RUN(mad_u32_u24);
+  RUN(mad_u64_u32); RUN(lshl_add_u64); RUN(cmp_lt_u64); RUN(cndmask); RUN(mov_dpp);
+  RUN(bpermute);
+  RUN(fma_f32); RUN(pk_fma_f32); RUN(fma_f64); RUN(mul_f64); RUN(add_f64); RUN(rndne_f64); RUN(floor_f64); RUN(min_f64);
+  RUN(cmp_gt_f64); RUN(cvt_f64_u32); RUN(cvt_u32_f64);
+
+  /* butterfly throughput */
+  {
+    const uint64_t q = 0x7fffffffe0001ULL;
+    std::vector<uint64_t> wi(2, 1);
+    auto cu = h_consts_u64(q, 1 << 14, wi);
+    auto cf = h_consts_f64(q, 1 << 14, wi);
+    const int reps = 256, blocks = 256 * 8;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto report = [&](const char *name, float ms) {
+      const double bf = (double)blocks * 256 * 32.0 * reps;
+      printf("%-28s %8.3f ms  %8.2f Gbutterfly/s  -> %6.2f M NTT/s at N=2^14 (VALU-only bound)\n", name, ms,
+             bf / ms * 1e-6, bf / ms * 1e-6 * 1e3 / 114688.0);
+    };
+    float ms;
+    for(int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((k_bfly<ArithU64, 0>), dim3(blocks), dim3(256), 0, 0, d_out, cu, h_tw_u64(123456789012345ULL, q), reps);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    report("bfly U64 (Harvey/Shoup)", ms);
+    for(int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((k_bfly<ArithF64, 0xF>), dim3(blocks), dim3(256), 0, 0, d_out, cf, h_tw_f64(123456789012345ULL, q), reps);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    report("bfly F64 reduce every stage", ms);
+    for(int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((k_bfly<ArithF64, 0x5>), dim3(blocks), dim3(256), 0, 0, d_out, cf, h_tw_f64(123456789012345ULL, q), reps);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    report("bfly F64 reduce every 2nd", ms);
+    for(int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((k_bfly<ArithF64, 0x0>), dim3(blocks), dim3(256), 0, 0, d_out, cf, h_tw_f64(123456789012345ULL, q), reps);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    report("bfly F64 no reduction", ms);
+  }
+  /* HBM copy */
+  {
+    const size_t bytes = (size_t)4 << 30;
+    uint4 *      src, *dst;
+    CK(hipMalloc(&src, bytes));
+    CK(hipMalloc(&dst, bytes));
+    CK(hipMemset(src, 1, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for(int blocks : {2048, 8192, 65536}) {
+      float best = 1e9;
+      for(int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, dst, src, bytes / 16);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      printf("copy 4 GiB, %6d blocks: %.3f ms  %.2f TB/s (read+write)\n", blocks, best, 2.0 * bytes / best * 1e-9);
+    }
+  }
+  return 0;
+}
