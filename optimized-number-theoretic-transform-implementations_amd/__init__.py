@@ -24,7 +24,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntt_mi355x.so")
+LIB_PATH = os.environ.get("NTT_LIB") or os.path.join(_HERE, "libntt_mi355x.so")  # NTT_LIB: A/B builds of the same library
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -71,14 +71,18 @@ struct ArithU64 {
   };
   /* value-range bookkeeping is static for this policy: [0,4q) fwd, [0,2q) inv */
   static constexpr bool kTracksBounds = false;
+  /* no 8-byte twiddle form: the Shoup quotient cannot be rebuilt without a division */
+  static constexpr bool kCompact = false;
+  using ctw                      = uint64_t;
+  static NTT_HD tw expand(ctw w, const consts &) { return tw{w, 0}; }
 
   static NTT_HD uint64_t csub(uint64_t v, uint64_t b) { return v < b ? v : v - b; }
 
   /* inputs may be anywhere in [0,8q) (the lazy radix-4 output range the
    * reference's bench feeds back in, tests/bench.c:123-137) */
-  template <bool INV> static NTT_HD val load(uint64_t raw, bool wide, const consts &c)
+  template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
   {
-    if(!wide) return raw;                    /* strict API: [0,q)         */
+    if(!WIDE) return raw;                    /* strict API: [0,q)         */
     raw = csub(raw, 2 * c.q2);               /* -> [0,4q): forward range  */
     return INV ? csub(raw, c.q2) : raw;      /* -> [0,2q): inverse range  */
   }
@@ -148,6 +152,13 @@ struct ArithF64 {
   using tw     = TwF64;
   using consts = F64Consts;
   static constexpr bool kTracksBounds = true;
+  /* compact 8-byte twiddle: only the balanced multiplier is stored and w/q is
+   * rebuilt as w*fl(1/q) (one FP64 multiply).  That quotient carries two
+   * roundings instead of one, so a product through a compact twiddle obeys
+   * |r| <= (1/2 + 1.5*B*theta/2) q -- the schedule below accounts for it. */
+  static constexpr bool kCompact = true;
+  using ctw                      = double;
+  static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, w * c.qinv}; }
 
   static NTT_HD double magic52() { return 4503599627370496.0; } /* 2^52 */
 
@@ -178,9 +189,9 @@ struct ArithF64 {
   }
   /* strict API: raw in [0,q).  WIDE (reference-signature shims): raw may be
    * anywhere in [0,8q) -- folded with integer conditional subtracts first. */
-  template <bool INV> static NTT_HD val load(uint64_t raw, bool wide, const consts &c)
+  template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
   {
-    if(wide) {
+    if(WIDE) {
       raw = raw < 4 * c.qi ? raw : raw - 4 * c.qi;
       raw = raw < 2 * c.qi ? raw : raw - 2 * c.qi;
       raw = raw < c.qi ? raw : raw - c.qi;
@@ -219,10 +230,9 @@ struct ArithF64 {
       uint64_t u;
     } x;
     x.d = (r < 0.0) ? a1 : a0;
-    uint64_t u = x.u & 0xFFFFFFFFFFFFFULL;
-    /* rint ties/ulp slack can leave r == q/2+.. or r+q == q exactly once in a
-     * blue moon; fold the single possible overshoot */
-    return u >= c.qi ? u - c.qi : u;
+    /* r >= 0: u = r <= q/2 + slack < q;  r < 0: u = r + q in [q/2 - slack, q):
+     * always canonical, no further fold needed */
+    return x.u & 0xFFFFFFFFFFFFFULL;
   }
   static NTT_HD uint64_t store_fwd(val v, const consts &c) { return to_canonical(v, c); }
   static NTT_HD uint64_t store_inv(val v, const consts &c) { return to_canonical(v, c); }
@@ -263,7 +273,9 @@ struct F64Sched {
 
 constexpr double f64_rho(double b, double theta2) { return 0.5 + b * theta2 * 1.001 + 0.001; }
 
-constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in)
+/* cmask: bit s set => the stage processed at position s multiplies by a compact
+ * (8-byte) twiddle, whose rebuilt quotient is 1.5x less accurate */
+constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask = 0)
 {
   /* class ksh: q <= 2^(51-ksh)*(1+2^-10) */
   double theta2 = 0.25 * 1.001; /* q/2^53 for ksh=0 */
@@ -275,7 +287,9 @@ constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in)
   lim *= (1.0 - 1.0 / 64.0);
   double   b    = b_in;
   uint32_t mask = 0;
+  const double theta2_full = theta2;
   for(int s = 0; s < nstages; s++) {
+    theta2 = ((cmask >> s) & 1u) ? 1.5 * theta2_full : theta2_full;
     if(!inverse) {
       const double nr = b + f64_rho(b, theta2);
       /* also keep the *next* stage feasible: after a no-reduce stage the next

@@ -182,6 +182,13 @@ template <int LOGN> struct Plan {
     }
     return true;
   }
+  /* group and local stage that own local stage sl of the block */
+  static constexpr int GROUP_OF(int sl)
+  {
+    int g = 0;
+    while(g + 1 < NG && S(g + 1) <= sl) g++;
+    return g;
+  }
   /* twiddle slot of a stage is wave-uniform when no lane bit reaches the
    * shifted-in part */
   static constexpr bool TW_UNIFORM(int g, int j)
@@ -201,6 +208,7 @@ template <int LOGN> struct Plan {
 template <class A> struct Params {
   uint64_t *             a;       /* [batch][N] coefficients, in place            */
   const typename A::tw * tw;      /* N records, bit-reversed power order          */
+  const typename A::ctw *tw8;     /* same slots, compact 8-byte form (forward FP64 only) */
   typename A::consts     c;
   uint32_t               logn;    /* log2 N of the whole transform                */
   uint32_t               s0;      /* global stages handled before (fwd) / after (inv) this pass */
@@ -218,9 +226,30 @@ NTT_HD uint32_t uniform_u32(uint32_t v)
 #endif
 }
 
-template <class A> NTT_HD typename A::tw load_tw(const typename A::tw *tab, uint32_t idx)
+/* Twiddle fetch.  UNIFORM: the slot is the same for the whole wave (first group
+ * and every group whose active bits lie above the lane bits): on the device the
+ * record is read through the constant address space so the compiler emits one
+ * s_load_dwordx4 into SGPRs instead of 64 identical vector-lane requests -- the
+ * vector memory pipe (TA) was the bottleneck with per-lane loads (profiles/r01). */
+template <class A, bool UNIFORM, int G = 0> NTT_HD typename A::tw load_tw(const typename A::tw *tab, uint32_t idx)
 {
+#ifdef NTT_ABL_CONSTTW /* timing ablation only: no twiddle traffic for the groups in the mask (wrong results) */
+  if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
+    typename A::tw t = tab[0];
+    (void)idx;
+    return t;
+  }
+#endif
+#if 1
+#  if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW)
+  if constexpr(UNIFORM) {
+    typedef const typename A::tw __attribute__((address_space(4))) * ctab_t;
+    ctab_t ct = (ctab_t)(uintptr_t)tab;
+    return ct[idx];
+  }
+#  endif
   return tab[idx];
+#endif
 }
 
 /* ------------------------------------------------------------------ */
@@ -233,6 +262,43 @@ template <class A> NTT_HD typename A::tw load_tw(const typename A::tw *tab, uint
  * p.lastinv (inverse only): local stage 0 is global stage 0 and folds N^-1
  *          (reference src/ntt_reference.c:55-65)
  */
+/* Per-lane (non-uniform) twiddles of the forward FP64 transform are fetched in
+ * the compact 8-byte form: half the bytes, half the landing registers, and the
+ * two twiddles of a last-stage pair become one 16-byte load. */
+template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, int j)
+{
+#ifdef NTT_NO_COMPACT_TW
+  return false;
+#else
+  return A::kCompact && !INV && !Plan<LOGN>::TW_UNIFORM(g, j);
+#endif
+}
+
+/* twiddles of local stage J of group G for the thread's 8 butterflies (slot
+ * pairs in ascending E0 order); identical slots are merged by the compiler */
+template <class A, int LOGN, int G, int J, bool INV>
+NTT_HD void load_stage_tw(typename A::tw (&w)[kE / 2], uint32_t ib, uint32_t blk, const Params<A> &p)
+{
+  using P           = Plan<LOGN>;
+  constexpr int SL  = P::S(G) + J;
+  constexpr int SH  = LOGN - SL;
+  constexpr int AB  = P::ABIT(G, J);
+  const uint32_t gs = p.s0 + SL;
+  uint32_t       tb = (1u << gs) + (blk << SL) + (ib >> SH);
+  if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
+  static_for<0, kE / 2>([&](auto bb) {
+    constexpr int B = decltype(bb)::value;
+    /* B-th slot index with bit AB clear */
+    constexpr int      E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+    constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+    if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
+      w[B] = A::expand(p.tw8[tb + OFF], p.c);
+    } else {
+      w[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
+    }
+  });
+}
+
 template <class A, int LOGN, int G, bool INV, uint32_t MASK>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p)
@@ -241,34 +307,37 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
   constexpr int R    = P::R(G);
   constexpr int SG   = P::S(G);
   const uint32_t ib  = P::IBASE(G, t);
+#ifdef NTT_ABL_NOCOMPUTE /* timing ablation only: data movement skeleton (wrong results) */
+  return;
+#endif
+  /* software pipeline over the stages: the twiddles of the next stage are
+   * requested before the butterflies of the current one are issued */
+  typename A::tw wcur[kE / 2], wnxt[kE / 2];
+  load_stage_tw<A, LOGN, G, (INV ? R - 1 : 0), INV>(wcur, ib, blk, p);
   static_for<0, R>([&](auto jj) {
     /* forward walks local stages upward, inverse downward */
     constexpr int J  = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
     constexpr int SL = SG + J;                 /* local stage              */
-    constexpr int SH = LOGN - SL;              /* index bits consumed      */
     constexpr int AB = P::ABIT(G, J);
     constexpr int POS = INV ? (LOGN - 1 - SL) : SL; /* processing position */
     constexpr bool RED = (MASK >> POS) & 1u;
-    const uint32_t gs  = p.s0 + SL;            /* global stage             */
-    uint32_t       tb  = (1u << gs) + (blk << SL) + (ib >> SH);
-    if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
-    static_for<0, kE>([&](auto ee) {
-      constexpr int E0 = decltype(ee)::value;
-      if constexpr(((E0 >> AB) & 1) == 0) {
-        constexpr int      E1  = E0 | (1 << AB);
-        constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
-        if(INV && SL == 0 && p.lastinv) {
-          A::inv_bfly_last(x[E0], x[E1], p.c);
-        } else {
-          const typename A::tw w = load_tw<A>(p.tw, tb + OFF);
-          if constexpr(INV) {
-            A::template inv_bfly<RED>(x[E0], x[E1], w, p.c);
-          } else {
-            A::template fwd_bfly<RED>(x[E0], x[E1], w, p.c);
-          }
-        }
+    constexpr int JN  = INV ? J - 1 : J + 1;   /* stage processed next     */
+    if constexpr(JN >= 0 && JN < R) load_stage_tw<A, LOGN, G, JN, INV>(wnxt, ib, blk, p);
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int B  = decltype(bb)::value;
+      constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      constexpr int E1 = E0 | (1 << AB);
+      if(INV && SL == 0 && p.lastinv) {
+        A::inv_bfly_last(x[E0], x[E1], p.c);
+      } else if constexpr(INV) {
+        A::template inv_bfly<RED>(x[E0], x[E1], wcur[B], p.c);
+      } else {
+        A::template fwd_bfly<RED>(x[E0], x[E1], wcur[B], p.c);
       }
     });
+    if constexpr(JN >= 0 && JN < R) {
+      static_for<0, kE / 2>([&](auto bb) { wcur[decltype(bb)::value] = wnxt[decltype(bb)::value]; });
+    }
   });
 }
 
@@ -308,16 +377,37 @@ struct alignas(16) u64x2 {
   uint64_t a, b;
 };
 
+/* raw u64 -> policy representation for all 16 slots; the lazy-input ("wide")
+ * variant is selected by ONE wave-uniform branch around the whole tile */
+template <class A, bool INV>
+NTT_HD void convert_inputs(typename A::val (&x)[kE], const uint64_t (&raw)[kE], bool wide,
+                           const typename A::consts &c)
+{
+  if(wide) {
+    static_for<0, kE>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      x[E]            = A::template load<INV, true>(raw[E], c);
+    });
+  } else {
+    static_for<0, kE>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      x[E]            = A::template load<INV, false>(raw[E], c);
+    });
+  }
+}
+
 /* first-kind group: slot e <-> index (e << LT) + t : 8-byte coalesced */
 template <class A, int LOGN, bool INV>
 NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64_t *blk,
                               bool wide, const typename A::consts &c)
 {
   using P = Plan<LOGN>;
+  uint64_t raw[kE];
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    x[E]            = A::template load<INV>(blk[((uint32_t)E << P::LT) + t], wide, c);
+    raw[E]          = blk[((uint32_t)E << P::LT) + t];
   });
+  convert_inputs<A, INV>(x, raw, wide, c);
 }
 
 /* last-kind group: slots come in runs of 2^RL consecutive indices */
@@ -328,12 +418,14 @@ NTT_HD void global_load_last(typename A::val (&x)[kE], uint32_t t, const uint64_
   using P              = Plan<LOGN>;
   constexpr int G      = P::NG - 1;
   const uint32_t ib    = P::IBASE(G, t);
+  uint64_t raw[kE];
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
     const u64x2   v = *reinterpret_cast<const u64x2 *>(blk + ib + P::IOFF(G, E));
-    x[E]            = A::template load<INV>(v.a, wide, c);
-    x[E + 1]        = A::template load<INV>(v.b, wide, c);
+    raw[E]          = v.a;
+    raw[E + 1]      = v.b;
   });
+  convert_inputs<A, INV>(x, raw, wide, c);
 }
 
 template <class A, int LOGN, bool INV>
@@ -373,7 +465,12 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
   } else {
     /* the schedule is causal, so when the last inverse stage is the folded
      * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
-    return f64_schedule(INV, LOGN, KSH, 1.0).mask;
+    uint32_t cmask = 0;
+    for(int sl = 0; sl < LOGN; sl++) {
+      const int g = Plan<LOGN>::GROUP_OF(sl);
+      if(stage_is_compact<A, LOGN, INV>(g, sl - Plan<LOGN>::S(g))) cmask |= 1u << (INV ? LOGN - 1 - sl : sl);
+    }
+    return f64_schedule(INV, LOGN, KSH, 1.0, cmask).mask;
   }
 }
 
@@ -399,7 +496,8 @@ NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint
   typename A::val x[NE];
   static_for<0, NE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    x[E]            = A::template load<INV>(base[(uint64_t)E << lsp], wide, c);
+    const uint64_t r = base[(uint64_t)E << lsp];
+    x[E]             = wide ? A::template load<INV, true>(r, c) : A::template load<INV, false>(r, c);
   });
   static_for<0, R>([&](auto jj) {
     constexpr int  J   = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;

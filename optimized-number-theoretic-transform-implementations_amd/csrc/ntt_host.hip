@@ -87,10 +87,12 @@ struct ntt_plan {
   bool     has_fwd = false, has_inv = false;
   void *   d_fwd   = nullptr;
   void *   d_inv   = nullptr;
+  void *   d_fwd8  = nullptr; /* compact forward twiddles (FP64 policy) */
   ArithU64::consts cu{};
   F64Consts        cf{};
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
+  int              num_cus    = 256;
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
@@ -147,6 +149,12 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->arith    = ar;
   p->generic  = env_int("NTT_GENERIC", 0) != 0;
   p->max_grid = env_int("NTT_MAX_GRID", 0);
+  {
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+      p->num_cus = prop.multiProcessorCount;
+    }
+  }
   p->has_fwd  = !fwd.empty();
   p->has_inv  = !inv.empty();
   std::vector<uint64_t> inv_for_consts = inv.empty() ? std::vector<uint64_t>(2, 1) : inv;
@@ -169,6 +177,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   rc = NTT_OK;
   if(ar == NTT_ARITH_F64) {
     if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, fwd, q, h_tw_f64);
+    if(!rc && p->has_fwd) rc = upload_table<double>(&p->d_fwd8, fwd, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
     if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv, q, h_tw_f64);
   } else {
     if(p->has_fwd) rc = upload_table<TwU64>(&p->d_fwd, fwd, q, h_tw_u64);
@@ -207,6 +216,7 @@ extern "C" void ntt_plan_destroy(ntt_plan *p)
   (void)hipSetDevice(p->device);
   if(p->d_fwd) (void)hipFree(p->d_fwd);
   if(p->d_inv) (void)hipFree(p->d_inv);
+  if(p->d_fwd8) (void)hipFree(p->d_fwd8);
   if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
@@ -257,6 +267,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     PassArgs    pa{};
     pa.a        = d_a;
     pa.tw       = inverse ? p->d_inv : p->d_fwd;
+    pa.tw8      = inverse ? nullptr : p->d_fwd8;
     pa.consts   = p->arith == NTT_ARITH_U64 ? (const void *)&p->cu : (const void *)&p->cf;
     pa.batch    = batch;
     pa.logn     = (uint32_t)p->m;
@@ -267,6 +278,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.wide     = wide && k == 0;
     pa.lastinv  = inverse && ps.s == 0;
     pa.max_grid = p->max_grid;
+    pa.num_cus  = p->num_cus;
     pa.stream   = (hipStream_t)stream;
     hipError_t e = dispatch_pass(p, pa);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

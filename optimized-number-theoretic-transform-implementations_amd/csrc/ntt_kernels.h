@@ -22,12 +22,29 @@
 
 namespace ntt {
 
-template <int LOGN> struct Geom {
-  using P                  = Plan<LOGN>;
-  static constexpr int WG  = P::T < 256 ? 256 : P::T; /* threads per workgroup    */
-  static constexpr int BPW = WG / P::T;               /* blocks per workgroup     */
+#ifndef NTT_VT14
+#  define NTT_VT14 2
+#endif
+#ifndef NTT_VT13
+#  define NTT_VT13 1
+#endif
+
+template <int LOGN, bool INV> struct Geom {
+  using P = Plan<LOGN>;
+  /* VT "virtual threads" of the plan are executed by one hardware thread: for
+   * the largest blocks this halves the waves per workgroup (2 per SIMD instead
+   * of 4) and doubles the VGPR budget to 256, which is what lets the compiler
+   * keep a dozen twiddle loads plus the next block's coefficients in flight
+   * (with 128 VGPRs it serialised them one load at a time: profiles/r01). */
+#ifdef NTT_NO_PREFETCH
+  static constexpr int VT  = 1;
+#else
+  static constexpr int VT  = INV ? 1 : (LOGN == 14 ? NTT_VT14 : (LOGN == 13 ? NTT_VT13 : 1));
+#endif
+  static constexpr int WG  = P::T < 256 ? 256 : P::T / VT; /* threads per workgroup */
+  static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x) */
-  static constexpr int WPS = 4;
+  static constexpr int WPS = 4 / VT;
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -43,6 +60,9 @@ template <class A, int LOGN, int GW, int GR>
 __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
 {
   using P = Plan<LOGN>;
+#ifdef NTT_ABL_NOEXCH /* timing ablation only: no LDS exchange, no barriers (wrong results) */
+  return;
+#endif
 #ifdef NTT_SAFE_BARRIERS
   constexpr bool local = false;
 #else
@@ -61,11 +81,49 @@ __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, t
   }
 }
 
+/* the same exchange for VT virtual threads per hardware thread (virtual thread
+ * v of hardware thread tid is plan thread tid + v*WG; both live in the same
+ * virtual wave pair, so wave-locality is preserved) */
+template <class A, int LOGN, int GW, int GR, int VT, int WG>
+__device__ __forceinline__ void exchange_vt(typename A::val (&x)[VT][kE], uint32_t tid, typename A::val *lds)
+{
+  using P = Plan<LOGN>;
+#ifdef NTT_ABL_NOEXCH
+  return;
+#endif
+#ifdef NTT_SAFE_BARRIERS
+  constexpr bool local = false;
+#else
+  constexpr bool local = P::WAVE_LOCAL(GW, GR);
+#endif
+  if constexpr(local) {
+    static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
+    wave_sync();
+    static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
+    wave_sync();
+  } else {
+    __syncthreads();
+    static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
+    __syncthreads();
+    static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
+  }
+}
+
+/* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
+template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+{
+  using P = Plan<LOGN>;
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    raw[E]          = blk[((uint32_t)E << P::LT) + t];
+  });
+}
+
 template <class A, int LOGN, bool INV, int KSH>
-__global__ void __launch_bounds__(Geom<LOGN>::WG, Geom<LOGN>::WPS) fused_kernel(const Params<A> p)
+__global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS)) fused_kernel(const Params<A> p)
 {
   using P                 = Plan<LOGN>;
-  using G                 = Geom<LOGN>;
+  using G                 = Geom<LOGN, INV>;
   constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>();
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS];
 
@@ -75,6 +133,55 @@ __global__ void __launch_bounds__(Geom<LOGN>::WG, Geom<LOGN>::WPS) fused_kernel(
   typename A::val *  lds = lds_all + sub * P::LDS_ELEMS;
   const uint32_t     bmask = (1u << p.s0) - 1u;
 
+#ifndef NTT_NO_PREFETCH
+  /* Persistent forward loop with register prefetch (one block per workgroup):
+   * the HBM loads of the NEXT block are issued right after this block's first
+   * exchange and land while the remaining ~10 stages run, so the only exposed
+   * load latency is the very first block's. */
+  if constexpr(!INV && G::BPW == 1) {
+    constexpr int  VT     = G::VT;
+    const uint64_t stride = gridDim.x;
+    uint64_t       b      = blockIdx.x;
+    if(b >= p.nblocks) return;
+    uint64_t raw[VT][kE];
+    static_for<0, VT>([&](auto vv) {
+      constexpr int V = decltype(vv)::value;
+      prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (b << LOGN));
+    });
+    for(; b < p.nblocks; b += stride) {
+      const uint32_t blk  = (uint32_t)b & bmask;
+      uint64_t *     base = p.a + (b << LOGN);
+      typename A::val x[VT][kE];
+      static_for<0, VT>([&](auto vv) {
+        constexpr int V = decltype(vv)::value;
+        convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
+        run_group<A, LOGN, 0, false, MASK>(x[V], tid + V * G::WG, blk, p);
+      });
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = decltype(gg)::value;
+        exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+        if constexpr(GI == 0) {
+          const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
+          static_for<0, VT>([&](auto vv) {
+            constexpr int V = decltype(vv)::value;
+            prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
+          });
+        }
+        static_for<0, VT>([&](auto vv) {
+          constexpr int V = decltype(vv)::value;
+          run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
+        });
+      });
+      static_for<0, VT>([&](auto vv) {
+        constexpr int V = decltype(vv)::value;
+        global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
+      });
+    }
+    return;
+  }
+#endif
+  /* generic loop: inverse transforms, small blocks (several per workgroup) */
+  if constexpr(G::VT == 1)
   for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
     uint64_t   b    = b0 + sub;
     const bool live = b < p.nblocks;
@@ -126,6 +233,7 @@ __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch
 struct PassArgs {
   uint64_t *  a;
   const void *tw;     /* device table of A::tw             */
+  const void *tw8;    /* device table of A::ctw (may be null for policies without a compact form) */
   const void *consts; /* host pointer to A::consts         */
   uint64_t    batch;
   uint32_t    logn;   /* whole transform                   */
@@ -136,6 +244,7 @@ struct PassArgs {
   int         wide;
   int         lastinv;
   int         max_grid; /* cap on workgroups (0 = default) */
+  int         num_cus;  /* compute units of the device     */
   hipStream_t stream;
 };
 
@@ -143,10 +252,11 @@ template <class A, int KSH> hipError_t launch_pass(const PassArgs &pa);
 
 template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const PassArgs &pa)
 {
-  using G = Geom<LOGN>;
+  using G = Geom<LOGN, INV>;
   Params<A> p{};
   p.a       = pa.a;
   p.tw      = static_cast<const typename A::tw *>(pa.tw);
+  p.tw8     = static_cast<const typename A::ctw *>(pa.tw8);
   p.c       = *static_cast<const typename A::consts *>(pa.consts);
   p.logn    = pa.logn;
   p.s0      = (uint32_t)pa.s;
@@ -154,7 +264,19 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   p.lastinv = (uint32_t)pa.lastinv;
   p.nblocks = pa.batch << pa.s;
   uint64_t wgs = (p.nblocks + G::BPW - 1) / G::BPW;
-  const uint64_t cap = pa.max_grid > 0 ? (uint64_t)pa.max_grid : (1ull << 20);
+  uint64_t cap = 1ull << 20;
+#ifndef NTT_NO_PREFETCH
+  if(!INV && G::BPW == 1) {
+    /* persistent prefetching loop: exactly the resident workgroups (LDS- and
+     * wave-limited), each striding over the blocks */
+    constexpr int lds_bytes = (int)(Plan<LOGN>::LDS_ELEMS * sizeof(typename A::val));
+    constexpr int by_lds    = 163840 / lds_bytes;
+    constexpr int by_waves  = (G::WPS * 4 * 64) / G::WG;
+    constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
+    cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+  }
+#endif
+  if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   hipLaunchKernelGGL((fused_kernel<A, LOGN, INV, KSH>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);

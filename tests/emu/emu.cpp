@@ -79,7 +79,7 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
 
 template <class A, bool INV, int KSH>
 static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
-                   const typename A::consts &c, bool generic, bool wide)
+                   const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
 {
   const PassList L = make_passes(m, generic);
   for(int k = 0; k < L.n; k++) {
@@ -91,6 +91,7 @@ static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab
       Params<A> p{};
       p.a       = a;
       p.tw      = tab;
+      p.tw8     = tab8;
       p.c       = c;
       p.logn    = (uint32_t)m;
       p.s0      = (uint32_t)ps.s;
@@ -156,8 +157,12 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
   if(!h_f64_eligible(q)) return -2;
-  std::vector<TwF64> tab(N);
-  for(uint64_t i = 0; i < N; i++) tab[i] = h_tw_f64(src[i], q);
+  std::vector<TwF64>  tab(N);
+  std::vector<double> tab8(N);
+  for(uint64_t i = 0; i < N; i++) {
+    tab[i]  = h_tw_f64(src[i], q);
+    tab8[i] = tab[i].w;
+  }
   const auto c   = h_consts_f64(q, N, wi);
   int        ksh = h_f64_ksh(q);
   if(ksh_force >= 0) {
@@ -167,7 +172,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
   const int cls = ksh >= 18 ? 18 : (ksh >= 1 ? 1 : 0);
 #define RUN(K)                                                                              \
   return inverse ? emu_run<ArithF64, true, K>(a, batch, m, tab.data(), c, generic, wide)   \
-                 : emu_run<ArithF64, false, K>(a, batch, m, tab.data(), c, generic, wide);
+                 : emu_run<ArithF64, false, K>(a, batch, m, tab.data(), c, generic, wide, tab8.data());
   if(cls == 18) { RUN(18) }
   if(cls == 1) { RUN(1) }
   RUN(0)

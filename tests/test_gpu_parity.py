@@ -267,4 +267,4 @@ def test_reference_test_driver_drop_in():
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("Test ") == 19
     assert "Bad results" not in out.stdout
-    assert out.stdout.count("Running ") >= 19 * 9
+    assert out.stdout.count("Running ") == 19 * 8   # 8 variants per case on a non-IFMA, non-s390x build

@@ -123,7 +123,7 @@ template <class A, uint32_t MASK> __global__ void __launch_bounds__(256) k_bfly(
 {
   typename A::val x[16];
   typename A::tw  w[4];
-  for(int i = 0; i < 16; i++) x[i] = A::template load<false>((uint64_t)(threadIdx.x * 16 + i + 1), false, c);
+  for(int i = 0; i < 16; i++) x[i] = A::template load<false, false>((uint64_t)(threadIdx.x * 16 + i + 1), c);
   for(int i = 0; i < 4; i++) {
     w[i] = w0;
   }
