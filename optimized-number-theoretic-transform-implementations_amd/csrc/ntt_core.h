@@ -189,6 +189,22 @@ template <int LOGN> struct Plan {
     while(g + 1 < NG && S(g + 1) <= sl) g++;
     return g;
   }
+  /* B-th butterfly of local stage j of group g: its lower slot, and the first
+   * butterfly of that stage that uses the same twiddle */
+  static constexpr int BFLY_E0(int g, int j, int b)
+  {
+    const int ab = ABIT(g, j);
+    return ((b >> ab) << (ab + 1)) | (b & ((1 << ab) - 1));
+  }
+  static constexpr int BFLY_FIRST(int g, int j, int b)
+  {
+    const int      sh  = LOGN - (S(g) + j);
+    const uint32_t off = IOFF(g, BFLY_E0(g, j, b)) >> sh;
+    for(int k = 0; k < b; k++) {
+      if((IOFF(g, BFLY_E0(g, j, k)) >> sh) == off) return k;
+    }
+    return b;
+  }
   /* twiddle slot of a stage is wave-uniform when no lane bit reaches the
    * shifted-in part */
   static constexpr bool TW_UNIFORM(int g, int j)
@@ -274,34 +290,54 @@ template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, in
 #endif
 }
 
-/* twiddles of local stage J of group G for the thread's 8 butterflies (slot
- * pairs in ascending E0 order); identical slots are merged by the compiler */
+/* One stage's twiddles for the thread's 8 butterflies (ascending E0 order).
+ * Compact stages keep the 8-byte value in registers and rebuild w/q at the
+ * point of use; the others hold full records (SGPRs when wave-uniform).  Only
+ * the first butterfly of every distinct slot actually loads. */
+template <class A> struct StageTw {
+  typename A::tw  f[kE / 2];
+  typename A::ctw c[kE / 2];
+};
+
 template <class A, int LOGN, int G, int J, bool INV>
-NTT_HD void load_stage_tw(typename A::tw (&w)[kE / 2], uint32_t ib, uint32_t blk, const Params<A> &p)
+NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params<A> &p,
+                          const typename A::ctw *ltw = nullptr)
 {
   using P           = Plan<LOGN>;
   constexpr int SL  = P::S(G) + J;
   constexpr int SH  = LOGN - SL;
-  constexpr int AB  = P::ABIT(G, J);
   const uint32_t gs = p.s0 + SL;
   uint32_t       tb = (1u << gs) + (blk << SL) + (ib >> SH);
   if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
   static_for<0, kE / 2>([&](auto bb) {
     constexpr int B = decltype(bb)::value;
-    /* B-th slot index with bit AB clear */
-    constexpr int      E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
-    constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
-    if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
-      w[B] = A::expand(p.tw8[tb + OFF], p.c);
-    } else {
-      w[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
+    if constexpr(P::BFLY_FIRST(G, J, B) == B) {
+      constexpr uint32_t OFF = P::IOFF(G, P::BFLY_E0(G, J, B)) >> SH;
+      if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
+        /* ltw: this group's slice of the compact table, resident in LDS (slot
+         * index minus the first slot of the group's first stage) */
+        w.c[B] = ltw ? ltw[tb + OFF - (1u << P::S(G))] : p.tw8[tb + OFF];
+      } else {
+        w.f[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
+      }
     }
   });
 }
 
-template <class A, int LOGN, int G, bool INV, uint32_t MASK>
+template <class A, int LOGN, int G, int J, bool INV, int B>
+NTT_HD typename A::tw stage_tw(const StageTw<A> &w, const typename A::consts &c)
+{
+  constexpr int F = Plan<LOGN>::BFLY_FIRST(G, J, B);
+  if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
+    return A::expand(w.c[F], c);
+  } else {
+    return w.f[F];
+  }
+}
+
+template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
-                      const Params<A> &p)
+                      const Params<A> &p, const typename A::ctw *ltw = nullptr)
 {
   using P            = Plan<LOGN>;
   constexpr int R    = P::R(G);
@@ -310,10 +346,15 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
 #ifdef NTT_ABL_NOCOMPUTE /* timing ablation only: data movement skeleton (wrong results) */
   return;
 #endif
-  /* software pipeline over the stages: the twiddles of the next stage are
-   * requested before the butterflies of the current one are issued */
-  typename A::tw wcur[kE / 2], wnxt[kE / 2];
-  load_stage_tw<A, LOGN, G, (INV ? R - 1 : 0), INV>(wcur, ib, blk, p);
+  /* Per-lane twiddles that come from global memory are software-pipelined over
+   * the stages (the next stage's are requested before this stage's butterflies
+   * issue); scalar-cache and LDS-resident twiddles are cheap enough to fetch
+   * at the point of use, which keeps them out of the VGPR budget. */
+  StageTw<A> wcur, wnxt;
+  constexpr int JFIRST = INV ? R - 1 : 0;
+  if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !LTW) {
+    load_stage_tw<A, LOGN, G, JFIRST, INV>(wcur, ib, blk, p, nullptr);
+  }
   static_for<0, R>([&](auto jj) {
     /* forward walks local stages upward, inverse downward */
     constexpr int J  = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
@@ -321,23 +362,68 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int AB = P::ABIT(G, J);
     constexpr int POS = INV ? (LOGN - 1 - SL) : SL; /* processing position */
     constexpr bool RED = (MASK >> POS) & 1u;
-    constexpr int JN  = INV ? J - 1 : J + 1;   /* stage processed next     */
-    if constexpr(JN >= 0 && JN < R) load_stage_tw<A, LOGN, G, JN, INV>(wnxt, ib, blk, p);
+    constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
+    constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
+    constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
+    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV>(wcur, ib, blk, p, LTW ? ltw : nullptr);
+    if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV>(wnxt, ib, blk, p, nullptr);
     static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
-      constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      constexpr int E0 = P::BFLY_E0(G, J, B);
       constexpr int E1 = E0 | (1 << AB);
       if(INV && SL == 0 && p.lastinv) {
         A::inv_bfly_last(x[E0], x[E1], p.c);
       } else if constexpr(INV) {
-        A::template inv_bfly<RED>(x[E0], x[E1], wcur[B], p.c);
+        A::template inv_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
       } else {
-        A::template fwd_bfly<RED>(x[E0], x[E1], wcur[B], p.c);
+        A::template fwd_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
       }
     });
-    if constexpr(JN >= 0 && JN < R) {
-      static_for<0, kE / 2>([&](auto bb) { wcur[decltype(bb)::value] = wnxt[decltype(bb)::value]; });
-    }
+    if constexpr(PIPN) wcur = wnxt;
+  });
+}
+
+/* Forward, compact-capable policies: fetch ALL twiddles of group G early (8-byte
+ * form, R x 8 registers-pairs) so they can be requested ahead of the next
+ * block's coefficient prefetch -- vmcnt retires in order, and a twiddle load
+ * queued behind 16 HBM loads would otherwise wait for all of them. */
+template <class A, int LOGN, int G>
+NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint32_t blk, const Params<A> &p)
+{
+  using P           = Plan<LOGN>;
+  constexpr int R   = P::R(G);
+  const uint32_t ib = P::IBASE(G, t);
+  static_for<0, R>([&](auto jj) {
+    constexpr int J   = decltype(jj)::value;
+    constexpr int SL  = P::S(G) + J;
+    constexpr int SH  = LOGN - SL;
+    constexpr int AB  = P::ABIT(G, J);
+    const uint32_t tb = (1u << (p.s0 + SL)) + (blk << SL) + (ib >> SH);
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int      B   = decltype(bb)::value;
+      constexpr int      E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+      if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[tb + OFF];
+    });
+  });
+}
+
+template <class A, int LOGN, int G, uint32_t MASK>
+NTT_HD void run_group_preloaded(typename A::val (&x)[kE], const typename A::ctw (&pre)[4][kE / 2],
+                                const Params<A> &p)
+{
+  using P         = Plan<LOGN>;
+  constexpr int R = P::R(G);
+  static_for<0, R>([&](auto jj) {
+    constexpr int  J   = decltype(jj)::value;
+    constexpr int  SL  = P::S(G) + J;
+    constexpr int  AB  = P::ABIT(G, J);
+    constexpr bool RED = (MASK >> SL) & 1u;
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int B  = decltype(bb)::value;
+      constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      A::template fwd_bfly<RED>(x[E0], x[E0 | (1 << AB)], A::expand(pre[J][P::BFLY_FIRST(G, J, B)], p.c), p.c);
+    });
   });
 }
 

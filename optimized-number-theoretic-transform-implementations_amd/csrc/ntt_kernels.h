@@ -23,7 +23,7 @@
 namespace ntt {
 
 #ifndef NTT_VT14
-#  define NTT_VT14 2
+#  define NTT_VT14 1
 #endif
 #ifndef NTT_VT13
 #  define NTT_VT13 1
@@ -45,6 +45,15 @@ template <int LOGN, bool INV> struct Geom {
   static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x) */
   static constexpr int WPS = 4 / VT;
+  /* compact twiddles of the second-to-last group kept in LDS for the whole
+   * launch (entries; 0 = not used): 2^14 -> stages 8..11 = 3840 doubles = 30 KB,
+   * which together with the 128.1 KB exchange buffer still fits the CU's 160 KB */
+#if defined(NTT_NO_LDS_TW) || defined(NTT_NO_PREFETCH) || defined(NTT_NO_COMPACT_TW)
+  static constexpr int LDS_TW = 0;
+#else
+  static constexpr int LDS_TW =
+    (!INV && LOGN == 14) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
+#endif
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -125,7 +134,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
   using P                 = Plan<LOGN>;
   using G                 = Geom<LOGN, INV>;
   constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>();
-  __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS];
+  constexpr int LDS_TW = A::kCompact ? G::LDS_TW : 0;
+  __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
   const uint32_t     tid = threadIdx.x;
   const uint32_t     sub = tid >> P::LT;
@@ -134,15 +144,35 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
   const uint32_t     bmask = (1u << p.s0) - 1u;
 
 #ifndef NTT_NO_PREFETCH
-  /* Persistent forward loop with register prefetch (one block per workgroup):
-   * the HBM loads of the NEXT block are issued right after this block's first
-   * exchange and land while the remaining ~10 stages run, so the only exposed
-   * load latency is the very first block's. */
+  /* Persistent forward loop (one block per workgroup, grid = resident workgroups).
+   * Ordering of the vector-memory queue is what matters here, because vmcnt
+   * retires in order: per block the last group's twiddles are requested first,
+   * then the NEXT block's 16 coefficient loads; the second-to-last group reads
+   * its twiddles from an LDS-resident table (lgkmcnt) and the first two groups
+   * through the scalar cache.  So no twiddle wait ever sits behind HBM loads,
+   * and the prefetched block lands during ~10 stages of butterflies. */
   if constexpr(!INV && G::BPW == 1) {
     constexpr int  VT     = G::VT;
+    constexpr int  GL     = P::NG - 1;          /* last group                      */
+    constexpr int  GT     = P::NG - 2;          /* group fed from the LDS table    */
+#ifndef NTT_PF_LATE
+    constexpr bool PRE    = false;
+#else
+    constexpr bool PRE    = A::kCompact && stage_is_compact<A, LOGN, false>(GL, 0);
+#endif
+    constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
     if(b >= p.nblocks) return;
+    const typename A::ctw *ltw = nullptr;
+    if constexpr(LTW) {
+      if(p.s0 == 0) { /* the table slice is block-independent only for whole-polynomial blocks */
+        typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+        for(uint32_t i = tid; i < (uint32_t)LDS_TW; i += G::WG) tabl[i] = p.tw8[(1u << P::S(GT)) + i];
+        ltw = tabl;
+        __syncthreads();
+      }
+    }
     uint64_t raw[VT][kE];
     static_for<0, VT>([&](auto vv) {
       constexpr int V = decltype(vv)::value;
@@ -152,6 +182,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[VT][kE];
+      typename A::ctw pre[VT][4][kE / 2];
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
@@ -160,7 +191,19 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+#ifdef NTT_PF_LATE
+        /* variant: all of the last group's twiddles first, then the next block's
+         * coefficients -- nothing this block still waits for is queued behind HBM */
+        if constexpr(GI + 1 == GL) {
+          if constexpr(PRE) {
+            static_for<0, VT>([&](auto vv) {
+              constexpr int V = decltype(vv)::value;
+              preload_group_tw<A, LOGN, GL>(pre[V], tid + V * G::WG, blk, p);
+            });
+          }
+#else
         if constexpr(GI == 0) {
+#endif
           const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
           static_for<0, VT>([&](auto vv) {
             constexpr int V = decltype(vv)::value;
@@ -169,7 +212,13 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
         }
         static_for<0, VT>([&](auto vv) {
           constexpr int V = decltype(vv)::value;
-          run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
+          if constexpr(PRE && GI + 1 == GL) {
+            run_group_preloaded<A, LOGN, GL, MASK>(x[V], pre[V], p);
+          } else if constexpr(GI + 1 == GT) {
+            run_group<A, LOGN, GI + 1, false, MASK, LTW>(x[V], tid + V * G::WG, blk, p, ltw);
+          } else {
+            run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
+          }
         });
       });
       static_for<0, VT>([&](auto vv) {
@@ -269,7 +318,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   if(!INV && G::BPW == 1) {
     /* persistent prefetching loop: exactly the resident workgroups (LDS- and
      * wave-limited), each striding over the blocks */
-    constexpr int lds_bytes = (int)(Plan<LOGN>::LDS_ELEMS * sizeof(typename A::val));
+    constexpr int lds_bytes = (int)((Plan<LOGN>::LDS_ELEMS + (A::kCompact ? G::LDS_TW : 0)) * sizeof(typename A::val));
     constexpr int by_lds    = 163840 / lds_bytes;
     constexpr int by_waves  = (G::WPS * 4 * 64) / G::WG;
     constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
