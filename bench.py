@@ -98,6 +98,20 @@ def cpu_baseline(budget_s=12.0):
                       "single core %.1f us/NTT" % (total, dt, cores, best * 1e6)}
 
 
+def measured_traffic(batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), valid for the default workload only."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["batch"] == batch and t["N"] == N:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +119,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=TOTAL_BATCH // SHARDS, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--logn", type=int, default=LOGN, help="(experiments) other transform sizes; the metric is quoted on 14")
     args = ap.parse_args()
+    global N, BYTES_PER_NTT, ROOT_W
+    if args.logn != LOGN:
+        import ontt as _o
+        N = 1 << args.logn
+        BYTES_PER_NTT = 16 * N
+        ROOT_W = _o.load().min_root(Q, N)
+        if args.batch == TOTAL_BATCH // SHARDS:
+            args.batch = (TOTAL_BATCH // SHARDS) * (1 << LOGN) // N   # same bytes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +212,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no collective" % world,
                        "arith": "f64-balanced" if info["arith"] == 2 else "u64-shoup", "hbm_passes": info["hbm_passes"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(batch),
                          "kernel": "fused_kernel<%s,14,fwd>" % ("ArithF64" if info["arith"] == 2 else "ArithU64"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": batch * BYTES_PER_NTT},
         }

@@ -316,6 +316,11 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
       if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
         /* ltw: this group's slice of the compact table, resident in LDS (slot
          * index minus the first slot of the group's first stage) */
+#ifdef NTT_ABL_CONSTTW
+        if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
+          w.c[B] = p.tw8[1];
+        } else
+#endif
         w.c[B] = ltw ? ltw[tb + OFF - (1u << P::S(G))] : p.tw8[tb + OFF];
       } else {
         w.f[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
@@ -403,6 +408,11 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
       constexpr int      B   = decltype(bb)::value;
       constexpr int      E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
       constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+#ifdef NTT_ABL_CONSTTW
+      if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
+        if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[1];
+      } else
+#endif
       if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[tb + OFF];
     });
   });
@@ -450,9 +460,13 @@ NTT_HD void lds_gather(typename A::val (&x)[kE], uint32_t t, const typename A::v
 {
   using P           = Plan<LOGN>;
   constexpr int ROW = P::ROW;
+  /* two base addresses (rows 0-7 / 8-15) so that every ds_read_b64 uses an
+   * immediate offset below 64 KiB instead of a VGPR address per row */
+  const typename A::val *lo = lds + t;
+  const typename A::val *hi = lds + 8 * ROW + t;
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    x[E]            = lds[E * ROW + t];
+    x[E]            = (E < 8 ? lo : hi)[(E & 7) * ROW];
   });
 }
 
@@ -490,8 +504,9 @@ NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64
   using P = Plan<LOGN>;
   uint64_t raw[kE];
   static_for<0, kE>([&](auto ee) {
-    constexpr int E = decltype(ee)::value;
-    raw[E]          = blk[((uint32_t)E << P::LT) + t];
+    constexpr int   E   = decltype(ee)::value;
+    const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
+    raw[E]              = row[t];
   });
   convert_inputs<A, INV>(x, raw, wide, c);
 }

@@ -56,6 +56,39 @@ template <int LOGN, bool INV> struct Geom {
 #endif
 };
 
+#ifdef NTT_STAMPS
+/* diagnostic build only: per-phase s_memtime stamps of every wave of the first
+ * 256 workgroups (never compiled into the shipped library) */
+__device__ unsigned long long g_stamps[256][16][12];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+template <class T, int VTN> __device__ __forceinline__ void pin_all(T (&x)[VTN][kE])
+{
+#pragma unroll
+  for(int v = 0; v < VTN; v++) {
+#pragma unroll
+    for(int e = 0; e < kE; e++) asm volatile("" ::"v"(x[v][e]));
+  }
+}
+#  define STAMP(ph)                                                                                   \
+    do {                                                                                              \
+      pin_all(x);                                                                                     \
+      const unsigned long long now_ = stamp_now();                                                    \
+      if((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][threadIdx.x >> 6][ph] += now_ - last_; \
+      last_ = now_;                                                                                   \
+    } while(0)
+#else
+#  define STAMP(ph) \
+    do {            \
+    } while(0)
+#endif
+
 __device__ __forceinline__ void wave_sync()
 {
   /* LDS operations of one wave execute in issue order; only the compiler has to
@@ -123,8 +156,9 @@ template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&ra
 {
   using P = Plan<LOGN>;
   static_for<0, kE>([&](auto ee) {
-    constexpr int E = decltype(ee)::value;
-    raw[E]          = blk[((uint32_t)E << P::LT) + t];
+    constexpr int   E   = decltype(ee)::value;
+    const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
+    raw[E]              = row[t];
   });
 }
 
@@ -173,11 +207,18 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
         __syncthreads();
       }
     }
+#ifdef NTT_STAGGER
+    /* de-phase neighbouring CUs so that their HBM bursts do not coincide */
+    for(int i = 0; i < (int)(blockIdx.x % NTT_STAGGER); i++) __builtin_amdgcn_s_sleep(127);
+#endif
     uint64_t raw[VT][kE];
     static_for<0, VT>([&](auto vv) {
       constexpr int V = decltype(vv)::value;
       prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (b << LOGN));
     });
+#ifdef NTT_STAMPS
+    unsigned long long last_ = stamp_now();
+#endif
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
@@ -186,11 +227,29 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
+      });
+#if !defined(NTT_PF_LATE) && !defined(NTT_PF_MID)
+      {
+        /* request the next block as soon as this block's raw words have been consumed:
+         * its HBM loads are then in flight for the whole iteration (measured best of
+         * three placements: after the first exchange -4%, inside the last group -3%) */
+        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
+        static_for<0, VT>([&](auto vv) {
+          constexpr int V = decltype(vv)::value;
+          prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
+        });
+      }
+#endif
+      STAMP(0); /* wait for prefetched coefficients + convert */
+      static_for<0, VT>([&](auto vv) {
+        constexpr int V = decltype(vv)::value;
         run_group<A, LOGN, 0, false, MASK>(x[V], tid + V * G::WG, blk, p);
       });
+      STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+        STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
 #ifdef NTT_PF_LATE
         /* variant: all of the last group's twiddles first, then the next block's
          * coefficients -- nothing this block still waits for is queued behind HBM */
@@ -201,8 +260,10 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
               preload_group_tw<A, LOGN, GL>(pre[V], tid + V * G::WG, blk, p);
             });
           }
-#else
+#elif defined(NTT_PF_MID)
         if constexpr(GI == 0) {
+#else
+        if constexpr(false) {
 #endif
           const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
           static_for<0, VT>([&](auto vv) {
@@ -220,11 +281,13 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
             run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
           }
         });
+        STAMP(3 + 2 * GI); /* prefetch issue (GI==0) + group GI+1 */
       });
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
       });
+      STAMP(10); /* final reduction + stores */
     }
     return;
   }

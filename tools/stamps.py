@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the persistent forward kernel (needs a -DNTT_STAMPS build:
+tools/build_variant.sh stamps "-DNTT_STAMPS";  NTT_LIB=build/libntt_stamps.so python3 tools/stamps.py)"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ontt
+lib = ontt.load()
+N, Q, W = 1 << 14, 0x7fffffffe0001, 83051296654
+batch = 131072
+plan = lib.Plan(N, Q, W)
+buf = lib.DeviceBuffer(batch * N)
+lib.fill_uniform(buf.ptr, batch * N, Q, 1)
+plan.fwd(buf.ptr, batch); lib.stream_sync()
+f = lib._lib.ntt_debug_stamps
+f.argtypes = [C.c_void_p, C.c_int]
+assert f(None, 1) == 0
+plan.fwd(buf.ptr, batch); lib.stream_sync()
+out = np.zeros((256, 16, 12), dtype=np.uint64)
+assert f(out.ctypes.data, 0) == 0
+iters = batch / 256
+names = ["wait prefetch+convert", "group A", "exch A->B (2 barriers)", "prefetch issue + group B", "exch B->C", "group C",
+         "exch C->D", "group D", "-", "-", "final reduce + stores", "-"]
+per = out.astype(np.float64).mean(axis=(0, 1)) / iters
+tot = per.sum()
+# kernel 0 of the symbol lives in ONE instantiation TU; only the F64 K0 kernel ran
+print("cycles per block-iteration (mean over 256 WGs x 16 waves): total %.0f (s_memtime ticks = shader cycles)" % tot)
+for n, v in zip(names, per):
+    if v > 0: print("  %-28s %8.0f  %5.1f%%" % (n, v, 100 * v / tot))
+spread = out.astype(np.float64).sum(axis=2).mean(axis=0) / iters
+print("per-wave totals min/max: %.0f / %.0f" % (spread.min(), spread.max()))

@@ -148,6 +148,25 @@ __global__ void __launch_bounds__(256) k_copy(uint4 *dst, const uint4 *src, size
   for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+/* memory-pipe variants of the copy: 8 B/lane, and 16 B/lane stores at 32-B lane stride (two passes) */
+__global__ void __launch_bounds__(256) k_copy8(uint2 *dst, const uint2 *src, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_copy8ld_16st_strided(uint4 *dst, const uint2 *src, size_t n16)
+{
+  /* each thread: 4 x 8-byte loads (rows 2048 elements apart, like the NTT's first group), then two 16-byte
+   * stores at 32-byte lane stride (like its last group) */
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16 / 2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = i >> 10, t = i & 1023;
+    const uint2 *s   = src + blk * 4096;
+    uint2        a = s[t], b = s[t + 1024], c = s[t + 2048], d = s[t + 3072];
+    uint4 *      o = dst + blk * 2048 + 2 * t;
+    o[0]           = make_uint4(a.x, a.y, b.x, b.y);
+    o[1]           = make_uint4(c.x, c.y, d.x, d.y);
+  }
+}
+
 static double clock_ghz = 2.4;
 
 template <class K> static void run_op(const char *name, K kernel, uint64_t *d_out, int instr_per_iter = 1)
@@ -191,7 +210,27 @@ int main()
     std::vector<uint64_t> wi(2, 1);
     auto cu = h_consts_u64(q, 1 << 14, wi);
     auto cf = h_consts_f64(q, 1 << 14, wi);
-    const int reps = 256, blocks = 256 * 8;
+    const int reps = 256;
+    int       blocks = 256 * 8;
+    for(int wps : {1, 2, 4, 8}) {
+      /* occupancy sweep: wps waves per SIMD (256-thread blocks, wps per CU-quarter) */
+      blocks = 256 * wps;
+      hipEvent_t a0, a1;
+      CK(hipEventCreate(&a0));
+      CK(hipEventCreate(&a1));
+      float msv = 0;
+      for(int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(a0));
+        hipLaunchKernelGGL((k_bfly<ArithF64, 0x5>), dim3(blocks), dim3(256), 0, 0, d_out, cf, h_tw_f64(123456789012345ULL, q), reps);
+        CK(hipEventRecord(a1));
+        CK(hipEventSynchronize(a1));
+        CK(hipEventElapsedTime(&msv, a0, a1));
+      }
+      const double bf = (double)blocks * 256 * 32.0 * reps;
+      printf("bfly F64 (reduce every 2nd) at %d waves/SIMD: %8.2f Gbutterfly/s -> %6.2f M NTT/s-equivalent\n", wps,
+             bf / msv * 1e-6, bf / msv * 1e-6 * 1e3 / 114688.0);
+    }
+    blocks = 256 * 8;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -256,6 +295,28 @@ int main()
         best = ms < best ? ms : best;
       }
       printf("copy 4 GiB, %6d blocks: %.3f ms  %.2f TB/s (read+write)\n", blocks, best, 2.0 * bytes / best * 1e-9);
+      best = 1e9;
+      for(int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy8, dim3(blocks), dim3(256), 0, 0, (uint2 *)dst, (const uint2 *)src, bytes / 8);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      printf("copy8 (8 B/lane) %6d blocks: %.3f ms  %.2f TB/s\n", blocks, best, 2.0 * bytes / best * 1e-9);
+      best = 1e9;
+      for(int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy8ld_16st_strided, dim3(blocks), dim3(256), 0, 0, dst, (const uint2 *)src, bytes / 16);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      printf("copy 4x8B-row loads + 2x16B strided stores %6d blocks: %.3f ms  %.2f TB/s\n", blocks, best, 2.0 * bytes / best * 1e-9);
     }
   }
   return 0;
