@@ -112,6 +112,25 @@ def measured_traffic(batch):
     return None
 
 
+def shard_of_rank(rank, per_gpu_batch, n):
+    """Weak-scaling shard of the global batch: rank r owns polynomials
+    [r*per_gpu_batch, (r+1)*per_gpu_batch); returns (first polynomial, first coefficient
+    index) -- the latter seeds the device-side generator so shards are distinct and any
+    polynomial can be regenerated on a host.  No data moves between ranks."""
+    first = rank * per_gpu_batch
+    return first, first * n
+
+
+def allreduce_max(dist, value, device=None):
+    """max over ranks of a python float (the bench contract's elapsed time); identity without dist"""
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +171,7 @@ def main():
     lib._check(lib._lib.ntt_stream_create(dev, C.byref(stream_h)))
     stream = stream_h.value
     # synthetic, device-generated, rank-distinct inputs: a[p][i] = splitmix64(seed ^ (offset+i)) mod q
-    offset = rank * batch * N
+    _, offset = shard_of_rank(rank, batch, N)
     lib.fill_uniform(buf.ptr, batch * N, Q, SEED, offset, device=dev, stream=stream)
     lib.stream_sync(dev, stream)
 
@@ -189,11 +208,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = ev1.elapsed_ms_since(ev0) / max(args.steps, 1)   # avg launch duration on the launch stream
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = allreduce_max(dist, elapsed, device="cuda" if dist is not None else None)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
