@@ -562,10 +562,11 @@ static bool h_is_prime(uint64_t n)
 
 extern "C" uint64_t ntt_min_root(uint64_t q, uint64_t N)
 {
-  if(!is_pow2(N) || q < 3 || (q - 1) % (2 * N)) return 0;
+  if(!is_pow2(N) || q < 3 || (q - 1) % (2 * N) || !h_is_prime(q)) return 0;
   const uint64_t cof = (q - 1) / (2 * N);
   uint64_t       g   = 0;
-  for(uint64_t x = 2; x < q && !g; x++) {
+  /* half of all residues qualify for a prime q; the bound only guards against misuse */
+  for(uint64_t x = 2; x < q && x < 100000 && !g; x++) {
     const uint64_t c = h_powmod(x, cof, q);
     if(h_powmod(c, N, q) == q - 1) g = c;
   }

@@ -384,10 +384,10 @@ int orc_is_prime(uint64_t n)
  * smallest. */
 uint64_t orc_min_root(uint64_t q, uint64_t N)
 {
-  if((q - 1) % (2 * N) != 0) return 0;
+  if((q - 1) % (2 * N) != 0 || !orc_is_prime(q)) return 0;
   const uint64_t cof = (q - 1) / (2 * N);
   uint64_t       g   = 0;
-  for(uint64_t x = 2; x < q; x++) {
+  for(uint64_t x = 2; x < q && x < 100000; x++) {
     const uint64_t c = orc_powmod(x, cof, q);
     if(orc_powmod(c, N, q) == q - 1) { /* order exactly 2N */
       g = c;

@@ -91,6 +91,7 @@ def test_parameter_helpers(lib, oracle, kat):
         assert lib.min_root(c["q"], 1 << c["m"]) == c["w"]
     assert lib.find_prime(50, 1 << 14) == oracle.find_prime(50, 1 << 14)
     assert lib.min_root(7, 16) == 0
+    assert lib.min_root(0x3fffffffe8001, 1 << 12) == 0     # composite modulus: refused, not searched forever
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/tests"), reason="reference tree only exists in the build container")

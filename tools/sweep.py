@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Throughput sweep over sizes / directions / arithmetic (GPU box): one line per configuration.
+usage: python3 tools/sweep.py [--logn 10 12 14 16 17] [--ops fwd inv mul] [--bytes 8e9]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ontt
+lib = ontt.load()
+ap = argparse.ArgumentParser()
+ap.add_argument("--logn", type=int, nargs="+", default=[10, 12, 13, 14, 15, 16, 17])
+ap.add_argument("--ops", nargs="+", default=["fwd", "inv"])
+ap.add_argument("--bytes", type=float, default=8e9)
+ap.add_argument("--qs", nargs="+", default=["0x7fffffffe0001"])
+ap.add_argument("--arith", nargs="+", default=["auto"])
+ap.add_argument("--steps", type=int, default=10)
+a = ap.parse_args()
+AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64}
+print("%-6s %-18s %-5s %-5s %10s %12s %9s %6s" % ("logn", "q", "arith", "op", "batch", "M NTT/s", "GB/s", "frac"))
+for qs in a.qs:
+    q = int(qs, 0)
+    for ln in a.logn:
+        n = 1 << ln
+        if (q - 1) % (2 * n): continue
+        w = lib.min_root(q, n)
+        batch = max(1, int(a.bytes / (8 * n)))
+        for ar in a.arith:
+            try:
+                plan = lib.Plan(n, q, w, arith=AR[ar])
+            except lib.NttError as e:
+                print(ln, qs, ar, "unsupported:", e); continue
+            nb = 3 if "mul" in a.ops else 1
+            bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
+            for i, b in enumerate(bufs): lib.fill_uniform(b.ptr, batch * n, q, 77 + i)
+            for op in a.ops:
+                def run():
+                    if op == "fwd": plan.fwd(bufs[0].ptr, batch)
+                    elif op == "inv": plan.inv(bufs[0].ptr, batch)
+                    else: plan.negacyclic_mul(bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, batch)
+                for _ in range(2): run()
+                e0, e1 = lib.Event(), lib.Event()
+                lib.stream_sync(); e0.record()
+                for _ in range(a.steps): run()
+                e1.record(); ms = e1.elapsed_ms_since(e0) / a.steps
+                per = {"fwd": 16, "inv": 16, "mul": 72}[op] * n      # algorithmic bytes per polynomial
+                gbs = batch * per / ms / 1e6
+                print("%-6d %-18s %-5s %-5s %10d %12.3f %9.0f %6.3f" % (ln, qs, ["auto","u64","f64"][plan.info()["arith"]], op, batch, batch / ms / 1e3, gbs, gbs / 8000))
+            for b in bufs: b.free()
+            plan.destroy()
