@@ -141,6 +141,7 @@ struct ArithU64 {
  */
 struct F64Consts {
   double q, qinv;  /* q and fl(1/q)                                      */
+  double qinv_lo;  /* 1/q - fl(1/q): second word of the reciprocal       */
   double half_q;   /* q/2 rounded down, for balanced input conversion    */
   TwF64  ninv;     /* N^-1 (balanced) and ninv/q                         */
   TwF64  wninv;    /* N^-1 * winv[1] (balanced) and its /q               */
@@ -153,12 +154,12 @@ struct ArithF64 {
   using consts = F64Consts;
   static constexpr bool kTracksBounds = true;
   /* compact 8-byte twiddle: only the balanced multiplier is stored and w/q is
-   * rebuilt as w*fl(1/q) (one FP64 multiply).  That quotient carries two
-   * roundings instead of one, so a product through a compact twiddle obeys
-   * |r| <= (1/2 + 1.5*B*theta/2) q -- the schedule below accounts for it. */
+   * rebuilt with a two-word reciprocal, fma(w, qinv, w*qinv_lo): the result is
+   * within 2^-53(1/2 + 2^-10) relative of w/q, i.e. as good as the stored
+   * quotient of a full record, so the same bounds apply. */
   static constexpr bool kCompact = true;
   using ctw                      = double;
-  static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, w * c.qinv}; }
+  static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, fma_(w, c.qinv, w * c.qinv_lo)}; }
 
   static NTT_HD double magic52() { return 4503599627370496.0; } /* 2^52 */
 

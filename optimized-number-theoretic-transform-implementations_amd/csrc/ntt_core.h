@@ -205,6 +205,22 @@ template <int LOGN> struct Plan {
     }
     return b;
   }
+  /* number of consecutive table slots [0,span) the 8 butterflies of local stage j
+   * of group g use relative to the thread's base slot, or 0 if they are not a
+   * dense range (then they are fetched one by one) */
+  static constexpr int UNIFORM_SPAN(int g, int j)
+  {
+    const int sh  = LOGN - (S(g) + j);
+    uint32_t  mx  = 0;
+    uint32_t  set = 0;
+    for(int b = 0; b < kE / 2; b++) {
+      const uint32_t off = IOFF(g, BFLY_E0(g, j, b)) >> sh;
+      if(off >= 32) return 0;
+      set |= 1u << off;
+      mx = off > mx ? off : mx;
+    }
+    return set == ((mx + 1 >= 32) ? 0xffffffffu : ((1u << (mx + 1)) - 1)) ? (int)(mx + 1) : 0;
+  }
   /* twiddle slot of a stage is wave-uniform when no lane bit reaches the
    * shifted-in part */
   static constexpr bool TW_UNIFORM(int g, int j)
@@ -278,7 +294,7 @@ template <class A, bool UNIFORM, int G = 0> NTT_HD typename A::tw load_tw(const 
  * p.lastinv (inverse only): local stage 0 is global stage 0 and folds N^-1
  *          (reference src/ntt_reference.c:55-65)
  */
-/* Per-lane (non-uniform) twiddles of the forward FP64 transform are fetched in
+/* Per-lane (non-uniform) twiddles of the FP64 policy are fetched in
  * the compact 8-byte form: half the bytes, half the landing registers, and the
  * two twiddles of a last-stage pair become one 16-byte load. */
 template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, int j)
@@ -286,7 +302,8 @@ template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, in
 #ifdef NTT_NO_COMPACT_TW
   return false;
 #else
-  return A::kCompact && !INV && !Plan<LOGN>::TW_UNIFORM(g, j);
+  (void)INV;
+  return A::kCompact && !Plan<LOGN>::TW_UNIFORM(g, j);
 #endif
 }
 
@@ -309,6 +326,27 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
   const uint32_t gs = p.s0 + SL;
   uint32_t       tb = (1u << gs) + (blk << SL) + (ib >> SH);
   if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW) && !defined(NTT_NO_WIDE_SMEM)
+  /* wave-uniform stage: its 2^J records are consecutive slots -> fetch them as
+   * ONE aggregate through the constant address space (s_load_dwordx4/8/16), so a
+   * group issues 4-5 scalar loads up front instead of 15 load/wait pairs */
+  if constexpr(P::TW_UNIFORM(G, J) && P::UNIFORM_SPAN(G, J) > 0) {
+    constexpr int NREC = P::UNIFORM_SPAN(G, J);
+    struct alignas(16) Block {
+      typename A::tw r[NREC];
+    };
+    typedef const Block __attribute__((address_space(4))) * cblk_t;
+    const Block blkrec = *(cblk_t)(uintptr_t)(p.tw + tb);
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int B = decltype(bb)::value;
+      if constexpr(P::BFLY_FIRST(G, J, B) == B) {
+        constexpr uint32_t OFF = P::IOFF(G, P::BFLY_E0(G, J, B)) >> SH;
+        w.f[B]                 = blkrec.r[OFF];
+      }
+    });
+    return;
+  }
+#endif
   static_for<0, kE / 2>([&](auto bb) {
     constexpr int B = decltype(bb)::value;
     if constexpr(P::BFLY_FIRST(G, J, B) == B) {
@@ -566,12 +604,9 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
   } else {
     /* the schedule is causal, so when the last inverse stage is the folded
      * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
-    uint32_t cmask = 0;
-    for(int sl = 0; sl < LOGN; sl++) {
-      const int g = Plan<LOGN>::GROUP_OF(sl);
-      if(stage_is_compact<A, LOGN, INV>(g, sl - Plan<LOGN>::S(g))) cmask |= 1u << (INV ? LOGN - 1 - sl : sl);
-    }
-    return f64_schedule(INV, LOGN, KSH, 1.0, cmask).mask;
+    /* compact twiddles are expanded with a two-word reciprocal and need no
+     * extra slack (cmask = 0) */
+    return f64_schedule(INV, LOGN, KSH, 1.0, 0).mask;
   }
 }
 

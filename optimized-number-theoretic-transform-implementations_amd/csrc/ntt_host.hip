@@ -88,11 +88,13 @@ struct ntt_plan {
   void *   d_fwd   = nullptr;
   void *   d_inv   = nullptr;
   void *   d_fwd8  = nullptr; /* compact forward twiddles (FP64 policy) */
+  void *   d_inv8  = nullptr; /* compact inverse twiddles (FP64 policy) */
   ArithU64::consts cu{};
   F64Consts        cf{};
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              num_cus    = 256;
+  int              chunk_mib  = 192; /* bytes of one multi-pass chunk (Infinity Cache residency) */
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
@@ -149,6 +151,8 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->arith    = ar;
   p->generic  = env_int("NTT_GENERIC", 0) != 0;
   p->max_grid = env_int("NTT_MAX_GRID", 0);
+  p->chunk_mib = env_int("NTT_CHUNK_MIB", 192);
+  if(p->chunk_mib < 1) p->chunk_mib = 1;
   {
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -179,6 +183,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
     if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, fwd, q, h_tw_f64);
     if(!rc && p->has_fwd) rc = upload_table<double>(&p->d_fwd8, fwd, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
     if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv, q, h_tw_f64);
+    if(!rc && p->has_inv) rc = upload_table<double>(&p->d_inv8, inv, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
   } else {
     if(p->has_fwd) rc = upload_table<TwU64>(&p->d_fwd, fwd, q, h_tw_u64);
     if(!rc && p->has_inv) rc = upload_table<TwU64>(&p->d_inv, inv, q, h_tw_u64);
@@ -217,6 +222,7 @@ extern "C" void ntt_plan_destroy(ntt_plan *p)
   if(p->d_fwd) (void)hipFree(p->d_fwd);
   if(p->d_inv) (void)hipFree(p->d_inv);
   if(p->d_fwd8) (void)hipFree(p->d_fwd8);
+  if(p->d_inv8) (void)hipFree(p->d_inv8);
   if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
@@ -262,26 +268,39 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   HIP_TRY(hipSetDevice(p->device));
   const PassList L = make_passes(p->m, p->generic);
-  for(int k = 0; k < L.n; k++) {
-    const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
-    PassArgs    pa{};
-    pa.a        = d_a;
-    pa.tw       = inverse ? p->d_inv : p->d_fwd;
-    pa.tw8      = inverse ? nullptr : p->d_fwd8;
-    pa.consts   = p->arith == NTT_ARITH_U64 ? (const void *)&p->cu : (const void *)&p->cf;
-    pa.batch    = batch;
-    pa.logn     = (uint32_t)p->m;
-    pa.fused    = ps.fused;
-    pa.r        = ps.r;
-    pa.s        = ps.s;
-    pa.inverse  = inverse;
-    pa.wide     = wide && k == 0;
-    pa.lastinv  = inverse && ps.s == 0;
-    pa.max_grid = p->max_grid;
-    pa.num_cus  = p->num_cus;
-    pa.stream   = (hipStream_t)stream;
-    hipError_t e = dispatch_pass(p, pa);
-    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  /* Multi-pass transforms (N > 2^14) are run chunk by chunk so that what one pass
+   * writes is still in the 256 MiB Infinity Cache when the next pass reads it:
+   * only the first read and the last write of a chunk have to reach HBM. */
+  uint64_t chunk = batch;
+  if(L.n > 1) {
+    const uint64_t budget = (uint64_t)p->chunk_mib << 20;
+    chunk                 = budget / (p->N * sizeof(uint64_t));
+    if(chunk < 1) chunk = 1;
+    if(chunk > batch) chunk = batch;
+  }
+  for(uint64_t first = 0; first < batch; first += chunk) {
+    const uint64_t nb = batch - first < chunk ? batch - first : chunk;
+    for(int k = 0; k < L.n; k++) {
+      const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
+      PassArgs    pa{};
+      pa.a        = d_a + first * p->N;
+      pa.tw       = inverse ? p->d_inv : p->d_fwd;
+      pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
+      pa.consts   = p->arith == NTT_ARITH_U64 ? (const void *)&p->cu : (const void *)&p->cf;
+      pa.batch    = nb;
+      pa.logn     = (uint32_t)p->m;
+      pa.fused    = ps.fused;
+      pa.r        = ps.r;
+      pa.s        = ps.s;
+      pa.inverse  = inverse;
+      pa.wide     = wide && k == 0;
+      pa.lastinv  = inverse && ps.s == 0;
+      pa.max_grid = p->max_grid;
+      pa.num_cus  = p->num_cus;
+      pa.stream   = (hipStream_t)stream;
+      hipError_t e = dispatch_pass(p, pa);
+      if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    }
   }
   return NTT_OK;
 }

@@ -52,7 +52,7 @@ template <int LOGN, bool INV> struct Geom {
   static constexpr int LDS_TW = 0;
 #else
   static constexpr int LDS_TW =
-    (!INV && LOGN == 14) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
+    (LOGN == 14) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
 #endif
 };
 
@@ -151,6 +151,32 @@ __device__ __forceinline__ void exchange_vt(typename A::val (&x)[VT][kE], uint32
   }
 }
 
+/* rows [E0,E1) of the first-kind group's raw coefficients (chunked prefetch variant) */
+template <int LOGN, int E0, int E1> __device__ __forceinline__ void prefetch_rows(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+{
+  using P = Plan<LOGN>;
+  static_for<E0, E1>([&](auto ee) {
+    constexpr int   E   = decltype(ee)::value;
+    const uint64_t *row = blk + ((uint32_t)E << P::LT);
+    raw[E]              = row[t];
+  });
+}
+
+/* raw coefficients in the last-kind layout (runs of 2^RL consecutive indices, 16-byte loads):
+ * what the inverse transform's first group consumes */
+template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    const u64x2   v = *reinterpret_cast<const u64x2 *>(blk + ib + P::IOFF(G, E));
+    raw[E]          = v.a;
+    raw[E + 1]      = v.b;
+  });
+}
+
 /* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
 template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
 {
@@ -228,7 +254,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
       });
-#if !defined(NTT_PF_LATE) && !defined(NTT_PF_MID)
+#if defined(NTT_PF_SPREAD)
+      {
+        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
+        static_for<0, VT>([&](auto vv) {
+          constexpr int V = decltype(vv)::value;
+          prefetch_rows<LOGN, 0, 4>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
+        });
+      }
+#elif !defined(NTT_PF_LATE) && !defined(NTT_PF_MID)
       {
         /* request the next block as soon as this block's raw words have been consumed:
          * its HBM loads are then in flight for the whole iteration (measured best of
@@ -250,6 +284,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
         constexpr int GI = decltype(gg)::value;
         exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
+#ifdef NTT_PF_SPREAD
+        {
+          /* variant: a quarter of the next block's rows after every exchange */
+          const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
+          static_for<0, VT>([&](auto vv) {
+            constexpr int V = decltype(vv)::value;
+            prefetch_rows<LOGN, 4 * (GI + 1), 4 * (GI + 2)>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
+          });
+        }
+#endif
 #ifdef NTT_PF_LATE
         /* variant: all of the last group's twiddles first, then the next block's
          * coefficients -- nothing this block still waits for is queued behind HBM */
@@ -292,6 +336,55 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
     return;
   }
 #endif
+#ifndef NTT_NO_PREFETCH
+  /* Persistent inverse loop: the mirror image of the forward one.  Groups run
+   * last -> first (Gentleman-Sande), the first group executed owns the per-lane
+   * twiddles, the next one reads the LDS-resident table, the remaining stages are
+   * wave-uniform; coefficients come in as 16-byte loads and leave as coalesced
+   * 8-byte stores. */
+  if constexpr(INV && G::BPW == 1 && G::VT == 1) {
+    constexpr int  GL     = P::NG - 1;
+    constexpr int  GT     = P::NG - 2;
+    constexpr bool LTW    = LDS_TW > 0;
+    const uint64_t stride = gridDim.x;
+    uint64_t       b      = blockIdx.x;
+    if(b >= p.nblocks) return;
+    const typename A::ctw *ltw = nullptr;
+    if constexpr(LTW) {
+      if(p.s0 == 0) {
+        typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+        for(uint32_t i = tid; i < (uint32_t)LDS_TW; i += G::WG) tabl[i] = p.tw8[(1u << P::S(GT)) + i];
+        ltw = tabl;
+        __syncthreads();
+      }
+    }
+    uint64_t raw[kE];
+    prefetch_last<LOGN>(raw, tid, p.a + (b << LOGN));
+    for(; b < p.nblocks; b += stride) {
+      const uint32_t blk  = (uint32_t)b & bmask;
+      uint64_t *     base = p.a + (b << LOGN);
+      typename A::val x[kE];
+      convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
+      {
+        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
+        prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN));
+      }
+      run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = P::NG - 1 - decltype(gg)::value;
+        exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
+        if constexpr(GI - 1 == GT && GT != GL) {
+          run_group<A, LOGN, GI - 1, true, MASK, LTW>(x, tid, blk, p, ltw);
+        } else {
+          run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+        }
+      });
+      global_store_first<A, LOGN, true>(x, tid, base, p.c);
+    }
+    return;
+  }
+#endif
+
   /* generic loop: inverse transforms, small blocks (several per workgroup) */
   if constexpr(G::VT == 1)
   for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
@@ -378,7 +471,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   uint64_t wgs = (p.nblocks + G::BPW - 1) / G::BPW;
   uint64_t cap = 1ull << 20;
 #ifndef NTT_NO_PREFETCH
-  if(!INV && G::BPW == 1) {
+  if(G::BPW == 1) {
     /* persistent prefetching loop: exactly the resident workgroups (LDS- and
      * wave-limited), each striding over the blocks */
     constexpr int lds_bytes = (int)((Plan<LOGN>::LDS_ELEMS + (A::kCompact ? G::LDS_TW : 0)) * sizeof(typename A::val));

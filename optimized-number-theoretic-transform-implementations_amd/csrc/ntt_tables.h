@@ -110,6 +110,7 @@ inline F64Consts h_consts_f64(uint64_t q, uint64_t N, const std::vector<uint64_t
   F64Consts c{};
   c.q      = (double)q;
   c.qinv   = (double)(1.0L / (long double)q);
+  c.qinv_lo = (double)(1.0L / (long double)q - (long double)c.qinv);
   c.half_q = (double)(q / 2);
   c.qi     = q;
   const uint64_t ninv = h_powmod(N % q, q - 2, q);

@@ -171,7 +171,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
   }
   const int cls = ksh >= 18 ? 18 : (ksh >= 1 ? 1 : 0);
 #define RUN(K)                                                                              \
-  return inverse ? emu_run<ArithF64, true, K>(a, batch, m, tab.data(), c, generic, wide)   \
+  return inverse ? emu_run<ArithF64, true, K>(a, batch, m, tab.data(), c, generic, wide, tab8.data())   \
                  : emu_run<ArithF64, false, K>(a, batch, m, tab.data(), c, generic, wide, tab8.data());
   if(cls == 18) { RUN(18) }
   if(cls == 1) { RUN(1) }
