@@ -430,7 +430,7 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
  * form, R x 8 registers-pairs) so they can be requested ahead of the next
  * block's coefficient prefetch -- vmcnt retires in order, and a twiddle load
  * queued behind 16 HBM loads would otherwise wait for all of them. */
-template <class A, int LOGN, int G>
+template <class A, int LOGN, int G, uint32_t STAGES = 0xFu>
 NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint32_t blk, const Params<A> &p)
 {
   using P           = Plan<LOGN>;
@@ -438,6 +438,7 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
   const uint32_t ib = P::IBASE(G, t);
   static_for<0, R>([&](auto jj) {
     constexpr int J   = decltype(jj)::value;
+    if constexpr(((STAGES >> J) & 1u) == 0) return;
     constexpr int SL  = P::S(G) + J;
     constexpr int SH  = LOGN - SL;
     constexpr int AB  = P::ABIT(G, J);

@@ -215,10 +215,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
     constexpr int  VT     = G::VT;
     constexpr int  GL     = P::NG - 1;          /* last group                      */
     constexpr int  GT     = P::NG - 2;          /* group fed from the LDS table    */
-#ifndef NTT_PF_LATE
+#ifndef NTT_PRE_AT
+#  define NTT_PRE_AT 0
+#endif
+#ifdef NTT_NO_PRELOAD_LAST
     constexpr bool PRE    = false;
 #else
-    constexpr bool PRE    = A::kCompact && stage_is_compact<A, LOGN, false>(GL, 0);
+    /* the last group's 12 per-lane twiddles (8-byte form) are requested well
+     * ahead of their use; for whole-polynomial blocks they do not depend on the
+     * block at all and stay in 24 VGPRs for the entire launch (LOGN 14 only:
+     * smaller blocks have several workgroups per CU hiding that latency) */
+    constexpr bool PRE    = A::kCompact && LOGN == 14 && stage_is_compact<A, LOGN, false>(GL, 0);
 #endif
     constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
@@ -245,11 +252,26 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
 #endif
+    typename A::ctw pre[VT][4][kE / 2];
+    /* 2^14 blocks are only ever whole polynomials (ntt_passplan.h: s0 == 0), so
+     * these twiddles do not depend on the block: the stages in RESIDENT are
+     * loaded once per launch, the others once per block right after the first
+     * exchange (the register allocator decides how much can stay: more than
+     * this spills, and a spill reload waits for the whole prefetch -- vmcnt) */
+#ifndef NTT_PRE_RESIDENT
+#  define NTT_PRE_RESIDENT 0
+#endif
+    constexpr uint32_t RESIDENT = PRE ? (uint32_t)NTT_PRE_RESIDENT : 0u;
+    if constexpr(RESIDENT != 0) {
+      static_for<0, VT>([&](auto vv) {
+        constexpr int V = decltype(vv)::value;
+        preload_group_tw<A, LOGN, GL, RESIDENT>(pre[V], tid + V * G::WG, 0, p);
+      });
+    }
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[VT][kE];
-      typename A::ctw pre[VT][4][kE / 2];
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
@@ -284,6 +306,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
         constexpr int GI = decltype(gg)::value;
         exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
+#if 1
+        /* blocks of a multi-pass transform: request the last group's twiddles right after the first exchange */
+        if constexpr(PRE && GI == NTT_PRE_AT && (RESIDENT & 0xFu) != 0xFu) {
+          static_for<0, VT>([&](auto vv) {
+            constexpr int V = decltype(vv)::value;
+            preload_group_tw<A, LOGN, GL, 0xFu & ~RESIDENT>(pre[V], tid + V * G::WG, blk, p);
+          });
+        }
+#endif
 #ifdef NTT_PF_SPREAD
         {
           /* variant: a quarter of the next block's rows after every exchange */
