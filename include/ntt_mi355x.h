@@ -99,6 +99,16 @@ NTT_API int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
 
+/* ---- RNS limbs (BASELINE config 5: 4-prime RNS pipeline).  plans[l] is the plan of
+ * prime q_l (same N, same device); data layout is [limb][batch][N], i.e. limb l of
+ * every polynomial is the contiguous [batch][N] slab at d_x + l*batch*N.  Each limb is
+ * an independent transform -- the reference has no counterpart; its closest
+ * primitive is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60). ---- */
+NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
+NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
+NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
+                                         uint64_t *d_b, uint64_t batch, void *stream);
+
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);
 NTT_API int ntt_dev_free(int device, void *d_ptr);

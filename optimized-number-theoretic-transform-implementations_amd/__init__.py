@@ -44,7 +44,8 @@ EXPORTED_SYMBOLS = [
     "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
     "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic",
     "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
-    "ntt_pointwise_mul_batch", "ntt_negacyclic_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_pointwise_mul_batch", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
+    "ntt_rns_negacyclic_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
@@ -83,6 +84,9 @@ for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batc
     _sig(_n, C.c_int, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_pointwise_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_negacyclic_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_rns_fwd_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_rns_inv_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_rns_negacyclic_mul_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
 _sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
@@ -266,6 +270,23 @@ class Plan:
             self.destroy()
         except Exception:
             pass
+
+
+def _plan_array(plans):
+    return (VOIDP * len(plans))(*[p.h for p in plans])
+
+
+def rns_fwd(plans, dptr, batch, stream=None):
+    """limbs laid out [limb][batch][N]"""
+    _check(_lib.ntt_rns_fwd_batch(len(plans), _plan_array(plans), dptr, batch, stream))
+
+
+def rns_inv(plans, dptr, batch, stream=None):
+    _check(_lib.ntt_rns_inv_batch(len(plans), _plan_array(plans), dptr, batch, stream))
+
+
+def rns_negacyclic_mul(plans, dc, da, db, batch, stream=None):
+    _check(_lib.ntt_rns_negacyclic_mul_batch(len(plans), _plan_array(plans), dc, da, db, batch, stream))
 
 
 def batch_multi(plans, dptrs, batches, inverse=False):

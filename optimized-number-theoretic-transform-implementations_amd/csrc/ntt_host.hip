@@ -405,6 +405,42 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
   return rc;
 }
 
+static int rns_check(int nlimbs, ntt_plan *const *plans)
+{
+  if(nlimbs <= 0 || !plans) return fail(NTT_ERR_ARG, "bad limb list");
+  for(int l = 0; l < nlimbs; l++) {
+    if(!plans[l] || plans[l]->N != plans[0]->N || plans[l]->device != plans[0]->device) {
+      return fail(NTT_ERR_ARG, "RNS limbs must share N and device");
+    }
+  }
+  return NTT_OK;
+}
+
+extern "C" int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  for(int l = 0; !rc && l < nlimbs; l++) rc = ntt_fwd_batch(plans[l], d_a + (uint64_t)l * batch * plans[l]->N, batch, stream);
+  return rc;
+}
+
+extern "C" int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  for(int l = 0; !rc && l < nlimbs; l++) rc = ntt_inv_batch(plans[l], d_a + (uint64_t)l * batch * plans[l]->N, batch, stream);
+  return rc;
+}
+
+extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
+                                            uint64_t *d_b, uint64_t batch, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  for(int l = 0; !rc && l < nlimbs; l++) {
+    const uint64_t off = (uint64_t)l * batch * plans[l]->N;
+    rc                 = ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);
+  }
+  return rc;
+}
+
 extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,
                                 void *stream)
 {

@@ -238,6 +238,61 @@ def test_linearity_full_batch(lib, oracle, kat):
     plan.destroy()
 
 
+def _rns_primes(lib, n, count=4, bits=50):
+    return [lib.find_prime(bits, n, skip) for skip in range(count)]
+
+
+def test_rns_pipeline_small(lib, oracle):
+    """fwd -> pointwise -> inv over 4 RNS limbs (layout [limb][batch][N]) vs the oracle, N=2^11"""
+    n, batch = 1 << 11, 3
+    qs = _rns_primes(lib, n)
+    assert len(set(qs)) == 4 and all(q % (2 * n) == 1 for q in qs)
+    plans = [lib.Plan(n, q, lib.min_root(q, n)) for q in qs]
+    a = np.concatenate([_inputs(oracle, n, q, batch, 300 + l) for l, q in enumerate(qs)])
+    b = np.concatenate([_inputs(oracle, n, q, batch, 400 + l) for l, q in enumerate(qs)])
+    da, db = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b)
+    lib.rns_negacyclic_mul(plans, da.ptr, da.ptr, db.ptr, batch)
+    got = da.download()
+    for l, q in enumerate(qs):
+        cx = oracle.ctx(n, q, lib.min_root(q, n))
+        s = slice(l * batch * n, (l + 1) * batch * n)
+        expect = cx.inv(oracle.pointwise(cx.fwd(a[s]), cx.fwd(b[s]), q))
+        assert np.array_equal(got[s], expect), l
+    # schoolbook cross-check of one polynomial of one limb
+    q = qs[2]
+    s0 = 2 * batch * n
+    assert np.array_equal(got[s0:s0 + n], oracle.schoolbook(a[s0:s0 + n].copy(), b[s0:s0 + n].copy(), n, q))
+
+
+def test_full_size_config5_share_rns_n131072(lib, oracle):
+    """BASELINE config 5, one GPU's share: N=2^17, 4-prime RNS, 512 polynomials per GPU
+    (2 GiB per operand): fwd/pointwise/inv pipeline, sampled polynomials vs the oracle,
+    and fwd->inv round trip checksums over the whole slab"""
+    n, batch = 1 << 17, 512
+    qs = _rns_primes(lib, n)
+    roots = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    slab = batch * n
+    da, db = lib.DeviceBuffer(4 * slab), lib.DeviceBuffer(4 * slab)
+    for l, q in enumerate(qs):
+        lib.fill_uniform(da.ptr + 8 * l * slab, slab, q, UNI_SEED, l * slab)
+        lib.fill_uniform(db.ptr + 8 * l * slab, slab, q, UNI_SEED + 1, l * slab)
+    cs0, cs1 = lib.DeviceBuffer(4 * batch), lib.DeviceBuffer(4 * batch)
+    lib.poly_checksum(cs0.ptr, da.ptr, n, 4 * batch)
+    lib.rns_fwd(plans, da.ptr, batch)
+    lib.rns_inv(plans, da.ptr, batch)
+    lib.poly_checksum(cs1.ptr, da.ptr, n, 4 * batch)
+    assert np.array_equal(cs0.download(), cs1.download())
+    lib.rns_negacyclic_mul(plans, da.ptr, da.ptr, db.ptr, batch)
+    for l, p in ((0, 0), (3, 511), (1, 77)):
+        q, w = qs[l], roots[l]
+        cx = oracle.ctx(n, q, w)
+        ia = oracle.fill_uniform(n, q, UNI_SEED, l * slab + p * n)
+        ib = oracle.fill_uniform(n, q, UNI_SEED + 1, l * slab + p * n)
+        expect = cx.inv(oracle.pointwise(cx.fwd(ia), cx.fwd(ib), q))
+        assert np.array_equal(da.download(n, l * slab + p * n), expect), (l, p)
+
+
 def test_multi_device_call(lib, oracle, kat):
     """ntt_batch_multi with however many devices are visible (1 on the test box)"""
     c = kat["cases"][9]
