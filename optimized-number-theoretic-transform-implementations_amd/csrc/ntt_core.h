@@ -516,6 +516,48 @@ struct alignas(16) u64x2 {
   uint64_t a, b;
 };
 
+/* Coefficient traffic is read once and written once per launch.  A non-temporal
+ * (streaming) cache policy for it was measured and LOSES 9 % on this kernel
+ * (profiles/r01: 14.7 vs 16.2 M NTT/s), so it is opt-in only (-DNTT_USE_NT). */
+NTT_HD uint64_t stream_load(const uint64_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+NTT_HD u64x2 stream_load2(const uint64_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
+  typedef unsigned long v2u __attribute__((ext_vector_type(2)));
+  const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
+  return u64x2{v.x, v.y};
+#else
+  return *reinterpret_cast<const u64x2 *>(p);
+#endif
+}
+NTT_HD void stream_store(uint64_t *p, uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+NTT_HD void stream_store2(uint64_t *p, u64x2 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
+  typedef unsigned long v2u __attribute__((ext_vector_type(2)));
+  v2u t;
+  t.x = v.a;
+  t.y = v.b;
+  __builtin_nontemporal_store(t, reinterpret_cast<v2u *>(p));
+#else
+  *reinterpret_cast<u64x2 *>(p) = v;
+#endif
+}
+
 /* raw u64 -> policy representation for all 16 slots; the lazy-input ("wide")
  * variant is selected by ONE wave-uniform branch around the whole tile */
 template <class A, bool INV>
@@ -545,7 +587,7 @@ NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64
   static_for<0, kE>([&](auto ee) {
     constexpr int   E   = decltype(ee)::value;
     const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
-    raw[E]              = row[t];
+    raw[E]              = stream_load(row + t);
   });
   convert_inputs<A, INV>(x, raw, wide, c);
 }
@@ -561,7 +603,7 @@ NTT_HD void global_load_last(typename A::val (&x)[kE], uint32_t t, const uint64_
   uint64_t raw[kE];
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = *reinterpret_cast<const u64x2 *>(blk + ib + P::IOFF(G, E));
+    const u64x2   v = stream_load2(blk + ib + P::IOFF(G, E));
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
@@ -575,7 +617,7 @@ NTT_HD void global_store_first(const typename A::val (&x)[kE], uint32_t t, uint6
   using P = Plan<LOGN>;
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    blk[((uint32_t)E << P::LT) + t] = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
+    stream_store(blk + ((uint32_t)E << P::LT) + t, INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c));
   });
 }
 
@@ -591,7 +633,7 @@ NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64
     u64x2         v;
     v.a = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
     v.b = INV ? A::store_inv(x[E + 1], c) : A::store_fwd(x[E + 1], c);
-    *reinterpret_cast<u64x2 *>(blk + ib + P::IOFF(G, E)) = v;
+    stream_store2(blk + ib + P::IOFF(G, E), v);
   });
 }
 

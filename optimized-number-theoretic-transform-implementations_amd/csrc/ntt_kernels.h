@@ -158,7 +158,7 @@ template <int LOGN, int E0, int E1> __device__ __forceinline__ void prefetch_row
   static_for<E0, E1>([&](auto ee) {
     constexpr int   E   = decltype(ee)::value;
     const uint64_t *row = blk + ((uint32_t)E << P::LT);
-    raw[E]              = row[t];
+    raw[E]              = stream_load(row + t);
   });
 }
 
@@ -171,7 +171,7 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
   const uint32_t ib = P::IBASE(G, t);
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = *reinterpret_cast<const u64x2 *>(blk + ib + P::IOFF(G, E));
+    const u64x2   v = stream_load2(blk + ib + P::IOFF(G, E));
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
@@ -184,7 +184,7 @@ template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&ra
   static_for<0, kE>([&](auto ee) {
     constexpr int   E   = decltype(ee)::value;
     const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
-    raw[E]              = row[t];
+    raw[E]              = stream_load(row + t);
   });
 }
 

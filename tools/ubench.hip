@@ -167,6 +167,31 @@ __global__ void __launch_bounds__(256) k_copy8ld_16st_strided(uint4 *dst, const 
   }
 }
 
+__global__ void __launch_bounds__(256) k_copy_nt(uint4 *dst, const uint4 *src, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load((const v4u *)src + i);
+    __builtin_nontemporal_store(v, (v4u *)dst + i);
+  }
+}
+__global__ void __launch_bounds__(256) k_copy_ntst(uint4 *dst, const uint4 *src, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(((const v4u *)src)[i], (v4u *)dst + i);
+  }
+}
+/* 4 independent 16-byte transfers per thread per iteration */
+__global__ void __launch_bounds__(256) k_copy_x4(uint4 *dst, const uint4 *src, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+}
+
 static double clock_ghz = 2.4;
 
 template <class K> static void run_op(const char *name, K kernel, uint64_t *d_out, int instr_per_iter = 1)
@@ -283,7 +308,7 @@ int main()
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for(int blocks : {2048, 8192, 65536}) {
+    for(int blocks : {1024, 2048, 8192, 65536}) {
       float best = 1e9;
       for(int rep = 0; rep < 5; rep++) {
         CK(hipEventRecord(e0));
@@ -306,6 +331,21 @@ int main()
         best = ms < best ? ms : best;
       }
       printf("copy8 (8 B/lane) %6d blocks: %.3f ms  %.2f TB/s\n", blocks, best, 2.0 * bytes / best * 1e-9);
+#define TRY(KN, LABEL)                                                                         \
+      best = 1e9;                                                                              \
+      for(int rep = 0; rep < 5; rep++) {                                                       \
+        CK(hipEventRecord(e0));                                                                \
+        hipLaunchKernelGGL(KN, dim3(blocks), dim3(256), 0, 0, dst, src, bytes / 16);           \
+        CK(hipEventRecord(e1));                                                                \
+        CK(hipEventSynchronize(e1));                                                           \
+        float ms;                                                                              \
+        CK(hipEventElapsedTime(&ms, e0, e1));                                                  \
+        best = ms < best ? ms : best;                                                          \
+      }                                                                                        \
+      printf("%-28s %6d blocks: %.3f ms  %.2f TB/s\n", LABEL, blocks, best, 2.0 * bytes / best * 1e-9);
+      TRY(k_copy_nt, "copy nt load + nt store")
+      TRY(k_copy_ntst, "copy plain load + nt store")
+      TRY(k_copy_x4, "copy 4x16B per thread")
       best = 1e9;
       for(int rep = 0; rep < 5; rep++) {
         CK(hipEventRecord(e0));
