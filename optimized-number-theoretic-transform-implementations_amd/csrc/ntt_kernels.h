@@ -147,6 +147,14 @@ __device__ __forceinline__ void exchange_vt(typename A::val (&x)[VT][kE], uint32
     __syncthreads();
     static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
     __syncthreads();
+#ifdef NTT_WAVE_STAGGER
+    /* de-phase the waves that share a SIMD (w, w+4, w+8, w+12) so that their
+     * wave-local exchanges and twiddle waits do not coincide */
+    {
+      const int k_ = (int)(__builtin_amdgcn_readfirstlane((int)(tid >> 8)) & 3);
+      for(int i = 0; i < k_; i++) __builtin_amdgcn_s_sleep(NTT_WAVE_STAGGER);
+    }
+#endif
     static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
   }
 }

@@ -19,6 +19,94 @@
 
 using namespace ntt;
 
+/* ------------------------------------------------------------------ */
+/* ArithF64Chk: the FP64 policy with every exactness claim of DESIGN.md */
+/* section 4 asserted at run time against 128-bit integer arithmetic.   */
+/* ------------------------------------------------------------------ */
+static uint64_t g_chk_fail  = 0;   /* number of violated claims          */
+static double   g_chk_maxb  = 0;   /* largest |value|/q seen             */
+static double   g_chk_maxr  = 0;   /* largest |product|/q seen           */
+
+struct ArithF64Chk : ArithF64 {
+  static __int128 as_int(double v)
+  {
+    if(v != __builtin_rint(v) || __builtin_fabs(v) >= 9007199254740992.0) g_chk_fail++; /* integer, < 2^53 */
+    return (__int128)v;
+  }
+  static void see(double v, const consts &c)
+  {
+    (void)as_int(v);
+    const double b = __builtin_fabs(v) / c.q;
+    if(b > g_chk_maxb) g_chk_maxb = b;
+  }
+  static double mulmod(const tw &t, double y, const consts &c)
+  {
+    const double   r  = ArithF64::mulmod(t, y, c);
+    const __int128 q  = (__int128)c.qi;
+    const __int128 ex = as_int(y) * as_int(t.w);
+    __int128       d  = (ex - as_int(r)) % q;
+    if(d != 0) g_chk_fail++;                              /* r == y*w (mod q), exactly */
+    const double rb = __builtin_fabs(r) / c.q;
+    if(rb > g_chk_maxr) g_chk_maxr = rb;
+    return r;
+  }
+  static double reduce(double v, const consts &c)
+  {
+    const double   r = ArithF64::reduce(v, c);
+    if((as_int(v) - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;
+    if(__builtin_fabs(r) > 0.5 * c.q + 2.0) g_chk_fail++;
+    return r;
+  }
+  template <bool RED> static void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double xr = RED ? reduce(x, c) : x;
+    const double m  = mulmod(t, y, c);
+    x               = xr + m;
+    y               = xr - m;
+    see(x, c);
+    see(y, c);
+  }
+  template <bool RED> static void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double s = x + y;
+    const double d = x - y;
+    see(s, c);
+    see(d, c);
+    x = RED ? reduce(s, c) : s;
+    y = mulmod(t, d, c);
+  }
+  static void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    see(s, c);
+    see(d, c);
+    x = mulmod(c.ninv, s, c);
+    y = mulmod(c.wninv, d, c);
+  }
+  static tw expand(ctw w, const consts &c)
+  {
+    const tw t = ArithF64::expand(w, c);
+    /* rebuilt quotient within 2^-52 relative of w/q */
+    const long double tq = (long double)w / (long double)c.q;
+    if(tq != 0 && __builtin_fabsl(((long double)t.wq - tq) / tq) > 2.3e-16L) g_chk_fail++;
+    return t;
+  }
+  static uint64_t store_fwd(val v, const consts &c)
+  {
+    const uint64_t u = ArithF64::to_canonical(v, c);
+    __int128       m = as_int(v) % (__int128)c.qi;
+    if(m < 0) m += c.qi;
+    if(u >= c.qi || (__int128)u != m) g_chk_fail++;
+    return u;
+  }
+  static uint64_t store_inv(val v, const consts &c) { return store_fwd(v, c); }
+};
+
 template <class A> struct Regs {
   typename A::val x[kE];
 };
@@ -157,6 +245,22 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
   if(!h_f64_eligible(q)) return -2;
+  if(arith == 2) { /* checked FP64 policy */
+    std::vector<TwF64>  tabc(N);
+    std::vector<double> tabc8(N);
+    for(uint64_t i = 0; i < N; i++) {
+      tabc[i]  = h_tw_f64(src[i], q);
+      tabc8[i] = tabc[i].w;
+    }
+    const auto cc = h_consts_f64(q, N, wi);
+    const int  kk = h_f64_ksh(q) >= 18 ? 18 : (h_f64_ksh(q) >= 1 ? 1 : 0);
+    if(kk == 18) return inverse ? emu_run<ArithF64Chk, true, 18>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data())
+                                : emu_run<ArithF64Chk, false, 18>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data());
+    if(kk == 1) return inverse ? emu_run<ArithF64Chk, true, 1>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data())
+                               : emu_run<ArithF64Chk, false, 1>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data());
+    return inverse ? emu_run<ArithF64Chk, true, 0>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data())
+                   : emu_run<ArithF64Chk, false, 0>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data());
+  }
   std::vector<TwF64>  tab(N);
   std::vector<double> tab8(N);
   for(uint64_t i = 0; i < N; i++) {
@@ -177,6 +281,18 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
   if(cls == 1) { RUN(1) }
   RUN(0)
 #undef RUN
+}
+
+/* counters of the checked policy: out = {violations, max |v|/q * 1e6, max |product|/q * 1e6}; reset */
+void emu_chk_stats(uint64_t *out, int reset)
+{
+  out[0] = g_chk_fail;
+  out[1] = (uint64_t)(g_chk_maxb * 1e6);
+  out[2] = (uint64_t)(g_chk_maxr * 1e6);
+  if(reset) {
+    g_chk_fail = 0;
+    g_chk_maxb = g_chk_maxr = 0;
+  }
 }
 
 /* pointwise product through both arithmetic policies */

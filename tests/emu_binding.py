@@ -20,6 +20,7 @@ class Emu:
         L.emu_transform.argtypes = [U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64] + [C.c_int] * 5
         L.emu_plan_info.argtypes = [C.c_int, U64P]
         L.emu_pointwise.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
+        L.emu_chk_stats.argtypes = [U64P, C.c_int]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
@@ -32,6 +33,12 @@ class Emu:
         assert self.lib.emu_plan_info(logn, v.ctypes.data_as(U64P)) == 0
         keys = ("NG", "R0", "RL", "T", "ROW", "LDS_ELEMS", "wave_local", "fmask", "imask", "conflict_free")
         return dict(zip(keys, [int(x) for x in v]))
+
+    def chk_stats(self, reset=True):
+        """(violations, max |v|/q, max |product|/q) recorded by the checked FP64 policy (arith=2)"""
+        v = np.zeros(3, dtype=np.uint64)
+        self.lib.emu_chk_stats(v.ctypes.data_as(U64P), int(reset))
+        return int(v[0]), v[1] / 1e6, v[2] / 1e6
 
     def pointwise(self, a, b, q, arith):
         c = np.zeros_like(a)

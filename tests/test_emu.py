@@ -101,6 +101,33 @@ def test_generated_primes(oracle, emu, bits, m):
         assert rc == 0 and np.array_equal(back, a)
 
 
+@pytest.mark.parametrize("i", [0, 6, 12, 13, 15, 17])
+def test_f64_exactness_claims_hold(kat, oracle, emu, i):
+    """DESIGN.md section 4, executed: every FP64 value is an integer below 2^53, every
+    product equals y*w mod q exactly (checked with 128-bit integers), the bound
+    B*q < 2^53 holds with margin, on random and adversarial inputs"""
+    CHK = 2
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    cx = oracle.ctx(n, q, w)
+    rnd = _inputs(oracle, n, q, 1, 900 + i)
+    sign = np.where(np.arange(n) % 2 == 0, q - 1, 1).astype(np.uint64)          # +-1 pattern
+    half = np.full(n, q // 2, dtype=np.uint64)                                      # largest balanced magnitude
+    allmax = np.full(n, q - 1, dtype=np.uint64)
+    emu.chk_stats(reset=True)
+    for a in (rnd, sign, half, allmax):
+        rc, got = emu.transform(a, m, q, w, CHK)
+        assert rc == 0 and np.array_equal(got, cx.fwd(a))
+        rc, back = emu.transform(got, m, q, w, CHK, inverse=True)
+        assert rc == 0 and np.array_equal(back, a)
+    fails, maxb, maxr = emu.chk_stats()
+    assert fails == 0
+    lim = 2.0 ** 53 / q
+    assert maxb < lim * (1 - 1 / 64), (maxb, lim)
+    assert maxr < 0.5 + maxb * q / 2.0 ** 53 * 1.01 + 0.01
+
+
 def test_f64_refuses_large_modulus(oracle, emu):
     q = oracle.find_prime(55, 1 << 10)
     w = oracle.min_root(q, 1 << 10)
