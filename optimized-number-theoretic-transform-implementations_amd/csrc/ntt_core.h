@@ -447,12 +447,30 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
       constexpr int      B   = decltype(bb)::value;
       constexpr int      E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
       constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+      /* two butterflies whose slots are (even, even+1) share one 16-byte load */
+      constexpr bool PAIR_LO = (B + 1 < kE / 2) && (OFF % 2 == 0) && P::BFLY_FIRST(G, J, B) == B &&
+                               P::BFLY_FIRST(G, J, B + 1 < kE / 2 ? B + 1 : B) == B + 1 &&
+                               (P::IOFF(G, P::BFLY_E0(G, J, B + 1 < kE / 2 ? B + 1 : B)) >> SH) == OFF + 1;
+      constexpr bool PAIR_HI = (B > 0) && (OFF % 2 == 1) && P::BFLY_FIRST(G, J, B) == B &&
+                               P::BFLY_FIRST(G, J, B > 0 ? B - 1 : 0) == B - 1 &&
+                               (P::IOFF(G, P::BFLY_E0(G, J, B > 0 ? B - 1 : 0)) >> SH) + 1 == OFF;
 #ifdef NTT_ABL_CONSTTW
       if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
         if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[1];
       } else
 #endif
-      if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[tb + OFF];
+      if constexpr(PAIR_LO && sizeof(typename A::ctw) == 8) {
+        struct alignas(16) Pair {
+          typename A::ctw a, b;
+        };
+        const Pair v  = *reinterpret_cast<const Pair *>(p.tw8 + tb + OFF); /* tb is even: slots of a pair stage */
+        pre[J][B]     = v.a;
+        pre[J][B + 1] = v.b;
+      } else if constexpr(PAIR_HI && sizeof(typename A::ctw) == 8) {
+        /* loaded together with its even partner */
+      } else if constexpr(P::BFLY_FIRST(G, J, B) == B) {
+        pre[J][B] = p.tw8[tb + OFF];
+      }
     });
   });
 }

@@ -130,7 +130,14 @@ template <class A, int LOGN, bool INV, int KSH> static void emu_fused(const Para
         for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
         for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
           lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
-          run_group<A, LOGN, G + 1, false, MASK>(regs[t].x, t, blk, p);
+          if constexpr(A::kCompact && G + 1 == P::NG - 1) {
+            /* the device kernel's early-preload path for the last group */
+            typename A::ctw pre[4][kE / 2];
+            preload_group_tw<A, LOGN, G + 1>(pre, t, blk, p);
+            run_group_preloaded<A, LOGN, G + 1, MASK>(regs[t].x, pre, p);
+          } else {
+            run_group<A, LOGN, G + 1, false, MASK>(regs[t].x, t, blk, p);
+          }
         }
       });
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_last<A, LOGN, false>(regs[t].x, t, base, p.c);
