@@ -153,12 +153,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev_mod = int(os.environ.get("NTT_BENCH_DEVICE_MOD", "0"))   # test hook: fold ranks onto fewer GPUs
+    if ndev_mod:
+        local_rank %= ndev_mod
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")      # "gloo" only for the folded test above
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     import numpy as np
     import ontt
     lib = ontt.load()
@@ -208,7 +215,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = ev1.elapsed_ms_since(ev0) / max(args.steps, 1)   # avg launch duration on the launch stream
-    elapsed = allreduce_max(dist, elapsed, device="cuda" if dist is not None else None)
+    elapsed = allreduce_max(dist, elapsed, device="cuda" if dist is not None and dist.get_backend() == "nccl" else None)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps

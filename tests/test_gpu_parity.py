@@ -323,3 +323,21 @@ def test_reference_test_driver_drop_in():
     assert out.stdout.count("Test ") == 19
     assert "Bad results" not in out.stdout
     assert out.stdout.count("Running ") == 19 * 8   # 8 variants per case on a non-IFMA, non-s390x build
+
+
+def test_bench_two_ranks_folded_on_one_gpu():
+    """bench.py's N>1 path end to end (torch.distributed.run, rank sharding, barrier, MAX-reduction,
+    rank-0 JSON) with two ranks folded onto the one GPU of the test box (gloo for the control plane:
+    RCCL refuses two ranks on one device; the data path has no collective anyway)"""
+    import json
+    import sys
+    env = dict(os.environ, NTT_BENCH_DEVICE_MOD="1", NTT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2 * 8192
+    assert d["value"] > 1e5 and "cpu_baseline" not in d
