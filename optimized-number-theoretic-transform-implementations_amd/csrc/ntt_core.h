@@ -326,6 +326,14 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
   const uint32_t gs = p.s0 + SL;
   uint32_t       tb = (1u << gs) + (blk << SL) + (ib >> SH);
   if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
+  /* LDS table: index = global slot number minus a wave-uniform rebase (block prefix
+   * and leading stages removed, group's first slot subtracted); the pointer itself
+   * always stays inside the table (a rebased pointer would leave the LDS aperture)
+   * (blocks of the maximum size are always whole polynomials -- ntt_passplan.h --
+   * so there the rebase is the compile-time constant 2^S(G); written separately
+   * because the general form costs that kernel a spill) */
+  const uint32_t tl = (LOGN == 14) ? tb - (1u << P::S(G))
+                                   : tb - ((1u << gs) + (blk << SL) - (1u << SL) + (1u << P::S(G)));
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW) && !defined(NTT_NO_WIDE_SMEM)
   /* wave-uniform stage: its 2^J records are consecutive slots -> fetch them as
    * ONE aggregate through the constant address space (s_load_dwordx4/8/16), so a
@@ -352,14 +360,15 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
     if constexpr(P::BFLY_FIRST(G, J, B) == B) {
       constexpr uint32_t OFF = P::IOFF(G, P::BFLY_E0(G, J, B)) >> SH;
       if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
-        /* ltw: this group's slice of the compact table, resident in LDS (slot
-         * index minus the first slot of the group's first stage) */
+        /* ltw: this group's slice of the compact table, resident in LDS, laid out
+         * by the slot the stage would use in a stand-alone 2^LOGN transform
+         * (block prefix and leading stages removed), minus the group's first slot */
 #ifdef NTT_ABL_CONSTTW
         if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
           w.c[B] = p.tw8[1];
         } else
 #endif
-        w.c[B] = ltw ? ltw[tb + OFF - (1u << P::S(G))] : p.tw8[tb + OFF];
+        w.c[B] = ltw ? ltw[tl + OFF] : p.tw8[tb + OFF];
       } else {
         w.f[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
       }

@@ -25,11 +25,17 @@ namespace ntt {
 #ifndef NTT_VT14
 #  define NTT_VT14 1
 #endif
+#ifndef NTT_PRE_ALSO
+#  define NTT_PRE_ALSO 0
+#endif
+#ifndef NTT_LTW_ALSO
+#  define NTT_LTW_ALSO 0 /* experiments: a second block size that keeps an LDS twiddle table */
+#endif
 #ifndef NTT_VT13
 #  define NTT_VT13 1
 #endif
 
-template <int LOGN, bool INV> struct Geom {
+template <int LOGN, bool INV, bool COMPACT> struct Geom {
   using P = Plan<LOGN>;
   /* VT "virtual threads" of the plan are executed by one hardware thread: for
    * the largest blocks this halves the waves per workgroup (2 per SIMD instead
@@ -43,17 +49,25 @@ template <int LOGN, bool INV> struct Geom {
 #endif
   static constexpr int WG  = P::T < 256 ? 256 : P::T / VT; /* threads per workgroup */
   static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
-  /* waves per SIMD the register allocator may assume (VGPR budget 512/x) */
-  static constexpr int WPS = 4 / VT;
+  /* placeholder, fixed below once the LDS footprint is known */
   /* compact twiddles of the second-to-last group kept in LDS for the whole
    * launch (entries; 0 = not used): 2^14 -> stages 8..11 = 3840 doubles = 30 KB,
-   * which together with the 128.1 KB exchange buffer still fits the CU's 160 KB */
+   * which together with the 128.1 KB exchange buffer still fits the CU's 160 KB;
+   * 2^12 -> stages 6..9 = 960 doubles, 4 workgroups of 39.6 KB per CU (measured
+   * +10 %); 2^13 -> one 94 KB workgroup per CU instead of two without a table
+   * (measured +2..3 %, and it serves the blocks of multi-pass transforms) */
 #if defined(NTT_NO_LDS_TW) || defined(NTT_NO_PREFETCH) || defined(NTT_NO_COMPACT_TW)
   static constexpr int LDS_TW = 0;
 #else
   static constexpr int LDS_TW =
-    (LOGN == 14) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
+    (COMPACT && (LOGN >= 12 || LOGN == NTT_LTW_ALSO)) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
 #endif
+  static constexpr int LDS_BYTES  = (BPW * P::LDS_ELEMS + LDS_TW) * 8;
+  static constexpr int WG_PER_CU0 = 163840 / LDS_BYTES;
+  /* waves per SIMD the register allocator may assume (VGPR budget 512/x): what
+   * the LDS footprint lets be resident, at most 4 */
+  static constexpr int WPS0 = (WG_PER_CU0 * (WG / 64)) / 4;
+  static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > 4 / VT ? 4 / VT : WPS0);
 };
 
 #ifdef NTT_STAMPS
@@ -197,12 +211,12 @@ template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&ra
 }
 
 template <class A, int LOGN, bool INV, int KSH>
-__global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS)) fused_kernel(const Params<A> p)
+__global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN, INV, A::kCompact>::WPS)) fused_kernel(const Params<A> p)
 {
   using P                 = Plan<LOGN>;
-  using G                 = Geom<LOGN, INV>;
+  using G                 = Geom<LOGN, INV, A::kCompact>;
   constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>();
-  constexpr int LDS_TW = A::kCompact ? G::LDS_TW : 0;
+  constexpr int LDS_TW = G::LDS_TW;
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
   const uint32_t     tid = threadIdx.x;
@@ -233,7 +247,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
      * ahead of their use; for whole-polynomial blocks they do not depend on the
      * block at all and stay in 24 VGPRs for the entire launch (LOGN 14 only:
      * smaller blocks have several workgroups per CU hiding that latency) */
-    constexpr bool PRE    = A::kCompact && LOGN == 14 && stage_is_compact<A, LOGN, false>(GL, 0);
+    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == NTT_PRE_ALSO) && stage_is_compact<A, LOGN, false>(GL, 0);
 #endif
     constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
@@ -241,9 +255,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
     if(b >= p.nblocks) return;
     const typename A::ctw *ltw = nullptr;
     if constexpr(LTW) {
-      if(p.s0 == 0) { /* the table slice is block-independent only for whole-polynomial blocks */
+      /* The table depends on the block's position inside its polynomial; a workgroup
+       * keeps one table for the whole launch, which is valid when its stride over the
+       * blocks is a multiple of the blocks per polynomial (always arranged by the host) */
+      if((stride & bmask) == 0) {
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
-        for(uint32_t i = tid; i < (uint32_t)LDS_TW; i += G::WG) tabl[i] = p.tw8[(1u << P::S(GT)) + i];
+        const uint32_t   blk0 = (uint32_t)b & bmask;
+        static_for<0, P::R(GT)>([&](auto jj) {
+          constexpr int SLJ = P::S(GT) + decltype(jj)::value;
+          const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
+          for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
+        });
         ltw = tabl;
         __syncthreads();
       }
@@ -390,9 +412,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV>::WG), (Geom<LOGN, INV>::WPS))
     if(b >= p.nblocks) return;
     const typename A::ctw *ltw = nullptr;
     if constexpr(LTW) {
-      if(p.s0 == 0) {
+      /* The table depends on the block's position inside its polynomial; a workgroup
+       * keeps one table for the whole launch, which is valid when its stride over the
+       * blocks is a multiple of the blocks per polynomial (always arranged by the host) */
+      if((stride & bmask) == 0) {
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
-        for(uint32_t i = tid; i < (uint32_t)LDS_TW; i += G::WG) tabl[i] = p.tw8[(1u << P::S(GT)) + i];
+        const uint32_t   blk0 = (uint32_t)b & bmask;
+        static_for<0, P::R(GT)>([&](auto jj) {
+          constexpr int SLJ = P::S(GT) + decltype(jj)::value;
+          const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
+          for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
+        });
         ltw = tabl;
         __syncthreads();
       }
@@ -496,7 +526,7 @@ template <class A, int KSH> hipError_t launch_pass(const PassArgs &pa);
 
 template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const PassArgs &pa)
 {
-  using G = Geom<LOGN, INV>;
+  using G = Geom<LOGN, INV, A::kCompact>;
   Params<A> p{};
   p.a       = pa.a;
   p.tw      = static_cast<const typename A::tw *>(pa.tw);
@@ -513,8 +543,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   if(G::BPW == 1) {
     /* persistent prefetching loop: exactly the resident workgroups (LDS- and
      * wave-limited), each striding over the blocks */
-    constexpr int lds_bytes = (int)((Plan<LOGN>::LDS_ELEMS + (A::kCompact ? G::LDS_TW : 0)) * sizeof(typename A::val));
-    constexpr int by_lds    = 163840 / lds_bytes;
+    constexpr int by_lds    = G::WG_PER_CU0;
     constexpr int by_waves  = (G::WPS * 4 * 64) / G::WG;
     constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
     cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
@@ -522,6 +551,9 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
 #endif
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   if(wgs > cap) wgs = cap;
+  /* a persistent workgroup must always see the same block position inside the
+   * polynomial (its LDS twiddle table depends on it): stride = multiple of 2^s */
+  if(G::BPW == 1 && pa.s > 0 && wgs >= (1ull << pa.s)) wgs &= ~((1ull << pa.s) - 1);
   if(wgs == 0) return hipSuccess;
   hipLaunchKernelGGL((fused_kernel<A, LOGN, INV, KSH>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
   return hipGetLastError();

@@ -101,3 +101,20 @@ def test_reference_drivers_compile_unchanged_against_our_headers(lib):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "dropin"], stdout=subprocess.DEVNULL)
     for exe in ("ntt-variants-dropin", "ntt-variants-bench-dropin"):
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", exe))
+
+
+def test_headline_kernels_do_not_spill():
+    """persistent kernels for blocks >= 2^12 must be scratch-free (a spill reload is a vmcnt(0) wait queued
+    behind the HBM prefetch: measured -40 %); read from the built objects' metadata, no GPU needed"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_spills
+    ks = check_spills.all_kernels()
+    assert len(ks) >= 80
+    fused = [k for k in ks if "fused_kernel" in k["name"] and "ArithF64" in k["name"]]
+    big = [k for k in fused if any(("ELi%dE" % ln) in k["name"] for ln in (12, 13, 14))]
+    assert len(big) == 3 * 3 * 2      # 3 block sizes x 3 headroom classes x fwd/inv
+    for k in big:
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    for k in ks:
+        assert k["group_segment_fixed_size"] <= 160 * 1024, k
