@@ -307,6 +307,16 @@ template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, in
 #endif
 }
 
+/* pointer to the LDS-resident compact twiddle table: kept in the LDS address
+ * space on the device so that reads are ds_read_b64 -- a generic pointer (e.g. a
+ * run-time select between LDS and global) turns them into flat loads, which
+ * also occupy the vector-memory pipe */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class A> using lds_ctw_ptr = const typename A::ctw __attribute__((address_space(3))) *;
+#else
+template <class A> using lds_ctw_ptr = const typename A::ctw *;
+#endif
+
 /* One stage's twiddles for the thread's 8 butterflies (ascending E0 order).
  * Compact stages keep the 8-byte value in registers and rebuild w/q at the
  * point of use; the others hold full records (SGPRs when wave-uniform).  Only
@@ -316,9 +326,9 @@ template <class A> struct StageTw {
   typename A::ctw c[kE / 2];
 };
 
-template <class A, int LOGN, int G, int J, bool INV>
+template <class A, int LOGN, int G, int J, bool INV, bool LTW = false>
 NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params<A> &p,
-                          const typename A::ctw *ltw = nullptr)
+                          lds_ctw_ptr<A> ltw = nullptr)
 {
   using P           = Plan<LOGN>;
   constexpr int SL  = P::S(G) + J;
@@ -368,7 +378,11 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
           w.c[B] = p.tw8[1];
         } else
 #endif
-        w.c[B] = ltw ? ltw[tl + OFF] : p.tw8[tb + OFF];
+        if constexpr(LTW) {
+          w.c[B] = ltw[tl + OFF];
+        } else {
+          w.c[B] = p.tw8[tb + OFF];
+        }
       } else {
         w.f[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
       }
@@ -389,7 +403,7 @@ NTT_HD typename A::tw stage_tw(const StageTw<A> &w, const typename A::consts &c)
 
 template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
-                      const Params<A> &p, const typename A::ctw *ltw = nullptr)
+                      const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
 {
   using P            = Plan<LOGN>;
   constexpr int R    = P::R(G);
@@ -405,7 +419,7 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
   StageTw<A> wcur, wnxt;
   constexpr int JFIRST = INV ? R - 1 : 0;
   if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !LTW) {
-    load_stage_tw<A, LOGN, G, JFIRST, INV>(wcur, ib, blk, p, nullptr);
+    load_stage_tw<A, LOGN, G, JFIRST, INV, false>(wcur, ib, blk, p, nullptr);
   }
   static_for<0, R>([&](auto jj) {
     /* forward walks local stages upward, inverse downward */
@@ -417,8 +431,8 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
     constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
     constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
-    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV>(wcur, ib, blk, p, LTW ? ltw : nullptr);
-    if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV>(wnxt, ib, blk, p, nullptr);
+    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW>(wcur, ib, blk, p, ltw);
+    if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
     static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = P::BFLY_E0(G, J, B);

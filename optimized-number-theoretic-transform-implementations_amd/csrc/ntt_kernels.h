@@ -253,12 +253,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
     if(b >= p.nblocks) return;
-    const typename A::ctw *ltw = nullptr;
+    lds_ctw_ptr<A> ltw = nullptr;
     if constexpr(LTW) {
       /* The table depends on the block's position inside its polynomial; a workgroup
-       * keeps one table for the whole launch, which is valid when its stride over the
-       * blocks is a multiple of the blocks per polynomial (always arranged by the host) */
-      if((stride & bmask) == 0) {
+       * keeps one table for the whole launch, which is valid because its stride over
+       * the blocks is a multiple of the blocks per polynomial (launch_fused enforces it) */
+      {
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
         const uint32_t   blk0 = (uint32_t)b & bmask;
         static_for<0, P::R(GT)>([&](auto jj) {
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
           for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
         });
-        ltw = tabl;
+        ltw = (lds_ctw_ptr<A>)tabl;
         __syncthreads();
       }
     }
@@ -380,8 +380,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           constexpr int V = decltype(vv)::value;
           if constexpr(PRE && GI + 1 == GL) {
             run_group_preloaded<A, LOGN, GL, MASK>(x[V], pre[V], p);
-          } else if constexpr(GI + 1 == GT) {
-            run_group<A, LOGN, GI + 1, false, MASK, LTW>(x[V], tid + V * G::WG, blk, p, ltw);
+          } else if constexpr(GI + 1 == GT && LTW) {
+            run_group<A, LOGN, GI + 1, false, MASK, true>(x[V], tid + V * G::WG, blk, p, ltw);
           } else {
             run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
           }
@@ -410,12 +410,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
     if(b >= p.nblocks) return;
-    const typename A::ctw *ltw = nullptr;
+    lds_ctw_ptr<A> ltw = nullptr;
     if constexpr(LTW) {
       /* The table depends on the block's position inside its polynomial; a workgroup
-       * keeps one table for the whole launch, which is valid when its stride over the
-       * blocks is a multiple of the blocks per polynomial (always arranged by the host) */
-      if((stride & bmask) == 0) {
+       * keeps one table for the whole launch, which is valid because its stride over
+       * the blocks is a multiple of the blocks per polynomial (launch_fused enforces it) */
+      {
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
         const uint32_t   blk0 = (uint32_t)b & bmask;
         static_for<0, P::R(GT)>([&](auto jj) {
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
           for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
         });
-        ltw = tabl;
+        ltw = (lds_ctw_ptr<A>)tabl;
         __syncthreads();
       }
     }
@@ -442,8 +442,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
         exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
-        if constexpr(GI - 1 == GT && GT != GL) {
-          run_group<A, LOGN, GI - 1, true, MASK, LTW>(x, tid, blk, p, ltw);
+        if constexpr(GI - 1 == GT && GT != GL && LTW) {
+          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw);
         } else {
           run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
         }
@@ -550,10 +550,14 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   }
 #endif
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
-  if(wgs > cap) wgs = cap;
   /* a persistent workgroup must always see the same block position inside the
-   * polynomial (its LDS twiddle table depends on it): stride = multiple of 2^s */
-  if(G::BPW == 1 && pa.s > 0 && wgs >= (1ull << pa.s)) wgs &= ~((1ull << pa.s) - 1);
+   * polynomial (its LDS twiddle table depends on it): the grid, which is its
+   * stride, is a multiple of the 2^s blocks per polynomial (nblocks always is) */
+  if(G::BPW == 1 && pa.s > 0) {
+    if(cap < (1ull << pa.s)) cap = 1ull << pa.s;
+    cap &= ~((1ull << pa.s) - 1);
+  }
+  if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   hipLaunchKernelGGL((fused_kernel<A, LOGN, INV, KSH>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
   return hipGetLastError();
