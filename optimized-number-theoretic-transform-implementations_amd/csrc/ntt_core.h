@@ -307,6 +307,14 @@ template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, in
 #endif
 }
 
+/* table[idx] with a 32-bit byte offset: tables are at most 2^28 records, so the
+ * offset fits and the load can use the scalar-base + 32-bit-lane-offset form
+ * instead of a 64-bit per-lane address (two carry-chained VALU adds and a hazard nop) */
+template <class T> NTT_HD const T &at32(const T *base, uint32_t idx)
+{
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
+
 /* pointer to the LDS-resident compact twiddle table: kept in the LDS address
  * space on the device so that reads are ds_read_b64 -- a generic pointer (e.g. a
  * run-time select between LDS and global) turns them into flat loads, which
@@ -381,7 +389,7 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
         if constexpr(LTW) {
           w.c[B] = ltw[tl + OFF];
         } else {
-          w.c[B] = p.tw8[tb + OFF];
+          w.c[B] = at32(p.tw8, tb + OFF);
         }
       } else {
         w.f[B] = load_tw<A, P::TW_UNIFORM(G, J), G>(p.tw, tb + OFF);
@@ -486,13 +494,13 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
         struct alignas(16) Pair {
           typename A::ctw a, b;
         };
-        const Pair v  = *reinterpret_cast<const Pair *>(p.tw8 + tb + OFF); /* tb is even: slots of a pair stage */
+        const Pair v  = at32(reinterpret_cast<const Pair *>(p.tw8), (tb + OFF) >> 1); /* tb+OFF is even: slots of a pair stage */
         pre[J][B]     = v.a;
         pre[J][B + 1] = v.b;
       } else if constexpr(PAIR_HI && sizeof(typename A::ctw) == 8) {
         /* loaded together with its even partner */
       } else if constexpr(P::BFLY_FIRST(G, J, B) == B) {
-        pre[J][B] = p.tw8[tb + OFF];
+        pre[J][B] = at32(p.tw8, tb + OFF);
       }
     });
   });
