@@ -344,14 +344,13 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
   const uint32_t gs = p.s0 + SL;
   uint32_t       tb = (1u << gs) + (blk << SL) + (ib >> SH);
   if constexpr(P::TW_UNIFORM(G, J)) tb = uniform_u32(tb);
-  /* LDS table: index = global slot number minus a wave-uniform rebase (block prefix
-   * and leading stages removed, group's first slot subtracted); the pointer itself
-   * always stays inside the table (a rebased pointer would leave the LDS aperture)
-   * (blocks of the maximum size are always whole polynomials -- ntt_passplan.h --
-   * so there the rebase is the compile-time constant 2^S(G); written separately
-   * because the general form costs that kernel a spill) */
-  const uint32_t tl = (LOGN == 14) ? tb - (1u << P::S(G))
-                                   : tb - ((1u << gs) + (blk << SL) - (1u << SL) + (1u << P::S(G)));
+  /* LDS table (second-to-last group): stored TRANSPOSED per stage, position
+   *   (2^J - 1) * 2^S(G)  +  u * 2^S(G)  +  prefix
+   * (u = slot offset inside the stage, prefix = the thread's index bits above the
+   * group = ib >> (LOGN - S(G))), so that neighbouring lanes -- which differ in the
+   * prefix -- read neighbouring 8-byte words: conflict-free ds_read_b64, where the
+   * natural order (prefix * 2^J + u) put them 2^J words apart (2-way conflicts). */
+  const uint32_t tl = (uint32_t)(((1u << J) - 1u) << P::S(G)) + (ib >> (LOGN - P::S(G)));
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW) && !defined(NTT_NO_WIDE_SMEM)
   /* wave-uniform stage: its 2^J records are consecutive slots -> fetch them as
    * ONE aggregate through the constant address space (s_load_dwordx4/8/16), so a
@@ -387,7 +386,7 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
         } else
 #endif
         if constexpr(LTW) {
-          w.c[B] = ltw[tl + OFF];
+          w.c[B] = ltw[tl + (OFF << P::S(G))];
         } else {
           w.c[B] = at32(p.tw8, tb + OFF);
         }

@@ -262,9 +262,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
         const uint32_t   blk0 = (uint32_t)b & bmask;
         static_for<0, P::R(GT)>([&](auto jj) {
-          constexpr int SLJ = P::S(GT) + decltype(jj)::value;
+          constexpr int JJ  = decltype(jj)::value;
+          constexpr int SGT = P::S(GT);
+          constexpr int SLJ = SGT + JJ;
           const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
-          for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
+          /* slot l = prefix * 2^J + u of the stage goes to (2^J-1)*2^S + u*2^S + prefix (see load_stage_tw) */
+          for(uint32_t l = tid; l < (1u << SLJ); l += G::WG) {
+            const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
+            tabl[(((1u << JJ) - 1u) << SGT) + (u << SGT) + prefix] = src[l];
+          }
         });
         ltw = (lds_ctw_ptr<A>)tabl;
         __syncthreads();
@@ -419,9 +425,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
         const uint32_t   blk0 = (uint32_t)b & bmask;
         static_for<0, P::R(GT)>([&](auto jj) {
-          constexpr int SLJ = P::S(GT) + decltype(jj)::value;
+          constexpr int JJ  = decltype(jj)::value;
+          constexpr int SGT = P::S(GT);
+          constexpr int SLJ = SGT + JJ;
           const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
-          for(uint32_t i = tid; i < (1u << SLJ); i += G::WG) tabl[(1u << SLJ) - (1u << P::S(GT)) + i] = src[i];
+          /* slot l = prefix * 2^J + u of the stage goes to (2^J-1)*2^S + u*2^S + prefix (see load_stage_tw) */
+          for(uint32_t l = tid; l < (1u << SLJ); l += G::WG) {
+            const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
+            tabl[(((1u << JJ) - 1u) << SGT) + (u << SGT) + prefix] = src[l];
+          }
         });
         ltw = (lds_ctw_ptr<A>)tabl;
         __syncthreads();
