@@ -505,21 +505,27 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
   });
 }
 
-template <class A, int LOGN, int G, uint32_t MASK>
+template <class A, int LOGN, int G, uint32_t MASK, bool INV = false>
 NTT_HD void run_group_preloaded(typename A::val (&x)[kE], const typename A::ctw (&pre)[4][kE / 2],
                                 const Params<A> &p)
 {
   using P         = Plan<LOGN>;
   constexpr int R = P::R(G);
   static_for<0, R>([&](auto jj) {
-    constexpr int  J   = decltype(jj)::value;
+    constexpr int  J   = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
     constexpr int  SL  = P::S(G) + J;
     constexpr int  AB  = P::ABIT(G, J);
-    constexpr bool RED = (MASK >> SL) & 1u;
+    constexpr int  POS = INV ? (LOGN - 1 - SL) : SL;
+    constexpr bool RED = (MASK >> POS) & 1u;
     static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
-      A::template fwd_bfly<RED>(x[E0], x[E0 | (1 << AB)], A::expand(pre[J][P::BFLY_FIRST(G, J, B)], p.c), p.c);
+      const typename A::tw w = A::expand(pre[J][P::BFLY_FIRST(G, J, B)], p.c);
+      if constexpr(INV) {
+        A::template inv_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
+      } else {
+        A::template fwd_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
+      }
     });
   });
 }

@@ -439,6 +439,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         __syncthreads();
       }
     }
+    /* the first executed group's per-lane twiddles do not change from block to
+     * block (the workgroup always sees the same block position): request the
+     * next iteration's copy at the end of the current one, so its L2 latency
+     * hides under the final stores and the conversion of the next block */
+#ifdef NTT_NO_INV_PRE
+    constexpr bool IPRE = false;
+#else
+    constexpr bool IPRE = A::kCompact && LOGN >= 13 && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4;
+#endif
+    typename A::ctw pre[4][kE / 2];
+    if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
     uint64_t raw[kE];
     prefetch_last<LOGN>(raw, tid, p.a + (b << LOGN));
     for(; b < p.nblocks; b += stride) {
@@ -450,7 +461,11 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
         prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN));
       }
-      run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+      if constexpr(IPRE) {
+        run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+      } else {
+        run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+      }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
         exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
@@ -460,6 +475,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
         }
       });
+      if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
       global_store_first<A, LOGN, true>(x, tid, base, p.c);
     }
     return;
