@@ -10,10 +10,14 @@
  *                element-wise VALU work.
  * column_kernel: strided passes for the leading stages of N > 2^14 and for tiny N.
  *
- * Launch geometry (wave64, 256 CUs): LOGN=14 -> 1024 threads (16 waves, 4 per
- * SIMD, <=128 VGPRs) and ~128 KiB of the CU's 160 KiB LDS; smaller blocks use
- * 256..512-thread workgroups so that several are resident per CU and one
- * group's HBM latency hides under another's butterflies.
+ * Launch geometry (wave64, 256 CUs): LOGN=14 -> one persistent 1024-thread
+ * workgroup per CU (16 waves, 4 per SIMD, <=128 VGPRs, no scratch) using 158 KiB
+ * of the CU's 160 KiB LDS (128.1 KiB exchange buffer + 30 KiB twiddle table);
+ * 2^13 -> one 512-thread workgroup (94 KiB), 2^12 -> four 256-thread workgroups
+ * (39.6 KiB each).  Blocks >= 2^12 run the persistent loops below (register
+ * prefetch of the next block, LDS-resident twiddle table); smaller blocks pack
+ * several per 256-thread workgroup and rely on multiple resident workgroups.
+ * Tuning history and rejected variants: profiles/r01/ablations.txt.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -37,11 +41,10 @@ namespace ntt {
 
 template <int LOGN, bool INV, bool COMPACT> struct Geom {
   using P = Plan<LOGN>;
-  /* VT "virtual threads" of the plan are executed by one hardware thread: for
-   * the largest blocks this halves the waves per workgroup (2 per SIMD instead
-   * of 4) and doubles the VGPR budget to 256, which is what lets the compiler
-   * keep a dozen twiddle loads plus the next block's coefficients in flight
-   * (with 128 VGPRs it serialised them one load at a time: profiles/r01). */
+  /* VT "virtual threads" of the plan executed by one hardware thread (VT = 2
+   * halves the waves per workgroup and doubles the VGPR budget to 256).  Kept
+   * as an experiment switch (-DNTT_VT14=2): measured 14.5 vs 16.0 M NTT/s, the
+   * 4-waves-per-SIMD geometry hides LDS and L2 latencies better. */
 #ifdef NTT_NO_PREFETCH
   static constexpr int VT  = 1;
 #else
@@ -49,7 +52,6 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
 #endif
   static constexpr int WG  = P::T < 256 ? 256 : P::T / VT; /* threads per workgroup */
   static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
-  /* placeholder, fixed below once the LDS footprint is known */
   /* compact twiddles of the second-to-last group kept in LDS for the whole
    * launch (entries; 0 = not used): 2^14 -> stages 8..11 = 3840 doubles = 30 KB,
    * which together with the 128.1 KB exchange buffer still fits the CU's 160 KB;
