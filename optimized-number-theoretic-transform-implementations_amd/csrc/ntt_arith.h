@@ -163,16 +163,18 @@ struct ArithF64 {
 
   static NTT_HD double magic52() { return 4503599627370496.0; } /* 2^52 */
 
-  /* u64 in [0,2^52) -> double, exact (mantissa splice); inputs of the strict
-   * API are in [0,q), q < 2^52 */
+  /* u64 in [0,2^52) -> double, exact, in ONE instruction: the bit pattern of
+   * u < 2^52 read as a double is the subnormal u * 2^-1074, and ldexp by 1074
+   * (v_ldexp_f64, exact) scales it back to the integer u.  FP64 subnormals are
+   * never flushed on gfx9 (and not on the CPU emulation either). */
   static NTT_HD double u64_to_f64_lt52(uint64_t u)
   {
     union {
       uint64_t u;
       double   d;
     } x;
-    x.u = u | 0x4330000000000000ULL;
-    return x.d - magic52();
+    x.u = u;
+    return __builtin_ldexp(x.d, 1074);
   }
   /* v - q*rint(v/q): |result| <= q/2 (+1 ulp of the quotient) */
   static NTT_HD double reduce(double v, const consts &c)
@@ -223,17 +225,19 @@ struct ArithF64 {
   /* balanced |v| < 2^53 -> canonical [0,q) as u64 */
   static NTT_HD uint64_t to_canonical(double v, const consts &c)
   {
-    const double r  = reduce(v, c);           /* |r| <= q/2 (+tiny)      */
-    const double a0 = r + magic52();          /* r >= 0 branch           */
-    const double a1 = r + (magic52() + c.q);  /* r <  0 branch: r + q    */
+    const double r = reduce(v, c); /* |r| <= q/2 (+tiny) */
+    /* (r + (r < 0 ? q : 0)) * 2^-1074 in one exact fma: the result is a
+     * subnormal whose bit pattern IS the canonical integer (the inverse of
+     * u64_to_f64_lt52).  The addend's bit pattern is q or 0 for the same reason.
+     * r >= 0: u = r <= q/2 + slack < q;  r < 0: u = r + q in [q/2 - slack, q):
+     * always canonical, no further fold needed (DESIGN.md 4.3) */
     union {
       double   d;
       uint64_t u;
-    } x;
-    x.d = (r < 0.0) ? a1 : a0;
-    /* r >= 0: u = r <= q/2 + slack < q;  r < 0: u = r + q in [q/2 - slack, q):
-     * always canonical, no further fold needed (DESIGN.md 4.3) */
-    return x.u & 0xFFFFFFFFFFFFFULL;
+    } k, x;
+    k.u = (r < 0.0) ? c.qi : 0ULL;
+    x.d = fma_(r, 0x1p-1074, k.d);
+    return x.u;
   }
   static NTT_HD uint64_t store_fwd(val v, const consts &c) { return to_canonical(v, c); }
   static NTT_HD uint64_t store_inv(val v, const consts &c) { return to_canonical(v, c); }

@@ -612,6 +612,18 @@ NTT_HD void stream_store2(uint64_t *p, u64x2 v)
 #endif
 }
 
+/* coefficient addresses as wave-uniform row pointer + 32-bit lane byte offset (a
+ * block is at most 2^14 coefficients), so that loads/stores take the
+ * scalar-base + lane-offset form and need no per-lane 64-bit address adds */
+NTT_HD const uint64_t *coef_at(const uint64_t *row, uint32_t idx)
+{
+  return reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(row) + (uint32_t)(idx * 8u));
+}
+NTT_HD uint64_t *coef_at(uint64_t *row, uint32_t idx)
+{
+  return reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(row) + (uint32_t)(idx * 8u));
+}
+
 /* raw u64 -> policy representation for all 16 slots; the lazy-input ("wide")
  * variant is selected by ONE wave-uniform branch around the whole tile */
 template <class A, bool INV>
@@ -641,7 +653,7 @@ NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64
   static_for<0, kE>([&](auto ee) {
     constexpr int   E   = decltype(ee)::value;
     const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
-    raw[E]              = stream_load(row + t);
+    raw[E]              = stream_load(coef_at(row, t));
   });
   convert_inputs<A, INV>(x, raw, wide, c);
 }
@@ -657,7 +669,7 @@ NTT_HD void global_load_last(typename A::val (&x)[kE], uint32_t t, const uint64_
   uint64_t raw[kE];
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = stream_load2(blk + ib + P::IOFF(G, E));
+    const u64x2   v = stream_load2(coef_at(blk + P::IOFF(G, E), ib));
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
@@ -671,7 +683,7 @@ NTT_HD void global_store_first(const typename A::val (&x)[kE], uint32_t t, uint6
   using P = Plan<LOGN>;
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    stream_store(blk + ((uint32_t)E << P::LT) + t, INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c));
+    stream_store(coef_at(blk + ((uint32_t)E << P::LT), t), INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c));
   });
 }
 
@@ -687,7 +699,7 @@ NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64
     u64x2         v;
     v.a = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
     v.b = INV ? A::store_inv(x[E + 1], c) : A::store_fwd(x[E + 1], c);
-    stream_store2(blk + ib + P::IOFF(G, E), v);
+    stream_store2(coef_at(blk + P::IOFF(G, E), ib), v);
   });
 }
 

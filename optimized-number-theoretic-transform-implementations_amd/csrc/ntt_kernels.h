@@ -182,8 +182,48 @@ template <int LOGN, int E0, int E1> __device__ __forceinline__ void prefetch_row
   static_for<E0, E1>([&](auto ee) {
     constexpr int   E   = decltype(ee)::value;
     const uint64_t *row = blk + ((uint32_t)E << P::LT);
-    raw[E]              = stream_load(row + t);
+    raw[E]              = stream_load(coef_at(row, t));
   });
+}
+
+/* A block seen through a buffer descriptor: the 16 row loads of a thread then share ONE
+ * 32-bit lane offset (t*8) and take the row offset as a scalar operand, instead of a
+ * 64-bit per-lane address each (two carry-chained VALU adds per row in the hot loop).
+ * blk is wave-uniform (derived from blockIdx and the loop counter only). */
+template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc(const uint64_t *blk)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(blk), /*stride*/ 0, (int)(8u << LOGN), 0x00020000);
+}
+__device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  return (uint64_t)v.x | ((uint64_t)v.y << 32);
+}
+__device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return u64x2{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
+}
+
+/* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
+template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+{
+  using P = Plan<LOGN>;
+#ifdef NTT_NO_BUFFER_LOADS
+  static_for<0, kE>([&](auto ee) {
+    constexpr int   E   = decltype(ee)::value;
+    const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
+    raw[E]              = stream_load(coef_at(row, t));
+  });
+#else
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    raw[E]          = buffer_load_u64(r, t * 8u, ((uint32_t)E << P::LT) * 8u);
+  });
+#endif
 }
 
 /* raw coefficients in the last-kind layout (runs of 2^RL consecutive indices, 16-byte loads):
@@ -193,23 +233,22 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
   const uint32_t ib = P::IBASE(G, t);
+#ifdef NTT_NO_BUFFER_LOADS
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = stream_load2(blk + ib + P::IOFF(G, E));
+    const u64x2   v = stream_load2(coef_at(blk + P::IOFF(G, E), ib));
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
-}
-
-/* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
-template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
-{
-  using P = Plan<LOGN>;
-  static_for<0, kE>([&](auto ee) {
-    constexpr int   E   = decltype(ee)::value;
-    const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
-    raw[E]              = stream_load(row + t);
+#else
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    const u64x2   v = buffer_load_u64x2(r, ib * 8u, P::IOFF(G, E) * 8u);
+    raw[E]          = v.a;
+    raw[E + 1]      = v.b;
   });
+#endif
 }
 
 template <class A, int LOGN, bool INV, int KSH>
