@@ -190,6 +190,20 @@ struct ArithF64 {
     const double d = fma_(-k, c.q, h);
     return d + l;
   }
+  /* product by a compact (8-byte) twiddle: the quotient is estimated from the
+   * rounded product itself, k = rint(fl(y*w) * fl(1/q)), so no w/q has to be
+   * stored or rebuilt.  Three roundings instead of two: the estimate is within
+   * 1.5 * 2^-52 relative of y*w/q (2^-52 for a stored quotient), which the
+   * reduction schedule accounts for (f64_schedule, cmask).  h - k*q is still an
+   * integer below 2^53 in magnitude, hence exact. */
+  static NTT_HD double mulmod_c(ctw w, double y, const consts &c)
+  {
+    const double h = y * w;
+    const double k = rint_(h * c.qinv);
+    const double l = fma_(y, w, -h);
+    const double d = fma_(-k, c.q, h);
+    return d + l;
+  }
   /* strict API: raw in [0,q).  WIDE (reference-signature shims): raw may be
    * anywhere in [0,8q) -- folded with integer conditional subtracts first. */
   template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
@@ -214,6 +228,21 @@ struct ArithF64 {
     const double d = x - y;
     x              = RED ? reduce(s, c) : s;
     y              = mulmod(t, d, c);
+  }
+  /* the same butterflies on a compact twiddle */
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    const double xr = RED ? reduce(x, c) : x;
+    const double m  = mulmod_c(w, y, c);
+    x               = xr + m;
+    y               = xr - m;
+  }
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = RED ? reduce(s, c) : s;
+    y              = mulmod_c(w, d, c);
   }
   static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
   {
@@ -279,7 +308,7 @@ struct F64Sched {
 constexpr double f64_rho(double b, double theta2) { return 0.5 + b * theta2 * 1.001 + 0.001; }
 
 /* cmask: bit s set => the stage processed at position s multiplies by a compact
- * (8-byte) twiddle, whose rebuilt quotient is 1.5x less accurate */
+ * (8-byte) twiddle, whose quotient estimate (mulmod_c) is 1.5x less accurate */
 constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask = 0)
 {
   /* class ksh: q <= 2^(51-ksh)*(1+2^-10) */

@@ -397,15 +397,12 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
   });
 }
 
+/* full record of butterfly B (non-compact stages only) */
 template <class A, int LOGN, int G, int J, bool INV, int B>
 NTT_HD typename A::tw stage_tw(const StageTw<A> &w, const typename A::consts &c)
 {
   constexpr int F = Plan<LOGN>::BFLY_FIRST(G, J, B);
-  if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
-    return A::expand(w.c[F], c);
-  } else {
-    return w.f[F];
-  }
+  return w.f[F];
 }
 
 template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
@@ -446,6 +443,14 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
       constexpr int E1 = E0 | (1 << AB);
       if(INV && SL == 0 && p.lastinv) {
         A::inv_bfly_last(x[E0], x[E1], p.c);
+      } else if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
+        /* compact twiddle used as is (policy overload taking A::ctw) */
+        constexpr int F = P::BFLY_FIRST(G, J, B);
+        if constexpr(INV) {
+          A::template inv_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);
+        } else {
+          A::template fwd_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);
+        }
       } else if constexpr(INV) {
         A::template inv_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
       } else {
@@ -520,7 +525,7 @@ NTT_HD void run_group_preloaded(typename A::val (&x)[kE], const typename A::ctw 
     static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
-      const typename A::tw w = A::expand(pre[J][P::BFLY_FIRST(G, J, B)], p.c);
+      const typename A::ctw w = pre[J][P::BFLY_FIRST(G, J, B)];
       if constexpr(INV) {
         A::template inv_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
       } else {
@@ -601,7 +606,7 @@ NTT_HD void stream_store(uint64_t *p, uint64_t v)
 }
 NTT_HD void stream_store2(uint64_t *p, u64x2 v)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
+#if defined(__HIP_DEVICE_COMPILE__) && (defined(NTT_USE_NT) || defined(NTT_NT_STORES))
   typedef unsigned long v2u __attribute__((ext_vector_type(2)));
   v2u t;
   t.x = v.a;
@@ -713,9 +718,17 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
   } else {
     /* the schedule is causal, so when the last inverse stage is the folded
      * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
-    /* compact twiddles are expanded with a two-word reciprocal and need no
-     * extra slack (cmask = 0) */
-    return f64_schedule(INV, LOGN, KSH, 1.0, 0).mask;
+    /* stages whose twiddles are compact estimate the quotient from the rounded
+     * product (ArithF64::mulmod_c): 1.5x the error term at those positions */
+    using P        = Plan<LOGN>;
+    uint32_t cmask = 0;
+    for(int g = 0; g < P::NG; g++) {
+      for(int j = 0; j < P::R(g); j++) {
+        const int sl = P::S(g) + j;
+        if(stage_is_compact<A, LOGN, INV>(g, j)) cmask |= 1u << (INV ? LOGN - 1 - sl : sl);
+      }
+    }
+    return f64_schedule(INV, LOGN, KSH, 1.0, cmask).mask;
   }
 }
 

@@ -114,6 +114,27 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* Split workgroup barrier for the write-after-read side of the cross-wave exchange.
+ * gfx950 has only the all-in-one s_barrier; the WAR condition ("every wave has
+ * finished reading the previous block's layout before anyone overwrites it") is
+ * met long before the next scatter, so each wave POSTS when its last LDS read of
+ * a block has been consumed and only CHECKS the count before the next scatter:
+ * waves that arrive early start writing instead of idling at a second barrier.
+ * LDS operations of a wave execute in issue order, so the post (a ds_add) cannot
+ * overtake the wave's earlier reads. */
+__device__ __forceinline__ void war_post(uint32_t *ctr, uint32_t tid)
+{
+  asm volatile("" ::: "memory");
+  if((tid & 63u) == 0u) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void war_wait(uint32_t *ctr, uint32_t target)
+{
+  while((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
 template <class A, int LOGN, int GW, int GR>
 __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
 {
@@ -186,6 +207,9 @@ template <int LOGN, int E0, int E1> __device__ __forceinline__ void prefetch_row
   });
 }
 
+#ifndef NTT_LOAD_AUX
+#  define NTT_LOAD_AUX 2 /* cache-policy bits of the coefficient loads: nt (measured +0.6..1 % over 0; sc0/sc1 no gain) */
+#endif
 /* A block seen through a buffer descriptor: the 16 row loads of a thread then share ONE
  * 32-bit lane offset (t*8) and take the row offset as a scalar operand, instead of a
  * 64-bit per-lane address each (two carry-chained VALU adds per row in the hot loop).
@@ -197,13 +221,13 @@ template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc
 __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, NTT_LOAD_AUX);
   return (uint64_t)v.x | ((uint64_t)v.y << 32);
 }
 __device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NTT_LOAD_AUX);
   return u64x2{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
 }
 
@@ -317,6 +341,18 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         __syncthreads();
       }
     }
+    /* measured: no gain over the plain second s_barrier (17.0 vs 17.1 M NTT/s), so opt-in */
+#ifdef NTT_SPLIT_WAR_BARRIER
+    constexpr bool SPLIT = VT == 1 && !P::WAVE_LOCAL(0, 1);
+#else
+    constexpr bool SPLIT = false;
+#endif
+    __shared__ uint32_t war_ctr;
+    uint32_t            war_it = 0;
+    if constexpr(SPLIT) {
+      if(tid == 0) war_ctr = 0;
+      __syncthreads();
+    }
 #ifdef NTT_STAGGER
     /* de-phase neighbouring CUs so that their HBM bursts do not coincide */
     for(int i = 0; i < (int)(blockIdx.x % NTT_STAGGER); i++) __builtin_amdgcn_s_sleep(127);
@@ -371,6 +407,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           constexpr int V = decltype(vv)::value;
           prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
         });
+#ifdef NTT_TOUCH_AHEAD
+        /* experiment: one 4-byte load per 128-byte line of the block after next, result
+         * unused -- pulls it towards L2 / Infinity Cache without holding registers */
+        {
+          const uint64_t tb = b + (uint64_t)NTT_TOUCH_AHEAD * stride < p.nblocks ? b + (uint64_t)NTT_TOUCH_AHEAD * stride : b;
+          const volatile uint32_t *tp = reinterpret_cast<const volatile uint32_t *>(p.a + (tb << LOGN)) + tid * ((8u << LOGN) / G::WG / 4u);
+          (void)*tp;
+        }
+#endif
       }
 #endif
       STAMP(0); /* wait for prefetched coefficients + convert */
@@ -381,7 +426,14 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
-        exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+        if constexpr(SPLIT && GI == 0) {
+          war_wait(&war_ctr, war_it * (uint32_t)(G::WG / 64));
+          lds_scatter<A, LOGN, 0, 1>(x[0], tid, lds_all);
+          __syncthreads();
+          lds_gather<A, LOGN, 0, 1>(x[0], tid, lds_all);
+        } else {
+          exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+        }
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
 #if 1
         /* blocks of a multi-pass transform: request the last group's twiddles right after the first exchange */
@@ -435,6 +487,11 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         });
         STAMP(3 + 2 * GI); /* prefetch issue (GI==0) + group GI+1 */
       });
+      if constexpr(SPLIT) {
+        /* every LDS read of this block has been consumed by the last group */
+        war_post(&war_ctr, tid);
+        war_it++;
+      }
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);

@@ -16,7 +16,10 @@ namespace ntt {
 
 constexpr int kFusedMin   = 6;
 constexpr int kFusedMax   = 14;
-constexpr int kFusedLarge = 13; /* block size used below column passes */
+#ifndef NTT_FUSED_LARGE
+#  define NTT_FUSED_LARGE 13
+#endif
+constexpr int kFusedLarge = NTT_FUSED_LARGE; /* block size used below column passes */
 
 struct Pass {
   int fused; /* 1: fused block pass, 0: column pass            */

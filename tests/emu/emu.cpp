@@ -50,6 +50,16 @@ struct ArithF64Chk : ArithF64 {
     if(rb > g_chk_maxr) g_chk_maxr = rb;
     return r;
   }
+  static double mulmod_c(ctw w, double y, const consts &c)
+  {
+    const double   r  = ArithF64::mulmod_c(w, y, c);
+    const __int128 q  = (__int128)c.qi;
+    const __int128 ex = as_int(y) * as_int(w);
+    if((ex - as_int(r)) % q != 0) g_chk_fail++;            /* r == y*w (mod q), exactly */
+    const double rb = __builtin_fabs(r) / c.q;
+    if(rb > g_chk_maxr) g_chk_maxr = rb;
+    return r;
+  }
   static double reduce(double v, const consts &c)
   {
     const double   r = ArithF64::reduce(v, c);
@@ -78,6 +88,28 @@ struct ArithF64Chk : ArithF64 {
     see(d, c);
     x = RED ? reduce(s, c) : s;
     y = mulmod(t, d, c);
+  }
+  template <bool RED> static void fwd_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double xr = RED ? reduce(x, c) : x;
+    const double m  = mulmod_c(w, y, c);
+    x               = xr + m;
+    y               = xr - m;
+    see(x, c);
+    see(y, c);
+  }
+  template <bool RED> static void inv_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double s = x + y;
+    const double d = x - y;
+    see(s, c);
+    see(d, c);
+    x = RED ? reduce(s, c) : s;
+    y = mulmod_c(w, d, c);
   }
   static void inv_bfly_last(val &x, val &y, const consts &c)
   {
