@@ -437,13 +437,24 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
     if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW>(wcur, ib, blk, p, ltw);
     if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
-    static_for<0, kE / 2>([&](auto bb) {
+    /* the stage that may carry the folded N^-1: ONE wave-uniform branch around its
+     * eight butterflies (not one per butterfly) */
+    bool folded = false;
+    if constexpr(INV && SL == 0) {
+      if(p.lastinv) {
+        folded = true;
+        static_for<0, kE / 2>([&](auto bb) {
+          constexpr int B  = decltype(bb)::value;
+          constexpr int E0 = P::BFLY_E0(G, J, B);
+          A::inv_bfly_last(x[E0], x[E0 | (1 << AB)], p.c);
+        });
+      }
+    }
+    if(!folded) static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = P::BFLY_E0(G, J, B);
       constexpr int E1 = E0 | (1 << AB);
-      if(INV && SL == 0 && p.lastinv) {
-        A::inv_bfly_last(x[E0], x[E1], p.c);
-      } else if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
+      if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
         /* compact twiddle used as is (policy overload taking A::ctw) */
         constexpr int F = P::BFLY_FIRST(G, J, B);
         if constexpr(INV) {

@@ -231,6 +231,48 @@ __device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uin
   return u64x2{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
 }
 
+/* the inverse loop's final stores (slot e <-> index (e << LT) + t, 8 bytes per lane) through
+ * the block descriptor: one lane offset, the row offset as a scalar operand */
+template <class A, int LOGN>
+__device__ __forceinline__ void buffer_store_first_inv(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk, const typename A::consts &c)
+{
+  using P                        = Plan<LOGN>;
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+  static_for<0, kE>([&](auto ee) {
+    constexpr int  E = decltype(ee)::value;
+    const uint64_t a = A::store_inv(x[E], c);
+    v2u32          v;
+    v.x = (unsigned)a;
+    v.y = (unsigned)(a >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(t * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
+  });
+}
+
+#ifdef NTT_STORE_AUX
+/* experiment: the forward loop's final stores through the block descriptor with explicit
+ * cache-policy bits (1 = sc0, 2 = nt, 16 = sc1) */
+template <class A, int LOGN>
+__device__ __forceinline__ void buffer_store_last(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk, const typename A::consts &c)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int  E = 2 * decltype(hh)::value;
+    const uint64_t a = A::store_fwd(x[E], c), b = A::store_fwd(x[E + 1], c);
+    v4u32          v;
+    v.x = (unsigned)a;
+    v.y = (unsigned)(a >> 32);
+    v.z = (unsigned)b;
+    v.w = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(P::IOFF(G, E) * 8u), NTT_STORE_AUX);
+  });
+}
+#endif
+
 /* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
 template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
 {
@@ -494,7 +536,11 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       }
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
+#ifdef NTT_STORE_AUX
+        buffer_store_last<A, LOGN>(x[V], tid + V * G::WG, base, p.c);
+#else
         global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
+#endif
       });
       STAMP(10); /* final reduction + stores */
     }
@@ -574,7 +620,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         }
       });
       if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
-      global_store_first<A, LOGN, true>(x, tid, base, p.c);
+      buffer_store_first_inv<A, LOGN>(x, tid, base, p.c);
     }
     return;
   }

@@ -3,7 +3,8 @@
  *
  *   6 <= m <= 14 : one fused pass (block = whole polynomial, one HBM round trip)
  *   m  > 14      : strided column passes of <= 4 stages over the leading
- *                  m-13 stages, then one fused pass over 2^13-point blocks
+ *                  m-14 stages, then one fused pass over 2^14-point blocks
+ *                  (measured 2-6 % faster than 2^13-point blocks)
  *                  (two or more HBM round trips; reference sizes m = 15,16,17,
  *                  tests/test_cases.h:184-203)
  *   m  < 6       : column passes only
@@ -17,7 +18,7 @@ namespace ntt {
 constexpr int kFusedMin   = 6;
 constexpr int kFusedMax   = 14;
 #ifndef NTT_FUSED_LARGE
-#  define NTT_FUSED_LARGE 13
+#  define NTT_FUSED_LARGE 14
 #endif
 constexpr int kFusedLarge = NTT_FUSED_LARGE; /* block size used below column passes */
 
