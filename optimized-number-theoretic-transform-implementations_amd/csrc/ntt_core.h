@@ -405,6 +405,84 @@ NTT_HD typename A::tw stage_tw(const StageTw<A> &w, const typename A::consts &c)
   return w.f[F];
 }
 
+/* ------------------------------------------------------------------ */
+/* which butterflies reduce (ArithF64)                                   */
+/* ------------------------------------------------------------------ */
+/*
+ * Forward (Cooley-Tukey): both outputs of a butterfly carry the same bound, so a
+ * stage either reduces its eight unmultiplied operands or none: MASK bit per
+ * processing position (f64_schedule).
+ *
+ * Inverse (Gentleman-Sande): the sum output doubles the bound while the product
+ * output comes back near q/2, and the next stage pairs sums with sums and
+ * products with products (the partner differs only in a bit not yet processed).
+ * Bounds are therefore tracked PER SLOT inside a group -- all slots of a thread
+ * share the worst case at a group boundary, where the partner's history is not
+ * known at compile time -- and a sum is reduced only when keeping it would push
+ * the next sum past the exactness limit.  At q ~ 2^51 this reduces 73 of the 112
+ * sums of a 2^14 block instead of all of them.  MASK = kRedPlanFlag | KSH selects
+ * this plan; the very last stage never reduces (its outputs are canonicalised or
+ * multiplied by N^-1, both exact below 2^53).
+ */
+constexpr uint32_t kRedPlanFlag = 0x80000000u;
+
+struct RedPlan {
+  uint8_t red[4][4]; /* [group][local stage]: bit b => butterfly b reduces its sum */
+  bool    ok;        /* every sum stays below the limit                            */
+  double  bout;      /* worst-case |value|/q leaving the block                     */
+};
+
+template <class A, int LOGN, int KSH> constexpr RedPlan make_inv_red_plan()
+{
+  using P = Plan<LOGN>;
+  RedPlan rp{};
+  rp.ok         = true;
+  double theta2 = 0.25 * 1.001;
+  double lim    = 4.0 / 1.001;
+  for(int i = 0; i < KSH; i++) {
+    theta2 *= 0.5;
+    lim *= 2.0;
+  }
+  lim *= (1.0 - 1.0 / 64.0);
+  double b_in = 1.0; /* inputs in [0,q) */
+  for(int g = P::NG - 1; g >= 0; g--) {
+    double bnd[kE] = {};
+    for(int e = 0; e < kE; e++) bnd[e] = b_in;
+    for(int jj = 0; jj < P::R(g); jj++) {
+      const int    j    = P::R(g) - 1 - jj;
+      const double t2   = stage_is_compact<A, LOGN, true>(g, j) ? 1.5 * theta2 : theta2;
+      const bool   last = (g == 0 && j == 0);
+      const int    ab   = P::ABIT(g, j);
+      for(int b = 0; b < kE / 2; b++) {
+        const int    e0 = P::BFLY_E0(g, j, b);
+        const int    e1 = e0 | (1 << ab);
+        const double sm = bnd[e0] + bnd[e1];
+        if(sm > lim) rp.ok = false;
+        const bool keep = last || (2.0 * sm <= lim);
+        if(!keep) rp.red[g][j] = (uint8_t)(rp.red[g][j] | (1u << b));
+        bnd[e0] = keep ? sm : 0.501;
+        bnd[e1] = f64_rho(sm, t2);
+      }
+    }
+    b_in = 0.0;
+    for(int e = 0; e < kE; e++) b_in = bnd[e] > b_in ? bnd[e] : b_in;
+  }
+  rp.bout = b_in;
+  return rp;
+}
+
+template <class A, int LOGN, bool INV, uint32_t MASK> constexpr bool bfly_reduces(int g, int j, int b)
+{
+  if constexpr(INV && (MASK & kRedPlanFlag) != 0) {
+    constexpr RedPlan rp = make_inv_red_plan<A, LOGN, (int)(MASK & 0xFFu)>();
+    static_assert(rp.ok, "inverse reduction plan exceeds the FP64 exactness limit");
+    return (rp.red[g][j] >> b) & 1u;
+  } else {
+    const int sl = Plan<LOGN>::S(g) + j;
+    return (MASK >> (INV ? (LOGN - 1 - sl) : sl)) & 1u;
+  }
+}
+
 template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
@@ -430,8 +508,6 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int J  = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
     constexpr int SL = SG + J;                 /* local stage              */
     constexpr int AB = P::ABIT(G, J);
-    constexpr int POS = INV ? (LOGN - 1 - SL) : SL; /* processing position */
-    constexpr bool RED = (MASK >> POS) & 1u;
     constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
     constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
     constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
@@ -454,6 +530,7 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = P::BFLY_E0(G, J, B);
       constexpr int E1 = E0 | (1 << AB);
+      constexpr bool RED = bfly_reduces<A, LOGN, INV, MASK>(G, J, B);
       if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
         /* compact twiddle used as is (policy overload taking A::ctw) */
         constexpr int F = P::BFLY_FIRST(G, J, B);
@@ -529,13 +606,11 @@ NTT_HD void run_group_preloaded(typename A::val (&x)[kE], const typename A::ctw 
   constexpr int R = P::R(G);
   static_for<0, R>([&](auto jj) {
     constexpr int  J   = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
-    constexpr int  SL  = P::S(G) + J;
     constexpr int  AB  = P::ABIT(G, J);
-    constexpr int  POS = INV ? (LOGN - 1 - SL) : SL;
-    constexpr bool RED = (MASK >> POS) & 1u;
     static_for<0, kE / 2>([&](auto bb) {
-      constexpr int B  = decltype(bb)::value;
-      constexpr int E0 = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      constexpr int  B   = decltype(bb)::value;
+      constexpr int  E0  = ((B >> AB) << (AB + 1)) | (B & ((1 << AB) - 1));
+      constexpr bool RED = bfly_reduces<A, LOGN, INV, MASK>(G, J, B);
       const typename A::ctw w = pre[J][P::BFLY_FIRST(G, J, B)];
       if constexpr(INV) {
         A::template inv_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
@@ -731,6 +806,7 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
      * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
     /* stages whose twiddles are compact estimate the quotient from the rounded
      * product (ArithF64::mulmod_c): 1.5x the error term at those positions */
+    if constexpr(INV) return kRedPlanFlag | (uint32_t)KSH; /* per-butterfly plan (bfly_reduces) */
     using P        = Plan<LOGN>;
     uint32_t cmask = 0;
     for(int g = 0; g < P::NG; g++) {

@@ -427,6 +427,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[VT][kE];
+#ifdef NTT_PRIO_MEM
+      __builtin_amdgcn_s_setprio(NTT_PRIO_MEM);
+#endif
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
@@ -459,6 +462,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         }
 #endif
       }
+#endif
+#ifdef NTT_PRIO_MEM
+      __builtin_amdgcn_s_setprio(0);
 #endif
       STAMP(0); /* wait for prefetched coefficients + convert */
       static_for<0, VT>([&](auto vv) {
@@ -536,12 +542,18 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       }
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
+#ifdef NTT_PRIO_ST
+        __builtin_amdgcn_s_setprio(NTT_PRIO_ST);
+#endif
 #ifdef NTT_STORE_AUX
         buffer_store_last<A, LOGN>(x[V], tid + V * G::WG, base, p.c);
 #else
         global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
 #endif
       });
+#ifdef NTT_PRIO_ST
+      __builtin_amdgcn_s_setprio(0);
+#endif
       STAMP(10); /* final reduction + stores */
     }
     return;
