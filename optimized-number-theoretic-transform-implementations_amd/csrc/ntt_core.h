@@ -661,47 +661,14 @@ struct alignas(16) u64x2 {
   uint64_t a, b;
 };
 
-/* Coefficient traffic is read once and written once per launch.  A non-temporal
- * (streaming) cache policy for it was measured and LOSES 9 % on this kernel
- * (profiles/r01: 14.7 vs 16.2 M NTT/s), so it is opt-in only (-DNTT_USE_NT). */
-NTT_HD uint64_t stream_load(const uint64_t *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-NTT_HD u64x2 stream_load2(const uint64_t *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
-  typedef unsigned long v2u __attribute__((ext_vector_type(2)));
-  const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
-  return u64x2{v.x, v.y};
-#else
-  return *reinterpret_cast<const u64x2 *>(p);
-#endif
-}
-NTT_HD void stream_store(uint64_t *p, uint64_t v)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NTT_USE_NT)
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-NTT_HD void stream_store2(uint64_t *p, u64x2 v)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && (defined(NTT_USE_NT) || defined(NTT_NT_STORES))
-  typedef unsigned long v2u __attribute__((ext_vector_type(2)));
-  v2u t;
-  t.x = v.a;
-  t.y = v.b;
-  __builtin_nontemporal_store(t, reinterpret_cast<v2u *>(p));
-#else
-  *reinterpret_cast<u64x2 *>(p) = v;
-#endif
-}
+/* Coefficient traffic is read once and written once per launch.  Cache-policy hints were
+ * measured on the 2^14 kernel (profiles/r01/ablations.txt): non-temporal STORES lose 4 %,
+ * sc1 stores 36 %; nt on the LOADS gains 0.6-1 % and is applied where the persistent loops
+ * issue them (ntt_kernels.h, buffer loads).  These generic helpers stay plain. */
+NTT_HD uint64_t stream_load(const uint64_t *p) { return *p; }
+NTT_HD u64x2    stream_load2(const uint64_t *p) { return *reinterpret_cast<const u64x2 *>(p); }
+NTT_HD void     stream_store(uint64_t *p, uint64_t v) { *p = v; }
+NTT_HD void     stream_store2(uint64_t *p, u64x2 v) { *reinterpret_cast<u64x2 *>(p) = v; }
 
 /* coefficient addresses as wave-uniform row pointer + 32-bit lane byte offset (a
  * block is at most 2^14 coefficients), so that loads/stores take the

@@ -114,27 +114,6 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* Split workgroup barrier for the write-after-read side of the cross-wave exchange.
- * gfx950 has only the all-in-one s_barrier; the WAR condition ("every wave has
- * finished reading the previous block's layout before anyone overwrites it") is
- * met long before the next scatter, so each wave POSTS when its last LDS read of
- * a block has been consumed and only CHECKS the count before the next scatter:
- * waves that arrive early start writing instead of idling at a second barrier.
- * LDS operations of a wave execute in issue order, so the post (a ds_add) cannot
- * overtake the wave's earlier reads. */
-__device__ __forceinline__ void war_post(uint32_t *ctr, uint32_t tid)
-{
-  asm volatile("" ::: "memory");
-  if((tid & 63u) == 0u) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void war_wait(uint32_t *ctr, uint32_t target)
-{
-  while((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-    __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-}
-
 template <class A, int LOGN, int GW, int GR>
 __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
 {
@@ -184,27 +163,8 @@ __device__ __forceinline__ void exchange_vt(typename A::val (&x)[VT][kE], uint32
     __syncthreads();
     static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
     __syncthreads();
-#ifdef NTT_WAVE_STAGGER
-    /* de-phase the waves that share a SIMD (w, w+4, w+8, w+12) so that their
-     * wave-local exchanges and twiddle waits do not coincide */
-    {
-      const int k_ = (int)(__builtin_amdgcn_readfirstlane((int)(tid >> 8)) & 3);
-      for(int i = 0; i < k_; i++) __builtin_amdgcn_s_sleep(NTT_WAVE_STAGGER);
-    }
-#endif
     static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
   }
-}
-
-/* rows [E0,E1) of the first-kind group's raw coefficients (chunked prefetch variant) */
-template <int LOGN, int E0, int E1> __device__ __forceinline__ void prefetch_rows(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
-{
-  using P = Plan<LOGN>;
-  static_for<E0, E1>([&](auto ee) {
-    constexpr int   E   = decltype(ee)::value;
-    const uint64_t *row = blk + ((uint32_t)E << P::LT);
-    raw[E]              = stream_load(coef_at(row, t));
-  });
 }
 
 #ifndef NTT_LOAD_AUX
@@ -248,30 +208,6 @@ __device__ __forceinline__ void buffer_store_first_inv(const typename A::val (&x
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(t * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
   });
 }
-
-#ifdef NTT_STORE_AUX
-/* experiment: the forward loop's final stores through the block descriptor with explicit
- * cache-policy bits (1 = sc0, 2 = nt, 16 = sc1) */
-template <class A, int LOGN>
-__device__ __forceinline__ void buffer_store_last(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk, const typename A::consts &c)
-{
-  using P           = Plan<LOGN>;
-  constexpr int G   = P::NG - 1;
-  const uint32_t ib = P::IBASE(G, t);
-  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
-  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-  static_for<0, kE / 2>([&](auto hh) {
-    constexpr int  E = 2 * decltype(hh)::value;
-    const uint64_t a = A::store_fwd(x[E], c), b = A::store_fwd(x[E + 1], c);
-    v4u32          v;
-    v.x = (unsigned)a;
-    v.y = (unsigned)(a >> 32);
-    v.z = (unsigned)b;
-    v.w = (unsigned)(b >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(P::IOFF(G, E) * 8u), NTT_STORE_AUX);
-  });
-}
-#endif
 
 /* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
 template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
@@ -344,9 +280,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     constexpr int  VT     = G::VT;
     constexpr int  GL     = P::NG - 1;          /* last group                      */
     constexpr int  GT     = P::NG - 2;          /* group fed from the LDS table    */
-#ifndef NTT_PRE_AT
-#  define NTT_PRE_AT 0
-#endif
 #ifdef NTT_NO_PRELOAD_LAST
     constexpr bool PRE    = false;
 #else
@@ -383,22 +316,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         __syncthreads();
       }
     }
-    /* measured: no gain over the plain second s_barrier (17.0 vs 17.1 M NTT/s), so opt-in */
-#ifdef NTT_SPLIT_WAR_BARRIER
-    constexpr bool SPLIT = VT == 1 && !P::WAVE_LOCAL(0, 1);
-#else
-    constexpr bool SPLIT = false;
-#endif
-    __shared__ uint32_t war_ctr;
-    uint32_t            war_it = 0;
-    if constexpr(SPLIT) {
-      if(tid == 0) war_ctr = 0;
-      __syncthreads();
-    }
-#ifdef NTT_STAGGER
-    /* de-phase neighbouring CUs so that their HBM bursts do not coincide */
-    for(int i = 0; i < (int)(blockIdx.x % NTT_STAGGER); i++) __builtin_amdgcn_s_sleep(127);
-#endif
     uint64_t raw[VT][kE];
     static_for<0, VT>([&](auto vv) {
       constexpr int V = decltype(vv)::value;
@@ -407,65 +324,29 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
 #endif
+    /* the last group's per-lane twiddles (8-byte form), requested once per block right
+     * after the first exchange.  Keeping them in registers across blocks was tried and
+     * spills -- and a spill reload waits for the whole prefetch (vmcnt) */
     typename A::ctw pre[VT][4][kE / 2];
-    /* 2^14 blocks are only ever whole polynomials (ntt_passplan.h: s0 == 0), so
-     * these twiddles do not depend on the block: the stages in RESIDENT are
-     * loaded once per launch, the others once per block right after the first
-     * exchange (the register allocator decides how much can stay: more than
-     * this spills, and a spill reload waits for the whole prefetch -- vmcnt) */
-#ifndef NTT_PRE_RESIDENT
-#  define NTT_PRE_RESIDENT 0
-#endif
-    constexpr uint32_t RESIDENT = PRE ? (uint32_t)NTT_PRE_RESIDENT : 0u;
-    if constexpr(RESIDENT != 0) {
-      static_for<0, VT>([&](auto vv) {
-        constexpr int V = decltype(vv)::value;
-        preload_group_tw<A, LOGN, GL, RESIDENT>(pre[V], tid + V * G::WG, 0, p);
-      });
-    }
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[VT][kE];
-#ifdef NTT_PRIO_MEM
-      __builtin_amdgcn_s_setprio(NTT_PRIO_MEM);
-#endif
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
         convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
       });
-#if defined(NTT_PF_SPREAD)
-      {
-        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-        static_for<0, VT>([&](auto vv) {
-          constexpr int V = decltype(vv)::value;
-          prefetch_rows<LOGN, 0, 4>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
-        });
-      }
-#elif !defined(NTT_PF_LATE) && !defined(NTT_PF_MID)
       {
         /* request the next block as soon as this block's raw words have been consumed:
          * its HBM loads are then in flight for the whole iteration (measured best of
-         * three placements: after the first exchange -4%, inside the last group -3%) */
+         * four placements: after the first exchange -4 %, inside the last group -3 %,
+         * a quarter after every exchange -7 %; profiles/r01/ablations.txt) */
         const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
         static_for<0, VT>([&](auto vv) {
           constexpr int V = decltype(vv)::value;
           prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
         });
-#ifdef NTT_TOUCH_AHEAD
-        /* experiment: one 4-byte load per 128-byte line of the block after next, result
-         * unused -- pulls it towards L2 / Infinity Cache without holding registers */
-        {
-          const uint64_t tb = b + (uint64_t)NTT_TOUCH_AHEAD * stride < p.nblocks ? b + (uint64_t)NTT_TOUCH_AHEAD * stride : b;
-          const volatile uint32_t *tp = reinterpret_cast<const volatile uint32_t *>(p.a + (tb << LOGN)) + tid * ((8u << LOGN) / G::WG / 4u);
-          (void)*tp;
-        }
-#endif
       }
-#endif
-#ifdef NTT_PRIO_MEM
-      __builtin_amdgcn_s_setprio(0);
-#endif
       STAMP(0); /* wait for prefetched coefficients + convert */
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
@@ -474,53 +355,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
-        if constexpr(SPLIT && GI == 0) {
-          war_wait(&war_ctr, war_it * (uint32_t)(G::WG / 64));
-          lds_scatter<A, LOGN, 0, 1>(x[0], tid, lds_all);
-          __syncthreads();
-          lds_gather<A, LOGN, 0, 1>(x[0], tid, lds_all);
-        } else {
-          exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
-        }
+        exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
-#if 1
-        /* blocks of a multi-pass transform: request the last group's twiddles right after the first exchange */
-        if constexpr(PRE && GI == NTT_PRE_AT && (RESIDENT & 0xFu) != 0xFu) {
+        if constexpr(PRE && GI == 0) {
           static_for<0, VT>([&](auto vv) {
             constexpr int V = decltype(vv)::value;
-            preload_group_tw<A, LOGN, GL, 0xFu & ~RESIDENT>(pre[V], tid + V * G::WG, blk, p);
-          });
-        }
-#endif
-#ifdef NTT_PF_SPREAD
-        {
-          /* variant: a quarter of the next block's rows after every exchange */
-          const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-          static_for<0, VT>([&](auto vv) {
-            constexpr int V = decltype(vv)::value;
-            prefetch_rows<LOGN, 4 * (GI + 1), 4 * (GI + 2)>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
-          });
-        }
-#endif
-#ifdef NTT_PF_LATE
-        /* variant: all of the last group's twiddles first, then the next block's
-         * coefficients -- nothing this block still waits for is queued behind HBM */
-        if constexpr(GI + 1 == GL) {
-          if constexpr(PRE) {
-            static_for<0, VT>([&](auto vv) {
-              constexpr int V = decltype(vv)::value;
-              preload_group_tw<A, LOGN, GL>(pre[V], tid + V * G::WG, blk, p);
-            });
-          }
-#elif defined(NTT_PF_MID)
-        if constexpr(GI == 0) {
-#else
-        if constexpr(false) {
-#endif
-          const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-          static_for<0, VT>([&](auto vv) {
-            constexpr int V = decltype(vv)::value;
-            prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
+            preload_group_tw<A, LOGN, GL>(pre[V], tid + V * G::WG, blk, p);
           });
         }
         static_for<0, VT>([&](auto vv) {
@@ -533,27 +373,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
             run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
           }
         });
-        STAMP(3 + 2 * GI); /* prefetch issue (GI==0) + group GI+1 */
+        STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
-      if constexpr(SPLIT) {
-        /* every LDS read of this block has been consumed by the last group */
-        war_post(&war_ctr, tid);
-        war_it++;
-      }
       static_for<0, VT>([&](auto vv) {
         constexpr int V = decltype(vv)::value;
-#ifdef NTT_PRIO_ST
-        __builtin_amdgcn_s_setprio(NTT_PRIO_ST);
-#endif
-#ifdef NTT_STORE_AUX
-        buffer_store_last<A, LOGN>(x[V], tid + V * G::WG, base, p.c);
-#else
         global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
-#endif
       });
-#ifdef NTT_PRIO_ST
-      __builtin_amdgcn_s_setprio(0);
-#endif
       STAMP(10); /* final reduction + stores */
     }
     return;
