@@ -121,6 +121,9 @@ def test_f64_exactness_claims_hold(kat, oracle, emu, i):
         assert rc == 0 and np.array_equal(got, cx.fwd(a))
         rc, back = emu.transform(got, m, q, w, CHK, inverse=True)
         assert rc == 0 and np.array_equal(back, a)
+        # the inverse's per-slot reduction plan on inputs it does not get from a forward transform
+        rc, inv = emu.transform(a, m, q, w, CHK, inverse=True)
+        assert rc == 0 and np.array_equal(inv, cx.inv(a))
     fails, maxb, maxr = emu.chk_stats()
     assert fails == 0
     lim = 2.0 ** 53 / q
