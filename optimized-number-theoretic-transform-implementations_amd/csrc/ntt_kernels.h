@@ -26,31 +26,19 @@
 
 namespace ntt {
 
-#ifndef NTT_VT14
-#  define NTT_VT14 1
-#endif
 #ifndef NTT_PRE_ALSO
 #  define NTT_PRE_ALSO 0
 #endif
 #ifndef NTT_LTW_ALSO
 #  define NTT_LTW_ALSO 0 /* experiments: a second block size that keeps an LDS twiddle table */
 #endif
-#ifndef NTT_VT13
-#  define NTT_VT13 1
-#endif
 
 template <int LOGN, bool INV, bool COMPACT> struct Geom {
   using P = Plan<LOGN>;
-  /* VT "virtual threads" of the plan executed by one hardware thread (VT = 2
-   * halves the waves per workgroup and doubles the VGPR budget to 256).  Kept
-   * as an experiment switch (-DNTT_VT14=2): measured 14.5 vs 16.0 M NTT/s, the
-   * 4-waves-per-SIMD geometry hides LDS and L2 latencies better. */
-#ifdef NTT_NO_PREFETCH
-  static constexpr int VT  = 1;
-#else
-  static constexpr int VT  = INV ? 1 : (LOGN == 14 ? NTT_VT14 : (LOGN == 13 ? NTT_VT13 : 1));
-#endif
-  static constexpr int WG  = P::T < 256 ? 256 : P::T / VT; /* threads per workgroup */
+  /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
+   * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
+   * and L2 latencies better.) */
+  static constexpr int WG  = P::T < 256 ? 256 : P::T;      /* threads per workgroup */
   static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
   /* compact twiddles of the second-to-last group kept in LDS for the whole
    * launch (entries; 0 = not used): 2^14 -> stages 8..11 = 3840 doubles = 30 KB,
@@ -69,7 +57,7 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x): what
    * the LDS footprint lets be resident, at most 4 */
   static constexpr int WPS0 = (WG_PER_CU0 * (WG / 64)) / 4;
-  static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > 4 / VT ? 4 / VT : WPS0);
+  static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > 4 ? 4 : WPS0);
 };
 
 #ifdef NTT_STAMPS
@@ -84,13 +72,10 @@ __device__ __forceinline__ unsigned long long stamp_now()
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
-template <class T, int VTN> __device__ __forceinline__ void pin_all(T (&x)[VTN][kE])
+template <class T> __device__ __forceinline__ void pin_all(T (&x)[kE])
 {
 #pragma unroll
-  for(int v = 0; v < VTN; v++) {
-#pragma unroll
-    for(int e = 0; e < kE; e++) asm volatile("" ::"v"(x[v][e]));
-  }
+  for(int e = 0; e < kE; e++) asm volatile("" ::"v"(x[e]));
 }
 #  define STAMP(ph)                                                                                   \
     do {                                                                                              \
@@ -136,34 +121,6 @@ __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, t
     lds_scatter<A, LOGN, GW, GR>(x, t, lds);
     __syncthreads();
     lds_gather<A, LOGN, GW, GR>(x, t, lds);
-  }
-}
-
-/* the same exchange for VT virtual threads per hardware thread (virtual thread
- * v of hardware thread tid is plan thread tid + v*WG; both live in the same
- * virtual wave pair, so wave-locality is preserved) */
-template <class A, int LOGN, int GW, int GR, int VT, int WG>
-__device__ __forceinline__ void exchange_vt(typename A::val (&x)[VT][kE], uint32_t tid, typename A::val *lds)
-{
-  using P = Plan<LOGN>;
-#ifdef NTT_ABL_NOEXCH
-  return;
-#endif
-#ifdef NTT_SAFE_BARRIERS
-  constexpr bool local = false;
-#else
-  constexpr bool local = P::WAVE_LOCAL(GW, GR);
-#endif
-  if constexpr(local) {
-    static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
-    wave_sync();
-    static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
-    wave_sync();
-  } else {
-    __syncthreads();
-    static_for<0, VT>([&](auto vv) { lds_scatter<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
-    __syncthreads();
-    static_for<0, VT>([&](auto vv) { lds_gather<A, LOGN, GW, GR>(x[decltype(vv)::value], tid + decltype(vv)::value * WG, lds); });
   }
 }
 
@@ -277,7 +234,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * through the scalar cache.  So no twiddle wait ever sits behind HBM loads,
    * and the prefetched block lands during ~10 stages of butterflies. */
   if constexpr(!INV && G::BPW == 1) {
-    constexpr int  VT     = G::VT;
     constexpr int  GL     = P::NG - 1;          /* last group                      */
     constexpr int  GT     = P::NG - 2;          /* group fed from the LDS table    */
 #ifdef NTT_NO_PRELOAD_LAST
@@ -316,69 +272,46 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         __syncthreads();
       }
     }
-    uint64_t raw[VT][kE];
-    static_for<0, VT>([&](auto vv) {
-      constexpr int V = decltype(vv)::value;
-      prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (b << LOGN));
-    });
+    uint64_t raw[kE];
+    prefetch_first<LOGN>(raw, tid, p.a + (b << LOGN));
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
 #endif
     /* the last group's per-lane twiddles (8-byte form), requested once per block right
      * after the first exchange.  Keeping them in registers across blocks was tried and
      * spills -- and a spill reload waits for the whole prefetch (vmcnt) */
-    typename A::ctw pre[VT][4][kE / 2];
+    typename A::ctw pre[4][kE / 2];
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
-      typename A::val x[VT][kE];
-      static_for<0, VT>([&](auto vv) {
-        constexpr int V = decltype(vv)::value;
-        convert_inputs<A, false>(x[V], raw[V], p.wide != 0, p.c);
-      });
+      typename A::val x[kE];
+      convert_inputs<A, false>(x, raw, p.wide != 0, p.c);
       {
         /* request the next block as soon as this block's raw words have been consumed:
          * its HBM loads are then in flight for the whole iteration (measured best of
          * four placements: after the first exchange -4 %, inside the last group -3 %,
          * a quarter after every exchange -7 %; profiles/r01/ablations.txt) */
         const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-        static_for<0, VT>([&](auto vv) {
-          constexpr int V = decltype(vv)::value;
-          prefetch_first<LOGN>(raw[V], tid + V * G::WG, p.a + (nb << LOGN));
-        });
+        prefetch_first<LOGN>(raw, tid, p.a + (nb << LOGN));
       }
       STAMP(0); /* wait for prefetched coefficients + convert */
-      static_for<0, VT>([&](auto vv) {
-        constexpr int V = decltype(vv)::value;
-        run_group<A, LOGN, 0, false, MASK>(x[V], tid + V * G::WG, blk, p);
-      });
+      run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
       STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
-        exchange_vt<A, LOGN, GI, GI + 1, VT, G::WG>(x, tid, lds_all);
+        exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
-        if constexpr(PRE && GI == 0) {
-          static_for<0, VT>([&](auto vv) {
-            constexpr int V = decltype(vv)::value;
-            preload_group_tw<A, LOGN, GL>(pre[V], tid + V * G::WG, blk, p);
-          });
+        if constexpr(PRE && GI == 0) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+        if constexpr(PRE && GI + 1 == GL) {
+          run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+        } else if constexpr(GI + 1 == GT && LTW) {
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw);
+        } else {
+          run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
         }
-        static_for<0, VT>([&](auto vv) {
-          constexpr int V = decltype(vv)::value;
-          if constexpr(PRE && GI + 1 == GL) {
-            run_group_preloaded<A, LOGN, GL, MASK>(x[V], pre[V], p);
-          } else if constexpr(GI + 1 == GT && LTW) {
-            run_group<A, LOGN, GI + 1, false, MASK, true>(x[V], tid + V * G::WG, blk, p, ltw);
-          } else {
-            run_group<A, LOGN, GI + 1, false, MASK>(x[V], tid + V * G::WG, blk, p);
-          }
-        });
         STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
-      static_for<0, VT>([&](auto vv) {
-        constexpr int V = decltype(vv)::value;
-        global_store_last<A, LOGN, false>(x[V], tid + V * G::WG, base, p.c);
-      });
+      global_store_last<A, LOGN, false>(x, tid, base, p.c);
       STAMP(10); /* final reduction + stores */
     }
     return;
@@ -390,7 +323,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * twiddles, the next one reads the LDS-resident table, the remaining stages are
    * wave-uniform; coefficients come in as 16-byte loads and leave as coalesced
    * 8-byte stores. */
-  if constexpr(INV && G::BPW == 1 && G::VT == 1) {
+  if constexpr(INV && G::BPW == 1) {
     constexpr int  GL     = P::NG - 1;
     constexpr int  GT     = P::NG - 2;
     constexpr bool LTW    = LDS_TW > 0;
@@ -463,8 +396,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
   }
 #endif
 
-  /* generic loop: inverse transforms, small blocks (several per workgroup) */
-  if constexpr(G::VT == 1)
+  /* generic loop: small blocks (several per workgroup), and every size in the NTT_NO_PREFETCH build */
   for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
     uint64_t   b    = b0 + sub;
     const bool live = b < p.nblocks;
