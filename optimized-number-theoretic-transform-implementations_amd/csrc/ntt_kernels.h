@@ -150,18 +150,17 @@ __device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uin
 
 /* the inverse loop's final stores (slot e <-> index (e << LT) + t, 8 bytes per lane) through
  * the block descriptor: one lane offset, the row offset as a scalar operand */
-template <class A, int LOGN>
-__device__ __forceinline__ void buffer_store_first_inv(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk, const typename A::consts &c)
+template <int LOGN>
+__device__ __forceinline__ void buffer_store_first_raw(const uint64_t (&u)[kE], uint32_t t, uint64_t *blk)
 {
   using P                        = Plan<LOGN>;
   const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
   typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
   static_for<0, kE>([&](auto ee) {
-    constexpr int  E = decltype(ee)::value;
-    const uint64_t a = A::store_inv(x[E], c);
-    v2u32          v;
-    v.x = (unsigned)a;
-    v.y = (unsigned)(a >> 32);
+    constexpr int E = decltype(ee)::value;
+    v2u32         v;
+    v.x = (unsigned)u[E];
+    v.y = (unsigned)(u[E] >> 32);
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(t * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
   });
 }
@@ -208,6 +207,35 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
     raw[E + 1]      = v.b;
   });
 #endif
+}
+
+/* Makes the compiler complete the loads behind a prefetched block at this point.  Used
+ * once, before a persistent loop is entered: the waits the compiler places inside the loop
+ * are the merge of both ways into it, and anything still pending on the way in from the
+ * prologue becomes an s_waitcnt vmcnt(n) that ALSO executes on every later iteration --
+ * where the only pending operations are the previous block's stores, i.e. it would wait
+ * for stores nobody needs. */
+__device__ __forceinline__ void pin_raw(const uint64_t (&raw)[kE])
+{
+#ifdef NTT_NO_PIN /* A/B switch */
+  return;
+#endif
+#pragma unroll
+  for(int e = 0; e < kE; e++) asm volatile("" ::"v"(raw[e]));
+}
+/* makes the compiler complete the loads behind a preloaded twiddle set at this point */
+template <class A, int LOGN, int G>
+__device__ __forceinline__ void pin_preloaded(const typename A::ctw (&pre)[4][kE / 2])
+{
+  using P = Plan<LOGN>;
+  /* plain unrolled loops: asm operands cannot name a reference captured by a lambda */
+#pragma unroll
+  for(int j = 0; j < P::R(G); j++) {
+#pragma unroll
+    for(int b = 0; b < kE / 2; b++) {
+      if(P::BFLY_FIRST(G, j, b) == b) asm volatile("" ::"v"(pre[j][b]));
+    }
+  }
 }
 
 template <class A, int LOGN, bool INV, int KSH>
@@ -274,6 +302,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     }
     uint64_t raw[kE];
     prefetch_first<LOGN>(raw, tid, p.a + (b << LOGN));
+    pin_raw(raw);
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
 #endif
@@ -366,6 +395,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
     uint64_t raw[kE];
     prefetch_last<LOGN>(raw, tid, p.a + (b << LOGN));
+    pin_raw(raw);
+    if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
@@ -389,8 +420,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
         }
       });
+      /* Next iteration's first-group twiddles: requested now, and waited for BEFORE the
+       * stores enter the vector-memory queue (their L2 latency hides under the sixteen
+       * canonicalisations in between).  With loads and stores both pending the compiler can
+       * only wait for vmcnt(0) -- one counter, completion order between the two kinds
+       * unknown -- so a load consumed after the stores were issued would cost a full store
+       * round trip at the start of every block. */
       if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
-      buffer_store_first_inv<A, LOGN>(x, tid, base, p.c);
+      uint64_t out[kE];
+      static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], p.c); });
+      if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
+      buffer_store_first_raw<LOGN>(out, tid, base);
     }
     return;
   }
