@@ -94,7 +94,7 @@ struct ntt_plan {
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              num_cus    = 256;
-  int              chunk_mib  = 192; /* bytes of one multi-pass chunk (Infinity Cache residency) */
+  int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
@@ -151,7 +151,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->arith    = ar;
   p->generic  = env_int("NTT_GENERIC", 0) != 0;
   p->max_grid = env_int("NTT_MAX_GRID", 0);
-  p->chunk_mib = env_int("NTT_CHUNK_MIB", 192);
+  p->chunk_mib = env_int("NTT_CHUNK_MIB", 256);
   if(p->chunk_mib < 1) p->chunk_mib = 1;
   {
     hipDeviceProp_t prop;
