@@ -352,7 +352,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * twiddles, the next one reads the LDS-resident table, the remaining stages are
    * wave-uniform; coefficients come in as 16-byte loads and leave as coalesced
    * 8-byte stores. */
-  if constexpr(INV && G::BPW == 1) {
+  /* (FP64 policy only: with the integer policy's larger temporaries this loop spills 6-10
+   * VGPRs and the plain loop below is 2-13 % faster -- measured, profiles/r01/ablations.txt) */
+  if constexpr(INV && G::BPW == 1 && A::kCompact) {
     constexpr int  GL     = P::NG - 1;
     constexpr int  GT     = P::NG - 2;
     constexpr bool LTW    = LDS_TW > 0;

@@ -118,3 +118,4 @@ def test_headline_kernels_do_not_spill():
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
     for k in ks:
         assert k["group_segment_fixed_size"] <= 160 * 1024, k
+        assert k["vgpr_spill_count"] == 0, k      # no kernel of the library spills vector registers
