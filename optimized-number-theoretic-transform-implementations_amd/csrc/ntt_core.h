@@ -129,6 +129,13 @@ template <int LOGN> struct Plan {
     for(int b = 0; b < LT; b++) v |= ((t >> b) & 1u) << TB(g, b);
     return v;
   }
+  /* mask of the index bits carried by the thread id in group g */
+  static constexpr uint32_t THREAD_BITS(int g)
+  {
+    uint32_t v = 0;
+    for(int b = 0; b < LT; b++) v |= 1u << TB(g, b);
+    return v;
+  }
   /* inverse maps: index -> (thread, slot) of group g */
   static constexpr uint32_t THREAD_OF(int g, uint32_t i)
   {
@@ -350,7 +357,14 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
    * group = ib >> (LOGN - S(G))), so that neighbouring lanes -- which differ in the
    * prefix -- read neighbouring 8-byte words: conflict-free ds_read_b64, where the
    * natural order (prefix * 2^J + u) put them 2^J words apart (2-way conflicts). */
-  const uint32_t tl = (uint32_t)(((1u << J) - 1u) << P::S(G)) + (ib >> (LOGN - P::S(G)));
+  /* In general both the thread's base index ib and the slot offset contribute to prefix and
+   * u (their bit sets are disjoint, so the fields simply add): middle groups have all of u in
+   * the slot and all of the prefix in the thread, a last group of fewer than four stages
+   * also carries prefix bits in its slots. */
+  constexpr uint32_t UMASK   = (1u << J) - 1u;
+  constexpr bool     IB_IN_U = ((P::THREAD_BITS(G) >> SH) & UMASK) != 0;
+  uint32_t           tl      = (uint32_t)(UMASK << P::S(G)) + (ib >> (LOGN - P::S(G)));
+  if constexpr(IB_IN_U) tl += ((ib >> SH) & UMASK) << P::S(G);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW) && !defined(NTT_NO_WIDE_SMEM)
   /* wave-uniform stage: its 2^J records are consecutive slots -> fetch them as
    * ONE aggregate through the constant address space (s_load_dwordx4/8/16), so a
@@ -386,7 +400,8 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
         } else
 #endif
         if constexpr(LTW) {
-          w.c[B] = ltw[tl + (OFF << P::S(G))];
+          constexpr uint32_t OFFT = ((OFF & UMASK) << P::S(G)) + (OFF >> J);
+          w.c[B]                  = ltw[tl + OFFT];
         } else {
           w.c[B] = at32(p.tw8, tb + OFF);
         }

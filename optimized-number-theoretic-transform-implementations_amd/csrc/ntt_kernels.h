@@ -29,9 +29,6 @@ namespace ntt {
 #ifndef NTT_PRE_ALSO
 #  define NTT_PRE_ALSO 0
 #endif
-#ifndef NTT_LTW_ALSO
-#  define NTT_LTW_ALSO 0 /* experiments: a second block size that keeps an LDS twiddle table */
-#endif
 
 template <int LOGN, bool INV, bool COMPACT> struct Geom {
   using P = Plan<LOGN>;
@@ -40,18 +37,44 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
    * and L2 latencies better.) */
   static constexpr int WG  = P::T < 256 ? 256 : P::T;      /* threads per workgroup */
   static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
-  /* compact twiddles of the second-to-last group kept in LDS for the whole
-   * launch (entries; 0 = not used): 2^14 -> stages 8..11 = 3840 doubles = 30 KB,
-   * which together with the 128.1 KB exchange buffer still fits the CU's 160 KB;
-   * 2^12 -> stages 6..9 = 960 doubles, 4 workgroups of 39.6 KB per CU (measured
-   * +10 %); 2^13 -> one 94 KB workgroup per CU instead of two without a table
-   * (measured +2..3 %, and it serves the blocks of multi-pass transforms) */
+  /* Compact twiddles kept in LDS for the whole launch, one table per stage group whose stages
+   * are all per-lane (entries; 0 = not used).  Which groups get one is a footprint decision:
+   *   2^14: the second-to-last group (stages 8..11, 3840 doubles = 30 KB next to the 128.1 KB
+   *         exchange buffer); the last group's 12288 entries do not fit and are preloaded;
+   *   2^13: every per-lane group (stages 4..7, 8..11 and 12: 2 + 30 + 32 KB): one 130 KB
+   *         workgroup per CU and no global twiddle loads at all;
+   *   2^12: the second-to-last group only (7.7 KB: 4 workgroups per CU, measured +10 %; the
+   *         last group's 24 KB would halve the resident workgroups). */
+  static constexpr bool group_is_per_lane(int g)
+  {
+    for(int j = 0; j < P::R(g); j++)
+      if(P::TW_UNIFORM(g, j)) return false;
+    return true;
+  }
+  static constexpr int TBL(int g)
+  {
 #if defined(NTT_NO_LDS_TW) || defined(NTT_NO_PREFETCH) || defined(NTT_NO_COMPACT_TW)
-  static constexpr int LDS_TW = 0;
+    return 0;
 #else
-  static constexpr int LDS_TW =
-    (COMPACT && (LOGN >= 12 || LOGN == NTT_LTW_ALSO)) ? ((1 << (P::S(P::NG - 2) + P::R(P::NG - 2))) - (1 << P::S(P::NG - 2))) : 0;
+    if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
+    bool on = false;
+    if(LOGN == 14 || LOGN == 12) on = (g == P::NG - 2);
+#  ifndef NTT_TBL13_ONE
+    if(LOGN == 13) on = true;
+#  else
+    if(LOGN == 13) on = (g == P::NG - 2);
+#  endif
+    return on ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
 #endif
+  }
+  /* first entry of group g's table behind the exchange buffer(s) */
+  static constexpr int TBL_OFF(int g)
+  {
+    int o = 0;
+    for(int h = 0; h < g; h++) o += TBL(h);
+    return o;
+  }
+  static constexpr int LDS_TW = TBL_OFF(P::NG);
   static constexpr int LDS_BYTES  = (BPW * P::LDS_ELEMS + LDS_TW) * 8;
   static constexpr int WG_PER_CU0 = 163840 / LDS_BYTES;
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x): what
@@ -238,6 +261,34 @@ __device__ __forceinline__ void pin_preloaded(const typename A::ctw (&pre)[4][kE
   }
 }
 
+/* Fills the LDS twiddle tables of a workgroup (Geom::TBL).  A table depends on the block's
+ * position inside its polynomial; a persistent workgroup keeps it for the whole launch, which
+ * is valid because its stride over the blocks is a multiple of the blocks per polynomial
+ * (launch_fused enforces it).  Stage J of group g is stored TRANSPOSED: slot
+ * l = prefix * 2^J + u goes to (2^J - 1) * 2^S + u * 2^S + prefix (see load_stage_tw). */
+template <class A, int LOGN, bool INV>
+__device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Params<A> &p, uint32_t blk0, uint32_t tid)
+{
+  using P = Plan<LOGN>;
+  using G = Geom<LOGN, INV, A::kCompact>;
+  static_for<0, P::NG>([&](auto gg) {
+    constexpr int GI = decltype(gg)::value;
+    if constexpr(G::TBL(GI) > 0) {
+      typename A::ctw *tg = tabl + G::TBL_OFF(GI);
+      static_for<0, P::R(GI)>([&](auto jj) {
+        constexpr int JJ  = decltype(jj)::value;
+        constexpr int SG  = P::S(GI);
+        constexpr int SLJ = SG + JJ;
+        const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
+        for(uint32_t l = tid; l < (1u << SLJ); l += G::WG) {
+          const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
+          tg[(((1u << JJ) - 1u) << SG) + (u << SG) + prefix] = src[l];
+        }
+      });
+    }
+  });
+}
+
 template <class A, int LOGN, bool INV, int KSH>
 __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN, INV, A::kCompact>::WPS)) fused_kernel(const Params<A> p)
 {
@@ -263,7 +314,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * and the prefetched block lands during ~10 stages of butterflies. */
   if constexpr(!INV && G::BPW == 1) {
     constexpr int  GL     = P::NG - 1;          /* last group                      */
-    constexpr int  GT     = P::NG - 2;          /* group fed from the LDS table    */
 #ifdef NTT_NO_PRELOAD_LAST
     constexpr bool PRE    = false;
 #else
@@ -271,34 +321,18 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
      * ahead of their use; for whole-polynomial blocks they do not depend on the
      * block at all and stay in 24 VGPRs for the entire launch (LOGN 14 only:
      * smaller blocks have several workgroups per CU hiding that latency) */
-    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == NTT_PRE_ALSO) && stage_is_compact<A, LOGN, false>(GL, 0);
+    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == NTT_PRE_ALSO) && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
 #endif
     constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
     if(b >= p.nblocks) return;
-    lds_ctw_ptr<A> ltw = nullptr;
+    /* twiddle tables of this workgroup, behind the exchange buffer */
+    typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+    const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
     if constexpr(LTW) {
-      /* The table depends on the block's position inside its polynomial; a workgroup
-       * keeps one table for the whole launch, which is valid because its stride over
-       * the blocks is a multiple of the blocks per polynomial (launch_fused enforces it) */
-      {
-        typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
-        const uint32_t   blk0 = (uint32_t)b & bmask;
-        static_for<0, P::R(GT)>([&](auto jj) {
-          constexpr int JJ  = decltype(jj)::value;
-          constexpr int SGT = P::S(GT);
-          constexpr int SLJ = SGT + JJ;
-          const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
-          /* slot l = prefix * 2^J + u of the stage goes to (2^J-1)*2^S + u*2^S + prefix (see load_stage_tw) */
-          for(uint32_t l = tid; l < (1u << SLJ); l += G::WG) {
-            const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
-            tabl[(((1u << JJ) - 1u) << SGT) + (u << SGT) + prefix] = src[l];
-          }
-        });
-        ltw = (lds_ctw_ptr<A>)tabl;
-        __syncthreads();
-      }
+      fill_lds_tables<A, LOGN, INV>(tabl, p, (uint32_t)b & bmask, tid);
+      __syncthreads();
     }
     uint64_t raw[kE];
     prefetch_first<LOGN>(raw, tid, p.a + (b << LOGN));
@@ -333,8 +367,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         if constexpr(PRE && GI == 0) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
-        } else if constexpr(GI + 1 == GT && LTW) {
-          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw);
+        } else if constexpr(G::TBL(GI + 1) > 0) {
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
           run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
         }
@@ -356,33 +390,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * VGPRs and the plain loop below is 2-13 % faster -- measured, profiles/r01/ablations.txt) */
   if constexpr(INV && G::BPW == 1 && A::kCompact) {
     constexpr int  GL     = P::NG - 1;
-    constexpr int  GT     = P::NG - 2;
     constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
     if(b >= p.nblocks) return;
-    lds_ctw_ptr<A> ltw = nullptr;
+    /* twiddle tables of this workgroup, behind the exchange buffer */
+    typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+    const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
     if constexpr(LTW) {
-      /* The table depends on the block's position inside its polynomial; a workgroup
-       * keeps one table for the whole launch, which is valid because its stride over
-       * the blocks is a multiple of the blocks per polynomial (launch_fused enforces it) */
-      {
-        typename A::ctw *tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
-        const uint32_t   blk0 = (uint32_t)b & bmask;
-        static_for<0, P::R(GT)>([&](auto jj) {
-          constexpr int JJ  = decltype(jj)::value;
-          constexpr int SGT = P::S(GT);
-          constexpr int SLJ = SGT + JJ;
-          const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
-          /* slot l = prefix * 2^J + u of the stage goes to (2^J-1)*2^S + u*2^S + prefix (see load_stage_tw) */
-          for(uint32_t l = tid; l < (1u << SLJ); l += G::WG) {
-            const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
-            tabl[(((1u << JJ) - 1u) << SGT) + (u << SGT) + prefix] = src[l];
-          }
-        });
-        ltw = (lds_ctw_ptr<A>)tabl;
-        __syncthreads();
-      }
+      fill_lds_tables<A, LOGN, INV>(tabl, p, (uint32_t)b & bmask, tid);
+      __syncthreads();
     }
     /* the first executed group's per-lane twiddles do not change from block to
      * block (the workgroup always sees the same block position): request the
@@ -391,7 +408,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
 #ifdef NTT_NO_INV_PRE
     constexpr bool IPRE = false;
 #else
-    constexpr bool IPRE = A::kCompact && LOGN >= 13 && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4;
+    constexpr bool IPRE = A::kCompact && LOGN >= 13 && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
 #endif
     typename A::ctw pre[4][kE / 2];
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
@@ -410,14 +427,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       }
       if constexpr(IPRE) {
         run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+      } else if constexpr(G::TBL(GL) > 0) {
+        run_group<A, LOGN, GL, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GL));
       } else {
         run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
       }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
         exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
-        if constexpr(GI - 1 == GT && GT != GL && LTW) {
-          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw);
+        if constexpr(G::TBL(GI - 1) > 0) {
+          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
         } else {
           run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
         }
