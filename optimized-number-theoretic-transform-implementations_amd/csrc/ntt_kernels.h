@@ -44,7 +44,10 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
    *   2^13: every per-lane group (stages 4..7, 8..11 and 12: 2 + 30 + 32 KB): one 130 KB
    *         workgroup per CU and no global twiddle loads at all;
    *   2^12: the second-to-last group only (7.7 KB: 4 workgroups per CU, measured +10 %; the
-   *         last group's 24 KB would halve the resident workgroups). */
+   *         last group's 24 KB would halve the resident workgroups);
+   *   2^10, 2^11: every per-lane group (8 / 16 KB per 256-thread workgroup of 4 / 2 blocks):
+   *         these sizes were texture-addresser-bound on their 27-31 per-lane global twiddle
+   *         loads per thread (TA 91 % busy). */
   static constexpr bool group_is_per_lane(int g)
   {
     for(int j = 0; j < P::R(g); j++)
@@ -59,6 +62,9 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
     if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
     bool on = false;
     if(LOGN == 14 || LOGN == 12) on = (g == P::NG - 2);
+#  ifndef NTT_NO_SMALL_TBL
+    if(LOGN == 10 || LOGN == 11) on = true; /* several blocks per workgroup share the tables */
+#  endif
 #  ifndef NTT_TBL13_ONE
     if(LOGN == 13) on = true;
 #  else
@@ -458,6 +464,13 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
 #endif
 
   /* generic loop: small blocks (several per workgroup), and every size in the NTT_NO_PREFETCH build */
+  const lds_ctw_ptr<A> gtw = (lds_ctw_ptr<A>)reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+  if constexpr(LDS_TW > 0) {
+    /* blocks below 2^14 are whole polynomials (ntt_passplan.h; launch_fused refuses anything
+     * else here), so every block of the workgroup uses the same tables */
+    fill_lds_tables<A, LOGN, INV>(reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS), p, 0u, tid);
+    __syncthreads();
+  }
   for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
     uint64_t   b    = b0 + sub;
     const bool live = b < p.nblocks;
@@ -471,16 +484,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, t, lds);
-        run_group<A, LOGN, GI + 1, false, MASK>(x, t, blk, p);
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
       if(live) global_store_last<A, LOGN, false>(x, t, base, p.c);
     } else {
       global_load_last<A, LOGN, true>(x, t, base, p.wide != 0, p.c);
-      run_group<A, LOGN, P::NG - 1, true, MASK>(x, t, blk, p);
+      run_group<A, LOGN, P::NG - 1, true, MASK, (G::TBL(P::NG - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(P::NG - 1));
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
         exchange<A, LOGN, GI, GI - 1>(x, t, lds);
-        run_group<A, LOGN, GI - 1, true, MASK>(x, t, blk, p);
+        run_group<A, LOGN, GI - 1, true, MASK, (G::TBL(GI - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI - 1));
       });
       if(live) global_store_first<A, LOGN, true>(x, t, base, p.c);
     }
@@ -551,6 +564,12 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
   }
 #endif
+  if(G::BPW > 1 && G::LDS_TW > 0) {
+    /* tables are filled once per workgroup: a few workgroups per resident slot, each looping */
+    if(pa.s != 0) return hipErrorInvalidValue;
+    constexpr int per_cu = G::WG_PER_CU0 < 8 ? G::WG_PER_CU0 : 8;
+    cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
+  }
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   /* a persistent workgroup must always see the same block position inside the
    * polynomial (its LDS twiddle table depends on it): the grid, which is its
