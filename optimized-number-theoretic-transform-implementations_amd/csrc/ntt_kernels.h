@@ -45,9 +45,9 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
    *         workgroup per CU and no global twiddle loads at all;
    *   2^12: the second-to-last group only (7.7 KB: 4 workgroups per CU, measured +10 %; the
    *         last group's 24 KB would halve the resident workgroups);
-   *   2^10, 2^11: every per-lane group (8 / 16 KB per 256-thread workgroup of 4 / 2 blocks):
-   *         these sizes were texture-addresser-bound on their 27-31 per-lane global twiddle
-   *         loads per thread (TA 91 % busy). */
+   *   2^8..2^11: every per-lane group (at most 16 KB per 256-thread workgroup of 2..64
+   *         blocks): these sizes were texture-addresser-bound on their 27-31 per-lane global
+   *         twiddle loads per thread (TA 91 % busy). */
   static constexpr bool group_is_per_lane(int g)
   {
     for(int j = 0; j < P::R(g); j++)
@@ -63,7 +63,7 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
     bool on = false;
     if(LOGN == 14 || LOGN == 12) on = (g == P::NG - 2);
 #  ifndef NTT_NO_SMALL_TBL
-    if(LOGN == 10 || LOGN == 11) on = true; /* several blocks per workgroup share the tables */
+    if(LOGN >= 8 && LOGN <= 11) on = true; /* several blocks per workgroup share the tables (2^6, 2^7: measured no gain) */
 #  endif
 #  ifndef NTT_TBL13_ONE
     if(LOGN == 13) on = true;
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     typename A::val x[kE];
     if constexpr(!INV) {
       global_load_first<A, LOGN, false>(x, t, base, p.wide != 0, p.c);
-      run_group<A, LOGN, 0, false, MASK>(x, t, blk, p);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, t, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, t, lds);
