@@ -13,4 +13,5 @@ timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.err
 timeout 600 python3 tools/sweep.py --logn 8 9 10 11 12 13 14 15 16 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 > $out/sweep_sizes.txt 2>&1
 timeout 600 python3 tools/sweep.py --logn 17 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 | tail -2 >> $out/sweep_sizes.txt 2>&1
 timeout 900 python3 tools/sweep.py --logn 14 --ops fwd inv mul --arith f64 u64 --qs 0x7fffffffe0001 0x80000001c0001 0x3ffffffdf0001 0x7ffe0001 --bytes 4e9 > $out/sweep_arith.txt 2>&1
+(timeout 300 python3 tools/pipeline_bench.py; timeout 300 python3 tools/pipeline_bench.py --logn 16 --batch 1024; timeout 300 python3 tools/pipeline_bench.py --logn 14 --batch 4096) > $out/pipeline_rns.txt 2>&1
 tail -1 $out/bench.json; cat $out/pmc_summary.txt

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""BASELINE config 5, one GPU's share (GPU box): FHE-style fwd -> pointwise -> inv pipeline at N=2^17 over a
+4-prime RNS basis, 512 polynomial pairs per GPU; prints products/s and the bytes moved per second.
+usage: python3 tools/pipeline_bench.py [--logn 17] [--batch 512] [--limbs 4] [--bits 50] [--steps 5]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ontt
+lib = ontt.load()
+ap = argparse.ArgumentParser()
+ap.add_argument("--logn", type=int, default=17)
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--limbs", type=int, default=4)
+ap.add_argument("--bits", type=int, default=50)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+n = 1 << a.logn
+qs = [lib.find_prime(a.bits, n, k) for k in range(a.limbs)]
+plans = [lib.Plan(n, q, lib.min_root(q, n)) for q in qs]
+per = a.batch * n
+bufs = [lib.DeviceBuffer(a.limbs * per) for _ in range(3)]
+def fill():
+    for i, b in enumerate(bufs[:2]):
+        for l, q in enumerate(qs):
+            lib.fill_uniform(b.ptr + 8 * l * per, per, q, 1000 + i, l * per)
+def step():
+    lib.rns_negacyclic_mul(plans, bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, a.batch)
+fill(); step(); lib.stream_sync()
+e0, e1 = lib.Event(), lib.Event()
+tot = 0.0
+for _ in range(a.steps):
+    fill(); lib.stream_sync()           # operands are overwritten by the pipeline: regenerate outside the timed region
+    e0.record(); step(); e1.record()
+    tot += e1.elapsed_ms_since(e0)
+ms = tot / a.steps
+prods = a.batch / (ms * 1e-3)
+byts = 72 * n * a.limbs * a.batch / (ms * 1e-3)
+print("N=2^%d limbs=%d (%s) batch=%d : %.3f ms/step  %.0f RNS products/s  %.2f M limb-products/s  %.0f GB/s of 72N bytes per limb-product (%.1f %% of 8 TB/s)"
+      % (a.logn, a.limbs, ",".join(hex(q) for q in qs), a.batch, ms, prods, prods * a.limbs / 1e6, byts / 1e9, byts / 8e10))
