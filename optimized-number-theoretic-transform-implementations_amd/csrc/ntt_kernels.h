@@ -13,10 +13,11 @@
  * Launch geometry (wave64, 256 CUs): LOGN=14 -> one persistent 1024-thread
  * workgroup per CU (16 waves, 4 per SIMD, <=128 VGPRs, no scratch) using 158 KiB
  * of the CU's 160 KiB LDS (128.1 KiB exchange buffer + 30 KiB twiddle table);
- * 2^13 -> one 512-thread workgroup (94 KiB), 2^12 -> four 256-thread workgroups
- * (39.6 KiB each).  Blocks >= 2^12 run the persistent loops below (register
- * prefetch of the next block, LDS-resident twiddle table); smaller blocks pack
- * several per 256-thread workgroup and rely on multiple resident workgroups.
+ * 2^13 -> one 512-thread workgroup (128 KiB: every per-lane twiddle in LDS),
+ * 2^12 -> four 256-thread workgroups (39.6 KiB each).  Blocks >= 2^12 run the
+ * persistent loops below (register prefetch of the next block); smaller blocks
+ * pack several per 256-thread workgroup, share LDS twiddle tables from 2^8 up and
+ * rely on multiple resident workgroups instead of a prefetch.
  * Tuning history and rejected variants: profiles/r01/ablations.txt.
  */
 #pragma once
@@ -27,10 +28,10 @@
 namespace ntt {
 
 #ifndef NTT_PRE_ALSO
-#  define NTT_PRE_ALSO 12 /* measured +1.6 % at 2^12 */
+#  define NTT_PRE_ALSO 12 /* forward: last group's twiddles preloaded at this size too (2^14 always); measured +1.8 % */
 #endif
 #ifndef NTT_IPRE_MIN
-#  define NTT_IPRE_MIN 12 /* measured +2 % at 2^12 */
+#  define NTT_IPRE_MIN 12 /* inverse: first executed group's twiddles preloaded from this size up; measured +3.8 % at 2^12 */
 #endif
 
 template <int LOGN, bool INV, bool COMPACT> struct Geom {
