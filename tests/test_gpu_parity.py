@@ -140,6 +140,36 @@ def test_generated_parameters(lib, oracle, bits, m):
         plan.destroy()
 
 
+def test_randomised_sizes_moduli_batches(lib, oracle):
+    """seeded sweep over block sizes 2^6..2^15, the three FP64 headroom classes and the integer
+    policy, ragged batches and lazy ([0,8q)) inputs: every kernel variant and every LDS twiddle
+    table layout against the oracle"""
+    rng = np.random.default_rng(20261002)
+    checked = 0
+    for m in range(6, 16):
+        n = 1 << m
+        for bits in (20 + int(rng.integers(0, 12)), 34 + int(rng.integers(0, 15)), 50, 51):
+            q = lib.find_prime(bits, n, int(rng.integers(0, 3)))
+            if q == 0:
+                continue
+            w = lib.min_root(q, n)
+            cx = oracle.ctx(n, q, w)
+            batch = int(rng.integers(1, 8))
+            a = _inputs(oracle, n, q, batch, 77 * m + bits)
+            expect = cx.fwd(a)
+            lazy = a + np.uint64(q) * rng.integers(0, 8, size=a.shape, dtype=np.uint64)   # same residues, in [0,8q)
+            for arith in _arith_modes(lib, q):
+                plan = lib.Plan(n, q, w, arith=arith)
+                assert np.array_equal(plan.fwd_host(a), expect), (m, hex(q), arith, "fwd")
+                assert np.array_equal(plan.fwd_host(lazy, wide=True), expect), (m, hex(q), arith, "fwd wide")
+                assert np.array_equal(plan.inv_host(expect), a), (m, hex(q), arith, "inv")
+                lazy_e = expect + np.uint64(q) * rng.integers(0, 8, size=a.shape, dtype=np.uint64)
+                assert np.array_equal(plan.inv_host(lazy_e, wide=True), a), (m, hex(q), arith, "inv wide")
+                plan.destroy()
+                checked += 1
+    assert checked >= 60
+
+
 def test_empty_batch_and_bad_arguments(lib):
     plan = lib.Plan(256, 0x1e01, 62)
     plan.fwd(None, 0)
