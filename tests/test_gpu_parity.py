@@ -123,7 +123,7 @@ def test_reference_signatures(lib, oracle, kat, i):
     assert np.array_equal(a, a_orig)
 
 
-@pytest.mark.parametrize("bits,m", [(50, 14), (50, 12), (52, 16), (49, 13), (40, 11), (31, 10), (60, 12), (45, 6), (20, 3), (33, 7)])
+@pytest.mark.parametrize("bits,m", [(50, 14), (50, 12), (52, 16), (49, 13), (40, 11), (31, 10), (60, 12), (45, 6), (20, 3), (33, 7), (50, 18), (45, 20)])
 def test_generated_parameters(lib, oracle, bits, m):
     n = 1 << m
     q = lib.find_prime(bits, n)
