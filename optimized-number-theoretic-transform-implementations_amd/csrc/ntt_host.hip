@@ -664,14 +664,20 @@ std::vector<CompatPlan> g_plans;
 uint64_t *              g_stage       = nullptr;
 size_t                  g_stage_bytes = 0;
 
+/* identifies a caller table by 256 evenly spaced entries (plus the last one): two tables for
+ * the same (N, q, direction) come from different roots and differ in essentially every slot
+ * above 0, and hashing all N entries cost a third of a call at N = 2^17 */
 uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
 {
-  uint64_t h = 0xcbf29ce484222325ULL;
-  for(uint64_t i = 0; i < n; i++) {
+  uint64_t       h    = 0xcbf29ce484222325ULL;
+  const uint64_t step = n > 256 ? n / 256 : 1;
+  for(uint64_t i = 0; i < n; i += step) {
     h ^= w[i * stride];
     h *= 0x100000001b3ULL;
     h ^= h >> 29;
   }
+  h ^= w[(n - 1) * stride];
+  h *= 0x100000001b3ULL;
   return h;
 }
 
