@@ -298,7 +298,7 @@ template <class A, bool UNIFORM, int G = 0> NTT_HD typename A::tw load_tw(const 
  * x[16]  : the thread's coefficients (slot e <-> index IBASE(t)+IOFF(e))
  * t      : thread id inside the block;  blk: block id inside the polynomial
  * MASK   : ArithF64 reduction schedule, bit = processing position of the stage
- * p.lastinv (inverse only): local stage 0 is global stage 0 and folds N^-1
+ * MASK & kLastInvFlag (inverse only): local stage 0 is global stage 0 and folds N^-1
  *          (reference src/ntt_reference.c:55-65)
  */
 /* Per-lane (non-uniform) twiddles of the FP64 policy are fetched in
@@ -440,6 +440,10 @@ NTT_HD typename A::tw stage_tw(const StageTw<A> &w, const typename A::consts &c)
  * multiplied by N^-1, both exact below 2^53).
  */
 constexpr uint32_t kRedPlanFlag = 0x80000000u;
+/* MASK bit: the pass ends with global stage 0 of an inverse transform (N^-1 is folded in).
+ * Compile-time rather than a kernel argument: with a run-time branch both variants of the
+ * last group live in one kernel and the 2^14 inverse spills. */
+constexpr uint32_t kLastInvFlag = 0x40000000u;
 
 struct RedPlan {
   uint8_t red[4][4]; /* [group][local stage]: bit b => butterfly b reduces its sum */
@@ -498,6 +502,64 @@ template <class A, int LOGN, bool INV, uint32_t MASK> constexpr bool bfly_reduce
   }
 }
 
+/* every stage of group g has a wave-uniform twiddle slot */
+template <int LOGN> constexpr bool group_all_uniform(int g)
+{
+  using P = Plan<LOGN>;
+  for(int j = 0; j < P::R(g); j++)
+    if(!P::TW_UNIFORM(g, j)) return false;
+  return true;
+}
+/* inverse, group 0: slot bits toggled by the stages executed before local stage j (j+1 .. R-1) */
+template <int LOGN> constexpr uint32_t group0_done_mask(int j)
+{
+  using P    = Plan<LOGN>;
+  uint32_t m = 0;
+  for(int k = j + 1; k < P::R(0); k++) m |= 1u << P::ABIT(0, k);
+  return m;
+}
+
+/* Final group of a whole inverse transform, N^-1 folded into the twiddles.  A value is scaled
+ * at the first product it passes inside this group (twiddle N^-1 * w, 16 records kept behind
+ * the inverse table, wave-uniform like the group's plain twiddles); a butterfly whose inputs are both scaled
+ * already -- its slot has a set bit among the bits this group processed before -- runs
+ * unchanged; only slot 0, a sum on every stage of the group, needs the explicit product by
+ * N^-1, in the very last butterfly.  (The reference scales all eight sums of its last stage,
+ * src/ntt_reference.c:55-65: seven of those products are saved per thread.) */
+template <class A, int LOGN, uint32_t MASK>
+NTT_HD void run_group0_folded(typename A::val (&x)[kE], uint32_t ib, uint32_t blk, const Params<A> &p)
+{
+  using P         = Plan<LOGN>;
+  constexpr int R = P::R(0);
+  static_for<0, R>([&](auto jj) {
+    constexpr int      J    = R - 1 - decltype(jj)::value;
+    constexpr int      SL   = J; /* S(0) == 0 */
+    constexpr int      AB   = P::ABIT(0, J);
+    constexpr uint32_t DONE = group0_done_mask<LOGN>(J);
+    StageTw<A>         w;
+    load_stage_tw<A, LOGN, 0, J, true, false>(w, ib, blk, p, nullptr);
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int      B   = decltype(bb)::value;
+      constexpr int      E0  = P::BFLY_E0(0, J, B);
+      constexpr int      E1  = E0 | (1 << AB);
+      constexpr bool     RED = bfly_reduces<A, LOGN, true, MASK>(0, J, B);
+      constexpr uint32_t OFF = P::IOFF(0, E0) >> (LOGN - SL);
+      if constexpr((E0 & DONE) != 0) {
+        A::template inv_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, 0, J, true, B>(w, p.c), p.c);
+      } else if constexpr(SL == 0) {
+        A::inv_bfly_last(x[E0], x[E1], p.c); /* slot 0: explicit N^-1 on the sum */
+      } else {
+        /* record N + slot of the inverse table (ntt_host.hip).  blk is 0 here (a whole
+         * transform: s0 == 0); keeping it in the index ties the load to the block loop, so
+         * these 7 records are re-read from the scalar cache per block instead of being
+         * hoisted into 28 more SGPRs for the whole launch (which spilled) */
+        const typename A::tw wn = load_tw<A, true, 0>(p.tw, uniform_u32((1u << p.logn) + (blk << SL) + (1u << SL) + OFF));
+        A::template inv_bfly<RED>(x[E0], x[E1], wn, p.c);
+      }
+    });
+  });
+}
+
 template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
@@ -513,6 +575,10 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
    * the stages (the next stage's are requested before this stage's butterflies
    * issue); scalar-cache and LDS-resident twiddles are cheap enough to fetch
    * at the point of use, which keeps them out of the VGPR budget. */
+  if constexpr(INV && G == 0 && (MASK & kLastInvFlag) != 0 && group_all_uniform<LOGN>(0)) {
+    run_group0_folded<A, LOGN, MASK>(x, ib, blk, p);
+    return;
+  }
   StageTw<A> wcur, wnxt;
   constexpr int JFIRST = INV ? R - 1 : 0;
   if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !LTW) {
@@ -528,20 +594,17 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
     if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW>(wcur, ib, blk, p, ltw);
     if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
-    /* the stage that may carry the folded N^-1: ONE wave-uniform branch around its
-     * eight butterflies (not one per butterfly) */
-    bool folded = false;
-    if constexpr(INV && SL == 0) {
-      if(p.lastinv) {
-        folded = true;
-        static_for<0, kE / 2>([&](auto bb) {
-          constexpr int B  = decltype(bb)::value;
-          constexpr int E0 = P::BFLY_E0(G, J, B);
-          A::inv_bfly_last(x[E0], x[E0 | (1 << AB)], p.c);
-        });
-      }
+    constexpr bool FOLDED = INV && SL == 0 && (MASK & kLastInvFlag) != 0;
+    if constexpr(FOLDED) {
+      /* per-lane twiddles in the final group (blocks below 2^10): all eight sums of the last
+       * stage are scaled, as in the reference */
+      static_for<0, kE / 2>([&](auto bb) {
+        constexpr int B  = decltype(bb)::value;
+        constexpr int E0 = P::BFLY_E0(G, J, B);
+        A::inv_bfly_last(x[E0], x[E0 | (1 << AB)], p.c);
+      });
     }
-    if(!folded) static_for<0, kE / 2>([&](auto bb) {
+    if constexpr(!FOLDED) static_for<0, kE / 2>([&](auto bb) {
       constexpr int B  = decltype(bb)::value;
       constexpr int E0 = P::BFLY_E0(G, J, B);
       constexpr int E1 = E0 | (1 << AB);

@@ -179,14 +179,18 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
     if(force == 0 || (force == 1 && k >= 1)) p->kcls = force;
   }
   rc = NTT_OK;
+  /* the full inverse table carries 16 extra records behind its N slots: N^-1 * winv[k], k < 16,
+   * the twiddles of the last inverse group with the scaling folded in (run_group0_folded) */
+  const std::vector<uint64_t> inv_ext =
+    p->has_inv ? h_with_folded_ninv(inv, ninv_override ? ninv_override % q : h_powmod(N % q, q - 2, q), q) : inv;
   if(ar == NTT_ARITH_F64) {
     if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, fwd, q, h_tw_f64);
     if(!rc && p->has_fwd) rc = upload_table<double>(&p->d_fwd8, fwd, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
-    if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv, q, h_tw_f64);
+    if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv_ext, q, h_tw_f64);
     if(!rc && p->has_inv) rc = upload_table<double>(&p->d_inv8, inv, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
   } else {
     if(p->has_fwd) rc = upload_table<TwU64>(&p->d_fwd, fwd, q, h_tw_u64);
-    if(!rc && p->has_inv) rc = upload_table<TwU64>(&p->d_inv, inv, q, h_tw_u64);
+    if(!rc && p->has_inv) rc = upload_table<TwU64>(&p->d_inv, inv_ext, q, h_tw_u64);
   }
   if(rc) {
     ntt_plan_destroy(p);

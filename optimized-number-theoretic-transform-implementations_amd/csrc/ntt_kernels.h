@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ntt_core.h"
+#include "ntt_passplan.h"
 
 namespace ntt {
 
@@ -299,12 +300,12 @@ __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Par
   });
 }
 
-template <class A, int LOGN, bool INV, int KSH>
+template <class A, int LOGN, bool INV, int KSH, bool LASTINV = false>
 __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN, INV, A::kCompact>::WPS)) fused_kernel(const Params<A> p)
 {
   using P                 = Plan<LOGN>;
   using G                 = Geom<LOGN, INV, A::kCompact>;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>();
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>() | (INV && LASTINV ? kLastInvFlag : 0u);
   constexpr int LDS_TW = G::LDS_TW;
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
@@ -584,7 +585,20 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   }
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
-  hipLaunchKernelGGL((fused_kernel<A, LOGN, INV, KSH>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+  if constexpr(INV) {
+    /* the inverse kernel exists in two variants: ending a whole transform (N^-1 folded into
+     * its last group) -- every block size -- and, for the block size used below column
+     * passes, not ending it */
+    if(pa.lastinv) {
+      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+    } else if constexpr(LOGN == kFusedLarge) {
+      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else {
+    hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+  }
   return hipGetLastError();
 }
 

@@ -59,6 +59,15 @@ inline std::vector<uint64_t> h_power_table(uint64_t root, uint64_t N, uint64_t q
   return t;
 }
 
+/* inverse power table followed by 16 records N^-1 * winv[k], k < 16: the last inverse group's
+ * twiddles with the scaling folded in (run_group0_folded reads them at slots N + k) */
+inline std::vector<uint64_t> h_with_folded_ninv(const std::vector<uint64_t> &winv, uint64_t ninv, uint64_t q)
+{
+  std::vector<uint64_t> v = winv;
+  for(size_t k = 0; k < 16; k++) v.push_back(k < winv.size() ? h_mulmod(ninv % q, winv[k], q) : ninv % q);
+  return v;
+}
+
 inline TwU64 h_tw_u64(uint64_t w, uint64_t q) { return TwU64{w, h_precon64(w, q)}; }
 
 /* balanced representative and its quotient by q, correctly rounded to within

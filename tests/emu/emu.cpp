@@ -143,10 +143,10 @@ template <class A> struct Regs {
   typename A::val x[kE];
 };
 
-template <class A, int LOGN, bool INV, int KSH> static void emu_fused(const Params<A> &p)
+template <class A, int LOGN, bool INV, int KSH, bool LASTINV> static void emu_fused(const Params<A> &p)
 {
   using P                 = Plan<LOGN>;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>();
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>() | (INV && LASTINV ? kLastInvFlag : 0u);
   std::vector<typename A::val> lds(P::LDS_ELEMS);
   std::vector<Regs<A>>         regs(P::T);
   for(uint64_t b = 0; b < p.nblocks; b++) {
@@ -226,8 +226,11 @@ static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab
       p.lastinv = lastinv;
       p.nblocks = batch << ps.s;
       switch(ps.r) {
-#define CASE(LN) \
-  case LN: emu_fused<A, LN, INV, KSH>(p); break;
+#define CASE(LN)                                           \
+  case LN:                                                 \
+    if(lastinv) emu_fused<A, LN, INV, KSH, true>(p);       \
+    else emu_fused<A, LN, INV, KSH, false>(p);             \
+    break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return -1;
@@ -275,19 +278,20 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
   const uint64_t rinv = h_powmod(root, q - 2, q);
   const auto     w    = h_power_table(root, N, q);
   const auto     wi   = h_power_table(rinv, N, q);
-  const auto &   src  = inverse ? wi : w;
+  const auto     wix  = h_with_folded_ninv(wi, h_powmod(N % q, q - 2, q), q); /* as the plan uploads it */
+  const auto &   src  = inverse ? wix : w;
   if(arith == 0) {
-    std::vector<TwU64> tab(N);
-    for(uint64_t i = 0; i < N; i++) tab[i] = h_tw_u64(src[i], q);
+    std::vector<TwU64> tab(src.size());
+    for(uint64_t i = 0; i < src.size(); i++) tab[i] = h_tw_u64(src[i], q);
     const auto c = h_consts_u64(q, N, wi);
     return inverse ? emu_run<ArithU64, true, 0>(a, batch, m, tab.data(), c, generic, wide)
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
   if(!h_f64_eligible(q)) return -2;
   if(arith == 2) { /* checked FP64 policy */
-    std::vector<TwF64>  tabc(N);
-    std::vector<double> tabc8(N);
-    for(uint64_t i = 0; i < N; i++) {
+    std::vector<TwF64>  tabc(src.size());
+    std::vector<double> tabc8(src.size());
+    for(uint64_t i = 0; i < src.size(); i++) {
       tabc[i]  = h_tw_f64(src[i], q);
       tabc8[i] = tabc[i].w;
     }
@@ -300,9 +304,9 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
     return inverse ? emu_run<ArithF64Chk, true, 0>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data())
                    : emu_run<ArithF64Chk, false, 0>(a, batch, m, tabc.data(), cc, generic, wide, tabc8.data());
   }
-  std::vector<TwF64>  tab(N);
-  std::vector<double> tab8(N);
-  for(uint64_t i = 0; i < N; i++) {
+  std::vector<TwF64>  tab(src.size());
+  std::vector<double> tab8(src.size());
+  for(uint64_t i = 0; i < src.size(); i++) {
     tab[i]  = h_tw_f64(src[i], q);
     tab8[i] = tab[i].w;
   }
