@@ -169,6 +169,24 @@ __global__ void __launch_bounds__(256) k_copy8ld_16st_strided(uint4 *dst, const 
 
 /* the same row loads, stores as in the NTT's last group (16 B at 32-B lane stride) or contiguous
  * (16 B at 16-B lane stride: every store instruction writes whole 128-B lines), plain or non-temporal */
+/* 16-byte stores whose lane pairs cover whole 32-byte sectors: store A writes the first half of every
+ * 64-byte chunk, store B the second half (what a lane-pair swap of the last group's quads would give) */
+__global__ void __launch_bounds__(256) k_rows_sector(uint4 *dst, const uint2 *src, size_t n16)
+{
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16 / 2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = i >> 10, t = i & 1023;
+    const uint2 *s   = src + blk * 4096;
+    uint2        a = s[t], b = s[t + 1024], c = s[t + 2048], d = s[t + 3072];
+    v4u          v0, v1;
+    v0.x = a.x; v0.y = a.y; v0.z = b.x; v0.w = b.y;
+    v1.x = c.x; v1.y = c.y; v1.z = d.x; v1.w = d.y;
+    v4u *o = (v4u *)dst + blk * 2048 + (t >> 1) * 4 + (t & 1);
+    o[0]   = v0;
+    o[2]   = v1;
+  }
+}
+
 template <bool CONTIG, bool NT>
 __global__ void __launch_bounds__(256) k_rows(uint4 *dst, const uint2 *src, size_t n16)
 {
@@ -398,6 +416,17 @@ int main()
       TRYR(false, true, dst, "rows -> strided stores nt")
       TRYR(true, false, dst, "rows -> contiguous stores")
       TRYR(true, true, dst, "rows -> contiguous stores nt")
+      best = 1e9;
+      for(int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_rows_sector, dim3(blocks), dim3(256), 0, 0, src, (const uint2 *)src, bytes / 16);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      printf("%-44s %6d blocks: %.3f ms  %.2f TB/s\n", "in place: rows -> 32-byte-sector stores", blocks, best, 2.0 * bytes / best * 1e-9);
       TRYR(false, false, src, "in place: rows -> strided stores")
       TRYR(false, true, src, "in place: rows -> strided stores nt")
       TRYR(true, false, src, "in place: rows -> contiguous stores")
