@@ -29,10 +29,10 @@
 namespace ntt {
 
 #ifndef NTT_PRE_ALSO
-#  define NTT_PRE_ALSO 12 /* forward: last group's twiddles preloaded at this size too (2^14 always); measured +1.8 % */
+#  define NTT_PRE_ALSO 12 /* forward: last group's twiddles register-resident at this size too (2^14 always) */
 #endif
 #ifndef NTT_IPRE_MIN
-#  define NTT_IPRE_MIN 12 /* inverse: first executed group's twiddles preloaded from this size up; measured +3.8 % at 2^12 */
+#  define NTT_IPRE_MIN 12 /* inverse: first executed group's twiddles register-resident from this size up */
 #endif
 
 template <int LOGN, bool INV, bool COMPACT> struct Geom {
@@ -351,10 +351,17 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
 #endif
-    /* the last group's per-lane twiddles (8-byte form), requested once per block right
-     * after the first exchange.  Keeping them in registers across blocks was tried and
-     * spills -- and a spill reload waits for the whole prefetch (vmcnt) */
+    /* The last group's per-lane twiddles (8-byte form, 24 VGPRs) stay in registers for the whole
+     * launch: a workgroup always sees the same block position (its stride over the blocks is a
+     * multiple of the blocks per polynomial, as for the LDS tables), so they never change.  This
+     * spilled while the kernel needed more registers elsewhere; since the instruction-count work
+     * it fits (120 VGPRs) and removes the per-block loads and the only vmcnt wait inside the
+     * loop -- the prefetched block now has the entire iteration to arrive (measured +2 %). */
     typename A::ctw pre[4][kE / 2];
+    if constexpr(PRE) {
+      preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
+      pin_preloaded<A, LOGN, GL>(pre);
+    }
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
@@ -375,7 +382,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
-        if constexpr(PRE && GI == 0) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
@@ -412,14 +418,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
       fill_lds_tables<A, LOGN, INV>(tabl, p, (uint32_t)b & bmask, tid);
       __syncthreads();
     }
-    /* the first executed group's per-lane twiddles do not change from block to
-     * block (the workgroup always sees the same block position): request the
-     * next iteration's copy at the end of the current one, so its L2 latency
-     * hides under the final stores and the conversion of the next block */
+    /* the first executed group's per-lane twiddles do not change from block to block (the
+     * workgroup always sees the same block position): loaded once, they stay in 24 VGPRs for
+     * the whole launch (measured +5 % at 2^14 over re-requesting them every block) */
 #ifdef NTT_NO_INV_PRE
     constexpr bool IPRE = false;
 #else
-    constexpr bool IPRE = A::kCompact && LOGN >= NTT_IPRE_MIN && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
+    /* (not for the 2^12 kernel of the q <= 2^50 class: its different reduction plan needs one register
+     * more and would spill; it keeps the per-stage loads) */
+    constexpr bool IPRE = A::kCompact && LOGN >= NTT_IPRE_MIN && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 &&
+                          !(LOGN == 12 && KSH == 1);
 #endif
     typename A::ctw pre[4][kE / 2];
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
@@ -452,16 +460,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
           run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
         }
       });
-      /* Next iteration's first-group twiddles: requested now, and waited for BEFORE the
-       * stores enter the vector-memory queue (their L2 latency hides under the sixteen
-       * canonicalisations in between).  With loads and stores both pending the compiler can
-       * only wait for vmcnt(0) -- one counter, completion order between the two kinds
-       * unknown -- so a load consumed after the stores were issued would cost a full store
-       * round trip at the start of every block. */
-      if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
       uint64_t out[kE];
       static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], p.c); });
-      if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
       buffer_store_first_raw<LOGN>(out, tid, base);
     }
     return;
