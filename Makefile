@@ -43,3 +43,10 @@ build/ubench: tools/ubench.hip $(HDRS)
 	mkdir -p build
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -I$(CSRC) -o $@ tools/ubench.hip
 .PHONY: ubench
+
+# data-movement skeletons of the 2^14 kernel (run on the GPU box: build/skel [GiB] [launches])
+skel: build/skel
+build/skel: tools/skel.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -o $@ tools/skel.hip
+.PHONY: skel

@@ -95,7 +95,8 @@ NTT_API int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint
                                     const uint64_t *d_b, uint64_t batch, void *stream);
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
  * fwd(a), fwd(b), pointwise, inv.  d_a and d_b are overwritten (left in the NTT
- * domain); d_c may alias d_a. */
+ * domain).  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
+ * a*a (the shared operand is transformed once); any other overlap is undefined. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
 
@@ -138,6 +139,13 @@ NTT_API int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, 
  * when all shards are done.  inverse != 0 selects the inverse transform. */
 NTT_API int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const *d_a,
                             const uint64_t *batch, int inverse);
+
+/* ---- reference-signature entry points: housekeeping ----
+ * The single-polynomial functions of ntt_reference.h / ntt_radix4.h / ntt_radix4x4.h / ntt_seal.h keep
+ * device tables for the caller tables they have seen (keyed on a hash of every entry, at most 32 plans,
+ * least recently used evicted) and one staging buffer.  ntt_compat_release() frees all of it. */
+NTT_API void ntt_compat_release(void);
+NTT_API int  ntt_compat_cached_plans(void);
 
 /* ---- parameter helpers (reference: SageMath script, tests/test_cases.h:113-142) ---- */
 /* smallest primitive 2N-th root of unity mod q ("minimum root" rule); 0 if none */

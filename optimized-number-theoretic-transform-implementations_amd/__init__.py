@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = [
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
+    "ntt_compat_release", "ntt_compat_cached_plans",
     # reference signatures (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h)
     "fwd_ntt_ref_harvey_lazy", "inv_ntt_ref_harvey", "fwd_ntt_ref_harvey_lazy_dbl",
     "fwd_ntt_radix4_lazy", "inv_ntt_radix4", "fwd_ntt_radix4x4_lazy", "fwd_ntt_seal_lazy",
@@ -61,8 +62,13 @@ class NttError(RuntimeError):
 
 
 class MulOp(C.Structure):
-    """reference mul_op_t: two __uint128_t, passed by value (fast_mul_operators.h:10-13)."""
-    _fields_ = [("op_lo", C.c_uint64), ("op_hi", C.c_uint64), ("con_lo", C.c_uint64), ("con_hi", C.c_uint64)]
+    """reference mul_op_t: two __uint128_t, passed by value (fast_mul_operators.h:10-13).
+
+    __uint128_t is 16-byte aligned and ctypes has no 128-bit integer: the zero-length long double array
+    contributes nothing but its 16-byte alignment, so libffi places the by-value copy where the C callee
+    expects it even when other stack arguments precede it (tests/test_abi.py::test_mul_op_by_value_through_ctypes)."""
+    _fields_ = [("_align16", C.c_longdouble * 0),
+                ("op_lo", C.c_uint64), ("op_hi", C.c_uint64), ("con_lo", C.c_uint64), ("con_hi", C.c_uint64)]
 
 
 def _sig(name, restype, *argtypes):
@@ -101,6 +107,8 @@ _sig("ntt_event_elapsed_ms", C.c_int, C.c_int, VOIDP, VOIDP, C.POINTER(C.c_float
 _sig("ntt_fill_uniform", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_poly_checksum", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_batch_multi", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), U64P, C.c_int)
+_sig("ntt_compat_release", None)
+_sig("ntt_compat_cached_plans", C.c_int)
 _sig("ntt_min_root", C.c_uint64, C.c_uint64, C.c_uint64)
 _sig("ntt_find_prime", C.c_uint64, C.c_uint, C.c_uint64, C.c_uint)
 for _n in ("fwd_ntt_ref_harvey_lazy", "fwd_ntt_radix4_lazy", "fwd_ntt_radix4x4_lazy", "fwd_ntt_seal_lazy"):
@@ -116,6 +124,8 @@ def last_error():
 
 
 def _check(rc):
+    # ntt_last_error is thread-local in the library and only read here, on the failing thread, immediately
+    # after the failing call
     if rc != NTT_OK:
         raise NttError("ntt status %d: %s" % (rc, last_error()))
 
@@ -129,6 +139,14 @@ def device_count():
     if n < 0:
         raise NttError(last_error())
     return n
+
+
+def compat_release():
+    _lib.ntt_compat_release()
+
+
+def compat_cached_plans():
+    return int(_lib.ntt_compat_cached_plans())
 
 
 def min_root(q, n):
@@ -301,7 +319,9 @@ def batch_multi(plans, dptrs, batches, inverse=False):
 # reference-signature entry points on host numpy arrays (in place)
 # --------------------------------------------------------------------------
 def _mulop(op, con):
-    return MulOp(op & (2**64 - 1), op >> 64, con & (2**64 - 1), con >> 64)
+    m = MulOp()
+    m.op_lo, m.op_hi, m.con_lo, m.con_hi = op & (2**64 - 1), op >> 64, con & (2**64 - 1), con >> 64
+    return m
 
 
 def _reduce(a, q, k):

@@ -61,6 +61,28 @@ static int env_int(const char *name, int dflt)
   return v ? atoi(v) : dflt;
 }
 
+/* Every entry point selects the plan's (or the named) device for its own HIP calls and puts the
+ * caller's current device back on return, so the library can be mixed with torch / other HIP code
+ * that relies on hipSetDevice state. */
+struct DeviceGuard {
+  int  prev = -1;
+  bool ok   = false;
+  explicit DeviceGuard(int device)
+  {
+    if(hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard()
+  {
+    if(prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define USE_DEVICE(device)                                             \
+  DeviceGuard guard_(device);                                          \
+  if(!guard_.ok) return fail(NTT_ERR_HIP, "hipSetDevice failed")
+
 static int check_device(int device)
 {
   int        n = 0;
@@ -141,7 +163,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   int ar = 0;
   rc     = resolve_arith(arith, q, &ar);
   if(rc) return rc;
-  HIP_TRY(hipSetDevice(device));
+  USE_DEVICE(device);
   ntt_plan *p = new ntt_plan();
   p->device   = device;
   p->N        = N;
@@ -204,7 +226,12 @@ extern "C" int ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t 
 {
   if(!is_pow2(N) || q < 3 || root == 0 || root >= q) return fail(NTT_ERR_ARG, "bad N, q or root");
   if(h_powmod(root, N, q) != q - 1) return fail(NTT_ERR_ARG, "root is not a primitive 2N-th root of unity mod q");
+  /* root^-1 and N^-1 come from Fermat's little theorem, which holds only for a prime q: verify them
+   * instead of trusting the caller (a composite q can pass 2N | q-1 and root^N == -1) */
   const uint64_t rinv = h_powmod(root, q - 2, q);
+  if(h_mulmod(root, rinv, q) != 1 || h_mulmod(N % q, h_powmod(N % q, q - 2, q), q) != 1) {
+    return fail(NTT_ERR_ARG, "q is not prime (root^(q-2) is not the inverse of root)");
+  }
   return plan_build(out, device, N, q, root, h_power_table(root, N, q), h_power_table(rinv, N, q), arith, 0);
 }
 
@@ -213,6 +240,21 @@ extern "C" int ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t 
 {
   if(!w_powers && !w_inv_powers) return fail(NTT_ERR_ARG, "no table given");
   if(!is_pow2(N)) return fail(NTT_ERR_ARG, "N must be a power of two");
+  if(N < 2 || q < 3) return fail(NTT_ERR_ARG, "bad N or q");
+  /* cheap consistency checks of the caller's tables (reference layout, pre_compute.h:38-66): slot 0 is
+   * root^0, slot 1 is root^(N/2) -- a square root of -1 -- and the two tables are inverses of each other */
+  for(const uint64_t *t : {w_powers, w_inv_powers}) {
+    if(!t) continue;
+    if(t[0] != 1 || t[1] >= q || h_mulmod(t[1], t[1], q) != q - 1) {
+      return fail(NTT_ERR_ARG, "table is not a bit-reversed power table of a primitive 2N-th root of unity mod q");
+    }
+  }
+  if(w_powers && w_inv_powers) {
+    const uint64_t last = N - 1; /* root^(bitrev(N-1)) = root^(N-1) */
+    if(h_mulmod(w_powers[1], w_inv_powers[1], q) != 1 || h_mulmod(w_powers[last], w_inv_powers[last], q) != 1) {
+      return fail(NTT_ERR_ARG, "w_inv_powers is not the inverse of w_powers");
+    }
+  }
   std::vector<uint64_t> f, i;
   if(w_powers) f.assign(w_powers, w_powers + N);
   if(w_inv_powers) i.assign(w_inv_powers, w_inv_powers + N);
@@ -222,7 +264,7 @@ extern "C" int ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t 
 extern "C" void ntt_plan_destroy(ntt_plan *p)
 {
   if(!p) return;
-  (void)hipSetDevice(p->device);
+  DeviceGuard guard_(p->device);
   if(p->d_fwd) (void)hipFree(p->d_fwd);
   if(p->d_inv) (void)hipFree(p->d_inv);
   if(p->d_fwd8) (void)hipFree(p->d_fwd8);
@@ -270,7 +312,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(!p || (!d_a && batch)) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
-  HIP_TRY(hipSetDevice(p->device));
+  USE_DEVICE(p->device);
   const PassList L = make_passes(p->m, p->generic);
   /* Multi-pass transforms (N > 2^14) are run chunk by chunk so that what one pass
    * writes is still in the 256 MiB Infinity Cache when the next pass reads it:
@@ -386,7 +428,7 @@ extern "C" int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const u
 {
   if(!p || !d_c || !d_a || !d_b) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
-  HIP_TRY(hipSetDevice(p->device));
+  USE_DEVICE(p->device);
   const uint64_t n = batch * p->N;
   if(p->arith == NTT_ARITH_F64) {
     hipLaunchKernelGGL((pointwise_kernel<ArithF64>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_c, d_a,
@@ -402,8 +444,10 @@ extern "C" int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const u
 extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
                                         uint64_t batch, void *stream)
 {
+  /* d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
+   * would multiply fwd(fwd(a)) with itself) */
   int rc = ntt_fwd_batch(p, d_a, batch, stream);
-  if(!rc) rc = ntt_fwd_batch(p, d_b, batch, stream);
+  if(!rc && d_b != d_a) rc = ntt_fwd_batch(p, d_b, batch, stream);
   if(!rc) rc = ntt_pointwise_mul_batch(p, d_c, d_a, d_b, batch, stream);
   if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
   return rc;
@@ -451,7 +495,7 @@ extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t 
   int rc = check_device(device);
   if(rc) return rc;
   if(!d_a || q == 0) return fail(NTT_ERR_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(device));
+  USE_DEVICE(device);
   hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_a, n, q, seed,
                      offset);
   HIP_TRY(hipGetLastError());
@@ -465,7 +509,7 @@ extern "C" int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_
   if(rc) return rc;
   if(!d_out || !d_a) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
-  HIP_TRY(hipSetDevice(device));
+  USE_DEVICE(device);
   const unsigned g = batch > 8192 ? 8192u : (unsigned)batch;
   hipLaunchKernelGGL(checksum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, d_out, d_a, N, batch);
   HIP_TRY(hipGetLastError());
@@ -486,12 +530,12 @@ extern "C" int ntt_device_count(void)
   return n;
 }
 
-#define DEV_PROLOG(device)           \
-  do {                               \
-    int rc_ = check_device(device);  \
-    if(rc_) return rc_;              \
-    HIP_TRY(hipSetDevice(device));   \
-  } while(0)
+#define DEV_PROLOG(device)          \
+  {                                 \
+    int rc_ = check_device(device); \
+    if(rc_) return rc_;             \
+  }                                 \
+  USE_DEVICE(device)
 
 extern "C" int ntt_dev_malloc(int device, void **d_ptr, size_t bytes)
 {
@@ -578,13 +622,13 @@ extern "C" int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const
   for(int g = 0; g < ndev; g++) {
     ntt_plan *p = plans[g];
     if(!p) return fail(NTT_ERR_ARG, "null plan");
-    HIP_TRY(hipSetDevice(p->device));
+    USE_DEVICE(p->device);
     if(!p->own_stream) HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     int rc = run_transform(p, d_a[g], batch[g], inverse != 0, false, (void *)p->own_stream);
     if(rc) return rc;
   }
   for(int g = 0; g < ndev; g++) {
-    HIP_TRY(hipSetDevice(plans[g]->device));
+    USE_DEVICE(plans[g]->device);
     HIP_TRY(hipStreamSynchronize(plans[g]->own_stream));
   }
   return NTT_OK;
@@ -658,31 +702,40 @@ extern "C" uint64_t ntt_find_prime(unsigned bits, uint64_t N, unsigned skip)
 namespace {
 
 struct CompatPlan {
-  uint64_t  N, q, key, ninv;
+  uint64_t  N, q, key, ninv, stride;
   bool      inverse;
   ntt_plan *plan;
+  uint64_t  last_use;
 };
 
 std::mutex              g_mu;
 std::vector<CompatPlan> g_plans;
+uint64_t                g_use_clock   = 0;
 uint64_t *              g_stage       = nullptr;
 size_t                  g_stage_bytes = 0;
+int                     g_stage_dev   = -1;
+constexpr size_t        kCompatPlansMax = 32; /* least-recently-used plan is destroyed beyond this */
 
-/* identifies a caller table by 256 evenly spaced entries (plus the last one): two tables for
- * the same (N, q, direction) come from different roots and differ in essentially every slot
- * above 0, and hashing all N entries cost a third of a call at N = 2^17 */
+/* Identifies a caller table by ALL of its entries (position-sensitive multiply-add hash, four
+ * independent lanes so the host compiler vectorises it: ~0.1 ms at N = 2^17, a fraction of the two PCIe
+ * copies of the same call).  A sampled digest would hand a stale plan to a table that was edited in place
+ * or that differs only in unsampled slots -- silently wrong results on a path whose only job is
+ * correctness. */
 uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
 {
-  uint64_t       h    = 0xcbf29ce484222325ULL;
-  const uint64_t step = n > 256 ? n / 256 : 1;
-  for(uint64_t i = 0; i < n; i += step) {
-    h ^= w[i * stride];
-    h *= 0x100000001b3ULL;
-    h ^= h >> 29;
+  uint64_t h[4] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL, 0x94d049bb133111ebULL, 0xcbf29ce484222325ULL};
+  uint64_t i    = 0;
+  for(; i + 4 <= n; i += 4) {
+    for(int l = 0; l < 4; l++) h[l] = (h[l] ^ w[(i + l) * stride]) * 0x100000001b3ULL + (i + l);
   }
-  h ^= w[(n - 1) * stride];
-  h *= 0x100000001b3ULL;
-  return h;
+  for(; i < n; i++) h[0] = (h[0] ^ w[i * stride]) * 0x100000001b3ULL + i;
+  uint64_t r = n;
+  for(int l = 0; l < 4; l++) {
+    r ^= h[l];
+    r *= 0xff51afd7ed558ccdULL;
+    r ^= r >> 33;
+  }
+  return r;
 }
 
 [[noreturn]] void die(const char *fn)
@@ -700,8 +753,12 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
   const int                   device = env_int("NTT_DEVICE", 0);
   const uint64_t              key    = table_key(w, N, stride);
   ntt_plan *                  plan   = nullptr;
-  for(const CompatPlan &c : g_plans) {
-    if(c.N == N && c.q == q && c.key == key && c.inverse == inverse && c.ninv == ninv) plan = c.plan;
+  for(CompatPlan &c : g_plans) {
+    if(c.N == N && c.q == q && c.key == key && c.stride == stride && c.inverse == inverse && c.ninv == ninv &&
+       c.plan->device == device) {
+      plan       = c.plan;
+      c.last_use = ++g_use_clock;
+    }
   }
   if(!plan) {
     std::vector<uint64_t> tab(N), none;
@@ -709,16 +766,31 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     int rc = inverse ? plan_build(&plan, device, N, q, 0, none, tab, NTT_ARITH_AUTO, ninv)
                      : plan_build(&plan, device, N, q, 0, tab, none, NTT_ARITH_AUTO, 0);
     if(rc) die(fn);
-    g_plans.push_back(CompatPlan{N, q, key, ninv, inverse, plan});
+    if(g_plans.size() >= kCompatPlansMax) {
+      size_t lru = 0;
+      for(size_t k = 1; k < g_plans.size(); k++) {
+        if(g_plans[k].last_use < g_plans[lru].last_use) lru = k;
+      }
+      ntt_plan_destroy(g_plans[lru].plan);
+      g_plans.erase(g_plans.begin() + (long)lru);
+    }
+    g_plans.push_back(CompatPlan{N, q, key, ninv, stride, inverse, plan, ++g_use_clock});
   }
   const uint64_t batch = a2 ? 2 : 1;
   const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
-  if(hipSetDevice(device) != hipSuccess) {
+  DeviceGuard guard(device);
+  if(!guard.ok) {
     g_err = "hipSetDevice";
     die(fn);
   }
-  if(bytes > g_stage_bytes) {
-    if(g_stage) (void)hipFree(g_stage);
+  if(bytes > g_stage_bytes || g_stage_dev != device) {
+    if(g_stage) {
+      DeviceGuard old(g_stage_dev);
+      (void)hipFree(g_stage);
+      g_stage       = nullptr;
+      g_stage_bytes = 0;
+    }
+    g_stage_dev = device;
     if(hipMalloc((void **)&g_stage, bytes) != hipSuccess) {
       g_err = "hipMalloc staging buffer";
       die(fn);
@@ -741,6 +813,27 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
 }
 
 } // namespace
+
+/* frees what the reference-signature entry points keep between calls (cached plans with their device
+ * tables, the staging buffer).  Safe to call at any time; the next call rebuilds what it needs. */
+extern "C" void ntt_compat_release(void)
+{
+  std::lock_guard<std::mutex> lock(g_mu);
+  for(CompatPlan &c : g_plans) ntt_plan_destroy(c.plan);
+  g_plans.clear();
+  if(g_stage) {
+    DeviceGuard guard(g_stage_dev);
+    (void)hipFree(g_stage);
+  }
+  g_stage       = nullptr;
+  g_stage_bytes = 0;
+  g_stage_dev   = -1;
+}
+extern "C" int ntt_compat_cached_plans(void)
+{
+  std::lock_guard<std::mutex> lock(g_mu);
+  return (int)g_plans.size();
+}
 
 extern "C" {
 

@@ -38,6 +38,53 @@ def test_mul_op_abi():
                     "-I" + os.path.join(ROOT, "include", "internal"), "-x", "c", "-"], input=src, text=True, check=True)
 
 
+def test_mul_op_by_value_through_ctypes(lib, tmp_path):
+    """the ctypes MulOp reaches a C callee intact even behind seven integer arguments (the first six go in
+    registers, the seventh on the stack: an 8-aligned struct copy would then land 8 bytes off)"""
+    import ctypes as C
+    src = tmp_path / "probe.c"
+    src.write_text('#include "fast_mul_operators.h"\n'
+                   "uint64_t probe(long a,long b,long c,long d,long e,long f,long g, mul_op_t m)"
+                   "{(void)a;(void)b;(void)c;(void)d;(void)e;(void)f;"
+                   " return (uint64_t)m.op + 3*(uint64_t)(m.op>>64) + 5*(uint64_t)m.con + 7*(uint64_t)(m.con>>64) + (uint64_t)g;}\n")
+    so = tmp_path / "probe.so"
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "include", "internal"), "-o", str(so), str(src)])
+    probe = C.CDLL(str(so)).probe
+    probe.restype = C.c_uint64
+    probe.argtypes = [C.c_long] * 7 + [lib.MulOp]
+    assert C.sizeof(lib.MulOp) == 32 and C.alignment(lib.MulOp) == 16
+    m = lib._mulop((13 << 64) | 11, (19 << 64) | 17)
+    assert probe(1, 2, 3, 4, 5, 6, 100, m) == 11 + 3 * 13 + 5 * 17 + 7 * 19 + 100
+
+
+def test_plan_create_rejects_composite_modulus(lib):
+    """q = 65 = 5 * 13 passes the cheap tests (4 | q-1, 8^2 = -1 mod 65) but is not prime: N^(q-2) is not
+    N^-1, the plan would scale by garbage.  Refused before any device is touched."""
+    import ctypes as C
+    h = C.c_void_p()
+    rc = lib._lib.ntt_plan_create(C.byref(h), 0, 2, 65, 8, 0)
+    assert rc == -1 and "prime" in lib.last_error()
+
+
+def test_traffic_json_matches_bench():
+    """roofline.traffic in the bench line is read from a committed PMC summary: the file must name the kernel
+    and batch bench.py launches by default, otherwise bench.py reports null rather than a stale number"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(bench.TRAFFIC_JSON) as f:
+        t = json.load(f)
+    assert t["kernel"] == bench.kernel_name(2) and t["batch"] == bench.per_gpu_batch("weak", 1) and t["N"] == bench.N
+    assert t["hbm_bytes_per_launch"] == 2 * 1024 * t["FETCH_SIZE_KB"] + 1024 * t["WRITE_SIZE_KB"]
+    assert bench.measured_traffic(t["batch"], t["kernel"]) == t["hbm_bytes_per_launch"]
+    assert bench.measured_traffic(t["batch"], "fused_kernel<ArithU64,14,fwd>") is None
+    assert bench.measured_traffic(t["batch"] // 2, t["kernel"]) is None
+    # no more than 2 % above the algorithmic bytes: anything else means re-reads crept in
+    assert 1.0 <= t["hbm_bytes_per_launch"] / (t["batch"] * 16 * t["N"]) < 1.02
+
+
 def test_headers_compile_as_c_and_cxx():
     for comp, std in (("gcc", "-std=gnu11"), ("g++", "-std=c++17")):
         src = "\n".join('#include "%s"' % h for h in ("ntt_mi355x.h", "ntt_reference.h", "ntt_radix4.h",

@@ -346,8 +346,10 @@ def test_reference_test_driver_drop_in():
     unchanged against include/ and linked to libntt_mi355x.so (oracle/Makefile
     `dropin`), run here on the GPU: 19 cases, zero 'Bad results'"""
     exe = os.path.join(ROOT, "oracle", "_ref", "ntt-variants-dropin")
-    if not os.path.exists(exe):
-        pytest.skip("drop-in binary not built (needs /root/reference at build time)")
+    # a GPU box that lacks the binary has lost the boundary row's only through-the-reference-driver
+    # check: that is a failure, not a skip (the binary is built here by `make -C oracle dropin` and
+    # travels with the snapshot; oracle/_ref is git-ignored but not gpurun-ignored)
+    assert os.path.exists(exe), "oracle/_ref/ntt-variants-dropin did not travel to the GPU box"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("Test ") == 19
@@ -371,3 +373,121 @@ def test_bench_two_ranks_folded_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2 * 8192
     assert d["value"] > 1e5 and "cpu_baseline" not in d
+
+
+def test_bench_single_process_two_shards_folded_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: ONE process drives both shards (one stream and one
+    pair of events each, one host clock), here folded onto the one GPU of the test box"""
+    import json
+    import sys
+    env = dict(os.environ, NTT_BENCH_DEVICE_MOD="1")
+    env.pop("WORLD_SIZE", None)
+    for scaling, per_gpu in (("weak", 4096), ("strong", None)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--scaling", scaling, "--no-cpu-baseline"]
+        if per_gpu:
+            cmd += ["--batch", str(per_gpu)]
+        else:
+            cmd += ["--logn", "8"]          # strong: 2^20 * 2^14 / 2^8 polynomials of 2^8 split over 2 (same bytes)
+            cmd += ["--batch", str(1 << 16)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling
+        assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"]
+        assert len(d["roofline"]["kernel_ms_per_gpu"]) == 2 and d["value"] > 1e5
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("NTT_BENCH_DEVICE_MOD", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0", "--batch", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)
+
+
+def test_squaring_aliases_both_operands(lib, oracle):
+    """negacyclic_mul with d_a == d_b is a*a (the shared buffer used to be transformed twice)"""
+    n, batch = 1 << 10, 3
+    q = lib.find_prime(50, n)
+    w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w)
+    a = _inputs(oracle, n, q, batch, 77)
+    da, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(a.size)
+    plan.negacyclic_mul(dc.ptr, da.ptr, da.ptr, batch)
+    got = dc.download()
+    for p in range(batch):
+        ap = a[p * n:(p + 1) * n].copy()
+        assert np.array_equal(got[p * n:(p + 1) * n], oracle.schoolbook(ap, ap.copy(), n, q)), p
+    # fully in place as well: c == a == b
+    da.upload(a)
+    plan.negacyclic_mul(da.ptr, da.ptr, da.ptr, batch)
+    assert np.array_equal(da.download(), got)
+    plan.destroy()
+
+
+def test_caller_n_inv_is_honoured(lib, oracle, kat):
+    """the by-value mul_op_t really reaches the library: a sentinel n_inv = 2*N^-1 doubles every output"""
+    c = kat["cases"][4]
+    n, q, w = 1 << c["m"], c["q"], c["w"]
+    cx = oracle.ctx(n, q, w)
+    a = oracle.fill_uniform(n, q, 99)
+    fa = cx.fwd(a)
+    ninv2 = (2 * cx.c.ninv) % q
+    con = (ninv2 << 64) // q
+    for fn, tab, tcon in ((lib.inv_ntt_ref_harvey, "winv", "winv_con"), (lib.inv_ntt_radix4, "einv", "einv_con")):
+        x = fa.copy()
+        if fn is lib.inv_ntt_ref_harvey:
+            fn(x, n, q, ninv2, con, 64, cx.table(tab), cx.table(tcon))
+        else:
+            fn(x, n, q, ninv2, con, cx.table(tab), cx.table(tcon))
+        assert np.array_equal(x, (a * np.uint64(2)) % np.uint64(q))
+
+
+def test_compat_cache_sees_every_table_entry(lib, oracle, kat):
+    """the reference-signature shims key their cached plans on ALL table entries: editing one unsampled slot in
+    place must change the result (a sampled digest kept serving the stale plan), and the cache is bounded"""
+    c = kat["cases"][6]
+    n, q, w = 1 << c["m"], c["q"], c["w"]
+    cx = oracle.ctx(n, q, w)
+    tab, con = cx.table("w"), cx.table("wcon")
+    a = oracle.fill_uniform(n, q, 5)
+    x = a.copy()
+    lib.fwd_ntt_ref_harvey(x, n, q, tab, con)
+    assert np.array_equal(x, cx.fwd(a))
+    k = 3 * n // 4 + 1                                    # a slot no 256-stride sample would hit
+    assert k % max(n // 256, 1) != 0
+    tab2 = tab.copy()
+    tab2[k] = (int(tab2[k]) + 1) % q
+    y = a.copy()
+    lib.fwd_ntt_ref_harvey(y, n, q, tab2, con)
+    assert not np.array_equal(y, x)
+    lib.compat_release()
+    assert lib.compat_cached_plans() == 0
+    for i in range(40):                                   # 40 distinct tables: the cache stays at <= 32 plans
+        t = tab.copy()
+        t[2] = (int(t[2]) + 1 + i) % q
+        z = a.copy()
+        lib.fwd_ntt_ref_harvey(z, n, q, t, con)
+    assert 0 < lib.compat_cached_plans() <= 32
+    z = a.copy()
+    lib.fwd_ntt_ref_harvey(z, n, q, tab, con)             # the original table still gives the right answer
+    assert np.array_equal(z, cx.fwd(a))
+    lib.compat_release()
+
+
+def test_current_device_is_restored(lib):
+    """entry points leave the caller's current HIP device as they found it (torch interoperability)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(cur)) == 0
+    before = cur.value
+    plan = lib.Plan(256, 0x1e01, 62, device=0)
+    buf = lib.DeviceBuffer(256)
+    plan.fwd(buf.ptr, 1)
+    lib.stream_sync(0, None)
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
+    plan.destroy()
