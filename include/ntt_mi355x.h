@@ -53,8 +53,20 @@ typedef enum ntt_status {
 typedef enum ntt_arith {
   NTT_ARITH_AUTO = 0, /* FP64 path when q allows it, else 64-bit integer Shoup      */
   NTT_ARITH_U64  = 1, /* reference-identical Harvey/Shoup lazy arithmetic, any q<2^61 */
-  NTT_ARITH_F64  = 2  /* balanced FP64 arithmetic, q <= 2^51(1+2^-10)                 */
+  NTT_ARITH_F64  = 2, /* balanced FP64 arithmetic, q <= 2^51(1+2^-10)                 */
+  NTT_ARITH_U64_R4 = 3 /* the reference's radix-4 butterflies with the shared-quotient double
+                        * product (include/internal/fast_mul_operators.h:62-70,108-149) on the 2N-entry
+                        * expanded table (src/ntt_radix4.c:7-114); single-pass sizes 2^6..2^14, q < 2^60.
+                        * Never chosen by AUTO. */
 } ntt_arith;
+
+typedef enum ntt_option {
+  NTT_OPT_MAX_GRID  = 1, /* cap on workgroups per launch (0 = the kernels' own choice)             */
+  NTT_OPT_CHUNK_MIB = 2, /* bytes of one chunk of a multi-pass transform, MiB (default 256)        */
+  NTT_OPT_F64_CLASS = 3, /* force a coarser FP64 headroom class (0, 1 or 18) than q permits: tests  */
+  NTT_OPT_TWO_PHASE = 4  /* N = 2^15..2^17: 1 = both passes of a polynomial in one workgroup (one launch),
+                          * 0 = one launch per pass over the whole batch */
+} ntt_option;
 
 typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
 
@@ -80,11 +92,23 @@ NTT_API void ntt_plan_destroy(ntt_plan *p);
 NTT_API int  ntt_plan_info(const ntt_plan *p, uint64_t info[8]);
 /* force the strided multi-pass path (self-check of the fused kernels) */
 NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
+/* tuning / test knobs of one plan (ntt_option); nothing in the library reads environment variables for these */
+NTT_API int  ntt_plan_set_option(ntt_plan *p, int option, int64_t value);
 
 /* ---- batched transforms: d_a is device memory laid out [batch][N], in place ---- */
 NTT_API int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_inv_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
-/* same, but inputs may be lazy values in [0,8q) (what the reference's *_lazy
+/* lazy outputs: the reference's *_lazy contract (include/ntt_reference.h:13-17, tests/bench.c:123-137) --
+ * the final reduction is left to the consumer.  Forward: values in [0,4q) (radix-4 policy: [0,8q), bit-identical
+ * to fwd_ntt_radix4_lazy); inverse: [0,2q).  Feed them to the *_wide entry points, to
+ * ntt_pointwise_mul_batch... after reduce_*_to_q, or to the fused product below.  A policy that has no
+ * cheaper lazy form for a direction (FP64 inverse) returns reduced values, which satisfy the contract. */
+NTT_API int ntt_fwd_batch_lazy(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+NTT_API int ntt_inv_batch_lazy(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
+/* every combination in one call: flags = NTT_FLAG_* or'ed together */
+enum { NTT_FLAG_INVERSE = 1, NTT_FLAG_WIDE_IN = 2, NTT_FLAG_LAZY_OUT = 4 };
+NTT_API int ntt_transform_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, unsigned flags, void *stream);
+/* same as ntt_fwd_batch / ntt_inv_batch, but inputs may be lazy values in [0,8q) (what the reference's *_lazy
  * entry points accept and emit); outputs are still in [0,q) */
 NTT_API int ntt_fwd_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_inv_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
@@ -93,9 +117,13 @@ NTT_API int ntt_inv_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch,
 /* d_c[i] = d_a[i]*d_b[i] mod q over n = batch*N values in [0,q); c may alias a or b */
 NTT_API int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a,
                                     const uint64_t *d_b, uint64_t batch, void *stream);
+/* the same with LAZY operands in [0,4q) (ntt_fwd_batch_lazy outputs); the product is fully reduced */
+NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a,
+                                         const uint64_t *d_b, uint64_t batch, void *stream);
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
- * fwd(a), fwd(b), pointwise, inv.  d_a and d_b are overwritten (left in the NTT
- * domain).  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
+ * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
+ * d_a and d_b are overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
+ * transform).  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);

@@ -37,14 +37,17 @@ U64P = C.POINTER(C.c_uint64)
 VOIDP = C.c_void_p
 
 NTT_OK = 0
-ARITH_AUTO, ARITH_U64, ARITH_F64 = 0, 1, 2
+ARITH_AUTO, ARITH_U64, ARITH_F64, ARITH_U64_R4 = 0, 1, 2, 3
+FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
+OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE = 1, 2, 3, 4
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
     "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
-    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic",
+    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option",
     "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
-    "ntt_pointwise_mul_batch", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
+    "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
+    "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
     "ntt_rns_negacyclic_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
@@ -86,9 +89,13 @@ _sig("ntt_plan_create_from_tables", C.c_int, C.POINTER(VOIDP), C.c_int, C.c_uint
 _sig("ntt_plan_destroy", None, VOIDP)
 _sig("ntt_plan_info", C.c_int, VOIDP, U64P)
 _sig("ntt_plan_set_generic", C.c_int, VOIDP, C.c_int)
-for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide"):
+_sig("ntt_plan_set_option", C.c_int, VOIDP, C.c_int, C.c_int64)
+for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide", "ntt_fwd_batch_lazy",
+           "ntt_inv_batch_lazy"):
     _sig(_n, C.c_int, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_transform_batch", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_pointwise_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_pointwise_mul_batch_lazy", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_negacyclic_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_rns_fwd_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_rns_inv_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, VOIDP)
@@ -245,35 +252,45 @@ class Plan:
     def set_generic(self, on):
         _check(_lib.ntt_plan_set_generic(self.h, int(on)))
 
-    def fwd(self, dptr, batch, stream=None, wide=False):
-        f = _lib.ntt_fwd_batch_wide if wide else _lib.ntt_fwd_batch
+    def set_option(self, option, value):
+        _check(_lib.ntt_plan_set_option(self.h, option, value))
+
+    def fwd(self, dptr, batch, stream=None, wide=False, lazy=False):
+        if wide and lazy:
+            _check(_lib.ntt_transform_batch(self.h, dptr, batch, FLAG_WIDE_IN | FLAG_LAZY_OUT, stream))
+            return
+        f = _lib.ntt_fwd_batch_lazy if lazy else (_lib.ntt_fwd_batch_wide if wide else _lib.ntt_fwd_batch)
         _check(f(self.h, dptr, batch, stream))
 
-    def inv(self, dptr, batch, stream=None, wide=False):
-        f = _lib.ntt_inv_batch_wide if wide else _lib.ntt_inv_batch
+    def inv(self, dptr, batch, stream=None, wide=False, lazy=False):
+        if wide and lazy:
+            _check(_lib.ntt_transform_batch(self.h, dptr, batch, FLAG_INVERSE | FLAG_WIDE_IN | FLAG_LAZY_OUT, stream))
+            return
+        f = _lib.ntt_inv_batch_lazy if lazy else (_lib.ntt_inv_batch_wide if wide else _lib.ntt_inv_batch)
         _check(f(self.h, dptr, batch, stream))
 
-    def pointwise_mul(self, dc, da, db, batch, stream=None):
-        _check(_lib.ntt_pointwise_mul_batch(self.h, dc, da, db, batch, stream))
+    def pointwise_mul(self, dc, da, db, batch, stream=None, lazy_in=False):
+        f = _lib.ntt_pointwise_mul_batch_lazy if lazy_in else _lib.ntt_pointwise_mul_batch
+        _check(f(self.h, dc, da, db, batch, stream))
 
     def negacyclic_mul(self, dc, da, db, batch, stream=None):
         _check(_lib.ntt_negacyclic_mul_batch(self.h, dc, da, db, batch, stream))
 
     # host-array conveniences used by the parity tests
-    def fwd_host(self, a, wide=False):
+    def fwd_host(self, a, wide=False, lazy=False):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         batch = a.size // self.N
         buf = DeviceBuffer(a.size, self.device).upload(a)
-        self.fwd(buf.ptr, batch, wide=wide)
+        self.fwd(buf.ptr, batch, wide=wide, lazy=lazy)
         out = buf.download()
         buf.free()
         return out
 
-    def inv_host(self, a, wide=False):
+    def inv_host(self, a, wide=False, lazy=False):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         batch = a.size // self.N
         buf = DeviceBuffer(a.size, self.device).upload(a)
-        self.inv(buf.ptr, batch, wide=wide)
+        self.inv(buf.ptr, batch, wide=wide, lazy=lazy)
         out = buf.download()
         buf.free()
         return out

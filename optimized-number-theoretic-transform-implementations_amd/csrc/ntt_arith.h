@@ -73,6 +73,7 @@ struct ArithU64 {
   static constexpr bool kTracksBounds = false;
   /* no 8-byte twiddle form: the Shoup quotient cannot be rebuilt without a division */
   static constexpr bool kCompact = false;
+  static constexpr bool kRadix4  = false;
   using ctw                      = uint64_t;
   static NTT_HD tw expand(ctw w, const consts &) { return tw{w, 0}; }
 
@@ -115,7 +116,14 @@ struct ArithU64 {
     y                = shoup(c.wninv, d, c);
   }
   static NTT_HD uint64_t store_fwd(val v, const consts &c) { return csub(csub(v, c.q2), c.q); }
+  /* lazy outputs: the reference's documented ranges (include/ntt_reference.h:13-17): forward [0,4q),
+   * inverse [0,2q) -- the conditional subtracts of the final reduction are left to the consumer */
   static NTT_HD uint64_t store_fwd_lazy(val v, const consts &) { return v; } /* < 4q */
+  static NTT_HD uint64_t store_inv_lazy(val v, const consts &) { return v; } /* < 2q */
+  /* both forms in one: keep = ~0 reduces, keep = 0 leaves the lazy value (a conditional subtract of 0 is the
+   * identity) -- the launch-uniform choice costs a scalar AND instead of a branch or a second kernel */
+  static NTT_HD uint64_t store_fwd_sel(val v, const consts &c, uint64_t keep) { return csub(csub(v, c.q2 & keep), c.q & keep); }
+  static NTT_HD uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return csub(v, c.q & keep); }
   static NTT_HD uint64_t store_inv(val v, const consts &c) { return csub(v, c.q); }
   static NTT_HD val      scale_ninv(val v, const consts &c) { return shoup(c.ninv, v, c); }
   /* pointwise product of two values in [0,q), result in [0,q).  The 128-bit
@@ -127,6 +135,97 @@ struct ArithU64 {
     const uint64_t r  = shoup(c.r64, hi, c) + shoup(c.one, lo, c); /* < 4q */
     return csub(csub(r, c.q2), c.q);
   }
+  /* lazy operands (any 64-bit values): the two Shoup folds accept them as they are */
+  static NTT_HD uint64_t mulmod_full_lazy4(uint64_t a, uint64_t b, const consts &c) { return mulmod_full(a, b, c); }
+};
+
+/* ------------------------------------------------------------------ */
+/* ArithU64R4: the reference's radix-4 formulation on the device        */
+/* ------------------------------------------------------------------ */
+/*
+ * Same integer arithmetic, but two stages at a time with the reference's radix-4 butterflies
+ * (include/internal/fast_mul_operators.h:108-149) and their shared-quotient double product
+ * (:62-70).  The plan's table is the reference's 2N-entry EXPANDED table (pre_compute.h:85-105)
+ * as 16-byte records {e[k], e_con[k]}: for the radix-2 slot s of the upper stage of a pair,
+ *   record 2s          = W1            (collect_roots, src/ntt_radix4.c:7-25: w[m1], m1 = 2(m+j))
+ *   records 4s .. 4s+3 = W2, W1*W2, W3, -W1*W3        (w[2*m1 .. 2*m1+3])
+ * Every butterfly is the reference's, applied to the same operands in the same order, so even the
+ * LAZY outputs ([0,8q), or [0,4q) when log2 N is odd) are bit-identical to fwd_ntt_radix4_lazy.
+ * Values travel between stage groups in [0,8q) (forward) / [0,2q) (inverse).
+ */
+struct ArithU64R4 : ArithU64 {
+  static constexpr bool kRadix4 = true;
+  struct pack {
+    TwU64 w1, w2, w12, w3, nw13;
+  };
+
+  /* fast_mul_operators.h:62-70: Q = hi64(con1*t1 + con2*t2) over the 128-bit sum (mod 2^128, like
+   * the reference's __uint128_t arithmetic); result t1*w1 + t2*w2 - Q*q in [0,2q) */
+  static NTT_HD uint64_t dbl_shoup(const TwU64 &a, const TwU64 &b, uint64_t t1, uint64_t t2, const consts &c)
+  {
+    const uint64_t lo1 = a.con * t1, lo2 = b.con * t2;
+    const uint64_t lo  = lo1 + lo2;
+    const uint64_t Q   = mulhi64(a.con, t1) + mulhi64(b.con, t2) + (lo < lo1 ? 1u : 0u);
+    return t1 * a.w + t2 * b.w - Q * c.q;
+  }
+  /* fast_mul_operators.h:56-60 */
+  static NTT_HD uint64_t shoup_q(const TwU64 &t, uint64_t y, const consts &c) { return csub(shoup(t, y, c), c.q); }
+
+  /* forward inputs are used as they come (the radix-4 butterfly takes [0,8q), :108-128); the inverse
+   * starts from [0,2q) (src/ntt_radix4.c:78-81) */
+  template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
+  {
+    if(!INV || !WIDE) return raw;
+    return csub(csub(raw, 2 * c.q2), c.q2);
+  }
+  /* fast_mul_operators.h:108-128.  X = a[i], Y = a[i+t], Z = a[i+2t], T = a[i+3t] */
+  static NTT_HD void r4_fwd(val &X, val &Y, val &Z, val &T, const pack &w, const consts &c)
+  {
+    const uint64_t q4 = 2 * c.q2;
+    const uint64_t Y1 = dbl_shoup(w.w2, w.w12, Y, T, c);
+    const uint64_t Y2 = dbl_shoup(w.w3, w.nw13, Y, T, c);
+    const uint64_t T1 = csub(X, q4);
+    const uint64_t T2 = shoup(w.w1, Z, c);
+    X                 = T1 + T2 + Y1;
+    Y                 = (T1 + T2 - Y1) + c.q2;
+    Z                 = (T1 - T2 + Y2) + c.q2;
+    T                 = (T1 - T2 - Y2) + q4;
+  }
+  /* fast_mul_operators.h:130-149 */
+  static NTT_HD void r4_inv(val &X, val &Y, val &Z, val &T, const pack &w, const consts &c)
+  {
+    const uint64_t q4 = 2 * c.q2;
+    const uint64_t T0 = Z + T;
+    const uint64_t T1 = X + Y;
+    const uint64_t T2 = q4 + X - Y;
+    const uint64_t T3 = q4 + Z - T;
+    X                 = csub(csub(T1 + T0, q4), c.q2);
+    Z                 = shoup_q(w.w1, q4 + T1 - T0, c);
+    Y                 = dbl_shoup(w.w2, w.w3, T2, T3, c);
+    T                 = dbl_shoup(w.w12, w.nw13, T2, T3, c);
+  }
+  /* trailing radix-2 stage of the forward transform when log2 N is odd (src/ntt_radix4.c:56-61) */
+  static NTT_HD void r2_fwd_tail(val &X, val &Y, const TwU64 &w, const consts &c)
+  {
+    X = csub(X, 2 * c.q2);
+    ArithU64::fwd_bfly<false>(X, Y, w, c);
+  }
+  /* leading radix-2 stage of the inverse when log2 N is odd (src/ntt_radix4.c:85-93) */
+  static NTT_HD void r2_inv_head(val &X, val &Y, const TwU64 &w, const consts &c)
+  {
+    X = csub(X, 2 * c.q2);
+    ArithU64::inv_bfly<false>(X, Y, w, c);
+  }
+  static NTT_HD uint64_t store_fwd(val v, const consts &c) { return csub(csub(csub(v, 2 * c.q2), c.q2), c.q); }
+  static NTT_HD uint64_t store_fwd_lazy(val v, const consts &) { return v; } /* < 8q */
+  /* final normalisation pass of the inverse, fused into the store (src/ntt_radix4.c:111-113) */
+  static NTT_HD uint64_t store_inv(val v, const consts &c) { return shoup_q(c.ninv, v, c); }
+  static NTT_HD uint64_t store_inv_lazy(val v, const consts &c) { return shoup(c.ninv, v, c); } /* < 2q */
+  static NTT_HD uint64_t store_fwd_sel(val v, const consts &c, uint64_t keep)
+  {
+    return csub(csub(csub(v, (2 * c.q2) & keep), c.q2 & keep), c.q & keep);
+  }
+  static NTT_HD uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return csub(shoup(c.ninv, v, c), c.q & keep); }
 };
 
 /* ------------------------------------------------------------------ */
@@ -146,6 +245,7 @@ struct F64Consts {
   TwF64  ninv;     /* N^-1 (balanced) and ninv/q                         */
   TwF64  wninv;    /* N^-1 * winv[1] (balanced) and its /q               */
   uint64_t qi;     /* q as integer                                       */
+  double   q2_sub; /* the double whose BIT PATTERN is the integer 2q (2q * 2^-1074): lazy outputs */
 };
 
 struct ArithF64 {
@@ -158,6 +258,7 @@ struct ArithF64 {
    * within 2^-53(1/2 + 2^-10) relative of w/q, i.e. as good as the stored
    * quotient of a full record, so the same bounds apply. */
   static constexpr bool kCompact = true;
+  static constexpr bool kRadix4  = false;
   using ctw                      = double;
   static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, fma_(w, c.qinv, w * c.qinv_lo)}; }
 
@@ -270,6 +371,24 @@ struct ArithF64 {
   }
   static NTT_HD uint64_t store_fwd(val v, const consts &c) { return to_canonical(v, c); }
   static NTT_HD uint64_t store_inv(val v, const consts &c) { return to_canonical(v, c); }
+  /* lazy forward output in [0,4q) (the reference's radix-2 lazy range, include/ntt_reference.h:13-17):
+   * v + 2q for |v| < 2q -- ONE exact fma instead of the seven instructions of to_canonical.  (v + 2q) is
+   * an integer below 4q <= 2^53, and an integer u < 2^53 scaled by 2^-1074 is the double whose bit
+   * pattern is u (subnormal below 2^52, first binade above).  The kernel's reduction schedule
+   * guarantees the bound (fused_mask with LAZY). */
+  static NTT_HD uint64_t store_fwd_lazy(val v, const consts &c)
+  {
+    union {
+      double   d;
+      uint64_t u;
+    } x;
+    x.d = fma_(v, 0x1p-1074, c.q2_sub);
+    return x.u;
+  }
+  /* the inverse's last group leaves sums of scaled values (|v| up to ~3q): no cheap lazy form exists
+   * below 2^53, so the "lazy" inverse output of this policy is the canonical one (a legal member of
+   * [0,2q)) */
+  static NTT_HD uint64_t store_inv_lazy(val v, const consts &c) { return to_canonical(v, c); }
   static NTT_HD val      scale_ninv(val v, const consts &c) { return mulmod(c.ninv, v, c); }
   /* pointwise product of two values in [0,q): b is re-centred so |a*b/q| <= q/2
    * and the on-the-fly quotient h*qinv is within 0.4 of the truth */
@@ -282,6 +401,22 @@ struct ArithF64 {
     const double k  = rint_(h * c.qinv);
     const double l  = fma_(x, y, -h);
     const double d  = fma_(-k, c.q, h);
+    return to_canonical(d + l, c);
+  }
+  /* the same for LAZY operands anywhere in [0,4q): one integer fold brings them below 2q (4q itself may exceed
+   * 2^53 for q just above 2^51, so the fold comes before the conversion), both are re-centred by q, b is then
+   * reduced to |y| <= q/2 so that the quotient estimate from the rounded product stays within 1 of the truth
+   * and h - k*q below 2^53 */
+  static NTT_HD uint64_t mulmod_full_lazy4(uint64_t a, uint64_t b, const consts &c)
+  {
+    a                  = a < 2 * c.qi ? a : a - 2 * c.qi;
+    b                  = b < 2 * c.qi ? b : b - 2 * c.qi;
+    const double x     = u64_to_f64_lt52(a) - c.q;
+    const double y     = reduce(u64_to_f64_lt52(b) - c.q, c);
+    const double h     = x * y;
+    const double k     = rint_(h * c.qinv);
+    const double l     = fma_(x, y, -h);
+    const double d     = fma_(-k, c.q, h);
     return to_canonical(d + l, c);
   }
 };
@@ -309,7 +444,22 @@ constexpr double f64_rho(double b, double theta2) { return 0.5 + b * theta2 * 1.
 
 /* cmask: bit s set => the stage processed at position s multiplies by a compact
  * (8-byte) twiddle, whose quotient estimate (mulmod_c) is 1.5x less accurate */
-constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask = 0)
+constexpr F64Sched f64_schedule_forced(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask, uint32_t force);
+
+/* bout_max: largest |value|/q the last stage may leave (forward only; 2 - slack for lazy outputs): stages are
+ * forced to reduce from the last one backwards until the bound holds */
+constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask = 0, double bout_max = 1e30)
+{
+  uint32_t force = 0;
+  F64Sched sc    = f64_schedule_forced(inverse, nstages, ksh, b_in, cmask, force);
+  for(int s = nstages - 1; s >= 0 && sc.bout > bout_max; s--) {
+    force |= 1u << s;
+    sc = f64_schedule_forced(inverse, nstages, ksh, b_in, cmask, force);
+  }
+  return sc;
+}
+
+constexpr F64Sched f64_schedule_forced(bool inverse, int nstages, int ksh, double b_in, uint32_t cmask, uint32_t force)
 {
   /* class ksh: q <= 2^(51-ksh)*(1+2^-10) */
   double theta2 = 0.25 * 1.001; /* q/2^53 for ksh=0 */
@@ -328,7 +478,7 @@ constexpr F64Sched f64_schedule(bool inverse, int nstages, int ksh, double b_in,
       const double nr = b + f64_rho(b, theta2);
       /* also keep the *next* stage feasible: after a no-reduce stage the next
        * one can always reduce, so only the immediate bound matters */
-      if(nr > lim) {
+      if(nr > lim || ((force >> s) & 1u)) {
         mask |= (1u << s);
         b = 0.501 + f64_rho(b, theta2);
       } else {

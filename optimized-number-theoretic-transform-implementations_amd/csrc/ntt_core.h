@@ -253,6 +253,7 @@ template <class A> struct Params {
   uint32_t               s0;      /* global stages handled before (fwd) / after (inv) this pass */
   uint32_t               wide;    /* inputs may be lazy ([0,8q)) instead of [0,q) */
   uint32_t               lastinv; /* inverse: this pass ends with global stage 0  */
+  uint32_t               lazy;    /* outputs of the pass that ends a transform stay in the reference's lazy range */
   uint64_t               nblocks; /* batch * 2^s0 blocks of 2^LOGN                */
 };
 
@@ -272,23 +273,14 @@ NTT_HD uint32_t uniform_u32(uint32_t v)
  * vector memory pipe (TA) was the bottleneck with per-lane loads (profiles/r01). */
 template <class A, bool UNIFORM, int G = 0> NTT_HD typename A::tw load_tw(const typename A::tw *tab, uint32_t idx)
 {
-#ifdef NTT_ABL_CONSTTW /* timing ablation only: no twiddle traffic for the groups in the mask (wrong results) */
-  if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
-    typename A::tw t = tab[0];
-    (void)idx;
-    return t;
-  }
-#endif
-#if 1
-#  if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW)
+#if defined(__HIP_DEVICE_COMPILE__)
   if constexpr(UNIFORM) {
     typedef const typename A::tw __attribute__((address_space(4))) * ctab_t;
     ctab_t ct = (ctab_t)(uintptr_t)tab;
     return ct[idx];
   }
-#  endif
-  return tab[idx];
 #endif
+  return tab[idx];
 }
 
 /* ------------------------------------------------------------------ */
@@ -306,12 +298,8 @@ template <class A, bool UNIFORM, int G = 0> NTT_HD typename A::tw load_tw(const 
  * two twiddles of a last-stage pair become one 16-byte load. */
 template <class A, int LOGN, bool INV> constexpr bool stage_is_compact(int g, int j)
 {
-#ifdef NTT_NO_COMPACT_TW
-  return false;
-#else
   (void)INV;
   return A::kCompact && !Plan<LOGN>::TW_UNIFORM(g, j);
-#endif
 }
 
 /* table[idx] with a 32-bit byte offset: tables are at most 2^28 records, so the
@@ -365,7 +353,7 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
   constexpr bool     IB_IN_U = ((P::THREAD_BITS(G) >> SH) & UMASK) != 0;
   uint32_t           tl      = (uint32_t)(UMASK << P::S(G)) + (ib >> (LOGN - P::S(G)));
   if constexpr(IB_IN_U) tl += ((ib >> SH) & UMASK) << P::S(G);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_SCALAR_TW) && !defined(NTT_NO_WIDE_SMEM)
+#if defined(__HIP_DEVICE_COMPILE__)
   /* wave-uniform stage: its 2^J records are consecutive slots -> fetch them as
    * ONE aggregate through the constant address space (s_load_dwordx4/8/16), so a
    * group issues 4-5 scalar loads up front instead of 15 load/wait pairs */
@@ -394,11 +382,6 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
         /* ltw: this group's slice of the compact table, resident in LDS, laid out
          * by the slot the stage would use in a stand-alone 2^LOGN transform
          * (block prefix and leading stages removed), minus the group's first slot */
-#ifdef NTT_ABL_CONSTTW
-        if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
-          w.c[B] = p.tw8[1];
-        } else
-#endif
         if constexpr(LTW) {
           constexpr uint32_t OFFT = ((OFF & UMASK) << P::S(G)) + (OFF >> J);
           w.c[B]                  = ltw[tl + OFFT];
@@ -560,6 +543,99 @@ NTT_HD void run_group0_folded(typename A::val (&x)[kE], uint32_t ib, uint32_t bl
   });
 }
 
+/* ------------------------------------------------------------------ */
+/* radix-4 stage pairs (ArithU64R4)                                      */
+/* ------------------------------------------------------------------ */
+/*
+ * The reference's radix-4 transform (src/ntt_radix4.c:27-114) inside a register-resident stage
+ * group: local stages (J, J+1) of the group form one radix-4 level.  With s = radix-2 table slot of
+ * stage J for a quad of slots, collect_roots (src/ntt_radix4.c:7-25) reads expanded records 2s
+ * (W1) and 4s..4s+3 (W2, W1W2, W3, -W1W3): one 16-byte and one 64-byte fetch, through the scalar cache
+ * when the slot is wave-uniform.  A group with an odd number of stages exists only as the last group
+ * of an odd-sized block: it is the reference's extra radix-2 stage (:56-61 forward, :85-93 inverse).
+ */
+template <class A, int LOGN, int G, int J> NTT_HD typename A::pack load_r4_pack(uint32_t ib, uint32_t blk, uint32_t e00off,
+                                                                                 const Params<A> &p)
+{
+  using P           = Plan<LOGN>;
+  constexpr int SL  = P::S(G) + J;
+  constexpr int SH  = LOGN - SL;
+  uint32_t      s   = (1u << (p.s0 + SL)) + (blk << SL) + (ib >> SH) + e00off;
+  constexpr bool U  = P::TW_UNIFORM(G, J);
+  if constexpr(U) s = uniform_u32(s);
+  typename A::pack w;
+  struct alignas(16) Four {
+    typename A::tw r[4];
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr(U) {
+    typedef const typename A::tw __attribute__((address_space(4))) * ctab_t;
+    typedef const Four __attribute__((address_space(4))) *           cfour_t;
+    w.w1         = ((ctab_t)(uintptr_t)p.tw)[2u * s];
+    const Four f = *(cfour_t)(uintptr_t)(p.tw + 4u * s);
+    w.w2         = f.r[0];
+    w.w12        = f.r[1];
+    w.w3         = f.r[2];
+    w.nw13       = f.r[3];
+    return w;
+  }
+#endif
+  w.w1         = at32(p.tw, 2u * s);
+  const Four f = at32(reinterpret_cast<const Four *>(p.tw), s);
+  w.w2         = f.r[0];
+  w.w12        = f.r[1];
+  w.w3         = f.r[2];
+  w.nw13       = f.r[3];
+  return w;
+}
+
+template <class A, int LOGN, int G, bool INV>
+NTT_HD void run_group_r4(typename A::val (&x)[kE], uint32_t t, uint32_t blk, const Params<A> &p)
+{
+  using P           = Plan<LOGN>;
+  constexpr int R   = P::R(G);
+  const uint32_t ib = P::IBASE(G, t);
+  if constexpr(R % 2 == 1) {
+    /* single radix-2 stage with the even slots of the expanded table: e[2k] = w[k] */
+    static_assert(R == 1 && G == P::NG - 1, "odd stage count only in the last group of an odd-sized block");
+    constexpr int  SL = P::S(G);
+    constexpr int  SH = LOGN - SL;
+    constexpr int  AB = P::ABIT(G, 0);
+    const uint32_t tb = (1u << (p.s0 + SL)) + (blk << SL) + (ib >> SH);
+    static_for<0, kE / 2>([&](auto bb) {
+      constexpr int      B   = decltype(bb)::value;
+      constexpr int      E0  = P::BFLY_E0(G, 0, B);
+      constexpr uint32_t OFF = P::IOFF(G, E0) >> SH;
+      const typename A::tw w = at32(p.tw, 2u * (tb + OFF));
+      if constexpr(INV) {
+        A::r2_inv_head(x[E0], x[E0 | (1 << AB)], w, p.c);
+      } else {
+        A::r2_fwd_tail(x[E0], x[E0 | (1 << AB)], w, p.c);
+      }
+    });
+  } else {
+    static_for<0, R / 2>([&](auto ll) {
+      constexpr int L  = INV ? (R / 2 - 1 - decltype(ll)::value) : decltype(ll)::value;
+      constexpr int J  = 2 * L;
+      constexpr int BA = P::ABIT(G, J);     /* slot bit of the upper stage: a[i] <-> a[i+2t] */
+      constexpr int BB = P::ABIT(G, J + 1); /* slot bit of the lower stage: a[i] <-> a[i+t]  */
+      constexpr int SH = LOGN - (P::S(G) + J);
+      static_for<0, kE>([&](auto ee) {
+        constexpr int E = decltype(ee)::value;
+        if constexpr(((E >> BA) & 1) == 0 && ((E >> BB) & 1) == 0) {
+          constexpr uint32_t OFF = P::IOFF(G, E) >> SH;
+          const typename A::pack w = load_r4_pack<A, LOGN, G, J>(ib, blk, OFF, p);
+          if constexpr(INV) {
+            A::r4_inv(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, p.c);
+          } else {
+            A::r4_fwd(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, p.c);
+          }
+        }
+      });
+    });
+  }
+}
+
 template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
@@ -568,9 +644,10 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
   constexpr int R    = P::R(G);
   constexpr int SG   = P::S(G);
   const uint32_t ib  = P::IBASE(G, t);
-#ifdef NTT_ABL_NOCOMPUTE /* timing ablation only: data movement skeleton (wrong results) */
-  return;
-#endif
+  if constexpr(A::kRadix4) {
+    run_group_r4<A, LOGN, G, INV>(x, t, blk, p);
+    return;
+  }
   /* Per-lane twiddles that come from global memory are software-pipelined over
    * the stages (the next stage's are requested before this stage's butterflies
    * issue); scalar-cache and LDS-resident twiddles are cheap enough to fetch
@@ -655,11 +732,6 @@ NTT_HD void preload_group_tw(typename A::ctw (&pre)[4][kE / 2], uint32_t t, uint
       constexpr bool PAIR_HI = (B > 0) && (OFF % 2 == 1) && P::BFLY_FIRST(G, J, B) == B &&
                                P::BFLY_FIRST(G, J, B > 0 ? B - 1 : 0) == B - 1 &&
                                (P::IOFF(G, P::BFLY_E0(G, J, B > 0 ? B - 1 : 0)) >> SH) + 1 == OFF;
-#ifdef NTT_ABL_CONSTTW
-      if constexpr((NTT_ABL_CONSTTW >> G) & 1) {
-        if constexpr(P::BFLY_FIRST(G, J, B) == B) pre[J][B] = p.tw8[1];
-      } else
-#endif
       if constexpr(PAIR_LO && sizeof(typename A::ctw) == 8) {
         struct alignas(16) Pair {
           typename A::ctw a, b;
@@ -812,20 +884,35 @@ NTT_HD void global_load_last(typename A::val (&x)[kE], uint32_t t, const uint64_
   convert_inputs<A, INV>(x, raw, wide, c);
 }
 
-template <class A, int LOGN, bool INV>
+/* policy value -> output word.  Lazy outputs (the reference's *_lazy contract, include/ntt_reference.h:13-17)
+ * skip the final reduction: for the FP64 policy that is a property of the kernel (LAZYT: its reduction
+ * schedule bounds the last stage), for the integer policies a run-time flag of the launch. */
+template <class A, bool INV, bool LAZYT> NTT_HD uint64_t out_word(typename A::val v, bool lazy_rt, const typename A::consts &c)
+{
+  if constexpr(A::kTracksBounds) {
+    (void)lazy_rt;
+    if constexpr(INV) return A::store_inv(v, c);
+    else return LAZYT ? A::store_fwd_lazy(v, c) : A::store_fwd(v, c);
+  } else {
+    const uint64_t keep = lazy_rt ? 0ull : ~0ull; /* launch-uniform: scalar */
+    return INV ? A::store_inv_sel(v, c, keep) : A::store_fwd_sel(v, c, keep);
+  }
+}
+
+template <class A, int LOGN, bool INV, bool LAZYT = false>
 NTT_HD void global_store_first(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
-                               const typename A::consts &c)
+                               const typename A::consts &c, bool lazy_rt = false)
 {
   using P = Plan<LOGN>;
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    stream_store(coef_at(blk + ((uint32_t)E << P::LT), t), INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c));
+    stream_store(coef_at(blk + ((uint32_t)E << P::LT), t), out_word<A, INV, LAZYT>(x[E], lazy_rt, c));
   });
 }
 
-template <class A, int LOGN, bool INV>
+template <class A, int LOGN, bool INV, bool LAZYT = false>
 NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
-                              const typename A::consts &c)
+                              const typename A::consts &c, bool lazy_rt = false)
 {
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
@@ -833,8 +920,8 @@ NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
     u64x2         v;
-    v.a = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
-    v.b = INV ? A::store_inv(x[E + 1], c) : A::store_fwd(x[E + 1], c);
+    v.a = out_word<A, INV, LAZYT>(x[E], lazy_rt, c);
+    v.b = out_word<A, INV, LAZYT>(x[E + 1], lazy_rt, c);
     stream_store2(coef_at(blk + P::IOFF(G, E), ib), v);
   });
 }
@@ -842,7 +929,10 @@ NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64
 /* ------------------------------------------------------------------ */
 /* reduction schedules (ArithF64) for a fused block pass                */
 /* ------------------------------------------------------------------ */
-template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
+/* |value|/q a lazy forward output may have: v + 2q must stay in [0,4q) */
+constexpr double kLazyBound = 1.99;
+
+template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uint32_t fused_mask()
 {
   if constexpr(!A::kTracksBounds) {
     return 0;
@@ -860,7 +950,7 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
         if(stage_is_compact<A, LOGN, INV>(g, j)) cmask |= 1u << (INV ? LOGN - 1 - sl : sl);
       }
     }
-    return f64_schedule(INV, LOGN, KSH, 1.0, cmask).mask;
+    return f64_schedule(INV, LOGN, KSH, 1.0, cmask, LAZY ? kLazyBound : 1e30).mask;
   }
 }
 
@@ -876,7 +966,7 @@ template <class A, int LOGN, bool INV, int KSH> constexpr uint32_t fused_mask()
 template <class A, int R, bool INV, uint32_t MASK>
 NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint32_t S,
                                bool wide, bool lastinv, const typename A::tw *tab,
-                               const typename A::consts &c)
+                               const typename A::consts &c, bool lazy_out = false)
 {
   constexpr int  NE   = 1 << R;
   const uint32_t lsp  = logn - S - R; /* log2 span */
@@ -914,7 +1004,7 @@ NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint
   });
   static_for<0, NE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    base[(uint64_t)E << lsp] = INV ? A::store_inv(x[E], c) : A::store_fwd(x[E], c);
+    base[(uint64_t)E << lsp] = out_word<A, INV, false>(x[E], lazy_out, c);
   });
 }
 

@@ -31,6 +31,7 @@ using namespace ntt;
 namespace ntt {
 /* defined in inst_*.hip */
 template <> hipError_t launch_pass<ArithU64, 0>(const PassArgs &);
+template <> hipError_t launch_pass<ArithU64R4, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 1>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 18>(const PassArgs &);
@@ -55,7 +56,7 @@ static int fail(int code, const std::string &msg)
     }                                                                                         \
   } while(0)
 
-static int env_int(const char *name, int dflt)
+[[maybe_unused]] static int env_int(const char *name, int dflt)
 {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -103,11 +104,11 @@ struct ntt_plan {
   int      device  = 0;
   uint64_t N       = 0, q = 0, root = 0;
   int      m       = 0;
-  int      arith   = NTT_ARITH_U64; /* resolved: U64 or F64 */
+  int      arith   = NTT_ARITH_U64; /* resolved: U64, F64 or U64_R4 */
   int      kcls    = 0;             /* instantiated FP64 headroom class */
   bool     generic = false;
   bool     has_fwd = false, has_inv = false;
-  void *   d_fwd   = nullptr;
+  void *   d_fwd   = nullptr; /* U64/F64: N records (+16 folded N^-1 records, inverse); U64_R4: 2N expanded records */
   void *   d_inv   = nullptr;
   void *   d_fwd8  = nullptr; /* compact forward twiddles (FP64 policy) */
   void *   d_inv8  = nullptr; /* compact inverse twiddles (FP64 policy) */
@@ -117,23 +118,30 @@ struct ntt_plan {
   int              max_grid   = 0;
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
+  bool             two_phase  = false; /* 2^15..2^17: both passes of a polynomial inside one workgroup (twophase_kernel) */
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 
-static int resolve_arith(int requested, uint64_t q, int *out)
+static int resolve_arith(int requested, uint64_t q, int m, int *out)
 {
-  const char *env = getenv("NTT_ARITH");
-  if(requested == NTT_ARITH_AUTO && env) {
-    if(!strcmp(env, "u64")) requested = NTT_ARITH_U64;
-    if(!strcmp(env, "f64")) requested = NTT_ARITH_F64;
-  }
   if(requested == NTT_ARITH_AUTO) requested = h_f64_eligible(q) ? NTT_ARITH_F64 : NTT_ARITH_U64;
   if(requested == NTT_ARITH_F64 && !h_f64_eligible(q)) {
     return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q <= 2^51(1+2^-10)");
   }
-  if(requested != NTT_ARITH_F64 && requested != NTT_ARITH_U64) return fail(NTT_ERR_ARG, "bad arith");
+  if(requested == NTT_ARITH_U64_R4 && (m < kFusedMin || m > kFusedMax)) {
+    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers single-pass sizes 2^6..2^14");
+  }
+  if(requested == NTT_ARITH_U64_R4 && q >= (1ull << 60)) return fail(NTT_ERR_UNSUPPORTED, "radix-4 lazy range needs 16q < 2^64");
+  if(requested != NTT_ARITH_F64 && requested != NTT_ARITH_U64 && requested != NTT_ARITH_U64_R4) return fail(NTT_ERR_ARG, "bad arith");
   *out = requested;
+  return NTT_OK;
+}
+
+template <class TW> static int upload_records(void **d_out, const std::vector<TW> &host)
+{
+  HIP_TRY(hipMalloc(d_out, host.size() * sizeof(TW)));
+  HIP_TRY(hipMemcpy(*d_out, host.data(), host.size() * sizeof(TW), hipMemcpyHostToDevice));
   return NTT_OK;
 }
 
@@ -142,15 +150,28 @@ static int upload_table(void **d_out, const std::vector<uint64_t> &w, uint64_t q
 {
   std::vector<TW> host(w.size());
   for(size_t i = 0; i < w.size(); i++) host[i] = mk(w[i], q);
-  HIP_TRY(hipMalloc(d_out, host.size() * sizeof(TW)));
-  HIP_TRY(hipMemcpy(*d_out, host.data(), host.size() * sizeof(TW), hipMemcpyHostToDevice));
-  return NTT_OK;
+  return upload_records(d_out, host);
 }
 
-/* fwd / inv: radix-2 power tables in bit-reversed order (either may be empty);
- * ninv_override: 0 = derive N^-1 */
-static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root,
-                      const std::vector<uint64_t> &fwd, const std::vector<uint64_t> &inv, int arith,
+/* integer records {w, con}: con from the caller's own precomputation when given (the reference passes
+ * w_con next to every table, tests/test_cases.h:226-251), else floor(w * 2^64 / q) */
+static int upload_u64(void **d_out, const std::vector<uint64_t> &w, const std::vector<uint64_t> &con, uint64_t q)
+{
+  std::vector<TwU64> host(w.size());
+  for(size_t i = 0; i < w.size(); i++) host[i] = i < con.size() ? TwU64{w[i], con[i]} : h_tw_u64(w[i], q);
+  return upload_records(d_out, host);
+}
+
+/* What a plan is built from: radix-2 power tables in bit-reversed order (either may be empty), optionally
+ * the caller's Shoup precomputation for them, and -- radix-4 policy built from caller tables -- the 2N-entry
+ * expanded tables as they are (pre_compute.h:85-105). */
+struct TableSet {
+  std::vector<uint64_t> fwd, inv, fwd_con, inv_con;
+  std::vector<uint64_t> efwd, einv, efwd_con, einv_con;
+};
+
+/* ninv_override: 0 = derive N^-1 */
+static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root, const TableSet &ts, int arith,
                       uint64_t ninv_override)
 {
   if(!out) return fail(NTT_ERR_ARG, "null plan pointer");
@@ -158,10 +179,10 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   if(!is_pow2(N) || N < 2 || N > (1ull << 28)) return fail(NTT_ERR_ARG, "N must be a power of two in [2,2^28]");
   if(q < 3 || !(q & 1) || q >= (1ull << 61)) return fail(NTT_ERR_ARG, "q must be odd, 3 <= q < 2^61");
   if((q - 1) % (2 * N) != 0) return fail(NTT_ERR_ARG, "2N must divide q-1");
-  int rc = check_device(device);
-  if(rc) return rc;
   int ar = 0;
-  rc     = resolve_arith(arith, q, &ar);
+  int rc = resolve_arith(arith, q, (int)h_log2(N), &ar);
+  if(rc) return rc;
+  rc = check_device(device);
   if(rc) return rc;
   USE_DEVICE(device);
   ntt_plan *p = new ntt_plan();
@@ -171,19 +192,19 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->root     = root;
   p->m        = (int)h_log2(N);
   p->arith    = ar;
-  p->generic  = env_int("NTT_GENERIC", 0) != 0;
-  p->max_grid = env_int("NTT_MAX_GRID", 0);
-  p->chunk_mib = env_int("NTT_CHUNK_MIB", 256);
-  if(p->chunk_mib < 1) p->chunk_mib = 1;
   {
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
       p->num_cus = prop.multiProcessorCount;
     }
   }
-  p->has_fwd  = !fwd.empty();
-  p->has_inv  = !inv.empty();
-  std::vector<uint64_t> inv_for_consts = inv.empty() ? std::vector<uint64_t>(2, 1) : inv;
+  const bool r4 = ar == NTT_ARITH_U64_R4;
+  p->has_fwd    = r4 ? !(ts.efwd.empty() && ts.fwd.empty()) : !ts.fwd.empty();
+  p->has_inv    = r4 ? !(ts.einv.empty() && ts.inv.empty()) : !ts.inv.empty();
+  /* inverse power table slot 1 (w^-N/2) is all the constants need */
+  std::vector<uint64_t> inv_for_consts(2, 1);
+  if(!ts.inv.empty()) inv_for_consts.assign(ts.inv.begin(), ts.inv.begin() + 2);
+  else if(ts.einv.size() >= 4) inv_for_consts[1] = ts.einv[2]; /* e[2k] = w[k] */
   p->cu = h_consts_u64(q, N, inv_for_consts);
   if(ninv_override) {
     p->cu.ninv  = h_tw_u64(ninv_override % q, q);
@@ -197,22 +218,32 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
     }
     const int k = h_f64_ksh(q);
     p->kcls     = k >= 18 ? 18 : (k >= 1 ? 1 : 0);
-    const int force = env_int("NTT_F64_CLASS", -1);
-    if(force == 0 || (force == 1 && k >= 1)) p->kcls = force;
   }
   rc = NTT_OK;
-  /* the full inverse table carries 16 extra records behind its N slots: N^-1 * winv[k], k < 16,
-   * the twiddles of the last inverse group with the scaling folded in (run_group0_folded) */
-  const std::vector<uint64_t> inv_ext =
-    p->has_inv ? h_with_folded_ninv(inv, ninv_override ? ninv_override % q : h_powmod(N % q, q - 2, q), q) : inv;
-  if(ar == NTT_ARITH_F64) {
-    if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, fwd, q, h_tw_f64);
-    if(!rc && p->has_fwd) rc = upload_table<double>(&p->d_fwd8, fwd, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
-    if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv_ext, q, h_tw_f64);
-    if(!rc && p->has_inv) rc = upload_table<double>(&p->d_inv8, inv, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
+  if(r4) {
+    /* expanded tables: the caller's, or derived from the power tables */
+    if(p->has_fwd) {
+      const std::vector<uint64_t> e = ts.efwd.empty() ? h_expand_radix4(ts.fwd, q) : ts.efwd;
+      rc                            = upload_u64(&p->d_fwd, e, ts.efwd_con, q);
+    }
+    if(!rc && p->has_inv) {
+      const std::vector<uint64_t> e = ts.einv.empty() ? h_expand_radix4(ts.inv, q) : ts.einv;
+      rc                            = upload_u64(&p->d_inv, e, ts.einv_con, q);
+    }
   } else {
-    if(p->has_fwd) rc = upload_table<TwU64>(&p->d_fwd, fwd, q, h_tw_u64);
-    if(!rc && p->has_inv) rc = upload_table<TwU64>(&p->d_inv, inv_ext, q, h_tw_u64);
+    /* the full inverse table carries 16 extra records behind its N slots: N^-1 * winv[k], k < 16,
+     * the twiddles of the last inverse group with the scaling folded in (run_group0_folded) */
+    const std::vector<uint64_t> inv_ext =
+      p->has_inv ? h_with_folded_ninv(ts.inv, ninv_override ? ninv_override % q : h_powmod(N % q, q - 2, q), q) : ts.inv;
+    if(ar == NTT_ARITH_F64) {
+      if(p->has_fwd) rc = upload_table<TwF64>(&p->d_fwd, ts.fwd, q, h_tw_f64);
+      if(!rc && p->has_fwd) rc = upload_table<double>(&p->d_fwd8, ts.fwd, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
+      if(!rc && p->has_inv) rc = upload_table<TwF64>(&p->d_inv, inv_ext, q, h_tw_f64);
+      if(!rc && p->has_inv) rc = upload_table<double>(&p->d_inv8, ts.inv, q, [](uint64_t w, uint64_t qq) { return h_tw_f64(w, qq).w; });
+    } else {
+      if(p->has_fwd) rc = upload_u64(&p->d_fwd, ts.fwd, ts.fwd_con, q);
+      if(!rc && p->has_inv) rc = upload_u64(&p->d_inv, inv_ext, ts.inv_con, q); /* caller precons cover the first N records */
+    }
   }
   if(rc) {
     ntt_plan_destroy(p);
@@ -232,7 +263,10 @@ extern "C" int ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t 
   if(h_mulmod(root, rinv, q) != 1 || h_mulmod(N % q, h_powmod(N % q, q - 2, q), q) != 1) {
     return fail(NTT_ERR_ARG, "q is not prime (root^(q-2) is not the inverse of root)");
   }
-  return plan_build(out, device, N, q, root, h_power_table(root, N, q), h_power_table(rinv, N, q), arith, 0);
+  TableSet ts;
+  ts.fwd = h_power_table(root, N, q);
+  ts.inv = h_power_table(rinv, N, q);
+  return plan_build(out, device, N, q, root, ts, arith, 0);
 }
 
 extern "C" int ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t N, uint64_t q,
@@ -255,10 +289,10 @@ extern "C" int ntt_plan_create_from_tables(ntt_plan **out, int device, uint64_t 
       return fail(NTT_ERR_ARG, "w_inv_powers is not the inverse of w_powers");
     }
   }
-  std::vector<uint64_t> f, i;
-  if(w_powers) f.assign(w_powers, w_powers + N);
-  if(w_inv_powers) i.assign(w_inv_powers, w_inv_powers + N);
-  return plan_build(out, device, N, q, 0, f, i, arith, 0);
+  TableSet ts;
+  if(w_powers) ts.fwd.assign(w_powers, w_powers + N);
+  if(w_inv_powers) ts.inv.assign(w_inv_powers, w_inv_powers + N);
+  return plan_build(out, device, N, q, 0, ts, arith, 0);
 }
 
 extern "C" void ntt_plan_destroy(ntt_plan *p)
@@ -281,7 +315,7 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[2] = (uint64_t)p->m;
   info[3] = (uint64_t)p->arith;
   info[4] = (uint64_t)p->kcls;
-  info[5] = (uint64_t)make_passes(p->m, p->generic).n;
+  info[5] = (uint64_t)make_passes(p->m, p->generic).n; /* HBM passes per transform (two-phase launches keep the second one on chip where they can) */
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
   return NTT_OK;
@@ -290,8 +324,38 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
 extern "C" int ntt_plan_set_generic(ntt_plan *p, int on)
 {
   if(!p) return fail(NTT_ERR_ARG, "null plan");
+  if(on && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy has no column-pass form");
   p->generic = on != 0;
   return NTT_OK;
+}
+
+extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
+{
+  if(!p) return fail(NTT_ERR_ARG, "null plan");
+  switch(option) {
+    case NTT_OPT_MAX_GRID:
+      if(value < 0) return fail(NTT_ERR_ARG, "max grid must be >= 0");
+      p->max_grid = (int)value;
+      return NTT_OK;
+    case NTT_OPT_CHUNK_MIB:
+      if(value < 1) return fail(NTT_ERR_ARG, "chunk must be >= 1 MiB");
+      p->chunk_mib = (int)value;
+      return NTT_OK;
+    case NTT_OPT_TWO_PHASE:
+      p->two_phase = value != 0;
+      return NTT_OK;
+    case NTT_OPT_F64_CLASS: {
+      /* a coarser (smaller) headroom class than the modulus allows is always valid: it only reduces more often */
+      if(p->arith != NTT_ARITH_F64) return fail(NTT_ERR_ARG, "not an FP64 plan");
+      const int k = h_f64_ksh(p->q);
+      if(value == 0 || (value == 1 && k >= 1) || (value == 18 && k >= 18)) {
+        p->kcls = (int)value;
+        return NTT_OK;
+      }
+      return fail(NTT_ERR_ARG, "headroom class not instantiated or not valid for this modulus");
+    }
+    default: return fail(NTT_ERR_ARG, "unknown option");
+  }
 }
 
 /* ------------------------------------------------------------------ */
@@ -300,6 +364,7 @@ extern "C" int ntt_plan_set_generic(ntt_plan *p, int on)
 static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
 {
   if(p->arith == NTT_ARITH_U64) return launch_pass<ArithU64, 0>(pa);
+  if(p->arith == NTT_ARITH_U64_R4) return launch_pass<ArithU64R4, 0>(pa);
   switch(p->kcls) {
     case 18: return launch_pass<ArithF64, 18>(pa);
     case 1: return launch_pass<ArithF64, 1>(pa);
@@ -307,13 +372,39 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   }
 }
 
-static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream)
+static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream,
+                         bool lazy = false)
 {
   if(!p || (!d_a && batch)) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
   const PassList L = make_passes(p->m, p->generic);
+  if(p->two_phase && !p->generic && p->m > kFusedMax && p->m <= kFusedMax + 3 &&
+     (p->arith == NTT_ARITH_F64 || p->m != kFusedMax + 1)) {
+    /* one launch, one workgroup per polynomial, both passes back to back (ntt_kernels.h: twophase_kernel) */
+    PassArgs pa{};
+    pa.a        = d_a;
+    pa.tw       = inverse ? p->d_inv : p->d_fwd;
+    pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
+    pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+    pa.batch    = batch;
+    pa.logn     = (uint32_t)p->m;
+    pa.fused    = 2;
+    pa.r        = p->m - kFusedMax;
+    pa.s        = 0;
+    pa.inverse  = inverse;
+    pa.wide     = wide;
+    pa.lastinv  = inverse;
+    pa.lazy     = lazy;
+    pa.ends     = 1;
+    pa.max_grid = p->max_grid;
+    pa.num_cus  = p->num_cus;
+    pa.stream   = (hipStream_t)stream;
+    hipError_t e = dispatch_pass(p, pa);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTT_OK;
+  }
   /* Multi-pass transforms (N > 2^14) are run chunk by chunk so that what one pass
    * writes is still in the 256 MiB Infinity Cache when the next pass reads it:
    * only the first read and the last write of a chunk have to reach HBM. */
@@ -332,7 +423,9 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
       pa.a        = d_a + first * p->N;
       pa.tw       = inverse ? p->d_inv : p->d_fwd;
       pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
-      pa.consts   = p->arith == NTT_ARITH_U64 ? (const void *)&p->cu : (const void *)&p->cf;
+      pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+      pa.lazy     = lazy;
+      pa.ends     = k == L.n - 1;
       pa.batch    = nb;
       pa.logn     = (uint32_t)p->m;
       pa.fused    = ps.fused;
@@ -358,6 +451,20 @@ extern "C" int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, v
 extern "C" int ntt_inv_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
 {
   return run_transform(p, d_a, batch, true, false, stream);
+}
+extern "C" int ntt_transform_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)(NTT_FLAG_INVERSE | NTT_FLAG_WIDE_IN | NTT_FLAG_LAZY_OUT)) return fail(NTT_ERR_ARG, "unknown flag");
+  return run_transform(p, d_a, batch, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream,
+                       (flags & NTT_FLAG_LAZY_OUT) != 0);
+}
+extern "C" int ntt_fwd_batch_lazy(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, false, false, stream, true);
+}
+extern "C" int ntt_inv_batch_lazy(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return run_transform(p, d_a, batch, true, false, stream, true);
 }
 extern "C" int ntt_fwd_batch_wide(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream)
 {
@@ -406,12 +513,13 @@ __global__ void __launch_bounds__(256) checksum_kernel(uint64_t *out, const uint
   }
 }
 
-template <class A>
+/* LAZYIN: operands in [0,4q) as ntt_fwd_batch_lazy leaves them; the product is always fully reduced */
+template <class A, bool LAZYIN>
 __global__ void __launch_bounds__(256) pointwise_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n,
                                                         const typename A::consts k)
 {
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    c[i] = A::mulmod_full(a[i], b[i], k);
+    c[i] = LAZYIN ? A::mulmod_full_lazy4(a[i], b[i], k) : A::mulmod_full(a[i], b[i], k);
   }
 }
 
@@ -423,32 +531,48 @@ static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
   return (unsigned)g;
 }
 
-extern "C" int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b,
-                                       uint64_t batch, void *stream)
+static int pointwise_launch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, uint64_t batch,
+                            void *stream, bool lazy_in)
 {
   if(!p || !d_c || !d_a || !d_b) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
   USE_DEVICE(p->device);
   const uint64_t n = batch * p->N;
+  const dim3     g(grid_for(n)), t(256);
+  hipStream_t    st = (hipStream_t)stream;
   if(p->arith == NTT_ARITH_F64) {
-    hipLaunchKernelGGL((pointwise_kernel<ArithF64>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_c, d_a,
-                       d_b, n, p->cf);
+    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithF64, true>), g, t, 0, st, d_c, d_a, d_b, n, p->cf);
+    else hipLaunchKernelGGL((pointwise_kernel<ArithF64, false>), g, t, 0, st, d_c, d_a, d_b, n, p->cf);
   } else {
-    hipLaunchKernelGGL((pointwise_kernel<ArithU64>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_c, d_a,
-                       d_b, n, p->cu);
+    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithU64, true>), g, t, 0, st, d_c, d_a, d_b, n, p->cu);
+    else hipLaunchKernelGGL((pointwise_kernel<ArithU64, false>), g, t, 0, st, d_c, d_a, d_b, n, p->cu);
   }
   HIP_TRY(hipGetLastError());
   return NTT_OK;
 }
 
+extern "C" int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b,
+                                       uint64_t batch, void *stream)
+{
+  return pointwise_launch(p, d_c, d_a, d_b, batch, stream, false);
+}
+extern "C" int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b,
+                                            uint64_t batch, void *stream)
+{
+  return pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
+}
+
 extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
                                         uint64_t batch, void *stream)
 {
-  /* d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
+  /* the chain never leaves the lazy domain: both forward transforms skip their final reduction,
+   * the pointwise product takes [0,4q) operands, only the inverse's output is reduced.
+   * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
-  int rc = ntt_fwd_batch(p, d_a, batch, stream);
-  if(!rc && d_b != d_a) rc = ntt_fwd_batch(p, d_b, batch, stream);
-  if(!rc) rc = ntt_pointwise_mul_batch(p, d_c, d_a, d_b, batch, stream);
+  if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
+  int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
+  if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);
+  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
   if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
   return rc;
 }
@@ -744,27 +868,64 @@ uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
   abort();
 }
 
-/* w: caller table; stride 1 = radix-2 table, stride 2 = radix-4 expanded table
- * whose even slots are the radix-2 entries (pre_compute.h:85-105) */
+/* Which arithmetic serves the reference-signature entry points.
+ *   default  the reference's own integer arithmetic on the caller's tables AND precomputations as they
+ *            are: Harvey radix-2 butterflies for the *_ref_harvey / *_seal signatures, the radix-4
+ *            butterflies on the 2N-entry expanded table for *_radix4 / *_radix4x4 (2^6 <= N <= 2^14; other
+ *            sizes fall back to radix-2 on the table's even slots).  Even the LAZY outputs equal the
+ *            reference's bit for bit.
+ *   NTT_COMPAT_ARITH=f64  the FP64 engine where q allows it (outputs reduced: a legal lazy value) --
+ *            lets the reference's own drivers exercise the throughput kernels. */
+enum CompatKind { kCompatR2 = 0, kCompatR4 = 1 };
+
+int compat_arith(uint64_t q, uint64_t N, CompatKind kind)
+{
+  const char *env = getenv("NTT_COMPAT_ARITH");
+  if(env && !strcmp(env, "f64") && h_f64_eligible(q)) return NTT_ARITH_F64;
+  const int m = (int)h_log2(N);
+  if(kind == kCompatR4 && m >= kFusedMin && m <= kFusedMax && q < (1ull << 60)) return NTT_ARITH_U64_R4;
+  return NTT_ARITH_U64;
+}
+
+/* w, w_con: caller tables.  kind R2: N-entry radix-2 tables.  kind R4: 2N-entry expanded tables
+ * (pre_compute.h:85-105), whose even slots are the radix-2 entries. */
 void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t q, const uint64_t *w,
-                uint64_t stride, bool inverse, uint64_t ninv)
+                const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv)
 {
   std::lock_guard<std::mutex> lock(g_mu);
   const int                   device = env_int("NTT_DEVICE", 0);
-  const uint64_t              key    = table_key(w, N, stride);
-  ntt_plan *                  plan   = nullptr;
+  const int                   arith  = compat_arith(q, N, kind);
+  const uint64_t              entries = kind == kCompatR4 ? 2 * N : N;
+  /* the integer policies use the caller's precomputation too: it is part of the key */
+  const uint64_t key = table_key(w, entries, 1) ^ (arith != NTT_ARITH_F64 && w_con ? table_key(w_con, entries, 1) * 3 : 0);
+  ntt_plan *     plan = nullptr;
   for(CompatPlan &c : g_plans) {
-    if(c.N == N && c.q == q && c.key == key && c.stride == stride && c.inverse == inverse && c.ninv == ninv &&
-       c.plan->device == device) {
+    if(c.N == N && c.q == q && c.key == key && c.stride == (uint64_t)kind && c.inverse == inverse && c.ninv == ninv &&
+       c.plan->device == device && c.plan->arith == arith) {
       plan       = c.plan;
       c.last_use = ++g_use_clock;
     }
   }
   if(!plan) {
-    std::vector<uint64_t> tab(N), none;
-    for(uint64_t k = 0; k < N; k++) tab[k] = w[k * stride];
-    int rc = inverse ? plan_build(&plan, device, N, q, 0, none, tab, NTT_ARITH_AUTO, ninv)
-                     : plan_build(&plan, device, N, q, 0, tab, none, NTT_ARITH_AUTO, 0);
+    TableSet              ts;
+    std::vector<uint64_t> tab, con;
+    if(arith == NTT_ARITH_U64_R4) {
+      tab.assign(w, w + 2 * N);
+      if(w_con) con.assign(w_con, w_con + 2 * N);
+      (inverse ? ts.einv : ts.efwd)         = tab;
+      (inverse ? ts.einv_con : ts.efwd_con) = con;
+    } else {
+      const uint64_t stride = kind == kCompatR4 ? 2 : 1;
+      tab.resize(N);
+      for(uint64_t k = 0; k < N; k++) tab[k] = w[k * stride];
+      if(w_con && arith == NTT_ARITH_U64) {
+        con.resize(N);
+        for(uint64_t k = 0; k < N; k++) con[k] = w_con[k * stride];
+      }
+      (inverse ? ts.inv : ts.fwd)         = tab;
+      (inverse ? ts.inv_con : ts.fwd_con) = con;
+    }
+    int rc = plan_build(&plan, device, N, q, 0, ts, arith, inverse ? ninv : 0);
     if(rc) die(fn);
     if(g_plans.size() >= kCompatPlansMax) {
       size_t lru = 0;
@@ -774,7 +935,7 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
       ntt_plan_destroy(g_plans[lru].plan);
       g_plans.erase(g_plans.begin() + (long)lru);
     }
-    g_plans.push_back(CompatPlan{N, q, key, ninv, stride, inverse, plan, ++g_use_clock});
+    g_plans.push_back(CompatPlan{N, q, key, ninv, (uint64_t)kind, inverse, plan, ++g_use_clock});
   }
   const uint64_t batch = a2 ? 2 : 1;
   const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
@@ -803,7 +964,8 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     g_err = "hipMemcpy H2D";
     die(fn);
   }
-  if(run_transform(plan, g_stage, batch, inverse, true, nullptr)) die(fn);
+  /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
+  if(run_transform(plan, g_stage, batch, inverse, true, nullptr, !inverse)) die(fn);
   ok = hipMemcpy(a1, g_stage, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
   if(ok && a2) ok = hipMemcpy(a2, g_stage + N, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
   if(!ok) {
@@ -839,56 +1001,51 @@ extern "C" {
 
 void fwd_ntt_ref_harvey_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
-  (void)w_con; /* the device derives its own precomputation from w */
-  compat_run("fwd_ntt_ref_harvey_lazy", a, nullptr, N, q, w, 1, false, 0);
+  compat_run("fwd_ntt_ref_harvey_lazy", a, nullptr, N, q, w, w_con, kCompatR2, false, 0);
 }
 
 void fwd_ntt_ref_harvey_lazy_dbl(uint64_t a1[], uint64_t a2[], uint64_t N, uint64_t q, const uint64_t w[],
                                  const uint64_t w_con[])
 {
-  (void)w_con;
-  compat_run("fwd_ntt_ref_harvey_lazy_dbl", a1, a2, N, q, w, 1, false, 0);
+  compat_run("fwd_ntt_ref_harvey_lazy_dbl", a1, a2, N, q, w, w_con, kCompatR2, false, 0);
 }
 
 void inv_ntt_ref_harvey(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, uint64_t word_size,
                         const uint64_t w[], const uint64_t w_con[])
 {
-  (void)w_con;
-  (void)word_size;
-  compat_run("inv_ntt_ref_harvey", a, nullptr, N, q, w, 1, true, (uint64_t)n_inv.op);
+  (void)word_size; /* 64 for every in-scope caller (tests/test_cases.h:231,244) */
+  compat_run("inv_ntt_ref_harvey", a, nullptr, N, q, w, w_con, kCompatR2, true, (uint64_t)n_inv.op);
 }
 
 void fwd_ntt_radix4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
-  (void)w_con;
-  compat_run("fwd_ntt_radix4_lazy", a, nullptr, N, q, w, 2, false, 0);
+  compat_run("fwd_ntt_radix4_lazy", a, nullptr, N, q, w, w_con, kCompatR4, false, 0);
 }
 
 void inv_ntt_radix4(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, const uint64_t w[],
                     const uint64_t w_con[])
 {
-  (void)w_con;
-  compat_run("inv_ntt_radix4", a, nullptr, N, q, w, 2, true, (uint64_t)n_inv.op);
+  compat_run("inv_ntt_radix4", a, nullptr, N, q, w, w_con, kCompatR4, true, (uint64_t)n_inv.op);
 }
 
+/* the radix-16 blocking of the reference (src/ntt_radix4x4.c:41-114) applies the same radix-4 butterflies
+ * in a cache-friendlier order: values and lazy ranges are those of fwd_ntt_radix4_lazy; on the device the
+ * register-resident stage groups play that role */
 void fwd_ntt_radix4x4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
-  (void)w_con;
-  compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, 2, false, 0);
+  compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, w_con, kCompatR4, false, 0);
 }
 
 void fwd_ntt_seal_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
-  (void)w_con;
-  compat_run("fwd_ntt_seal_lazy", a, nullptr, N, q, w, 1, false, 0);
+  compat_run("fwd_ntt_seal_lazy", a, nullptr, N, q, w, w_con, kCompatR2, false, 0);
 }
 
 void inv_ntt_seal(uint64_t a[], uint64_t N, uint64_t q, uint64_t n_inv, uint64_t n_inv_con, const uint64_t w[],
                   const uint64_t w_con[])
 {
-  (void)w_con;
   (void)n_inv_con;
-  compat_run("inv_ntt_seal", a, nullptr, N, q, w, 1, true, n_inv);
+  compat_run("inv_ntt_seal", a, nullptr, N, q, w, w_con, kCompatR2, true, n_inv);
 }
 
 } /* extern "C" */

@@ -28,14 +28,16 @@
 
 namespace ntt {
 
-#ifndef NTT_PRE_ALSO
-#  define NTT_PRE_ALSO 12 /* forward: last group's twiddles register-resident at this size too (2^14 always) */
-#endif
-#ifndef NTT_IPRE_MIN
-#  define NTT_IPRE_MIN 12 /* inverse: first executed group's twiddles register-resident from this size up */
-#endif
+constexpr int kPreAlso = 12; /* forward: last group's twiddles register-resident at this size too (2^14 always) */
+constexpr int kIpreMin = 12; /* inverse: first executed group's twiddles register-resident from this size up */
 
-template <int LOGN, bool INV, bool COMPACT> struct Geom {
+/* FLAVOR: 0 integer radix-2, 1 FP64 (compact twiddles, LDS tables, persistent inverse), 2 integer radix-4 (five-record
+ * twiddle packs and 128-bit double products: it gets the register budget of two waves per SIMD where the
+ * workgroup size allows) */
+template <class A> constexpr int flavor_of() { return A::kCompact ? 1 : (A::kRadix4 ? 2 : 0); }
+
+template <int LOGN, bool INV, int FLAVOR> struct Geom {
+  static constexpr bool COMPACT = FLAVOR == 1;
   using P = Plan<LOGN>;
   /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
    * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
@@ -61,22 +63,12 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
   }
   static constexpr int TBL(int g)
   {
-#if defined(NTT_NO_LDS_TW) || defined(NTT_NO_PREFETCH) || defined(NTT_NO_COMPACT_TW)
-    return 0;
-#else
     if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
     bool on = false;
     if(LOGN == 14 || LOGN == 12) on = (g == P::NG - 2);
-#  ifndef NTT_NO_SMALL_TBL
     if(LOGN >= 8 && LOGN <= 11) on = true; /* several blocks per workgroup share the tables (2^6, 2^7: measured no gain) */
-#  endif
-#  ifndef NTT_TBL13_ONE
     if(LOGN == 13) on = true;
-#  else
-    if(LOGN == 13) on = (g == P::NG - 2);
-#  endif
     return on ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
-#endif
   }
   /* first entry of group g's table behind the exchange buffer(s) */
   static constexpr int TBL_OFF(int g)
@@ -91,7 +83,8 @@ template <int LOGN, bool INV, bool COMPACT> struct Geom {
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x): what
    * the LDS footprint lets be resident, at most 4 */
   static constexpr int WPS0 = (WG_PER_CU0 * (WG / 64)) / 4;
-  static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > 4 ? 4 : WPS0);
+  static constexpr int WPSC = FLAVOR == 2 ? (WG / 256 > 2 ? WG / 256 : 2) : 4;
+  static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > WPSC ? WPSC : WPS0);
 };
 
 #ifdef NTT_STAMPS
@@ -137,14 +130,7 @@ template <class A, int LOGN, int GW, int GR>
 __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
 {
   using P = Plan<LOGN>;
-#ifdef NTT_ABL_NOEXCH /* timing ablation only: no LDS exchange, no barriers (wrong results) */
-  return;
-#endif
-#ifdef NTT_SAFE_BARRIERS
-  constexpr bool local = false;
-#else
   constexpr bool local = P::WAVE_LOCAL(GW, GR);
-#endif
   if constexpr(local) {
     lds_scatter<A, LOGN, GW, GR>(x, t, lds);
     wave_sync();
@@ -158,9 +144,7 @@ __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, t
   }
 }
 
-#ifndef NTT_LOAD_AUX
-#  define NTT_LOAD_AUX 2 /* cache-policy bits of the coefficient loads: nt (measured +0.6..1 % over 0; sc0/sc1 no gain) */
-#endif
+constexpr int kLoadAux = 2; /* cache-policy bits of the coefficient loads: nt (measured +0.6..1 % over 0; sc0/sc1 no gain) */
 /* A block seen through a buffer descriptor: the 16 row loads of a thread then share ONE
  * 32-bit lane offset (t*8) and take the row offset as a scalar operand, instead of a
  * 64-bit per-lane address each (two carry-chained VALU adds per row in the hot loop).
@@ -172,13 +156,13 @@ template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc
 __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, NTT_LOAD_AUX);
+  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kLoadAux);
   return (uint64_t)v.x | ((uint64_t)v.y << 32);
 }
 __device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NTT_LOAD_AUX);
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kLoadAux);
   return u64x2{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
 }
 
@@ -203,19 +187,11 @@ __device__ __forceinline__ void buffer_store_first_raw(const uint64_t (&u)[kE], 
 template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
 {
   using P = Plan<LOGN>;
-#ifdef NTT_NO_BUFFER_LOADS
-  static_for<0, kE>([&](auto ee) {
-    constexpr int   E   = decltype(ee)::value;
-    const uint64_t *row = blk + ((uint32_t)E << P::LT); /* wave-uniform base, one lane offset */
-    raw[E]              = stream_load(coef_at(row, t));
-  });
-#else
   const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
     raw[E]          = buffer_load_u64(r, t * 8u, ((uint32_t)E << P::LT) * 8u);
   });
-#endif
 }
 
 /* raw coefficients in the last-kind layout (runs of 2^RL consecutive indices, 16-byte loads):
@@ -225,14 +201,6 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
   const uint32_t ib = P::IBASE(G, t);
-#ifdef NTT_NO_BUFFER_LOADS
-  static_for<0, kE / 2>([&](auto hh) {
-    constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = stream_load2(coef_at(blk + P::IOFF(G, E), ib));
-    raw[E]          = v.a;
-    raw[E + 1]      = v.b;
-  });
-#else
   const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
@@ -240,7 +208,6 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
-#endif
 }
 
 /* Makes the compiler complete the loads behind a prefetched block at this point.  Used
@@ -251,9 +218,6 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
  * for stores nobody needs. */
 __device__ __forceinline__ void pin_raw(const uint64_t (&raw)[kE])
 {
-#ifdef NTT_NO_PIN /* A/B switch */
-  return;
-#endif
 #pragma unroll
   for(int e = 0; e < kE; e++) asm volatile("" ::"v"(raw[e]));
 }
@@ -281,7 +245,7 @@ template <class A, int LOGN, bool INV>
 __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Params<A> &p, uint32_t blk0, uint32_t tid)
 {
   using P = Plan<LOGN>;
-  using G = Geom<LOGN, INV, A::kCompact>;
+  using G = Geom<LOGN, INV, flavor_of<A>()>;
   static_for<0, P::NG>([&](auto gg) {
     constexpr int GI = decltype(gg)::value;
     if constexpr(G::TBL(GI) > 0) {
@@ -300,12 +264,16 @@ __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Par
   });
 }
 
-template <class A, int LOGN, bool INV, int KSH, bool LASTINV = false>
-__global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN, INV, A::kCompact>::WPS)) fused_kernel(const Params<A> p)
+/* LAZY (forward, FP64 policy): outputs in [0,4q) instead of [0,q) -- a kernel variant of its own because
+ * the reduction schedule has to bound the last stage (fused_mask); the integer policies take the run-time
+ * flag Params::lazy instead. */
+template <class A, int LOGN, bool INV, int KSH, bool LASTINV = false, bool LAZY = false>
+__global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<LOGN, INV, flavor_of<A>()>::WPS)) fused_kernel(const Params<A> p)
 {
   using P                 = Plan<LOGN>;
-  using G                 = Geom<LOGN, INV, A::kCompact>;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>() | (INV && LASTINV ? kLastInvFlag : 0u);
+  using G                 = Geom<LOGN, INV, flavor_of<A>()>;
+  static_assert(!LAZY || (!INV && A::kTracksBounds), "the LAZY variant exists for the FP64 forward kernels only");
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u);
   constexpr int LDS_TW = G::LDS_TW;
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
@@ -315,7 +283,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
   typename A::val *  lds = lds_all + sub * P::LDS_ELEMS;
   const uint32_t     bmask = (1u << p.s0) - 1u;
 
-#ifndef NTT_NO_PREFETCH
   /* Persistent forward loop (one block per workgroup, grid = resident workgroups).
    * Ordering of the vector-memory queue is what matters here, because vmcnt
    * retires in order: per block the last group's twiddles are requested first,
@@ -323,17 +290,13 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
    * its twiddles from an LDS-resident table (lgkmcnt) and the first two groups
    * through the scalar cache.  So no twiddle wait ever sits behind HBM loads,
    * and the prefetched block lands during ~10 stages of butterflies. */
-  if constexpr(!INV && G::BPW == 1) {
+  if constexpr(!INV && G::BPW == 1 && !A::kRadix4) {
     constexpr int  GL     = P::NG - 1;          /* last group                      */
-#ifdef NTT_NO_PRELOAD_LAST
-    constexpr bool PRE    = false;
-#else
     /* the last group's 12 per-lane twiddles (8-byte form) are requested well
      * ahead of their use; for whole-polynomial blocks they do not depend on the
      * block at all and stay in 24 VGPRs for the entire launch (LOGN 14 only:
      * smaller blocks have several workgroups per CU hiding that latency) */
-    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == NTT_PRE_ALSO) && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
-#endif
+    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == kPreAlso) && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
     constexpr bool LTW    = LDS_TW > 0;
     const uint64_t stride = gridDim.x;
     uint64_t       b      = blockIdx.x;
@@ -391,13 +354,11 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         }
         STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
-      global_store_last<A, LOGN, false>(x, tid, base, p.c);
+      global_store_last<A, LOGN, false, LAZY>(x, tid, base, p.c, p.lazy != 0);
       STAMP(10); /* final reduction + stores */
     }
     return;
   }
-#endif
-#ifndef NTT_NO_PREFETCH
   /* Persistent inverse loop: the mirror image of the forward one.  Groups run
    * last -> first (Gentleman-Sande), the first group executed owns the per-lane
    * twiddles, the next one reads the LDS-resident table, the remaining stages are
@@ -421,14 +382,10 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     /* the first executed group's per-lane twiddles do not change from block to block (the
      * workgroup always sees the same block position): loaded once, they stay in 24 VGPRs for
      * the whole launch (measured +5 % at 2^14 over re-requesting them every block) */
-#ifdef NTT_NO_INV_PRE
-    constexpr bool IPRE = false;
-#else
     /* (not for the 2^12 kernel of the q <= 2^50 class: its different reduction plan needs one register
      * more and would spill; it keeps the per-stage loads) */
-    constexpr bool IPRE = A::kCompact && LOGN >= NTT_IPRE_MIN && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 &&
+    constexpr bool IPRE = A::kCompact && LOGN >= kIpreMin && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 &&
                           !(LOGN == 12 && KSH == 1);
-#endif
     typename A::ctw pre[4][kE / 2];
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
     uint64_t raw[kE];
@@ -466,9 +423,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
     }
     return;
   }
-#endif
 
-  /* generic loop: small blocks (several per workgroup), and every size in the NTT_NO_PREFETCH build */
+  /* generic loop: small blocks (several per workgroup), the integer policy's inverse */
   const lds_ctw_ptr<A> gtw = (lds_ctw_ptr<A>)reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
   if constexpr(LDS_TW > 0) {
     /* blocks below 2^14 are whole polynomials (ntt_passplan.h; launch_fused refuses anything
@@ -491,7 +447,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         exchange<A, LOGN, GI, GI + 1>(x, t, lds);
         run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
-      if(live) global_store_last<A, LOGN, false>(x, t, base, p.c);
+      if(live) global_store_last<A, LOGN, false, LAZY>(x, t, base, p.c, p.lazy != 0);
     } else {
       global_load_last<A, LOGN, true>(x, t, base, p.wide != 0, p.c);
       run_group<A, LOGN, P::NG - 1, true, MASK, (G::TBL(P::NG - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(P::NG - 1));
@@ -500,14 +456,114 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, A::kCompact>::WG), (Geom<LOGN
         exchange<A, LOGN, GI, GI - 1>(x, t, lds);
         run_group<A, LOGN, GI - 1, true, MASK, (G::TBL(GI - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI - 1));
       });
-      if(live) global_store_first<A, LOGN, true>(x, t, base, p.c);
+      if(live) global_store_first<A, LOGN, true>(x, t, base, p.c, p.lazy != 0);
     }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* N = 2^15 .. 2^17: both HBM passes of a polynomial inside ONE workgroup */
+/* ------------------------------------------------------------------ */
+/*
+ * A transform larger than one fused block needs two passes over the polynomial: LEAD = m - 14 strided stages
+ * (the columns) and the fused 2^14-point blocks.  As two launches over the whole batch every coefficient
+ * crosses HBM four times (measured 0.33-0.35 of the 16*N roofline, profiles/r01/sweep_sizes.txt).  Here one
+ * 1024-thread workgroup owns a whole polynomial (1/2/4/8 blocks = 128 KiB .. 1 MiB) and runs the column stages
+ * and then its blocks back to back, so what the first pass wrote is read again by the same CU a few
+ * microseconds later -- at most 256 polynomials (256 MiB at 2^17) are in that state chip-wide, which the L2s
+ * and the 256 MiB Infinity Cache absorb instead of HBM (tools/skel.hip "two-phase": 0.43-0.46 against 0.34 for
+ * two launches, memory only).  No inter-workgroup synchronisation: the hand-off is a workgroup barrier.
+ * Reference precedent for "finish one sub-transform while its data is still close":
+ * third_party/hexl/fwd-ntt-avx512.c:311-329 (depth-first recursion).
+ */
+/* the column phase of twophase_kernel */
+template <class A, int LEAD, bool INV, uint32_t CMASK, int UNROLL>
+__device__ __forceinline__ void twophase_columns(uint64_t *base, uint32_t tid, bool wide, bool lastinv, bool lazy_out,
+                                                           const typename A::tw *tab, const typename A::consts &c)
+{
+#pragma unroll UNROLL
+  for(uint32_t k = 0; k < (uint32_t)kE; k++) {
+    column_pass_thread<A, LEAD, INV, CMASK>(base, k * 1024u + tid, (uint32_t)(kFusedLarge + LEAD), 0, wide, lastinv, tab, c, lazy_out);
+  }
+}
+
+template <class A, int LEAD, bool INV, int KSH>
+__global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
+{
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, INV, flavor_of<A>()>;
+  static_assert(G::BPW == 1 && P::T == 1024, "two-phase kernel is built on the 2^14 block");
+  constexpr uint32_t MASK  = fused_mask<A, LOGN, INV, KSH>();     /* forward: the transform's last pass; inverse: not its last */
+  constexpr uint32_t CMASK = column_mask<A, LEAD, INV, KSH>();
+  constexpr int      NBLK  = 1 << LEAD;
+  __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+  const lds_ctw_ptr<A>   gtw  = (lds_ctw_ptr<A>)tabl;
+  const uint32_t         tid  = threadIdx.x;
+  Params<A>              p    = pin;
+  p.s0                        = LEAD;
+  /* words exchanged between the two phases: the integer policies keep the reference's lazy ranges, the FP64
+   * policy canonical words (out_word ignores the flag for it) */
+  constexpr bool MID_LAZY = !A::kTracksBounds;
+  constexpr int  COL_UNROLL = A::kTracksBounds ? 2 : 1; /* two columns in flight for the FP64 policy; the integer one would spill */
+
+  for(uint64_t poly = blockIdx.x; poly < p.nblocks; poly += gridDim.x) {
+    uint64_t *const base = p.a + (poly << (LOGN + LEAD));
+    if constexpr(!INV) {
+      /* phase 1: stages 0..LEAD-1 on elements 2^14 apart; thread t owns columns t, t+1024, ... */
+      twophase_columns<A, LEAD, false, CMASK, COL_UNROLL>(base, tid, p.wide != 0, false, MID_LAZY, p.tw, p.c);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      /* phase 2: the blocks */
+      for(uint32_t blk = 0; blk < (uint32_t)NBLK; blk++) {
+        if constexpr(G::LDS_TW > 0) {
+          __syncthreads(); /* the previous block's readers of the table are done */
+          fill_lds_tables<A, LOGN, INV>(tabl, p, blk, tid);
+          __syncthreads();
+        }
+        uint64_t *const bb = base + ((uint64_t)blk << LOGN);
+        typename A::val x[kE];
+        global_load_first<A, LOGN, false>(x, tid, bb, false, p.c);
+        run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tid, blk, p, gtw);
+        static_for<0, P::NG - 1>([&](auto gg) {
+          constexpr int GI = decltype(gg)::value;
+          exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
+          run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(GI + 1));
+        });
+        global_store_last<A, LOGN, false, false>(x, tid, bb, p.c, p.lazy != 0);
+      }
+    } else {
+      for(uint32_t blk = 0; blk < (uint32_t)NBLK; blk++) {
+        if constexpr(G::LDS_TW > 0) {
+          __syncthreads();
+          fill_lds_tables<A, LOGN, INV>(tabl, p, blk, tid);
+          __syncthreads();
+        }
+        uint64_t *const bb = base + ((uint64_t)blk << LOGN);
+        typename A::val x[kE];
+        global_load_last<A, LOGN, true>(x, tid, bb, p.wide != 0, p.c);
+        run_group<A, LOGN, P::NG - 1, true, MASK, (G::TBL(P::NG - 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(P::NG - 1));
+        static_for<0, P::NG - 1>([&](auto gg) {
+          constexpr int GI = P::NG - 1 - decltype(gg)::value;
+          exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
+          run_group<A, LOGN, GI - 1, true, MASK, (G::TBL(GI - 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(GI - 1));
+        });
+        global_store_first<A, LOGN, true>(x, tid, bb, p.c, MID_LAZY);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      twophase_columns<A, LEAD, true, CMASK, COL_UNROLL>(base, tid, false, true, p.lazy != 0, p.tw, p.c);
+    }
+    __syncthreads(); /* the LDS exchange buffer and table are reused by the next polynomial */
   }
 }
 
 template <class A, int R, bool INV, int KSH>
 __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S,
-                                                     uint32_t wide, uint32_t lastinv,
+                                                     uint32_t wide, uint32_t lastinv, uint32_t lazy,
                                                      const typename A::tw *tab, const typename A::consts c)
 {
   constexpr uint32_t MASK  = column_mask<A, R, INV, KSH>();
@@ -517,7 +573,7 @@ __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch
       g += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t poly = g >> lcols;
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
-    column_pass_thread<A, R, INV, MASK>(a + (poly << logn), col, logn, S, wide != 0, lastinv != 0, tab, c);
+    column_pass_thread<A, R, INV, MASK>(a + (poly << logn), col, logn, S, wide != 0, lastinv != 0, tab, c, lazy != 0);
   }
 }
 
@@ -531,12 +587,14 @@ struct PassArgs {
   const void *consts; /* host pointer to A::consts         */
   uint64_t    batch;
   uint32_t    logn;   /* whole transform                   */
-  int         fused;  /* Pass::fused                       */
+  int         fused;  /* Pass::fused; 2 = both passes of a 2^15..2^17 transform in one launch (r = m - 14) */
   int         r;      /* Pass::r                           */
   int         s;      /* Pass::s                           */
   int         inverse;
   int         wide;
   int         lastinv;
+  int         lazy;     /* the caller asked for lazy outputs of the whole transform */
+  int         ends;     /* this pass is the last one of the transform */
   int         max_grid; /* cap on workgroups (0 = default) */
   int         num_cus;  /* compute units of the device     */
   hipStream_t stream;
@@ -544,9 +602,15 @@ struct PassArgs {
 
 template <class A, int KSH> hipError_t launch_pass(const PassArgs &pa);
 
+/* What a pass stores: the last pass of a transform honours the caller's lazy flag; every earlier pass of an
+ * integer policy keeps the reference's lazy ranges in HBM (no reduction between stages, as in
+ * src/ntt_reference.c:17-30 -- which also makes the final lazy values the reference's bit for bit).  The FP64
+ * policy ignores the run-time flag (its passes exchange canonical words). */
+inline int pass_lazy(const PassArgs &pa) { return pa.ends ? pa.lazy : 1; }
+
 template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const PassArgs &pa)
 {
-  using G = Geom<LOGN, INV, A::kCompact>;
+  using G = Geom<LOGN, INV, flavor_of<A>()>;
   Params<A> p{};
   p.a       = pa.a;
   p.tw      = static_cast<const typename A::tw *>(pa.tw);
@@ -556,10 +620,10 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   p.s0      = (uint32_t)pa.s;
   p.wide    = (uint32_t)pa.wide;
   p.lastinv = (uint32_t)pa.lastinv;
+  p.lazy    = (uint32_t)pass_lazy(pa);
   p.nblocks = pa.batch << pa.s;
   uint64_t wgs = (p.nblocks + G::BPW - 1) / G::BPW;
   uint64_t cap = 1ull << 20;
-#ifndef NTT_NO_PREFETCH
   if(G::BPW == 1) {
     /* persistent prefetching loop: exactly the resident workgroups (LDS- and
      * wave-limited), each striding over the blocks */
@@ -568,7 +632,6 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
     cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
   }
-#endif
   if(G::BPW > 1 && G::LDS_TW > 0) {
     /* tables are filled once per workgroup: a few workgroups per resident slot, each looping */
     if(pa.s != 0) return hipErrorInvalidValue;
@@ -597,9 +660,46 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
       return hipErrorInvalidValue;
     }
   } else {
-    hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+    if constexpr(A::kTracksBounds) {
+      if(pa.ends && pa.lazy) {
+        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+        return hipGetLastError();
+      }
+    }
+    hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
   }
   return hipGetLastError();
+}
+
+/* pa.r = LEAD (1..3): the whole transform of 2^(14+LEAD) points in one launch; pa.batch polynomials */
+/* (integer policy, N = 2^15: the combined kernel spills nine registers -- measured slower than two launches;
+ * two_phase_supported() keeps that case on the per-pass path) */
+template <class A, int LEAD> constexpr bool two_phase_built() { return A::kTracksBounds || LEAD != 1; }
+
+template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const PassArgs &pa)
+{
+  if constexpr(!two_phase_built<A, LEAD>()) {
+    return hipErrorNotSupported;
+  } else {
+  Params<A> p{};
+  p.a       = pa.a;
+  p.tw      = static_cast<const typename A::tw *>(pa.tw);
+  p.tw8     = static_cast<const typename A::ctw *>(pa.tw8);
+  p.c       = *static_cast<const typename A::consts *>(pa.consts);
+  p.logn    = pa.logn;
+  p.s0      = (uint32_t)LEAD;
+  p.wide    = (uint32_t)pa.wide;
+  p.lastinv = (uint32_t)pa.inverse;
+  p.lazy    = (uint32_t)pa.lazy;
+  p.nblocks = pa.batch;
+  uint64_t wgs = pa.batch;
+  uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
+  if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+  if(wgs > cap) wgs = cap;
+  if(wgs == 0) return hipSuccess;
+  hipLaunchKernelGGL((twophase_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, p);
+  return hipGetLastError();
+  }
 }
 
 template <class A, int R, bool INV, int KSH> hipError_t launch_column(const PassArgs &pa)
@@ -610,7 +710,7 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   hipLaunchKernelGGL((column_kernel<A, R, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, pa.a,
-                     pa.batch, pa.logn, (uint32_t)pa.s, (uint32_t)pa.wide, (uint32_t)pa.lastinv,
+                     pa.batch, pa.logn, (uint32_t)pa.s, (uint32_t)pa.wide, (uint32_t)pa.lastinv, (uint32_t)pass_lazy(pa),
                      static_cast<const typename A::tw *>(pa.tw),
                      *static_cast<const typename A::consts *>(pa.consts));
   return hipGetLastError();
@@ -620,6 +720,14 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
 #define NTT_DEFINE_LAUNCH_PASS(A, KSH)                                                   \
   template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
   {                                                                                      \
+    if(pa.fused == 2) {                                                                  \
+      switch(pa.r) {                                                                     \
+        case 1: return pa.inverse ? launch_twophase<A, 1, true, KSH>(pa) : launch_twophase<A, 1, false, KSH>(pa); \
+        case 2: return pa.inverse ? launch_twophase<A, 2, true, KSH>(pa) : launch_twophase<A, 2, false, KSH>(pa); \
+        case 3: return pa.inverse ? launch_twophase<A, 3, true, KSH>(pa) : launch_twophase<A, 3, false, KSH>(pa); \
+        default: return hipErrorInvalidValue;                                            \
+      }                                                                                  \
+    }                                                                                    \
     if(pa.fused) {                                                                       \
       switch(pa.r) {                                                                     \
         NTT_FUSED_CASES(A, KSH)                                                          \
@@ -631,6 +739,17 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
       case 2: return pa.inverse ? launch_column<A, 2, true, KSH>(pa) : launch_column<A, 2, false, KSH>(pa); \
       case 3: return pa.inverse ? launch_column<A, 3, true, KSH>(pa) : launch_column<A, 3, false, KSH>(pa); \
       case 4: return pa.inverse ? launch_column<A, 4, true, KSH>(pa) : launch_column<A, 4, false, KSH>(pa); \
+      default: return hipErrorInvalidValue;                                              \
+    }                                                                                    \
+  }
+
+/* policies without a column-pass form (ArithU64R4) */
+#define NTT_DEFINE_LAUNCH_PASS_FUSED_ONLY(A, KSH)                                        \
+  template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
+  {                                                                                      \
+    if(!pa.fused) return hipErrorInvalidValue;                                           \
+    switch(pa.r) {                                                                       \
+      NTT_FUSED_CASES(A, KSH)                                                            \
       default: return hipErrorInvalidValue;                                              \
     }                                                                                    \
   }

@@ -17,10 +17,7 @@ namespace ntt {
 
 constexpr int kFusedMin   = 6;
 constexpr int kFusedMax   = 14;
-#ifndef NTT_FUSED_LARGE
-#  define NTT_FUSED_LARGE 14
-#endif
-constexpr int kFusedLarge = NTT_FUSED_LARGE; /* block size used below column passes */
+constexpr int kFusedLarge = 14; /* block size used below column passes */
 
 struct Pass {
   int fused; /* 1: fused block pass, 0: column pass            */

@@ -70,6 +70,20 @@ inline std::vector<uint64_t> h_with_folded_ninv(const std::vector<uint64_t> &win
 
 inline TwU64 h_tw_u64(uint64_t w, uint64_t q) { return TwU64{w, h_precon64(w, q)}; }
 
+/* the reference's 2N-entry radix-4 table from a radix-2 power table (pre_compute.h:85-105):
+ * e[2k] = w[k];  e[4k+1] = w[k]*w[2k];  e[4k+3] = q - w[k]*w[2k+1]  (k < N/2) */
+inline std::vector<uint64_t> h_expand_radix4(const std::vector<uint64_t> &w, uint64_t q)
+{
+  const size_t          n = w.size();
+  std::vector<uint64_t> e(2 * n, 0);
+  for(size_t k = 0; k < n; k++) e[2 * k] = w[k];
+  for(size_t k = 1; k < n / 2; k++) { /* slots 1 and 3 stay 0 as in the reference (:90-93) */
+    e[4 * k + 1] = h_mulmod(w[k], w[2 * k], q);
+    e[4 * k + 3] = q - h_mulmod(w[k], w[2 * k + 1], q);
+  }
+  return e;
+}
+
 /* balanced representative and its quotient by q, correctly rounded to within
  * one long-double rounding (relative error < 2^-53 * (1 + 2^-10)) */
 inline TwF64 h_tw_f64(uint64_t w, uint64_t q)
@@ -122,6 +136,14 @@ inline F64Consts h_consts_f64(uint64_t q, uint64_t N, const std::vector<uint64_t
   c.qinv_lo = (double)(1.0L / (long double)q - (long double)c.qinv);
   c.half_q = (double)(q / 2);
   c.qi     = q;
+  {
+    union {
+      uint64_t u;
+      double   d;
+    } b;
+    b.u      = 2 * q;
+    c.q2_sub = b.d;
+  }
   const uint64_t ninv = h_powmod(N % q, q - 2, q);
   c.ninv              = h_tw_f64(ninv, q);
   const uint64_t mw   = winv.size() > 1 ? h_mulmod(ninv, winv[1], q) : ninv;

@@ -143,10 +143,10 @@ template <class A> struct Regs {
   typename A::val x[kE];
 };
 
-template <class A, int LOGN, bool INV, int KSH, bool LASTINV> static void emu_fused(const Params<A> &p)
+template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false> static void emu_fused(const Params<A> &p)
 {
   using P                 = Plan<LOGN>;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>() | (INV && LASTINV ? kLastInvFlag : 0u);
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u);
   std::vector<typename A::val> lds(P::LDS_ELEMS);
   std::vector<Regs<A>>         regs(P::T);
   for(uint64_t b = 0; b < p.nblocks; b++) {
@@ -172,7 +172,7 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV> static void emu_fu
           }
         }
       });
-      for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_last<A, LOGN, false>(regs[t].x, t, base, p.c);
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_last<A, LOGN, false, LAZY>(regs[t].x, t, base, p.c, p.lazy != 0);
     } else {
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
         global_load_last<A, LOGN, true>(regs[t].x, t, base, p.wide, p.c);
@@ -186,34 +186,40 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV> static void emu_fu
           run_group<A, LOGN, G - 1, true, MASK>(regs[t].x, t, blk, p);
         }
       });
-      for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, base, p.c);
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, base, p.c, p.lazy != 0);
     }
   }
 }
 
 template <class A, int R, bool INV, int KSH>
 static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, bool wide, bool lastinv,
-                       const typename A::tw *tab, const typename A::consts &c)
+                       const typename A::tw *tab, const typename A::consts &c, bool lazy_out)
 {
   constexpr uint32_t MASK = column_mask<A, R, INV, KSH>();
   const uint64_t     cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
     for(uint64_t col = 0; col < cols; col++) {
-      column_pass_thread<A, R, INV, MASK>(a + (pidx << logn), (uint32_t)col, logn, S, wide, lastinv, tab, c);
+      column_pass_thread<A, R, INV, MASK>(a + (pidx << logn), (uint32_t)col, logn, S, wide, lastinv, tab, c, lazy_out);
     }
   }
 }
+
+static bool g_lazy = false; /* lazy outputs for the next emu_transform (set by emu_set_lazy) */
 
 template <class A, bool INV, int KSH>
 static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
                    const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
 {
   const PassList L = make_passes(m, generic);
+  const bool lazy  = g_lazy;
   for(int k = 0; k < L.n; k++) {
     const Pass &ps      = L.p[INV ? L.n - 1 - k : k];
     const bool  lastinv = INV && ps.s == 0;
     /* only the first pass of a transform sees caller data */
     const bool w = wide && k == 0;
+    /* what the pass stores: as the library's pass_lazy() */
+    const bool ends  = k == L.n - 1;
+    const bool plazy = ends ? lazy : true;
     if(ps.fused) {
       Params<A> p{};
       p.a       = a;
@@ -224,23 +230,29 @@ static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab
       p.s0      = (uint32_t)ps.s;
       p.wide    = w;
       p.lastinv = lastinv;
+      p.lazy    = plazy;
       p.nblocks = batch << ps.s;
       switch(ps.r) {
-#define CASE(LN)                                           \
-  case LN:                                                 \
-    if(lastinv) emu_fused<A, LN, INV, KSH, true>(p);       \
-    else emu_fused<A, LN, INV, KSH, false>(p);             \
+#define CASE(LN)                                                                            \
+  case LN:                                                                                  \
+    if(lastinv) emu_fused<A, LN, INV, KSH, true>(p);                                        \
+    else if constexpr(!INV && A::kTracksBounds) {                                           \
+      if(ends && lazy) emu_fused<A, LN, INV, KSH, false, true>(p);                          \
+      else emu_fused<A, LN, INV, KSH, false>(p);                                            \
+    } else emu_fused<A, LN, INV, KSH, false>(p);                                            \
     break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return -1;
       }
+    } else if constexpr(A::kRadix4) {
+      return -4; /* no column-pass form */
     } else {
       switch(ps.r) {
-        case 1: emu_column<A, 1, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c); break;
-        case 2: emu_column<A, 2, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c); break;
-        case 3: emu_column<A, 3, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c); break;
-        case 4: emu_column<A, 4, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c); break;
+        case 1: emu_column<A, 1, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c, plazy); break;
+        case 2: emu_column<A, 2, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c, plazy); break;
+        case 3: emu_column<A, 3, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c, plazy); break;
+        case 4: emu_column<A, 4, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c, plazy); break;
         default: return -1;
       }
     }
@@ -287,6 +299,15 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
     return inverse ? emu_run<ArithU64, true, 0>(a, batch, m, tab.data(), c, generic, wide)
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
+  if(arith == 3) { /* the reference's radix-4 formulation on the expanded table */
+    if(m < kFusedMin || m > kFusedMax || generic) return -4;
+    const auto         e = h_expand_radix4(inverse ? wi : w, q);
+    std::vector<TwU64> tab(e.size());
+    for(uint64_t i = 0; i < e.size(); i++) tab[i] = h_tw_u64(e[i], q);
+    const auto c = h_consts_u64(q, N, wi);
+    return inverse ? emu_run<ArithU64R4, true, 0>(a, batch, m, tab.data(), c, false, wide)
+                   : emu_run<ArithU64R4, false, 0>(a, batch, m, tab.data(), c, false, wide);
+  }
   if(!h_f64_eligible(q)) return -2;
   if(arith == 2) { /* checked FP64 policy */
     std::vector<TwF64>  tabc(src.size());
@@ -326,6 +347,15 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 #undef RUN
 }
 
+void emu_set_lazy(int on) { g_lazy = on != 0; }
+
+/* the product's host-side builder of the 2N-entry radix-4 table (ntt_tables.h), for the table tests */
+void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q)
+{
+  const auto v = h_expand_radix4(std::vector<uint64_t>(w, w + N), q);
+  memcpy(e, v.data(), v.size() * sizeof(uint64_t));
+}
+
 /* counters of the checked policy: out = {violations, max |v|/q * 1e6, max |product|/q * 1e6}; reset */
 void emu_chk_stats(uint64_t *out, int reset)
 {
@@ -350,6 +380,21 @@ int emu_pointwise(uint64_t *c_out, const uint64_t *a, const uint64_t *b, uint64_
   if(!h_f64_eligible(q)) return -2;
   const auto c = h_consts_f64(q, 2, dummy);
   for(uint64_t i = 0; i < n; i++) c_out[i] = ArithF64::mulmod_full(a[i], b[i], c);
+  return 0;
+}
+
+/* pointwise product of LAZY operands in [0,4q) */
+int emu_pointwise_lazy(uint64_t *c_out, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t q, int arith)
+{
+  std::vector<uint64_t> dummy(2, 1);
+  if(arith == 0) {
+    const auto c = h_consts_u64(q, 2, dummy);
+    for(uint64_t i = 0; i < n; i++) c_out[i] = ArithU64::mulmod_full_lazy4(a[i], b[i], c);
+    return 0;
+  }
+  if(!h_f64_eligible(q)) return -2;
+  const auto c = h_consts_f64(q, 2, dummy);
+  for(uint64_t i = 0; i < n; i++) c_out[i] = ArithF64::mulmod_full_lazy4(a[i], b[i], c);
   return 0;
 }
 

@@ -21,12 +21,24 @@ class Emu:
         L.emu_plan_info.argtypes = [C.c_int, U64P]
         L.emu_pointwise.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_chk_stats.argtypes = [U64P, C.c_int]
+        L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
+        L.emu_set_lazy.argtypes = [C.c_int]
+        L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
 
-    def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1):
+    def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
+        """arith: 0 = integer radix-2, 1 = FP64, 2 = checked FP64, 3 = integer radix-4 (expanded table)"""
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        self.lib.emu_set_lazy(int(lazy))
         rc = self.lib.emu_transform(a.ctypes.data_as(U64P), a.size >> m, m, q, root, arith, int(inverse),
                                     int(generic), int(wide), ksh)
+        self.lib.emu_set_lazy(0)
         return rc, a
+
+    def expand_radix4(self, w, q):
+        w = np.ascontiguousarray(w, dtype=np.uint64)
+        e = np.zeros(2 * w.size, dtype=np.uint64)
+        self.lib.emu_expand_radix4(e.ctypes.data_as(U64P), w.ctypes.data_as(U64P), w.size, q)
+        return e
 
     def plan_info(self, logn):
         v = np.zeros(10, dtype=np.uint64)
@@ -39,6 +51,12 @@ class Emu:
         v = np.zeros(3, dtype=np.uint64)
         self.lib.emu_chk_stats(v.ctypes.data_as(U64P), int(reset))
         return int(v[0]), v[1] / 1e6, v[2] / 1e6
+
+    def pointwise_lazy(self, a, b, q, arith):
+        c = np.zeros_like(a)
+        rc = self.lib.emu_pointwise_lazy(c.ctypes.data_as(U64P), a.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
+                                         a.size, q, arith)
+        return rc, c
 
     def pointwise(self, a, b, q, arith):
         c = np.zeros_like(a)

@@ -47,6 +47,24 @@ class Ctx:
     def fwd_r4(self, a):
         return self._batch(self.orc.lib.orc_fwd_r4_batch, a)
 
+    def _lazy(self, fn, tab, con, a):
+        """single-polynomial *_lazy entry points of the oracle, applied to every polynomial of a"""
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        assert a.size % self.N == 0
+        t, c = self.table(tab), self.table(con)
+        for p in range(a.size // self.N):
+            v = a[p * self.N:(p + 1) * self.N]
+            fn(ptr(v), self.N, self.q, ptr(t), ptr(c))
+        return a
+
+    def fwd_lazy(self, a):
+        """fwd_ntt_ref_harvey_lazy: outputs in [0,4q) (oracle restatement of src/ntt_reference.c:11-31)"""
+        return self._lazy(self.orc.lib.orc_fwd_r2_lazy, "w", "wcon", a)
+
+    def fwd_r4_lazy(self, a):
+        """fwd_ntt_radix4_lazy: outputs in [0,8q) (src/ntt_radix4.c:27-62)"""
+        return self._lazy(self.orc.lib.orc_fwd_r4_lazy, "e", "econ", a)
+
     def inv(self, a):
         return self._batch(self.orc.lib.orc_inv_r2_batch, a)
 
@@ -71,6 +89,8 @@ class Oracle:
         L.orc_ctx_free.argtypes = [C.c_void_p]
         for f in ("orc_fwd_r2_batch", "orc_fwd_r4_batch", "orc_inv_r2_batch", "orc_inv_r4_batch"):
             getattr(L, f).argtypes = [U64P, C.c_uint64, C.c_void_p]
+        for f in ("orc_fwd_r2_lazy", "orc_fwd_r4_lazy"):
+            getattr(L, f).argtypes = [U64P, C.c_uint64, C.c_uint64, U64P, U64P]
         L.orc_fill_uniform.argtypes = [U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_fnv1a64.restype = C.c_uint64
         L.orc_fnv1a64.argtypes = [U64P, C.c_uint64]

@@ -152,3 +152,110 @@ def test_pointwise(oracle, emu, q):
     for arith in (U64, F64):
         rc, got = emu.pointwise(a, b, q, arith)
         assert rc == 0 and np.array_equal(got, expect)
+
+
+# ---------------------------------------------------------------------------------------------
+# radix-4 integer policy (reference fast_mul_operators.h:62-70,108-149, src/ntt_radix4.c:7-114)
+# and lazy outputs (include/ntt_reference.h:13-17)
+# ---------------------------------------------------------------------------------------------
+R4_CASES = [i for i in range(19)]
+
+
+@pytest.mark.parametrize("i", R4_CASES)
+def test_radix4_policy_matches_reference_lazy_values(kat, oracle, emu, i):
+    """the radix-4 kernels apply the reference's butterflies to the same operands in the same order: even the
+    LAZY outputs equal fwd_ntt_radix4_lazy bit for bit; the inverse (fully reduced) equals inv_ntt_radix4"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    a = oracle.fill_uniform(3 * n, q, 700 + i)
+    if not 6 <= m <= 14:
+        assert emu.transform(a, m, q, w, 3)[0] == -4          # no column-pass form: the library refuses too
+        return
+    cx = oracle.ctx(n, q, w)
+    rc, lazy = emu.transform(a, m, q, w, 3, lazy=True)
+    assert rc == 0
+    assert np.array_equal(lazy, cx.fwd_r4_lazy(a))
+    assert int(lazy.max()) < (8 if m % 2 == 0 else 4) * q
+    rc, red = emu.transform(a, m, q, w, 3)
+    assert rc == 0 and np.array_equal(red, cx.fwd(a))
+    # lazy values fed straight back in (tests/bench.c:123-137): same lazy outputs as the reference again
+    rc, lazy2 = emu.transform(lazy, m, q, w, 3, lazy=True, wide=True)
+    assert rc == 0 and np.array_equal(lazy2, cx.fwd_r4_lazy(lazy))
+    rc, back = emu.transform(red, m, q, w, 3, inverse=True)
+    assert rc == 0 and np.array_equal(back, a)
+    rc, back = emu.transform(lazy, m, q, w, 3, inverse=True, wide=True)
+    assert rc == 0 and np.array_equal(back, a)
+    rc, lz = emu.transform(red, m, q, w, 3, inverse=True, lazy=True)
+    assert rc == 0 and int(lz.max()) < 2 * q and np.array_equal(lz % np.uint64(q), a)
+
+
+def test_radix4_policy_large_moduli(oracle, emu):
+    """59- and 52-bit primes: the 128-bit double product really needs its carry"""
+    for bits, m in ((59, 8), (59, 13), (52, 14), (52, 11)):
+        n = 1 << m
+        q = oracle.find_prime(bits, n)
+        w = oracle.min_root(q, n)
+        a = oracle.fill_uniform(2 * n, q, bits * 100 + m)
+        cx = oracle.ctx(n, q, w)
+        rc, lazy = emu.transform(a, m, q, w, 3, lazy=True)
+        assert rc == 0 and np.array_equal(lazy, cx.fwd_r4_lazy(a)), (bits, m)
+        rc, back = emu.transform(lazy, m, q, w, 3, inverse=True, wide=True)
+        assert rc == 0 and np.array_equal(back, a), (bits, m)
+
+
+def test_expanded_table_builder(kat, oracle, emu):
+    for i in (0, 4, 9, 12):
+        c = kat["cases"][i]
+        cx = oracle.ctx(1 << c["m"], c["q"], c["w"])
+        assert np.array_equal(emu.expand_radix4(cx.table("w"), c["q"]), cx.table("e"))
+        assert np.array_equal(emu.expand_radix4(cx.table("winv"), c["q"]), cx.table("einv"))
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_lazy_outputs_radix2(kat, oracle, emu, i):
+    """integer policy: lazy forward outputs are the reference's fwd_ntt_ref_harvey_lazy values bit for bit
+    ([0,4q)), lazy inverse outputs lie in [0,2q); FP64 policy: [0,4q) forward, congruent to the oracle"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    a = oracle.fill_uniform(2 * n, q, 900 + i)
+    cx = oracle.ctx(n, q, w)
+    expect = cx.fwd(a)
+    rc, lz = emu.transform(a, m, q, w, 0, lazy=True)
+    assert rc == 0 and np.array_equal(lz, cx.fwd_lazy(a)) and int(lz.max()) < 4 * q
+    rc, back = emu.transform(lz, m, q, w, 0, inverse=True, wide=True, lazy=True)
+    assert rc == 0 and int(back.max()) < 2 * q and np.array_equal(back % np.uint64(q), a)
+    if q <= (1 << 51) + (1 << 41):
+        for arith in (1, 2):
+            rc, lf = emu.transform(a, m, q, w, arith, lazy=True)
+            assert rc == 0 and int(lf.max()) < 4 * q and np.array_equal(lf % np.uint64(q), expect), arith
+            rc, back = emu.transform(lf, m, q, w, arith, inverse=True, wide=True, lazy=True)
+            assert rc == 0 and np.array_equal(back, a)
+        if i == 12:
+            assert emu.chk_stats()[0] == 0
+
+
+def test_lazy_schedule_bounds_last_stage(emu):
+    """the LAZY forward schedule reduces late enough that |v| < 2q at the end (checked policy, worst class)"""
+    info = emu.plan_info(14)
+    assert info["fmask"] != 0
+
+
+@pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001, 0x10001])
+def test_pointwise_lazy_operands(oracle, emu, q):
+    """a, b anywhere in [0,4q) (extremes included): the product equals the exact one of the residues"""
+    rng = np.random.default_rng(q & 0xffff)
+    n = 4096
+    a = rng.integers(0, 4 * q, n, dtype=np.uint64)
+    b = rng.integers(0, 4 * q, n, dtype=np.uint64)
+    ext = np.array([0, 1, q - 1, q, q + 1, 2 * q - 1, 2 * q, 2 * q + 1, 3 * q, 4 * q - 1], dtype=np.uint64)
+    a[:100] = np.repeat(ext, 10)
+    b[:100] = np.tile(ext, 10)
+    expect = oracle.pointwise(a % np.uint64(q), b % np.uint64(q), q)
+    for arith in (0, 1):
+        rc, c = emu.pointwise_lazy(a, b, q, arith)
+        if arith == 1 and q > (1 << 51) + (1 << 41):
+            assert rc == -2
+            continue
+        assert rc == 0 and np.array_equal(c, expect), arith

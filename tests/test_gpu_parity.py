@@ -491,3 +491,157 @@ def test_current_device_is_restored(lib):
     lib.stream_sync(0, None)
     assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
     plan.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# radix-4 integer policy on the device, lazy outputs, plan options (round 2)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("i", range(19))
+def test_radix4_device_policy(lib, oracle, kat, i):
+    """NTT_ARITH_U64_R4: the reference's radix-4 butterflies / shared-quotient double products
+    (fast_mul_operators.h:62-70,108-149) and its 5-twiddle fetch (src/ntt_radix4.c:7-25) as HIP code.  Lazy
+    outputs equal fwd_ntt_radix4_lazy bit for bit; the inverse equals inv_ntt_radix4."""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    if not 6 <= m <= 14:
+        with pytest.raises(lib.NttError):
+            lib.Plan(n, q, w, arith=lib.ARITH_U64_R4)
+        return
+    batch = 5
+    a = oracle.fill_uniform(batch * n, q, 1300 + i)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith=lib.ARITH_U64_R4)
+    assert plan.info()["arith"] == lib.ARITH_U64_R4
+    lazy = plan.fwd_host(a, lazy=True)
+    assert np.array_equal(lazy, cx.fwd_r4_lazy(a))
+    assert np.array_equal(plan.fwd_host(a), cx.fwd(a))
+    assert np.array_equal(plan.fwd_host(lazy, wide=True), cx.fwd(lazy % np.uint64(q)))
+    assert np.array_equal(plan.inv_host(cx.fwd(a)), a)
+    assert np.array_equal(plan.inv_host(lazy, wide=True), a)
+    lz = plan.inv_host(cx.fwd(a), lazy=True)
+    assert int(lz.max()) < 2 * q and np.array_equal(lz % np.uint64(q), a)
+    plan.destroy()
+
+
+def test_radix4_device_policy_large_moduli(lib, oracle):
+    for bits, m in ((59, 8), (59, 14), (52, 14), (52, 11)):
+        n = 1 << m
+        q = oracle.find_prime(bits, n)
+        w = oracle.min_root(q, n)
+        a = oracle.fill_uniform(3 * n, q, bits * 10 + m)
+        cx = oracle.ctx(n, q, w)
+        plan = lib.Plan(n, q, w, arith=lib.ARITH_U64_R4)
+        lazy = plan.fwd_host(a, lazy=True)
+        assert np.array_equal(lazy, cx.fwd_r4_lazy(a)), (bits, m)
+        assert np.array_equal(plan.inv_host(lazy, wide=True), a), (bits, m)
+        plan.destroy()
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_lazy_outputs(lib, oracle, kat, i):
+    """ntt_fwd_batch_lazy / ntt_inv_batch_lazy: integer policy = the reference's lazy values bit for
+    bit; FP64 policy = values in [0,4q) congruent to them; lazy -> wide chains without any reduction pass"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    a = oracle.fill_uniform(3 * n, q, 1500 + i)
+    cx = oracle.ctx(n, q, w)
+    pu = lib.Plan(n, q, w, arith=lib.ARITH_U64)
+    lz = pu.fwd_host(a, lazy=True)
+    assert np.array_equal(lz, cx.fwd_lazy(a))
+    back = pu.inv_host(lz, wide=True, lazy=True)
+    assert int(back.max()) < 2 * q and np.array_equal(back % np.uint64(q), a)
+    pu.destroy()
+    if q <= (1 << 51) + (1 << 41):
+        pf = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+        lf = pf.fwd_host(a, lazy=True)
+        assert int(lf.max()) < 4 * q and np.array_equal(lf % np.uint64(q), cx.fwd(a))
+        assert np.array_equal(pf.inv_host(lf, wide=True, lazy=True), a)
+        pf.destroy()
+
+
+@pytest.mark.parametrize("i", range(19))
+def test_reference_lazy_signatures_are_bit_exact(lib, oracle, kat, i):
+    """the *_lazy entry points return exactly what the reference returns BEFORE its header-inline final
+    reduction: the integer policies run the reference's own butterflies on the caller's w AND w_con"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    cx = oracle.ctx(n, q, w)
+    a = oracle.fill_uniform(n, q, 1700 + i)
+    U64P = lib.U64P
+    tw, twc, e, ec = cx.table("w"), cx.table("wcon"), cx.table("e"), cx.table("econ")
+    x = a.copy()
+    lib._lib.fwd_ntt_ref_harvey_lazy(x.ctypes.data_as(U64P), n, q, tw.ctypes.data_as(U64P), twc.ctypes.data_as(U64P))
+    assert np.array_equal(x, cx.fwd_lazy(a))
+    x = a.copy()
+    lib._lib.fwd_ntt_seal_lazy(x.ctypes.data_as(U64P), n, q, tw.ctypes.data_as(U64P), twc.ctypes.data_as(U64P))
+    assert int(x.max()) < 4 * q and np.array_equal(x % np.uint64(q), cx.fwd(a))
+    for fn in (lib._lib.fwd_ntt_radix4_lazy, lib._lib.fwd_ntt_radix4x4_lazy):
+        x = a.copy()
+        fn(x.ctypes.data_as(U64P), n, q, e.ctypes.data_as(U64P), ec.ctypes.data_as(U64P))
+        if 6 <= m <= 14:
+            assert np.array_equal(x, cx.fwd_r4_lazy(a))
+        else:
+            assert int(x.max()) < 8 * q and np.array_equal(x % np.uint64(q), cx.fwd(a))
+    lib.compat_release()
+
+
+def test_plan_options(lib, oracle, kat):
+    """ntt_plan_set_option replaces the environment variables of round 1: every knob gives identical results"""
+    c = kat["cases"][17]                       # m = 16, q = 0x7fffffffe0001: multi-pass, chunked
+    n, q, w = 1 << c["m"], c["q"], c["w"]
+    a = oracle.fill_uniform(6 * n, q, 4242)
+    expect = oracle.ctx(n, q, w).fwd(a)
+    plan = lib.Plan(n, q, w)
+    for opt, val in ((lib.OPT_CHUNK_MIB, 1), (lib.OPT_MAX_GRID, 64), (lib.OPT_F64_CLASS, 0), (lib.OPT_CHUNK_MIB, 256),
+                     (lib.OPT_MAX_GRID, 0), (lib.OPT_TWO_PHASE, 0), (lib.OPT_MAX_GRID, 3), (lib.OPT_TWO_PHASE, 1), (lib.OPT_MAX_GRID, 0)):
+        plan.set_option(opt, val)
+        assert np.array_equal(plan.fwd_host(a), expect), (opt, val)
+        assert np.array_equal(plan.inv_host(expect), a), (opt, val)
+    with pytest.raises(lib.NttError):
+        plan.set_option(lib.OPT_F64_CLASS, 18)   # q is a 51-bit prime: class 18 is not valid for it
+    with pytest.raises(lib.NttError):
+        plan.set_option(99, 1)
+    plan.destroy()
+
+
+def test_reference_test_driver_drop_in_fp64_engine():
+    """the same unchanged reference driver with NTT_COMPAT_ARITH=f64: the reference-signature entry points are
+    then served by the FP64 throughput kernels wherever q <= 2^51"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ntt-variants-dropin")
+    assert os.path.exists(exe), "oracle/_ref/ntt-variants-dropin did not travel to the GPU box"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, NTT_COMPAT_ARITH="f64"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("Test ") == 19 and "Bad results" not in out.stdout
+
+
+@pytest.mark.parametrize("i", (14, 15, 16, 17, 18))
+@pytest.mark.parametrize("arith", ("u64", "f64"))
+def test_two_phase_equals_per_pass_path(lib, oracle, kat, i, arith):
+    """N = 2^15..2^17: the one-launch two-phase kernel and the round-1 per-pass launches (NTT_OPT_TWO_PHASE 0) give
+    the oracle's result, forward and inverse, wide and lazy, for batches around the grid size"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    ar = lib.ARITH_U64 if arith == "u64" else lib.ARITH_F64
+    if ar == lib.ARITH_F64 and q > (1 << 51) + (1 << 41):
+        pytest.skip("modulus above the FP64 range")
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith=ar)
+    for batch in (1, 5):
+        a = oracle.fill_uniform(batch * n, q, 2000 + i + batch)
+        expect = cx.fwd(a)
+        for two in (1, 0):
+            plan.set_option(lib.OPT_TWO_PHASE, two)
+            assert np.array_equal(plan.fwd_host(a), expect), (batch, two)
+            assert np.array_equal(plan.inv_host(expect), a), (batch, two)
+            lz = plan.fwd_host(a, lazy=True)
+            assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), expect)
+            assert np.array_equal(plan.inv_host(lz, wide=True), a)
+    plan.set_option(lib.OPT_TWO_PHASE, 1)
+    plan.set_option(lib.OPT_MAX_GRID, 2)          # more polynomials than workgroups: the persistent loop wraps
+    a = oracle.fill_uniform(7 * n, q, 77)
+    assert np.array_equal(plan.fwd_host(a), cx.fwd(a))
+    plan.destroy()

@@ -13,8 +13,10 @@ ap.add_argument("--bytes", type=float, default=8e9)
 ap.add_argument("--qs", nargs="+", default=["0x7fffffffe0001"])
 ap.add_argument("--arith", nargs="+", default=["auto"])
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--two-phase", type=int, default=0, help="N=2^15..2^17: 1 = one launch per transform (default), 0 = one launch per pass")
 a = ap.parse_args()
-AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64}
+ap2 = None
+AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64, "r4": lib.ARITH_U64_R4}
 print("%-6s %-18s %-5s %-5s %10s %12s %9s %6s" % ("logn", "q", "arith", "op", "batch", "M NTT/s", "GB/s", "frac"))
 for qs in a.qs:
     q = int(qs, 0)
@@ -28,6 +30,7 @@ for qs in a.qs:
                 plan = lib.Plan(n, q, w, arith=AR[ar])
             except lib.NttError as e:
                 print(ln, qs, ar, "unsupported:", e); continue
+            plan.set_option(lib.OPT_TWO_PHASE, a.two_phase)
             nb = 3 if "mul" in a.ops else 1
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
             for i, b in enumerate(bufs): lib.fill_uniform(b.ptr, batch * n, q, 77 + i)
@@ -35,14 +38,16 @@ for qs in a.qs:
                 def run():
                     if op == "fwd": plan.fwd(bufs[0].ptr, batch)
                     elif op == "inv": plan.inv(bufs[0].ptr, batch)
+                    elif op == "fwdlazy": plan.fwd(bufs[0].ptr, batch, lazy=True, wide=True)   # lazy in, lazy out: chained
+                    elif op == "invlazy": plan.inv(bufs[0].ptr, batch, lazy=True, wide=True)
                     else: plan.negacyclic_mul(bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, batch)
                 for _ in range(2): run()
                 e0, e1 = lib.Event(), lib.Event()
                 lib.stream_sync(); e0.record()
                 for _ in range(a.steps): run()
                 e1.record(); ms = e1.elapsed_ms_since(e0) / a.steps
-                per = {"fwd": 16, "inv": 16, "mul": 72}[op] * n      # algorithmic bytes per polynomial
+                per = {"fwd": 16, "inv": 16, "fwdlazy": 16, "invlazy": 16, "mul": 72}[op] * n      # algorithmic bytes per polynomial
                 gbs = batch * per / ms / 1e6
-                print("%-6d %-18s %-5s %-5s %10d %12.3f %9.0f %6.3f" % (ln, qs, ["auto","u64","f64"][plan.info()["arith"]], op, batch, batch / ms / 1e3, gbs, gbs / 8000))
+                print("%-6d %-18s %-5s %-7s %10d %12.3f %9.0f %6.3f" % (ln, qs, ["auto","u64","f64","r4"][plan.info()["arith"]], op, batch, batch / ms / 1e3, gbs, gbs / 8000))
             for b in bufs: b.free()
             plan.destroy()
