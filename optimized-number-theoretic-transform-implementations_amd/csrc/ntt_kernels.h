@@ -210,6 +210,49 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
   });
 }
 
+/* Final stores of the forward transform as WHOLE LINES.  In the last group a lane owns runs of four consecutive
+ * coefficients (32 bytes): a 16-byte store instruction then writes half of every 32 bytes it touches -- 64
+ * half-filled chunks over 2 KiB.  One v_permlane32_swap per dword exchanges slot bit 1 with lane bit 5 first:
+ * lanes 0-31 then hold the even 16-byte chunks of a 1-KiB run and lanes 32-63 the odd ones, and every store
+ * instruction of the wave covers one contiguous KiB (tools/skel.hip: 0.674 -> 0.694 of the HBM peak for the
+ * memory skeleton).  This is the one place where a cross-lane move (north star: "wave64 shuffles") pays:
+ * 16 single-issue VALU instructions per thread against 32 LDS operations for an LDS transpose. */
+template <class A, int LOGN, bool LAZYT>
+__device__ __forceinline__ void store_last_whole_lines(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
+                                                       const typename A::consts &c, bool lazy_rt)
+{
+  using P          = Plan<LOGN>;
+  constexpr int G  = P::NG - 1;
+  constexpr int HB = P::TB(G, 5); /* index bit held by lane bit 5 */
+  static_assert(P::RL == 2 && P::NL == 6 && HB > 1, "needs runs of four coefficients per lane and full waves");
+  uint64_t u[kE];
+  static_for<0, kE>([&](auto ee) { u[decltype(ee)::value] = out_word<A, false, LAZYT>(x[decltype(ee)::value], lazy_rt, c); });
+  /* slots E (bit 1 clear) and E|2: swap the upper-half lanes of the first with the lower-half lanes of the second */
+  static_for<0, kE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    if constexpr((E & 2) == 0) {
+      const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u[E], (unsigned)u[E | 2], false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u[E] >> 32), (unsigned)(u[E | 2] >> 32), false, false);
+      u[E]          = (uint64_t)lo[0] | ((uint64_t)hi[0] << 32);
+      u[E | 2]      = (uint64_t)lo[1] | ((uint64_t)hi[1] << 32);
+    }
+  });
+  /* after the swap: slot bit 1 <-> index bit HB, lane bit 5 <-> index bit 1 */
+  const uint32_t ib   = (P::IBASE(G, t) & ~(1u << HB)) | (((t >> 5) & 1u) << 1);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  static_for<0, kE / 2>([&](auto hh) {
+    constexpr int      E   = 2 * decltype(hh)::value;
+    constexpr uint32_t OFF = (P::IOFF(G, E) & ~2u) | ((uint32_t)((E >> 1) & 1) << HB);
+    v4u32              v;
+    v.x = (unsigned)u[E];
+    v.y = (unsigned)(u[E] >> 32);
+    v.z = (unsigned)u[E + 1];
+    v.w = (unsigned)(u[E + 1] >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(OFF * 8u), 0);
+  });
+}
+
 /* Makes the compiler complete the loads behind a prefetched block at this point.  Used
  * once, before a persistent loop is entered: the waits the compiler places inside the loop
  * are the merge of both ways into it, and anything still pending on the way in from the
@@ -354,7 +397,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         }
         STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
-      global_store_last<A, LOGN, false, LAZY>(x, tid, base, p.c, p.lazy != 0);
+      /* whole-line stores: measured +0.6..0.9 % at 2^14, -0.5 % at 2^12 (profiles/r02/ablations.txt) */
+      if constexpr(LOGN == 14) {
+        store_last_whole_lines<A, LOGN, LAZY>(x, tid, base, p.c, p.lazy != 0);
+      } else {
+        global_store_last<A, LOGN, false, LAZY>(x, tid, base, p.c, p.lazy != 0);
+      }
       STAMP(10); /* final reduction + stores */
     }
     return;

@@ -35,6 +35,7 @@ for qs in a.qs:
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
             for i, b in enumerate(bufs): lib.fill_uniform(b.ptr, batch * n, q, 77 + i)
             for op in a.ops:
+                if op == "mul" and ar == "r4": continue      # the radix-4 policy has no product chain
                 def run():
                     if op == "fwd": plan.fwd(bufs[0].ptr, batch)
                     elif op == "inv": plan.inv(bufs[0].ptr, batch)
