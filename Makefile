@@ -50,3 +50,8 @@ build/skel: tools/skel.hip
 	mkdir -p build
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -o $@ tools/skel.hip
 .PHONY: skel
+
+# ASAN + UBSAN run of the CPU-side code (oracle, host table/pass planning, kernel templates in the emulator)
+sanitize:
+	$(MAKE) -C tests/sanitize run
+.PHONY: sanitize

@@ -380,8 +380,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
   const PassList L = make_passes(p->m, p->generic);
-  if(p->two_phase && !p->generic && p->m > kFusedMax && p->m <= kFusedMax + 3 &&
-     (p->arith == NTT_ARITH_F64 || p->m != kFusedMax + 1)) {
+  if(p->two_phase && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3) {
     /* one launch, one workgroup per polynomial, both passes back to back (ntt_kernels.h: twophase_kernel) */
     PassArgs pa{};
     pa.a        = d_a;

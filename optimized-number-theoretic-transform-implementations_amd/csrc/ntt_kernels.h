@@ -126,8 +126,15 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class A, int LOGN, int GW, int GR>
-__device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds)
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+/* between(): runs between the two barriers of a cross-wave exchange -- every wave has left the previous stage
+ * groups, nobody has entered the next ones: the place to rewrite LDS data shared by the whole workgroup
+ * (the two-phase kernel refreshes its twiddle table there at no extra barrier) */
+template <class A, int LOGN, int GW, int GR, class HOOK = NoHook>
+__device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, typename A::val *lds, HOOK between = HOOK())
 {
   using P = Plan<LOGN>;
   constexpr bool local = P::WAVE_LOCAL(GW, GR);
@@ -139,6 +146,7 @@ __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, t
   } else {
     __syncthreads(); /* every wave has finished reading the previous layout */
     lds_scatter<A, LOGN, GW, GR>(x, t, lds);
+    between();
     __syncthreads();
     lds_gather<A, LOGN, GW, GR>(x, t, lds);
   }
@@ -516,25 +524,147 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
  * A transform larger than one fused block needs two passes over the polynomial: LEAD = m - 14 strided stages
  * (the columns) and the fused 2^14-point blocks.  As two launches over the whole batch every coefficient
  * crosses HBM four times (measured 0.33-0.35 of the 16*N roofline, profiles/r01/sweep_sizes.txt).  Here one
- * 1024-thread workgroup owns a whole polynomial (1/2/4/8 blocks = 128 KiB .. 1 MiB) and runs the column stages
- * and then its blocks back to back, so what the first pass wrote is read again by the same CU a few
+ * 1024-thread workgroup owns a whole polynomial (2/4/8 blocks = 256 KiB .. 1 MiB) and runs the column stages
+ * and then its blocks back to back, so what the first pass wrote is read again by the same CU a few tens of
  * microseconds later -- at most 256 polynomials (256 MiB at 2^17) are in that state chip-wide, which the L2s
- * and the 256 MiB Infinity Cache absorb instead of HBM (tools/skel.hip "two-phase": 0.43-0.46 against 0.34 for
+ * and the 256 MiB Infinity Cache absorb instead of HBM (tools/skel.hip "two-phase": 0.39-0.46 against 0.34 for
  * two launches, memory only).  No inter-workgroup synchronisation: the hand-off is a workgroup barrier.
+ * Inside a workgroup the memory-bound column phase and the compute-bound block phase alternate; the CUs drift
+ * apart, so chip-wide both kinds of work are in flight at any time.  Both phases keep their own pipelines full:
+ *   columns: rounds of 16 values per thread, the next round's loads in flight while this one is computed
+ *            (double buffer), wave-uniform twiddles through the scalar cache;
+ *   blocks : the persistent loop of fused_kernel -- next block prefetched into registers, last group's
+ *            twiddles requested early, second-to-last group's twiddles from an LDS table that is REFRESHED
+ *            per block position between the two barriers of the cross-wave exchange (no extra barrier).
  * Reference precedent for "finish one sub-transform while its data is still close":
  * third_party/hexl/fwd-ntt-avx512.c:311-329 (depth-first recursion).
  */
-/* the column phase of twophase_kernel */
-template <class A, int LEAD, bool INV, uint32_t CMASK, int UNROLL>
-__device__ __forceinline__ void twophase_columns(uint64_t *base, uint32_t tid, bool wide, bool lastinv, bool lazy_out,
-                                                           const typename A::tw *tab, const typename A::consts &c)
+template <int LEAD> __device__ __forceinline__ __amdgpu_buffer_rsrc_t poly_rsrc(const uint64_t *poly)
 {
-#pragma unroll UNROLL
-  for(uint32_t k = 0; k < (uint32_t)kE; k++) {
-    column_pass_thread<A, LEAD, INV, CMASK>(base, k * 1024u + tid, (uint32_t)(kFusedLarge + LEAD), 0, wide, lastinv, tab, c, lazy_out);
-  }
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(poly), 0, (int)(8u << (kFusedLarge + LEAD)), 0x00020000);
 }
 
+/* One thread owns columns tid, tid + 1024, ... (16 of them); a round handles 16 >> LEAD columns = 16 values:
+ * value v = cc * 2^LEAD + e is element e (index e * 2^14 + column) of column cc of the round. */
+template <class A, int LEAD, bool INV, int KSH>
+__device__ __forceinline__ void twophase_columns(uint64_t *base, uint32_t tid, const Params<A> &p, bool wide_in, bool lazy_out)
+{
+  constexpr int      NE    = 1 << LEAD;
+  constexpr int      CPR   = kE / NE;
+  constexpr int      NR    = kE / CPR;
+  constexpr uint32_t CMASK = column_mask<A, LEAD, INV, KSH>();
+  const __amdgpu_buffer_rsrc_t r = poly_rsrc<LEAD>(base);
+  typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+  /* one raw buffer: the next round is requested as soon as this round's words have been converted, so its
+   * loads are in flight during the butterflies and the stores (the same scheme as the block loops) */
+  uint64_t raw[kE];
+  auto load_round = [&](auto rr, uint64_t(&dst)[kE]) {
+    constexpr int RD = decltype(rr)::value;
+    static_for<0, kE>([&](auto vv) {
+      constexpr int      V   = decltype(vv)::value;
+      constexpr uint32_t OFF = ((uint32_t)(V % NE) << kFusedLarge) + (uint32_t)(RD * CPR + V / NE) * 1024u;
+      dst[V]                 = buffer_load_u64(r, tid * 8u, OFF * 8u);
+    });
+  };
+  load_round(std::integral_constant<int, 0>{}, raw);
+  static_for<0, NR>([&](auto rr) {
+    constexpr int RD = decltype(rr)::value;
+    typename A::val x[kE];
+    convert_inputs<A, INV>(x, raw, wide_in, p.c);
+    if constexpr(RD + 1 < NR) load_round(std::integral_constant<int, RD + 1>{}, raw);
+    static_for<0, LEAD>([&](auto jj) {
+      constexpr int  J   = INV ? (LEAD - 1 - decltype(jj)::value) : decltype(jj)::value;
+      constexpr int  AB  = LEAD - 1 - J;
+      constexpr int  POS = INV ? (LEAD - 1 - J) : J;
+      constexpr bool RED = (CMASK >> POS) & 1u;
+      static_for<0, kE>([&](auto vv) {
+        constexpr int V  = decltype(vv)::value;
+        constexpr int E0 = V % NE;
+        if constexpr(((E0 >> AB) & 1) == 0) {
+          constexpr int V1 = V | (1 << AB);
+          if constexpr(INV && J == 0) {
+            A::inv_bfly_last(x[V], x[V1], p.c); /* global stage 0 ends the inverse transform: N^-1 folded in */
+          } else {
+            const typename A::tw w = load_tw<A, true>(p.tw, (1u << J) + (uint32_t)(E0 >> (LEAD - J)));
+            if constexpr(INV) {
+              A::template inv_bfly<RED>(x[V], x[V1], w, p.c);
+            } else {
+              A::template fwd_bfly<RED>(x[V], x[V1], w, p.c);
+            }
+          }
+        }
+      });
+    });
+    static_for<0, kE>([&](auto vv) {
+      constexpr int      V   = decltype(vv)::value;
+      constexpr uint32_t OFF = ((uint32_t)(V % NE) << kFusedLarge) + (uint32_t)(RD * CPR + V / NE) * 1024u;
+      const uint64_t     u   = out_word<A, INV, false>(x[V], lazy_out, p.c);
+      v2u32              w2;
+      w2.x = (unsigned)u;
+      w2.y = (unsigned)(u >> 32);
+      __builtin_amdgcn_raw_buffer_store_b64(w2, r, (int)(tid * 8u), (int)(OFF * 8u), 0);
+    });
+  });
+}
+
+/* second-to-last group's LDS twiddle table for block position blk: values into registers (at most 5 per thread),
+ * later written to LDS in the transposed layout of fill_lds_tables */
+template <class A, int LOGN, bool INV> struct TableRegs {
+  using P                  = Plan<LOGN>;
+  using G                  = Geom<LOGN, INV, flavor_of<A>()>;
+  static constexpr int GI  = P::NG - 2;
+  static constexpr int SG  = P::S(GI);
+  static constexpr int R   = P::R(GI);
+  static constexpr int CNT(int jj) { return ((1 << (SG + jj)) + G::WG - 1) / G::WG; }
+  static constexpr int TOTAL()
+  {
+    int n = 0;
+    for(int j = 0; j < R; j++) n += CNT(j);
+    return n;
+  }
+  typename A::ctw v[TOTAL() > 0 ? TOTAL() : 1];
+
+  __device__ __forceinline__ void load(const Params<A> &p, uint32_t blk, uint32_t tid)
+  {
+    asm volatile("" : "+v"(tid)); /* as in store(): keep the lane offsets out of the loop-invariant set */
+    int k = 0;
+    static_for<0, R>([&](auto jj) {
+      constexpr int JJ  = decltype(jj)::value;
+      constexpr int SLJ = SG + JJ;
+      const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk << SLJ);
+      static_for<0, CNT(JJ)>([&](auto cc) {
+        const uint32_t l = tid + (uint32_t)decltype(cc)::value * G::WG;
+        v[k]             = l < (1u << SLJ) ? at32(src, l) : typename A::ctw{};
+        k++;
+      });
+    });
+  }
+  __device__ __forceinline__ void store(typename A::ctw *tabl, uint32_t tid) const
+  {
+    /* recomputed per block on purpose: hoisted out of the block loop these five LDS addresses would occupy
+     * registers for the whole launch (they were the kernel's only spills) */
+    asm volatile("" : "+v"(tid));
+    typename A::ctw *tg = tabl + G::TBL_OFF(GI);
+    int              k  = 0;
+    static_for<0, R>([&](auto jj) {
+      constexpr int JJ  = decltype(jj)::value;
+      constexpr int SLJ = SG + JJ;
+      static_for<0, CNT(JJ)>([&](auto cc) {
+        const uint32_t l = tid + (uint32_t)decltype(cc)::value * G::WG;
+        if(l < (1u << SLJ)) {
+          const uint32_t u = l & ((1u << JJ) - 1u), prefix = l >> JJ;
+          tg[(((1u << JJ) - 1u) << SG) + (u << SG) + prefix] = v[k];
+        }
+        k++;
+      });
+    });
+  }
+};
+
+/* forward block loop: the exchange after which the last group's twiddles (kTpPreAt) and the next block
+ * (kTpPfAt) are requested -- as late as their latency allows, so that the registers carry them only then */
+constexpr int kTpPreAt = 1;
+constexpr int kTpPfAt  = 2;
 template <class A, int LEAD, bool INV, int KSH>
 __global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
 {
@@ -542,70 +672,125 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, INV, flavor_of<A>()>;
   static_assert(G::BPW == 1 && P::T == 1024, "two-phase kernel is built on the 2^14 block");
-  constexpr uint32_t MASK  = fused_mask<A, LOGN, INV, KSH>();     /* forward: the transform's last pass; inverse: not its last */
-  constexpr uint32_t CMASK = column_mask<A, LEAD, INV, KSH>();
-  constexpr int      NBLK  = 1 << LEAD;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH>(); /* forward: the transform's last pass; inverse: not its last */
+  constexpr int      NBLK = 1 << LEAD;
+  constexpr int      GL   = P::NG - 1;
+  constexpr bool     LTW  = G::LDS_TW > 0;
+  /* per-lane twiddles of the last group (forward) / first executed group (inverse) in registers, requested early */
+  constexpr bool     PRE  = A::kCompact && stage_is_compact<A, LOGN, INV>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
   __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
-  const lds_ctw_ptr<A>   gtw  = (lds_ctw_ptr<A>)tabl;
+  const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
   const uint32_t         tid  = threadIdx.x;
   Params<A>              p    = pin;
   p.s0                        = LEAD;
   /* words exchanged between the two phases: the integer policies keep the reference's lazy ranges, the FP64
    * policy canonical words (out_word ignores the flag for it) */
   constexpr bool MID_LAZY = !A::kTracksBounds;
-  constexpr int  COL_UNROLL = A::kTracksBounds ? 2 : 1; /* two columns in flight for the FP64 policy; the integer one would spill */
 
   for(uint64_t poly = blockIdx.x; poly < p.nblocks; poly += gridDim.x) {
     uint64_t *const base = p.a + (poly << (LOGN + LEAD));
     if constexpr(!INV) {
-      /* phase 1: stages 0..LEAD-1 on elements 2^14 apart; thread t owns columns t, t+1024, ... */
-      twophase_columns<A, LEAD, false, CMASK, COL_UNROLL>(base, tid, p.wide != 0, false, MID_LAZY, p.tw, p.c);
+      twophase_columns<A, LEAD, false, KSH>(base, tid, p, p.wide != 0, MID_LAZY);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      /* phase 2: the blocks */
+      uint64_t raw[kE];
+      prefetch_first<LOGN>(raw, tid, base);
+#pragma unroll 1
       for(uint32_t blk = 0; blk < (uint32_t)NBLK; blk++) {
-        if constexpr(G::LDS_TW > 0) {
-          __syncthreads(); /* the previous block's readers of the table are done */
-          fill_lds_tables<A, LOGN, INV>(tabl, p, blk, tid);
-          __syncthreads();
-        }
-        uint64_t *const bb = base + ((uint64_t)blk << LOGN);
+        uint64_t *const       bb = base + ((uint64_t)blk << LOGN);
+        TableRegs<A, LOGN, false> tr;
         typename A::val x[kE];
-        global_load_first<A, LOGN, false>(x, tid, bb, false, p.c);
-        run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tid, blk, p, gtw);
+        convert_inputs<A, false>(x, raw, false, p.c);
+        run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+        /* this block's table entries: requested only now (x and the prefetch are the only live values), they
+         * arrive while the waves meet at the exchange's first barrier and scatter */
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr(LTW) tr.load(p, blk, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        typename A::ctw pre[4][kE / 2];
         static_for<0, P::NG - 1>([&](auto gg) {
           constexpr int GI = decltype(gg)::value;
-          exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
-          run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(GI + 1));
+          if constexpr(GI == 0 && LTW) {
+            exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all, [&]() { tr.store(tabl, tid); });
+          } else {
+            exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
+          }
+          if constexpr(GI == kTpPreAt && PRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+          if constexpr(GI == kTpPfAt) {
+            /* the next block comes from the L2 / Infinity Cache (this workgroup's column phase wrote it): requested
+             * here, it has the rest of the block to arrive, and the register file is not carrying it during the
+             * first three groups.  Always issued (the last block re-requests itself): a conditional refill would
+             * keep the old words alive. */
+            const uint32_t nb = blk + 1 < (uint32_t)NBLK ? blk + 1 : blk;
+            prefetch_first<LOGN>(raw, tid, base + ((uint64_t)nb << LOGN));
+          }
+          if constexpr(PRE && GI + 1 == GL) {
+            run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+          } else if constexpr(G::TBL(GI + 1) > 0) {
+            run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
+          } else {
+            run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+          }
         });
-        global_store_last<A, LOGN, false, false>(x, tid, bb, p.c, p.lazy != 0);
+        store_last_whole_lines<A, LOGN, false>(x, tid, bb, p.c, p.lazy != 0);
       }
     } else {
-      for(uint32_t blk = 0; blk < (uint32_t)NBLK; blk++) {
-        if constexpr(G::LDS_TW > 0) {
-          __syncthreads();
-          fill_lds_tables<A, LOGN, INV>(tabl, p, blk, tid);
+      /* blocks first (their inputs come from HBM), then the columns */
+      uint64_t raw[kE];
+      prefetch_last<LOGN>(raw, tid, base);
+      typename A::ctw pre[4][kE / 2];
+      {
+        /* per-polynomial prologue: its lane offsets are recomputed here rather than kept in registers (or
+         * scratch) for the whole launch */
+        uint32_t tp = tid;
+        asm volatile("" : "+v"(tp));
+        if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tp, 0u, p);
+        if constexpr(LTW) {
+          __syncthreads(); /* the previous polynomial's readers of the table are done */
+          fill_lds_tables<A, LOGN, true>(tabl, p, 0u, tp);
           __syncthreads();
         }
+      }
+#pragma unroll 1
+      for(uint32_t blk = 0; blk < (uint32_t)NBLK; blk++) {
         uint64_t *const bb = base + ((uint64_t)blk << LOGN);
         typename A::val x[kE];
-        global_load_last<A, LOGN, true>(x, tid, bb, p.wide != 0, p.c);
-        run_group<A, LOGN, P::NG - 1, true, MASK, (G::TBL(P::NG - 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(P::NG - 1));
+        convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
+        const uint32_t nb = blk + 1 < (uint32_t)NBLK ? blk + 1 : blk; /* clamped: every refill below is unconditional */
+        prefetch_last<LOGN>(raw, tid, base + ((uint64_t)nb << LOGN));
+        if constexpr(PRE) {
+          run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+        } else {
+          run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+        }
+        TableRegs<A, LOGN, true> tr;
+        if constexpr(LTW) tr.load(p, nb, tid);
         static_for<0, P::NG - 1>([&](auto gg) {
           constexpr int GI = P::NG - 1 - decltype(gg)::value;
-          exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
-          run_group<A, LOGN, GI - 1, true, MASK, (G::TBL(GI - 1) > 0)>(x, tid, blk, p, gtw + G::TBL_OFF(GI - 1));
+          if constexpr(GI == 1 && LTW) {
+            exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all, [&]() { tr.store(tabl, tid); });
+            /* next block's first-group twiddles: their registers are free from here on */
+            if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tid, nb, p);
+          } else {
+            exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
+          }
+          if constexpr(G::TBL(GI - 1) > 0) {
+            run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
+          } else {
+            run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+          }
         });
-        global_store_first<A, LOGN, true>(x, tid, bb, p.c, MID_LAZY);
+        uint64_t out[kE];
+        static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = out_word<A, true, false>(x[decltype(ee)::value], MID_LAZY, p.c); });
+        buffer_store_first_raw<LOGN>(out, tid, bb);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      twophase_columns<A, LEAD, true, CMASK, COL_UNROLL>(base, tid, false, true, p.lazy != 0, p.tw, p.c);
+      twophase_columns<A, LEAD, true, KSH>(base, tid, p, false, p.lazy != 0);
     }
-    __syncthreads(); /* the LDS exchange buffer and table are reused by the next polynomial */
   }
 }
 
@@ -720,9 +905,10 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
 }
 
 /* pa.r = LEAD (1..3): the whole transform of 2^(14+LEAD) points in one launch; pa.batch polynomials */
-/* (integer policy, N = 2^15: the combined kernel spills nine registers -- measured slower than two launches;
- * two_phase_supported() keeps that case on the per-pass path) */
-template <class A, int LEAD> constexpr bool two_phase_built() { return A::kTracksBounds || LEAD != 1; }
+/* Built for the FP64 policy at N = 2^16 and 2^17 (BASELINE configs 3 and 5).  The integer policy's larger
+ * temporaries and the N = 2^15 inverse do not fit the 128-register budget of a 1024-thread workgroup without
+ * scratch: those cases stay on the one-launch-per-pass path (ntt_host.hip: two_phase_applies). */
+template <class A, int LEAD> constexpr bool two_phase_built() { return A::kTracksBounds && LEAD >= 2; }
 
 template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const PassArgs &pa)
 {

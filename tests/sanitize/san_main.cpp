@@ -1,0 +1,115 @@
+/*
+ * san_main.cpp -- AddressSanitizer + UndefinedBehaviorSanitizer run of the CPU-side code (TEST INFRASTRUCTURE).
+ *
+ * Mirrors the reference's sanitizer builds (cmake/compilation-flags.cmake:24-57, tests/pre-commit-script.sh:28-33)
+ * for what exists on the CPU here: the oracle (oracle/ntt_oracle.c), the host-side table/pass planning of the
+ * product (csrc/ntt_tables.h, ntt_passplan.h) and the kernel templates executed by the emulator (tests/emu/emu.cpp,
+ * i.e. csrc/ntt_core.h + ntt_arith.h: index maps, LDS layouts, twiddle addressing).  GPU code cannot run under
+ * sanitizers on this pool; this run proves the shared templates free of out-of-bounds accesses, signed overflow
+ * and misaligned accesses on the host.  Built and run by tests/test_sanitize.py (-m "not gpu") / `make sanitize`.
+ */
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ntt_oracle.h"
+
+extern "C" {
+int  emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root, int arith, int inverse, int generic,
+                   int wide, int ksh_force);
+void emu_set_lazy(int on);
+int  emu_pointwise(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t q, int arith);
+int  emu_pointwise_lazy(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t q, int arith);
+void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q);
+int  emu_plan_info(int logn, uint64_t *info);
+}
+
+static int g_fail = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if(!(cond)) {                                                          \
+      fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+      g_fail++;                                                            \
+    }                                                                      \
+  } while(0)
+
+struct Case {
+  int      m;
+  uint64_t q;
+};
+
+int main()
+{
+  /* (m, q): small and odd/even sizes of every kernel family, a 51-bit and a 59-bit modulus, one multi-pass size */
+  /* q = 0: the largest 59-bit prime for that size (exercises the carry of the 128-bit double product) */
+  const Case cases[] = {{4, 0x10001},         {6, 0x10001},         {7, 0x7ffe0001},        {8, 0x1ffc8001}, {9, 0x7fffffffe0001},
+                        {12, 0x80000001c0001}, {12, 0x7fffffffe0001}, {15, 0x7fffffffe0001}, {8, 0},          {12, 0}};
+  for(const Case &cs : cases) {
+    const uint64_t n = 1ull << cs.m, q = cs.q ? cs.q : orc_find_prime(59, n, 0);
+    if(!orc_is_prime(q) || (q - 1) % (2 * n)) {
+      fprintf(stderr, "skipping unusable case m=%d q=%llx\n", cs.m, (unsigned long long)q);
+      continue;
+    }
+    const uint64_t w = orc_min_root(q, n);
+    CHECK(w != 0);
+    orc_ctx *cx = orc_ctx_new(n, q, w);
+    CHECK(cx != nullptr);
+    const uint64_t        batch = 2;
+    std::vector<uint64_t> a(batch * n), ref(batch * n), got(batch * n), e(2 * n);
+    orc_fill_uniform(a.data(), batch * n, q, 0x5eed, cs.m);
+    ref = a;
+    orc_fwd_r2_batch(ref.data(), batch, cx);
+    emu_expand_radix4(e.data(), cx->w, n, q);
+    CHECK(memcmp(e.data(), cx->e, 2 * n * sizeof(uint64_t)) == 0);
+    for(int arith : {0, 1, 3}) {
+      if(arith == 1 && q > ((1ull << 51) + (1ull << 41))) continue;
+      if(arith == 3 && (cs.m < 6 || cs.m > 14)) continue;
+      for(int generic = 0; generic < 2; generic++) {
+        if(generic && (arith == 3 || cs.m > 12)) continue;
+        got = a;
+        CHECK(emu_transform(got.data(), batch, cs.m, q, w, arith, 0, generic, 0, -1) == 0);
+        CHECK(got == ref);
+        CHECK(emu_transform(got.data(), batch, cs.m, q, w, arith, 1, generic, 0, -1) == 0);
+        CHECK(got == a);
+      }
+      /* lazy outputs, fed back as wide inputs */
+      got = a;
+      emu_set_lazy(1);
+      CHECK(emu_transform(got.data(), batch, cs.m, q, w, arith, 0, 0, 0, -1) == 0);
+      emu_set_lazy(0);
+      for(uint64_t i = 0; i < batch * n; i++) CHECK(got[i] < 8 * q && got[i] % q == ref[i]);
+      CHECK(emu_transform(got.data(), batch, cs.m, q, w, arith, 1, 0, 1, -1) == 0);
+      CHECK(got == a);
+    }
+    /* pointwise products, strict and lazy operands */
+    std::vector<uint64_t> b(n), c(n), c2(n);
+    orc_fill_uniform(b.data(), n, q, 0xb, 0);
+    orc_pointwise(c.data(), a.data(), b.data(), n, q);
+    for(int arith : {0, 1}) {
+      if(arith == 1 && q > ((1ull << 51) + (1ull << 41))) continue;
+      CHECK(emu_pointwise(c2.data(), a.data(), b.data(), n, q, arith) == 0);
+      CHECK(c2 == c);
+      std::vector<uint64_t> al(a.begin(), a.begin() + n), bl(b);
+      for(uint64_t i = 0; i < n; i++) {
+        al[i] += (i % 4) * q;
+        bl[i] += ((i / 4) % 4) * q;
+      }
+      CHECK(emu_pointwise_lazy(c2.data(), al.data(), bl.data(), n, q, arith) == 0);
+      CHECK(c2 == c);
+    }
+    orc_ctx_free(cx);
+  }
+  uint64_t info[10];
+  for(int ln = 6; ln <= 14; ln++) {
+    CHECK(emu_plan_info(ln, info) == 0);
+    CHECK(info[9] == 1); /* every LDS exchange layout conflict-free */
+  }
+  if(g_fail) {
+    fprintf(stderr, "%d check(s) failed\n", g_fail);
+    return 1;
+  }
+  puts("sanitize: ok");
+  return 0;
+}
