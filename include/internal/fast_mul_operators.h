@@ -1,3 +1,7 @@
+// SPDX-License-Identifier: Apache-2.0
+// Interface-compatible with IBM/optimized-number-theoretic-transform-implementations (Copyright IBM Inc., Apache-2.0):
+// function names, signatures and arithmetic follow include/internal/fast_mul_operators.h of that repository so that its unchanged test and benchmark sources compile against
+// this directory.  Re-written for this library (bodies, ordering and comments are new); see NOTICE.
 /*
  * internal/fast_mul_operators.h -- host-side scalar primitives of the boundary.
  *

@@ -1,3 +1,7 @@
+// SPDX-License-Identifier: Apache-2.0
+// Interface-compatible with IBM/optimized-number-theoretic-transform-implementations (Copyright IBM Inc., Apache-2.0):
+// function names, signatures and table layouts follow include/internal/pre_compute.h of that repository so that its unchanged test and benchmark sources compile against
+// this directory.  Re-written for this library (bodies, ordering and comments are new); see NOTICE.
 /*
  * internal/pre_compute.h -- host-side table builders of the boundary.
  *

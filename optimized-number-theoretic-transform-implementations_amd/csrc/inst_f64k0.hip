@@ -3,6 +3,7 @@
 
 namespace ntt {
 NTT_DEFINE_LAUNCH_PASS(ArithF64, 0)
+NTT_DEFINE_LAUNCH_PRODUCT(ArithF64, 0)
 } /* namespace ntt */
 
 #ifdef NTT_STAMPS

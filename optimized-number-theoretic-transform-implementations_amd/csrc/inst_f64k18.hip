@@ -3,4 +3,5 @@
 
 namespace ntt {
 NTT_DEFINE_LAUNCH_PASS(ArithF64, 18)
+NTT_DEFINE_LAUNCH_PRODUCT(ArithF64, 18)
 } /* namespace ntt */

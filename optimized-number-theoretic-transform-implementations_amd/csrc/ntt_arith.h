@@ -352,6 +352,29 @@ struct ArithF64 {
     x              = mulmod(c.ninv, s, c);
     y              = mulmod(c.wninv, d, c);
   }
+  /* Gentleman-Sande butterfly with the twiddle given as -w^-1 (the forward table read in mirrored order,
+   * ntt_core.h load_stage_tw MIRROR): (x - y) * w^-1 = (y - x) * (-w^-1) */
+  template <bool RED> static NTT_HD void inv_bfly_mirror(val &x, val &y, ctw wneg, const consts &c)
+  {
+    const double s = x + y;
+    const double d = y - x;
+    x              = RED ? reduce(s, c) : s;
+    y              = mulmod_c(wneg, d, c);
+  }
+  /* Product in the NTT domain inside a kernel (fused product: forward transform of b -> times a^ -> inverse,
+   * without leaving the registers).  x: a forward output in balanced form, |x| <= B*q with B*q < 2^53;
+   * a: the other operand's transform as a stored word -- canonical [0,q) or, LAZY, a lazy output of this
+   * library ([0,4q), below 2^53).  Both factors are reduced to |.| <= q/2 first (3 instructions each, exact), so
+   * the product is at most q^2/4, the quotient estimate from the rounded product is within 0.2 of the truth,
+   * h - k*q is an integer below q and the result satisfies |r| <= 0.7 q: a valid input bound for the inverse
+   * transform's reduction plan (which assumes 1). */
+  template <bool LAZY> static NTT_HD val product_in_domain(val x, uint64_t a, const consts &c)
+  {
+    const double xr = reduce(x, c);
+    const double y0 = u64_to_f64_lt52(a);
+    const double y  = reduce(LAZY ? y0 - (c.q + c.q) : y0, c);
+    return mulmod_c(y, xr, c);
+  }
   /* balanced |v| < 2^53 -> canonical [0,q) as u64 */
   static NTT_HD uint64_t to_canonical(double v, const consts &c)
   {

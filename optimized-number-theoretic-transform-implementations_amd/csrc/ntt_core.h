@@ -329,10 +329,17 @@ template <class A> struct StageTw {
   typename A::ctw c[kE / 2];
 };
 
-template <class A, int LOGN, int G, int J, bool INV, bool LTW = false>
+/* MIRROR (with LTW, whole-polynomial blocks): an inverse stage served from the FORWARD table.  In the bit-reversed
+ * power layout w^-1 at slot 2^s + j equals -w at slot 2^(s+1) - 1 - j (root^N = -1, and complementing j
+ * complements its bit reversal), i.e. the inverse twiddles of a stage are the forward ones in reverse order and
+ * negated.  The sign is absorbed by the butterfly (A::inv_bfly_mirror multiplies y - x instead of x - y); the
+ * reversed slot is position C - pos of the transposed LDS table, C = 3 * (2^J - 1) * 2^S(G) + 2^S(G) - 1.  This
+ * lets the fused product kernel run its inverse half without a second 30 KB table in LDS. */
+template <class A, int LOGN, int G, int J, bool INV, bool LTW = false, bool MIRROR = false>
 NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params<A> &p,
                           lds_ctw_ptr<A> ltw = nullptr)
 {
+  static_assert(!MIRROR || LTW, "mirrored twiddles come from the LDS table");
   using P           = Plan<LOGN>;
   constexpr int SL  = P::S(G) + J;
   constexpr int SH  = LOGN - SL;
@@ -384,7 +391,12 @@ NTT_HD void load_stage_tw(StageTw<A> &w, uint32_t ib, uint32_t blk, const Params
          * (block prefix and leading stages removed), minus the group's first slot */
         if constexpr(LTW) {
           constexpr uint32_t OFFT = ((OFF & UMASK) << P::S(G)) + (OFF >> J);
-          w.c[B]                  = ltw[tl + OFFT];
+          if constexpr(MIRROR) {
+            constexpr uint32_t CJ = 3u * (UMASK << P::S(G)) + ((1u << P::S(G)) - 1u);
+            w.c[B]                = ltw[CJ - (tl + OFFT)];
+          } else {
+            w.c[B] = ltw[tl + OFFT];
+          }
         } else {
           w.c[B] = at32(p.tw8, tb + OFF);
         }
@@ -636,10 +648,11 @@ NTT_HD void run_group_r4(typename A::val (&x)[kE], uint32_t t, uint32_t blk, con
   }
 }
 
-template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false>
+template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false, bool MIRROR = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
 {
+  static_assert(!MIRROR || (INV && LTW), "MIRROR: an inverse group reading the forward LDS table");
   using P            = Plan<LOGN>;
   constexpr int R    = P::R(G);
   constexpr int SG   = P::S(G);
@@ -669,7 +682,7 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
     constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
     constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
-    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW>(wcur, ib, blk, p, ltw);
+    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW, MIRROR>(wcur, ib, blk, p, ltw);
     if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
     constexpr bool FOLDED = INV && SL == 0 && (MASK & kLastInvFlag) != 0;
     if constexpr(FOLDED) {
@@ -689,7 +702,9 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
       if constexpr(stage_is_compact<A, LOGN, INV>(G, J)) {
         /* compact twiddle used as is (policy overload taking A::ctw) */
         constexpr int F = P::BFLY_FIRST(G, J, B);
-        if constexpr(INV) {
+        if constexpr(MIRROR) {
+          A::template inv_bfly_mirror<RED>(x[E0], x[E1], wcur.c[F], p.c);
+        } else if constexpr(INV) {
           A::template inv_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);
         } else {
           A::template fwd_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);

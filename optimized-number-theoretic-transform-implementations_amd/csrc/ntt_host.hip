@@ -35,6 +35,9 @@ template <> hipError_t launch_pass<ArithU64R4, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 1>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 18>(const PassArgs &);
+template <> hipError_t launch_product<ArithF64, 0>(const ProdArgs &);
+template <> hipError_t launch_product<ArithF64, 1>(const ProdArgs &);
+template <> hipError_t launch_product<ArithF64, 18>(const ProdArgs &);
 } // namespace ntt
 
 /* ------------------------------------------------------------------ */
@@ -118,6 +121,7 @@ struct ntt_plan {
   int              max_grid   = 0;
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
+  bool             fused_product = true; /* N = 2^14, FP64: ntt_negacyclic_mul_batch as fwd(a) + fused_product_kernel */
   bool             two_phase  = false; /* 2^15..2^17: both passes of a polynomial inside one workgroup (twophase_kernel) */
 };
 
@@ -344,6 +348,9 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
     case NTT_OPT_TWO_PHASE:
       p->two_phase = value != 0;
       return NTT_OK;
+    case NTT_OPT_FUSED_PRODUCT:
+      p->fused_product = value != 0;
+      return NTT_OK;
     case NTT_OPT_F64_CLASS: {
       /* a coarser (smaller) headroom class than the modulus allows is always valid: it only reduces more often */
       if(p->arith != NTT_ARITH_F64) return fail(NTT_ERR_ARG, "not an FP64 plan");
@@ -569,6 +576,32 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
+  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m == kFusedMax && !p->generic && p->has_fwd && p->has_inv &&
+     d_a != d_b && d_a && d_b && d_c && batch) {
+    /* two launches, 40N bytes: a^ = fwd(a) (lazy words), then fused_product_kernel: b -> fwd -> * a^ -> inv -> c with b
+     * never leaving the CU in between (d_b itself is only read, unless d_c aliases it) */
+    int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
+    if(rc) return rc;
+    USE_DEVICE(p->device);
+    ProdArgs pa{};
+    pa.b        = d_b;
+    pa.ahat     = d_a;
+    pa.out      = d_c;
+    pa.tw_f     = p->d_fwd;
+    pa.tw8_f    = p->d_fwd8;
+    pa.tw_i     = p->d_inv;
+    pa.tw8_i    = p->d_inv8;
+    pa.consts   = &p->cf;
+    pa.batch    = batch;
+    pa.logn     = (uint32_t)p->m;
+    pa.a_lazy   = 1;
+    pa.max_grid = p->max_grid;
+    pa.num_cus  = p->num_cus;
+    pa.stream   = (hipStream_t)stream;
+    hipError_t e = p->kcls == 18 ? launch_product<ArithF64, 18>(pa) : (p->kcls == 1 ? launch_product<ArithF64, 1>(pa) : launch_product<ArithF64, 0>(pa));
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTT_OK;
+  }
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);
   if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);

@@ -794,6 +794,121 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* fused product: c = a * b in Z_q[X]/(X^N+1), b never leaves the CU     */
+/* ------------------------------------------------------------------ */
+/*
+ * The caller-side step either side of the path.  a^ = fwd(a) is in HBM (one ordinary forward
+ * launch).  This kernel then does, per polynomial and without touching HBM in between:
+ *     load b -> forward transform (14 stages) -> times a^ (read once, in the layout the last forward group
+ *     already has) -> inverse transform (14 stages, N^-1 folded) -> store c
+ * The forward transform ends and the inverse begins in the same thread <-> index layout (runs of four
+ * consecutive coefficients per lane), so the product needs no exchange.  HBM traffic of a product: 16N (fwd a)
+ * + 24N (this kernel) = 40N bytes instead of 72N for four launches (and 3 -> 2 launches); the kernel itself is
+ * bound by its 2 x 14 stages of butterflies, the 24N bytes hide behind them.
+ * Twiddles: forward half as fused_kernel (scalar cache / LDS table / registers); the inverse half reads its
+ * per-lane group from the SAME LDS table in mirrored order (load_stage_tw MIRROR: w^-1[2^s+j] = -w[2^(s+1)-1-j]),
+ * so no second table is needed in LDS; the first inverse group's 12 twiddles are requested while the forward
+ * half finishes and reuse the registers of the forward half's last group.
+ * Reference primitive this generalises: fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
+ */
+template <class A> struct ProdParams {
+  Params<A>              f;      /* forward tables; a = b's coefficients in, nblocks = polynomials */
+  const typename A::tw * tw_i;   /* inverse full records (+16 folded N^-1 records) */
+  const typename A::ctw *tw8_i;  /* inverse compact */
+  const uint64_t *       ahat;   /* fwd(a): canonical, or lazy [0,4q) when a_lazy */
+  uint64_t *             out;    /* c; may alias b or ahat */
+  uint32_t               a_lazy;
+};
+
+template <class A, int LOGN, int KSH, bool ALAZY>
+__global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS))
+  fused_product_kernel(const ProdParams<A> pp)
+{
+  using P = Plan<LOGN>;
+  using G = Geom<LOGN, false, flavor_of<A>()>;
+  static_assert(A::kCompact && G::BPW == 1 && LOGN == 14, "built for the FP64 policy on whole 2^14-point polynomials");
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | kLastInvFlag;
+  constexpr int      GL    = P::NG - 1;
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && P::R(GL) < 4, "twiddle placement this kernel assumes");
+  __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+  const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
+  const uint32_t         tid  = threadIdx.x;
+  /* whole polynomials of 2^LOGN points: the stage offset and size are compile-time constants here (as run-time
+   * kernel arguments they cost scalar registers the two halves do not have) */
+  Params<A> pf = pp.f;
+  pf.s0        = 0;
+  pf.logn      = LOGN;
+  pf.wide      = 0;
+  pf.lazy      = 0;
+  Params<A> pi = pf;
+  pi.tw                       = pp.tw_i;
+  pi.tw8                      = pp.tw8_i;
+  pi.lastinv                  = 1;
+  const uint64_t stride = gridDim.x;
+  uint64_t       b      = blockIdx.x;
+  if(b >= pf.nblocks) return;
+  fill_lds_tables<A, LOGN, false>(tabl, pf, 0u, tid);
+  __syncthreads();
+  uint64_t raw[kE];
+  prefetch_first<LOGN>(raw, tid, pf.a + (b << LOGN));
+  pin_raw(raw);
+  for(; b < pf.nblocks; b += stride) {
+    /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
+     * of registers and are therefore requested per polynomial.  They do not depend on the polynomial, so the
+     * compiler would hoist both sets (and their 24 lane offsets) out of the loop and spill; the opaque copy of
+     * the thread id ties them -- and every other lane-dependent address of the two halves (six exchanges, two
+     * prefetches, the stores): hoisted, those were spilled and reloaded from scratch behind the HBM prefetch --
+     * to the iteration. */
+    uint32_t tl = tid;
+    asm volatile("" : "+v"(tl));
+    typename A::ctw pre[4][kE / 2];
+    preload_group_tw<A, LOGN, GL>(pre, tl, 0u, pf);
+    typename A::val x[kE];
+    convert_inputs<A, false>(x, raw, false, pf.c);
+    /* a^ in the last group's layout: requested now, used after the 14 forward stages */
+    prefetch_last<LOGN>(raw, tl, pp.ahat + (b << LOGN));
+    run_group<A, LOGN, 0, false, MASKF>(x, tl, 0u, pf);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, tl, lds_all);
+      if constexpr(GI + 1 == GL) {
+        run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
+      } else if constexpr(G::TBL(GI + 1) > 0) {
+        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tl, 0u, pf, ltw + G::TBL_OFF(GI + 1));
+      } else {
+        run_group<A, LOGN, GI + 1, false, MASKF>(x, tl, 0u, pf);
+      }
+    });
+    /* the inverse's first group: its twiddles land while the product is computed */
+    asm volatile("" : "+v"(tl));
+    preload_group_tw<A, LOGN, GL>(pre, tl, 0u, pi);
+    static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<ALAZY>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    /* the next polynomial's loads reuse a^'s registers: not before the last product has read them (interleaved by
+     * the scheduler, the two lived side by side and spilled) */
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const uint64_t nb = b + stride < pf.nblocks ? b + stride : b;
+      prefetch_first<LOGN>(raw, tl, pf.a + (nb << LOGN));
+    }
+    run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = P::NG - 1 - decltype(gg)::value;
+      exchange<A, LOGN, GI, GI - 1>(x, tl, lds_all);
+      if constexpr(G::TBL(GI - 1) > 0) {
+        run_group<A, LOGN, GI - 1, true, MASKI, true, true>(x, tl, 0u, pi, ltw + G::TBL_OFF(GI - 1));
+      } else {
+        run_group<A, LOGN, GI - 1, true, MASKI>(x, tl, 0u, pi);
+      }
+    });
+    uint64_t out[kE];
+    static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
+    buffer_store_first_raw<LOGN>(out, tl, pp.out + (b << LOGN));
+  }
+}
+
 template <class A, int R, bool INV, int KSH>
 __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S,
                                                      uint32_t wide, uint32_t lastinv, uint32_t lazy,
@@ -834,6 +949,21 @@ struct PassArgs {
 };
 
 template <class A, int KSH> hipError_t launch_pass(const PassArgs &pa);
+
+/* fused product (fused_product_kernel): c = inv(fwd(b) * ahat), whole polynomials of 2^14 points */
+struct ProdArgs {
+  uint64_t *      b;
+  const uint64_t *ahat;
+  uint64_t *      out;
+  const void *    tw_f, *tw8_f, *tw_i, *tw8_i;
+  const void *    consts;
+  uint64_t        batch;
+  uint32_t        logn;
+  int             a_lazy;
+  int             max_grid, num_cus;
+  hipStream_t     stream;
+};
+template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
 
 /* What a pass stores: the last pass of a transform honours the caller's lazy flag; every earlier pass of an
  * integer policy keeps the reference's lazy ranges in HBM (no reduction between stages, as in
@@ -949,6 +1079,40 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
                      *static_cast<const typename A::consts *>(pa.consts));
   return hipGetLastError();
 }
+
+template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
+{
+  if constexpr(!A::kCompact) {
+    return hipErrorNotSupported;
+  } else {
+    if(pa.logn != 14) return hipErrorNotSupported;
+    ProdParams<A> pp{};
+    pp.f.a       = pa.b;
+    pp.f.tw      = static_cast<const typename A::tw *>(pa.tw_f);
+    pp.f.tw8     = static_cast<const typename A::ctw *>(pa.tw8_f);
+    pp.f.c       = *static_cast<const typename A::consts *>(pa.consts);
+    pp.f.logn    = pa.logn;
+    pp.f.s0      = 0;
+    pp.f.nblocks = pa.batch;
+    pp.tw_i      = static_cast<const typename A::tw *>(pa.tw_i);
+    pp.tw8_i     = static_cast<const typename A::ctw *>(pa.tw8_i);
+    pp.ahat      = pa.ahat;
+    pp.out       = pa.out;
+    pp.a_lazy    = (uint32_t)pa.a_lazy;
+    uint64_t wgs = pa.batch;
+    uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
+    if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+    if(wgs > cap) wgs = cap;
+    if(wgs == 0) return hipSuccess;
+    /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
+    if(!pa.a_lazy) return hipErrorNotSupported;
+    hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    return hipGetLastError();
+  }
+}
+
+#define NTT_DEFINE_LAUNCH_PRODUCT(A, KSH) \
+  template <> hipError_t launch_product<A, KSH>(const ProdArgs &pa) { return launch_product_impl<A, KSH>(pa); }
 
 /* body of launch_pass<A,KSH>; each instantiating .hip file expands this once */
 #define NTT_DEFINE_LAUNCH_PASS(A, KSH)                                                   \

@@ -120,6 +120,26 @@ struct ArithF64Chk : ArithF64 {
     x = mulmod(c.ninv, s, c);
     y = mulmod(c.wninv, d, c);
   }
+  template <bool RED> static void inv_bfly_mirror(val &x, val &y, ctw wneg, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double s = x + y;
+    const double d = y - x;
+    see(s, c);
+    see(d, c);
+    x = RED ? reduce(s, c) : s;
+    y = mulmod_c(wneg, d, c);
+  }
+  template <bool LAZY> static val product_in_domain(val x, uint64_t a, const consts &c)
+  {
+    see(x, c);
+    const double   r  = ArithF64::product_in_domain<LAZY>(x, a, c);
+    const __int128 ex = as_int(x) * (__int128)(a % c.qi);
+    if((ex - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;      /* r == x * a (mod q), exactly */
+    if(__builtin_fabs(r) > 0.75 * c.q) g_chk_fail++;              /* the bound the inverse plan relies on */
+    return r;
+  }
   static tw expand(ctw w, const consts &c)
   {
     const tw t = ArithF64::expand(w, c);
@@ -188,6 +208,79 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false>
       });
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, base, p.c, p.lazy != 0);
     }
+  }
+}
+
+/* the fused product kernel (csrc/ntt_kernels.h fused_product_kernel) step by step: forward transform of b, product
+ * with a^ in the last group's layout, inverse transform whose per-lane group reads the FORWARD twiddle table in the
+ * LDS layout, mirrored (load_stage_tw MIRROR) */
+template <class A, int LOGN, int KSH, bool ALAZY>
+static void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, const Params<A> &pf,
+                              const Params<A> &pi)
+{
+  using P                  = Plan<LOGN>;
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | kLastInvFlag;
+  constexpr int      GL    = P::NG - 1;
+  constexpr int      GT    = GL - 1; /* the group whose twiddles live in the LDS table */
+  /* the table as fill_lds_tables lays it out (stage J transposed) */
+  constexpr int SG = P::S(GT);
+  std::vector<typename A::ctw> table((size_t)(((1 << P::R(GT)) - 1) << SG));
+  for(int jj = 0; jj < P::R(GT); jj++) {
+    const int              slj = SG + jj;
+    const typename A::ctw *src = pf.tw8 + ((size_t)1 << slj);
+    for(uint32_t l = 0; l < (1u << slj); l++) {
+      const uint32_t u = l & ((1u << jj) - 1u), prefix = l >> jj;
+      table[(((1u << jj) - 1u) << SG) + (u << SG) + prefix] = src[l];
+    }
+  }
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         regs(P::T);
+  for(uint64_t pb = 0; pb < batch; pb++) {
+    const uint64_t *bb = b + (pb << LOGN);
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      global_load_first<A, LOGN, false>(regs[t].x, t, bb, false, pf.c);
+      run_group<A, LOGN, 0, false, MASKF>(regs[t].x, t, 0u, pf);
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+        if constexpr(G + 1 == GL) {
+          typename A::ctw pre[4][kE / 2];
+          preload_group_tw<A, LOGN, GL>(pre, t, 0u, pf);
+          run_group_preloaded<A, LOGN, GL, MASKF>(regs[t].x, pre, pf);
+        } else if constexpr(G + 1 == GT) {
+          run_group<A, LOGN, G + 1, false, MASKF, true>(regs[t].x, t, 0u, pf, table.data());
+        } else {
+          run_group<A, LOGN, G + 1, false, MASKF>(regs[t].x, t, 0u, pf);
+        }
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      const uint32_t ib = P::IBASE(GL, t);
+      for(int e = 0; e < kE; e++) {
+        const uint64_t aw = ahat[(pb << LOGN) + ib + P::IOFF(GL, e)];
+        regs[t].x[e]      = A::template product_in_domain<ALAZY>(regs[t].x[e], aw, pf.c);
+      }
+      typename A::ctw pre[4][kE / 2];
+      preload_group_tw<A, LOGN, GL>(pre, t, 0u, pi);
+      run_group_preloaded<A, LOGN, GL, MASKI, true>(regs[t].x, pre, pi);
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = P::NG - 1 - decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+        if constexpr(G - 1 == GT) {
+          run_group<A, LOGN, G - 1, true, MASKI, true, true>(regs[t].x, t, 0u, pi, table.data());
+        } else {
+          run_group<A, LOGN, G - 1, true, MASKI>(regs[t].x, t, 0u, pi);
+        }
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, out + (pb << LOGN), pf.c);
   }
 }
 
@@ -358,6 +451,51 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 }
 
 void emu_set_lazy(int on) { g_lazy = on != 0; }
+
+#ifndef EMU_SAN_BUILD
+/* out = inv(fwd(b) * ahat) for polynomials of 2^14 points, as the fused product kernel computes it.  ahat: fwd(a),
+ * canonical or (a_lazy) lazy in [0,4q).  chk != 0 runs the checked FP64 policy. */
+int emu_fused_product14(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, uint64_t q, uint64_t root,
+                        int a_lazy, int chk)
+{
+  constexpr int  m = 14;
+  const uint64_t N = 1ull << m;
+  if(!h_f64_eligible(q)) return -2;
+  const uint64_t rinv = h_powmod(root, q - 2, q);
+  const auto     w    = h_power_table(root, N, q);
+  const auto     wi   = h_power_table(rinv, N, q);
+  const auto     wix  = h_with_folded_ninv(wi, h_powmod(N % q, q - 2, q), q);
+  std::vector<TwF64>  tf(w.size()), ti(wix.size());
+  std::vector<double> tf8(w.size()), ti8(wi.size());
+  for(size_t i = 0; i < w.size(); i++) {
+    tf[i]  = h_tw_f64(w[i], q);
+    tf8[i] = tf[i].w;
+  }
+  for(size_t i = 0; i < wix.size(); i++) ti[i] = h_tw_f64(wix[i], q);
+  for(size_t i = 0; i < wi.size(); i++) ti8[i] = h_tw_f64(wi[i], q).w;
+  const auto c   = h_consts_f64(q, N, wi);
+  const int  ksh = h_f64_ksh(q);
+  const int  cls = ksh >= 18 ? 18 : (ksh >= 1 ? 1 : 0);
+#define RUNP(POL, K)                                                                                        \
+  {                                                                                                         \
+    Params<POL> pf{}, pi{};                                                                                 \
+    pf.tw = tf.data(); pf.tw8 = tf8.data(); pf.c = c; pf.logn = m;                                           \
+    pi = pf; pi.tw = ti.data(); pi.tw8 = ti8.data(); pi.lastinv = 1;                                         \
+    if(a_lazy) emu_fused_product<POL, m, K, true>(out, ahat, b, batch, pf, pi);                              \
+    else emu_fused_product<POL, m, K, false>(out, ahat, b, batch, pf, pi);                                   \
+    return 0;                                                                                               \
+  }
+  if(chk) {
+    if(cls == 18) RUNP(ArithF64Chk, 18)
+    if(cls == 1) RUNP(ArithF64Chk, 1)
+    RUNP(ArithF64Chk, 0)
+  }
+  if(cls == 18) RUNP(ArithF64, 18)
+  if(cls == 1) RUNP(ArithF64, 1)
+  RUNP(ArithF64, 0)
+#undef RUNP
+}
+#endif
 
 /* the product's host-side builder of the 2N-entry radix-4 table (ntt_tables.h), for the table tests */
 void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q)

@@ -23,6 +23,7 @@ class Emu:
         L.emu_chk_stats.argtypes = [U64P, C.c_int]
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
+        L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
@@ -33,6 +34,15 @@ class Emu:
                                     int(generic), int(wide), ksh)
         self.lib.emu_set_lazy(0)
         return rc, a
+
+    def fused_product14(self, ahat, b, q, root, a_lazy=False, chk=False):
+        """inv(fwd(b) * ahat) as the fused product kernel computes it (N = 2^14)"""
+        ahat = np.ascontiguousarray(ahat, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(b)
+        rc = self.lib.emu_fused_product14(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
+                                          b.size >> 14, q, root, int(a_lazy), int(chk))
+        return rc, out
 
     def expand_radix4(self, w, q):
         w = np.ascontiguousarray(w, dtype=np.uint64)

@@ -259,3 +259,27 @@ def test_pointwise_lazy_operands(oracle, emu, q):
             assert rc == -2
             continue
         assert rc == 0 and np.array_equal(c, expect), arith
+
+
+@pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001])
+def test_fused_product_kernel_logic(oracle, emu, q):
+    """fused_product_kernel step by step on the CPU: forward of b, product with a^ in registers, inverse whose
+    per-lane group reads the FORWARD table mirrored (w^-1[2^s+j] = -w[2^(s+1)-1-j]); checked policy: every value
+    an integer below 2^53, every product exact, |product| <= 0.75 q"""
+    n = 1 << 14
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    a = oracle.fill_uniform(2 * n, q, 31)
+    b = oracle.fill_uniform(2 * n, q, 32)
+    b[:8] = [0, 1, q - 1, q - 2, 2, 3, q // 2, q // 2 + 1]
+    expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
+    assert np.array_equal(expect[:n], oracle.schoolbook(a[:n].copy(), b[:n].copy(), n, q))
+    emu.chk_stats()
+    for lazy in (False, True):
+        rc, ahat = emu.transform(a, 14, q, w, 1, lazy=lazy)
+        assert rc == 0
+        for chk in (True, False):
+            rc, c = emu.fused_product14(ahat, b, q, w, a_lazy=lazy, chk=chk)
+            assert rc == 0 and np.array_equal(c, expect), (lazy, chk)
+    fails, maxb, maxr = emu.chk_stats()
+    assert fails == 0

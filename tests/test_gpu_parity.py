@@ -645,3 +645,76 @@ def test_two_phase_equals_per_pass_path(lib, oracle, kat, i, arith):
     a = oracle.fill_uniform(7 * n, q, 77)
     assert np.array_equal(plan.fwd_host(a), cx.fwd(a))
     plan.destroy()
+
+
+@pytest.mark.parametrize("m,bits,batch", [(12, 50, 65536), (14, 51, 131072), (16, 51, 8192)])
+def test_full_batch_forward_cross_check(lib, oracle, kat, m, bits, batch):
+    """every polynomial of the config-2/3/4 shares, not a sample: the fused kernels and the independent
+    column-pass path (ntt_plan_set_generic) must give the same per-polynomial checksums of the FORWARD
+    transform (closes the gap a cancelling fwd/inv defect could hide in)"""
+    n = 1 << m
+    if bits == 51:
+        c = kat["cases"][12 if m == 14 else 17]
+        q, w = c["q"], c["w"]
+    else:
+        q = lib.find_prime(bits, n)
+        w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w)
+    buf = lib.DeviceBuffer(batch * n)
+    cs = [lib.DeviceBuffer(batch) for _ in range(2)]
+    for k, generic in enumerate((0, 1)):
+        lib.fill_uniform(buf.ptr, batch * n, q, UNI_SEED, 0)
+        plan.set_generic(generic)
+        plan.fwd(buf.ptr, batch)
+        lib.poly_checksum(cs[k].ptr, buf.ptr, n, batch)
+    a, b = cs[0].download(), cs[1].download()
+    assert np.array_equal(a, b)
+    # and the checksum itself is the oracle's for one polynomial
+    p = batch // 3
+    assert oracle.checksum(oracle.ctx(n, q, w).fwd(oracle.fill_uniform(n, q, UNI_SEED, p * n))) == int(b[p])
+    for x in (buf, *cs):
+        x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001])
+def test_fused_product_kernel(lib, oracle, q):
+    """N = 2^14, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
+    equals the oracle's inv(fwd(a) . fwd(b)), the four-launch chain (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial,
+    the schoolbook product; all aliasing forms; batches around the persistent grid"""
+    n = 1 << 14
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    for batch in (1, 3, 300):
+        a = oracle.fill_uniform(batch * n, q, 61)
+        b = oracle.fill_uniform(batch * n, q, 62)
+        if batch == 3:
+            b[:8] = [0, 1, q - 1, q - 2, 2, 3, q // 2, q // 2 + 1]
+        expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q)) if batch < 300 else None
+        da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+        outs = []
+        for fused in (1, 0):
+            plan.set_option(lib.OPT_FUSED_PRODUCT, fused)
+            da.upload(a), db.upload(b)
+            plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
+            outs.append(dc.download())
+        assert np.array_equal(outs[0], outs[1]), batch
+        if expect is not None:
+            assert np.array_equal(outs[0], expect), batch
+        plan.set_option(lib.OPT_FUSED_PRODUCT, 1)
+        for alias in ("a", "b"):
+            da.upload(a), db.upload(b)
+            plan.negacyclic_mul((da if alias == "a" else db).ptr, da.ptr, db.ptr, batch)
+            assert np.array_equal((da if alias == "a" else db).download(), outs[0]), (batch, alias)
+        da.upload(a)
+        plan.negacyclic_mul(dc.ptr, da.ptr, da.ptr, batch)          # squaring takes the four-launch chain
+        if batch == 1:
+            assert np.array_equal(dc.download(), oracle.schoolbook(a.copy(), a.copy(), n, q))
+        for x in (da, db, dc):
+            x.free()
+    a1, b1 = oracle.fill_uniform(n, q, 71), oracle.fill_uniform(n, q, 72)
+    da, db = lib.DeviceBuffer(n).upload(a1), lib.DeviceBuffer(n).upload(b1)
+    plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, 1)
+    assert np.array_equal(da.download(), oracle.schoolbook(a1.copy(), b1.copy(), n, q))
+    plan.destroy()
