@@ -568,6 +568,83 @@ extern "C" int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, co
   return pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
 }
 
+/* one pass of a transform on nb polynomials starting at d (shared by run_transform's loop and the fused product) */
+static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint64_t nb, bool inverse, bool wide, bool lazy,
+                           bool ends, void *stream)
+{
+  PassArgs pa{};
+  pa.a        = d;
+  pa.tw       = inverse ? p->d_inv : p->d_fwd;
+  pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
+  pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+  pa.batch    = nb;
+  pa.logn     = (uint32_t)p->m;
+  pa.fused    = ps.fused;
+  pa.r        = ps.r;
+  pa.s        = ps.s;
+  pa.inverse  = inverse;
+  pa.wide     = wide;
+  pa.lastinv  = inverse && ps.s == 0;
+  pa.lazy     = lazy;
+  pa.ends     = ends;
+  pa.max_grid = p->max_grid;
+  pa.num_cus  = p->num_cus;
+  pa.stream   = (hipStream_t)stream;
+  hipError_t e = dispatch_pass(p, pa);
+  if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return NTT_OK;
+}
+
+/* c = a * b with the fused product kernel (FP64, N = 2^14 .. 2^17).
+ *   N = 2^14 : a^ = fwd(a) (lazy words); ONE launch: b -> fwd -> * a^ -> inv -> c.            40N bytes, 2 launches.
+ *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14-point blocks (fwd block * a^ block
+ *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
+ *              inverse on c.                                                                   88N bytes, 5 launches
+ *              (120N and 7 launches for fwd, fwd, pointwise, inv). */
+static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream)
+{
+  int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
+  if(rc) return rc;
+  USE_DEVICE(p->device);
+  const PassList L     = make_passes(p->m, false);
+  uint64_t       chunk = batch;
+  if(L.n > 1) {
+    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t));
+    if(chunk < 1) chunk = 1;
+    if(chunk > batch) chunk = batch;
+  }
+  for(uint64_t first = 0; first < batch; first += chunk) {
+    const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
+    const uint64_t off = first * p->N;
+    for(int k = 0; k + 1 < L.n; k++) { /* forward column passes of b (every pass but the last, which is the block pass) */
+      rc = launch_one_pass(p, L.p[k], d_b + off, nb, false, false, false, false, stream);
+      if(rc) return rc;
+    }
+    ProdArgs pa{};
+    pa.b        = d_b + off;
+    pa.ahat     = d_a + off;
+    pa.out      = d_c + off;
+    pa.tw_f     = p->d_fwd;
+    pa.tw8_f    = p->d_fwd8;
+    pa.tw_i     = p->d_inv;
+    pa.tw8_i    = p->d_inv8;
+    pa.consts   = &p->cf;
+    pa.batch    = nb;
+    pa.logn     = (uint32_t)p->m;
+    pa.a_lazy   = 1;
+    pa.max_grid = p->max_grid;
+    pa.num_cus  = p->num_cus;
+    pa.stream   = (hipStream_t)stream;
+    hipError_t e = p->kcls == 18 ? launch_product<ArithF64, 18>(pa) : (p->kcls == 1 ? launch_product<ArithF64, 1>(pa) : launch_product<ArithF64, 0>(pa));
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    for(int k = L.n - 2; k >= 0; k--) { /* inverse column passes of c, the last one ends the transform (N^-1) */
+      rc = launch_one_pass(p, L.p[k], d_c + off, nb, true, false, false, k == 0, stream);
+      if(rc) return rc;
+    }
+  }
+  return NTT_OK;
+}
+
 extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
                                         uint64_t batch, void *stream)
 {
@@ -576,31 +653,9 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
-  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m == kFusedMax && !p->generic && p->has_fwd && p->has_inv &&
-     d_a != d_b && d_a && d_b && d_c && batch) {
-    /* two launches, 40N bytes: a^ = fwd(a) (lazy words), then fused_product_kernel: b -> fwd -> * a^ -> inv -> c with b
-     * never leaving the CU in between (d_b itself is only read, unless d_c aliases it) */
-    int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
-    if(rc) return rc;
-    USE_DEVICE(p->device);
-    ProdArgs pa{};
-    pa.b        = d_b;
-    pa.ahat     = d_a;
-    pa.out      = d_c;
-    pa.tw_f     = p->d_fwd;
-    pa.tw8_f    = p->d_fwd8;
-    pa.tw_i     = p->d_inv;
-    pa.tw8_i    = p->d_inv8;
-    pa.consts   = &p->cf;
-    pa.batch    = batch;
-    pa.logn     = (uint32_t)p->m;
-    pa.a_lazy   = 1;
-    pa.max_grid = p->max_grid;
-    pa.num_cus  = p->num_cus;
-    pa.stream   = (hipStream_t)stream;
-    hipError_t e = p->kcls == 18 ? launch_product<ArithF64, 18>(pa) : (p->kcls == 1 ? launch_product<ArithF64, 1>(pa) : launch_product<ArithF64, 0>(pa));
-    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return NTT_OK;
+  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax && p->m <= kFusedMax + 3 && !p->generic &&
+     p->has_fwd && p->has_inv && d_a != d_b && d_a && d_b && d_c && batch) {
+    return fused_product(p, d_c, d_a, d_b, batch, stream);
   }
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);

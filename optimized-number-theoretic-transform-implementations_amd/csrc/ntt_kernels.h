@@ -821,43 +821,52 @@ template <class A> struct ProdParams {
   uint32_t               a_lazy;
 };
 
-template <class A, int LOGN, int KSH, bool ALAZY>
+/* WHOLE: the block is the whole polynomial (N = 2^14).  !WHOLE: the blocks of a larger transform (N = 2^15..2^17,
+ * pp.f.s0 = log2 N - 14 leading stages done by column passes before and after this launch): the product is
+ * element-wise, so it fuses block by block just the same -- per limb col(a), blocks(a), col(b), THIS, col^-1(c):
+ * 88N bytes instead of 120N.  A workgroup then always sees the same block position (its stride is a multiple of the
+ * blocks per polynomial), whose forward table slice it keeps in LDS; the mirrored read would need the slice of the
+ * complementary position, so the inverse half takes that one group's twiddles from global memory instead. */
+template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE>
 __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS))
   fused_product_kernel(const ProdParams<A> pp)
 {
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, flavor_of<A>()>;
-  static_assert(A::kCompact && G::BPW == 1 && LOGN == 14, "built for the FP64 policy on whole 2^14-point polynomials");
+  static_assert(A::kCompact && G::BPW == 1 && LOGN == 14, "built for the FP64 policy on 2^14-point blocks");
   constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
-  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | kLastInvFlag;
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | (WHOLE ? kLastInvFlag : 0u);
   constexpr int      GL    = P::NG - 1;
   static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && P::R(GL) < 4, "twiddle placement this kernel assumes");
   __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
   const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
   const uint32_t         tid  = threadIdx.x;
-  /* whole polynomials of 2^LOGN points: the stage offset and size are compile-time constants here (as run-time
-   * kernel arguments they cost scalar registers the two halves do not have) */
+  /* whole polynomials: the stage offset and size are compile-time constants (as run-time kernel arguments they
+   * cost scalar registers the two halves do not have) */
   Params<A> pf = pp.f;
-  pf.s0        = 0;
-  pf.logn      = LOGN;
+  if constexpr(WHOLE) {
+    pf.s0   = 0;
+    pf.logn = LOGN;
+  }
   pf.wide      = 0;
   pf.lazy      = 0;
   Params<A> pi = pf;
   pi.tw                       = pp.tw_i;
   pi.tw8                      = pp.tw8_i;
-  pi.lastinv                  = 1;
+  pi.lastinv                  = WHOLE ? 1 : 0;
   const uint64_t stride = gridDim.x;
   uint64_t       b      = blockIdx.x;
   if(b >= pf.nblocks) return;
-  fill_lds_tables<A, LOGN, false>(tabl, pf, 0u, tid);
+  const uint32_t blk = WHOLE ? 0u : ((uint32_t)b & ((1u << pf.s0) - 1u)); /* the same for every block of this workgroup */
+  fill_lds_tables<A, LOGN, false>(tabl, pf, blk, tid);
   __syncthreads();
   uint64_t raw[kE];
   prefetch_first<LOGN>(raw, tid, pf.a + (b << LOGN));
   pin_raw(raw);
   for(; b < pf.nblocks; b += stride) {
     /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
-     * of registers and are therefore requested per polynomial.  They do not depend on the polynomial, so the
+     * of registers and are therefore requested per block.  They do not depend on the block, so the
      * compiler would hoist both sets (and their 24 lane offsets) out of the loop and spill; the opaque copy of
      * the thread id ties them -- and every other lane-dependent address of the two halves (six exchanges, two
      * prefetches, the stores): hoisted, those were spilled and reloaded from scratch behind the HBM prefetch --
@@ -865,28 +874,28 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
     uint32_t tl = tid;
     asm volatile("" : "+v"(tl));
     typename A::ctw pre[4][kE / 2];
-    preload_group_tw<A, LOGN, GL>(pre, tl, 0u, pf);
+    preload_group_tw<A, LOGN, GL>(pre, tl, blk, pf);
     typename A::val x[kE];
     convert_inputs<A, false>(x, raw, false, pf.c);
     /* a^ in the last group's layout: requested now, used after the 14 forward stages */
     prefetch_last<LOGN>(raw, tl, pp.ahat + (b << LOGN));
-    run_group<A, LOGN, 0, false, MASKF>(x, tl, 0u, pf);
+    run_group<A, LOGN, 0, false, MASKF>(x, tl, blk, pf);
     static_for<0, P::NG - 1>([&](auto gg) {
       constexpr int GI = decltype(gg)::value;
       exchange<A, LOGN, GI, GI + 1>(x, tl, lds_all);
       if constexpr(GI + 1 == GL) {
         run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
       } else if constexpr(G::TBL(GI + 1) > 0) {
-        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tl, 0u, pf, ltw + G::TBL_OFF(GI + 1));
+        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tl, blk, pf, ltw + G::TBL_OFF(GI + 1));
       } else {
-        run_group<A, LOGN, GI + 1, false, MASKF>(x, tl, 0u, pf);
+        run_group<A, LOGN, GI + 1, false, MASKF>(x, tl, blk, pf);
       }
     });
     /* the inverse's first group: its twiddles land while the product is computed */
     asm volatile("" : "+v"(tl));
-    preload_group_tw<A, LOGN, GL>(pre, tl, 0u, pi);
+    preload_group_tw<A, LOGN, GL>(pre, tl, blk, pi);
     static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<ALAZY>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
-    /* the next polynomial's loads reuse a^'s registers: not before the last product has read them (interleaved by
+    /* the next block's loads reuse a^'s registers: not before the last product has read them (interleaved by
      * the scheduler, the two lived side by side and spilled) */
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -897,10 +906,13 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
     static_for<0, P::NG - 1>([&](auto gg) {
       constexpr int GI = P::NG - 1 - decltype(gg)::value;
       exchange<A, LOGN, GI, GI - 1>(x, tl, lds_all);
-      if constexpr(G::TBL(GI - 1) > 0) {
-        run_group<A, LOGN, GI - 1, true, MASKI, true, true>(x, tl, 0u, pi, ltw + G::TBL_OFF(GI - 1));
+      if constexpr(WHOLE && G::TBL(GI - 1) > 0) {
+        run_group<A, LOGN, GI - 1, true, MASKI, true, true>(x, tl, blk, pi, ltw + G::TBL_OFF(GI - 1));
       } else {
-        run_group<A, LOGN, GI - 1, true, MASKI>(x, tl, 0u, pi);
+        /* (per-lane twiddles from global memory in the !WHOLE form: keep their requests behind the exchange --
+         * hoisted above it by the scheduler they occupied 30 registers during the previous group and spilled) */
+        if constexpr(!WHOLE && G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0);
+        run_group<A, LOGN, GI - 1, true, MASKI>(x, tl, blk, pi);
       }
     });
     uint64_t out[kE];
@@ -1085,28 +1097,33 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.logn != 14) return hipErrorNotSupported;
-    ProdParams<A> pp{};
+    if(pa.logn < 14 || pa.logn > 17) return hipErrorNotSupported;
+    const uint32_t s0 = pa.logn - 14; /* leading stages done by column passes around this launch */
+    ProdParams<A>  pp{};
     pp.f.a       = pa.b;
     pp.f.tw      = static_cast<const typename A::tw *>(pa.tw_f);
     pp.f.tw8     = static_cast<const typename A::ctw *>(pa.tw8_f);
     pp.f.c       = *static_cast<const typename A::consts *>(pa.consts);
     pp.f.logn    = pa.logn;
-    pp.f.s0      = 0;
-    pp.f.nblocks = pa.batch;
+    pp.f.s0      = s0;
+    pp.f.nblocks = pa.batch << s0;
     pp.tw_i      = static_cast<const typename A::tw *>(pa.tw_i);
     pp.tw8_i     = static_cast<const typename A::ctw *>(pa.tw8_i);
     pp.ahat      = pa.ahat;
     pp.out       = pa.out;
     pp.a_lazy    = (uint32_t)pa.a_lazy;
-    uint64_t wgs = pa.batch;
+    uint64_t wgs = pp.f.nblocks;
     uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
     if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+    /* a workgroup keeps the tables of ONE block position: its stride is a multiple of the blocks per polynomial */
+    if(cap < (1ull << s0)) cap = 1ull << s0;
+    cap &= ~((1ull << s0) - 1);
     if(wgs > cap) wgs = cap;
     if(wgs == 0) return hipSuccess;
     /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
     if(!pa.a_lazy) return hipErrorNotSupported;
-    hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
     return hipGetLastError();
   }
 }

@@ -718,3 +718,30 @@ def test_fused_product_kernel(lib, oracle, q):
     plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, 1)
     assert np.array_equal(da.download(), oracle.schoolbook(a1.copy(), b1.copy(), n, q))
     plan.destroy()
+
+
+@pytest.mark.parametrize("m", [15, 16, 17])
+def test_fused_product_kernel_large(lib, oracle, m):
+    """N = 2^15..2^17: the product fuses block by block (column stages on b, ONE launch fwd block * a^ block -> inverse
+    block, inverse column stages): equals the oracle and the four-transform chain, also chunk by chunk"""
+    n = 1 << m
+    q = lib.find_prime(50, n, 1)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    batch = 5
+    a = oracle.fill_uniform(batch * n, q, 81)
+    b = oracle.fill_uniform(batch * n, q, 82)
+    expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
+    da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+    for fused, chunk in ((1, 256), (1, 1), (0, 256)):
+        plan.set_option(lib.OPT_FUSED_PRODUCT, fused)
+        plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+        da.upload(a), db.upload(b)
+        plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), expect), (fused, chunk)
+    plan.set_option(lib.OPT_FUSED_PRODUCT, 1)
+    da.upload(a), db.upload(b)
+    plan.negacyclic_mul(db.ptr, da.ptr, db.ptr, batch)           # c aliases b
+    assert np.array_equal(db.download(), expect)
+    plan.destroy()
