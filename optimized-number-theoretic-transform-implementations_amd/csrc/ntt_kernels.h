@@ -454,6 +454,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       typename A::val x[kE];
       convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
       {
+        /* (whole-line loads through the same lane swap as the forward stores: measured 17.74 vs 17.75 M, not kept) */
         const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
         prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN));
       }
