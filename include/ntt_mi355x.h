@@ -80,7 +80,8 @@ NTT_API const char *ntt_version(void);
 /* ---- plans ----
  * root must be a primitive 2N-th root of unity mod q (the `w` column of
  * reference tests/test_cases.h:145-208).  The plan derives every table itself
- * with the reference's layouts (include/internal/pre_compute.h:38-83). */
+ * with the reference's layouts (include/internal/pre_compute.h:38-105) -- ON THE DEVICE: the host squares the
+ * root log2 N times, one GPU thread produces each table entry. */
 NTT_API int  ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t q,
                              uint64_t root, int arith);
 /* build from caller tables in the reference's radix-2 layout: w_powers[k] =
@@ -92,6 +93,11 @@ NTT_API void ntt_plan_destroy(ntt_plan *p);
 /* info[0..7] = {N, q, log2N, arith actually used, FP64 headroom class,
  *               number of HBM passes, device, root (0 if built from tables)} */
 NTT_API int  ntt_plan_info(const ntt_plan *p, uint64_t info[8]);
+/* copy a device table back (tests / debugging): which = 0 forward records, 1 inverse records (+16 folded N^-1 records),
+ * 2 / 3 the FP64 policy's compact forward / inverse tables.  Records are 16 bytes: {w, floor(w 2^64/q)} as two
+ * uint64_t (integer policies; 2N records of the expanded table for NTT_ARITH_U64_R4) or {balanced w, w/q} as two
+ * doubles (FP64). */
+NTT_API int  ntt_plan_export_table(const ntt_plan *p, int which, void *h_dst, size_t bytes);
 /* force the strided multi-pass path (self-check of the fused kernels) */
 NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
 /* tuning / test knobs of one plan (ntt_option); nothing in the library reads environment variables for these */

@@ -44,7 +44,7 @@ OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT = 1
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
     "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
-    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option",
+    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option", "ntt_plan_export_table",
     "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
     "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
     "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
@@ -90,6 +90,7 @@ _sig("ntt_plan_destroy", None, VOIDP)
 _sig("ntt_plan_info", C.c_int, VOIDP, U64P)
 _sig("ntt_plan_set_generic", C.c_int, VOIDP, C.c_int)
 _sig("ntt_plan_set_option", C.c_int, VOIDP, C.c_int, C.c_int64)
+_sig("ntt_plan_export_table", C.c_int, VOIDP, C.c_int, VOIDP, C.c_size_t)
 for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide", "ntt_fwd_batch_lazy",
            "ntt_inv_batch_lazy"):
     _sig(_n, C.c_int, VOIDP, VOIDP, C.c_uint64, VOIDP)
@@ -251,6 +252,14 @@ class Plan:
 
     def set_generic(self, on):
         _check(_lib.ntt_plan_set_generic(self.h, int(on)))
+
+    def export_table(self, which, n_records, dtype=np.uint64):
+        """device table `which` (0 fwd, 1 inv, 2/3 compact fwd/inv) as an array of shape (n_records, 2) -- or
+        (n_records,) for the compact tables -- of `dtype` (uint64 for the integer policies, float64 for FP64)"""
+        width = 1 if which >= 2 else 2
+        out = np.zeros(n_records * width, dtype=dtype)
+        _check(_lib.ntt_plan_export_table(self.h, which, out.ctypes.data, out.nbytes))
+        return out.reshape(n_records, width) if width == 2 else out
 
     def set_option(self, option, value):
         _check(_lib.ntt_plan_set_option(self.h, option, value))

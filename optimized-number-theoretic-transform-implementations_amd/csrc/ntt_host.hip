@@ -101,6 +101,101 @@ static int check_device(int device)
 }
 
 /* ------------------------------------------------------------------ */
+/* on-device table construction                             */
+/* ------------------------------------------------------------------ */
+/*
+ * The reference builds its tables on the host with % and / on 128-bit integers (tests/test_cases.h:212-311,
+ * include/internal/pre_compute.h:38-105: "we don't care about the performance").  A plan for N = 2^17 needs
+ * 2 x 2^17 modular powers plus one 128-by-64-bit division (integer policies) or one FP64 division (FP64 policy)
+ * per entry -- milliseconds on one host core per plan, times primes, times GPUs.  Here the host only squares
+ * the root log2 N times; every table entry is produced by one GPU thread:
+ *   w[k] = root^bitrev(k) = product of root^(2^j) over the set bits j of bitrev(k)   (reference layout, :38-51)
+ *   con  = floor(w * 2^64 / q) by 64 steps of shift-and-subtract (exact)                 (:68-77)
+ *   FP64 : balanced w and its correctly rounded quotient by q (v_div: IEEE division)
+ *   radix-4 expanded table e[2k] = w[k], e[4k+1] = w[k] w[2k], e[4k+3] = q - w[k] w[2k+1]  (:85-105)
+ * Caller-supplied tables (ntt_plan_create_from_tables, the reference-signature entry points) still take the host
+ * route: their entries are data, not something to regenerate.
+ */
+struct PowBasis {
+  uint64_t p[32]; /* base^(2^j) mod q */
+};
+
+__device__ __forceinline__ uint64_t dev_precon64(uint64_t w, uint64_t q)
+{
+  uint64_t r = w, con = 0; /* w < q < 2^61: 2r never overflows */
+  for(int i = 0; i < 64; i++) {
+    r <<= 1;
+    const uint64_t ge = r >= q;
+    r -= ge ? q : 0;
+    con = (con << 1) | ge;
+  }
+  return con;
+}
+
+__device__ __forceinline__ uint64_t dev_brev(uint64_t v, unsigned bits) { return bits ? (__brevll(v) >> (64 - bits)) : 0; }
+
+__global__ void __launch_bounds__(256) power_table_kernel(uint64_t *w, uint64_t N, unsigned m, PowBasis basis, ArithU64::consts c)
+{
+  for(uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = dev_brev(k, m);
+    uint64_t       acc = 1 % c.q;
+    for(unsigned j = 0; j < m; j++) {
+      if((e >> j) & 1) acc = ArithU64::mulmod_full(acc, basis.p[j], c);
+    }
+    w[k] = acc;
+  }
+}
+
+/* records N .. N+15 behind an inverse table: N^-1 * winv[k] (run_group0_folded) */
+__device__ __forceinline__ uint64_t folded_word(const uint64_t *w, uint64_t N, uint64_t k, uint64_t ninv, const ArithU64::consts &c)
+{
+  if(k < N) return w[k];
+  const uint64_t j = k - N;
+  return j < N ? ArithU64::mulmod_full(ninv, w[j], c) : ninv;
+}
+
+__global__ void __launch_bounds__(256) records_u64_kernel(TwU64 *out, const uint64_t *w, uint64_t N, uint64_t total, uint64_t ninv,
+                                                          ArithU64::consts c)
+{
+  for(uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = folded_word(w, N, k, ninv, c);
+    out[k]           = TwU64{v, dev_precon64(v, c.q)};
+  }
+}
+
+__global__ void __launch_bounds__(256) records_f64_kernel(TwF64 *out, double *out8, const uint64_t *w, uint64_t N, uint64_t total,
+                                                          uint64_t ninv, ArithU64::consts c)
+{
+  const double qd = (double)c.q; /* q < 2^52: exact */
+  for(uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v  = folded_word(w, N, k, ninv, c);
+    const double   wb = v > c.q / 2 ? -(double)(c.q - v) : (double)v;
+    out[k]            = TwF64{wb, wb / qd};
+    if(k < N) out8[k] = wb;
+  }
+}
+
+__global__ void __launch_bounds__(256) records_r4_kernel(TwU64 *out, const uint64_t *w, uint64_t N, ArithU64::consts c)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * N; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v;
+    if((i & 1) == 0) {
+      v = w[i >> 1];
+    } else {
+      const uint64_t k = i >> 2;
+      if(k == 0) {
+        v = 0; /* slots 1 and 3 stay 0 as in the reference (pre_compute.h:90-93) */
+      } else if((i & 3) == 1) {
+        v = ArithU64::mulmod_full(w[k], w[2 * k], c);
+      } else {
+        v = c.q - ArithU64::mulmod_full(w[k], w[2 * k + 1], c);
+      }
+    }
+    out[i] = TwU64{v, dev_precon64(v, c.q)};
+  }
+}
+
+/* ------------------------------------------------------------------ */
 /* plan                                                                */
 /* ------------------------------------------------------------------ */
 struct ntt_plan {
@@ -172,7 +267,48 @@ static int upload_u64(void **d_out, const std::vector<uint64_t> &w, const std::v
 struct TableSet {
   std::vector<uint64_t> fwd, inv, fwd_con, inv_con;
   std::vector<uint64_t> efwd, einv, efwd_con, einv_con;
+  uint64_t gen_root = 0, gen_root_inv = 0; /* both non-zero: generate every table on the device from these roots */
 };
+
+/* one direction's tables of plan p from `base` (root or its inverse), on the device */
+static int device_build_direction(ntt_plan *p, uint64_t base, bool inverse, uint64_t ninv)
+{
+  const uint64_t N = p->N, q = p->q;
+  PowBasis       basis{};
+  uint64_t       sq = base % q;
+  for(int j = 0; j < p->m && j < 32; j++) {
+    basis.p[j] = sq;
+    sq         = h_mulmod(sq, sq, q);
+  }
+  uint64_t *d_w = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_w, N * sizeof(uint64_t)));
+  const unsigned g = (unsigned)((N + 255) / 256 > 4096 ? 4096 : (N + 255) / 256);
+  hipLaunchKernelGGL(power_table_kernel, dim3(g), dim3(256), 0, 0, d_w, N, (unsigned)p->m, basis, p->cu);
+  int         rc    = NTT_OK;
+  void **     d_rec = inverse ? &p->d_inv : &p->d_fwd;
+  void **     d_cmp = inverse ? &p->d_inv8 : &p->d_fwd8;
+  hipError_t  e     = hipSuccess;
+  if(p->arith == NTT_ARITH_U64_R4) {
+    e = hipMalloc(d_rec, 2 * N * sizeof(TwU64));
+    if(e == hipSuccess) hipLaunchKernelGGL(records_r4_kernel, dim3(g), dim3(256), 0, 0, (TwU64 *)*d_rec, d_w, N, p->cu);
+  } else {
+    const uint64_t total = inverse ? N + 16 : N;
+    if(p->arith == NTT_ARITH_F64) {
+      e = hipMalloc(d_rec, total * sizeof(TwF64));
+      if(e == hipSuccess) e = hipMalloc(d_cmp, N * sizeof(double));
+      if(e == hipSuccess)
+        hipLaunchKernelGGL(records_f64_kernel, dim3(g), dim3(256), 0, 0, (TwF64 *)*d_rec, (double *)*d_cmp, d_w, N, total, ninv, p->cu);
+    } else {
+      e = hipMalloc(d_rec, total * sizeof(TwU64));
+      if(e == hipSuccess) hipLaunchKernelGGL(records_u64_kernel, dim3(g), dim3(256), 0, 0, (TwU64 *)*d_rec, d_w, N, total, ninv, p->cu);
+    }
+  }
+  if(e == hipSuccess) e = hipGetLastError();
+  if(e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(d_w);
+  if(e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? NTT_ERR_NOMEM : NTT_ERR_HIP, std::string("device table build: ") + hipGetErrorString(e));
+  return rc;
+}
 
 /* ninv_override: 0 = derive N^-1 */
 static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root, const TableSet &ts, int arith,
@@ -202,12 +338,14 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
       p->num_cus = prop.multiProcessorCount;
     }
   }
-  const bool r4 = ar == NTT_ARITH_U64_R4;
-  p->has_fwd    = r4 ? !(ts.efwd.empty() && ts.fwd.empty()) : !ts.fwd.empty();
-  p->has_inv    = r4 ? !(ts.einv.empty() && ts.inv.empty()) : !ts.inv.empty();
+  const bool r4  = ar == NTT_ARITH_U64_R4;
+  const bool gen = ts.gen_root != 0 && ts.gen_root_inv != 0;
+  p->has_fwd     = gen || (r4 ? !(ts.efwd.empty() && ts.fwd.empty()) : !ts.fwd.empty());
+  p->has_inv     = gen || (r4 ? !(ts.einv.empty() && ts.inv.empty()) : !ts.inv.empty());
   /* inverse power table slot 1 (w^-N/2) is all the constants need */
   std::vector<uint64_t> inv_for_consts(2, 1);
-  if(!ts.inv.empty()) inv_for_consts.assign(ts.inv.begin(), ts.inv.begin() + 2);
+  if(gen) inv_for_consts[1] = h_powmod(ts.gen_root_inv, N / 2, q);
+  else if(!ts.inv.empty()) inv_for_consts.assign(ts.inv.begin(), ts.inv.begin() + 2);
   else if(ts.einv.size() >= 4) inv_for_consts[1] = ts.einv[2]; /* e[2k] = w[k] */
   p->cu = h_consts_u64(q, N, inv_for_consts);
   if(ninv_override) {
@@ -224,7 +362,11 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
     p->kcls     = k >= 18 ? 18 : (k >= 1 ? 1 : 0);
   }
   rc = NTT_OK;
-  if(r4) {
+  if(gen) {
+    const uint64_t ninv = ninv_override ? ninv_override % q : h_powmod(N % q, q - 2, q);
+    rc                  = device_build_direction(p, ts.gen_root, false, ninv);
+    if(!rc) rc = device_build_direction(p, ts.gen_root_inv, true, ninv);
+  } else if(r4) {
     /* expanded tables: the caller's, or derived from the power tables */
     if(p->has_fwd) {
       const std::vector<uint64_t> e = ts.efwd.empty() ? h_expand_radix4(ts.fwd, q) : ts.efwd;
@@ -268,8 +410,8 @@ extern "C" int ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t 
     return fail(NTT_ERR_ARG, "q is not prime (root^(q-2) is not the inverse of root)");
   }
   TableSet ts;
-  ts.fwd = h_power_table(root, N, q);
-  ts.inv = h_power_table(rinv, N, q);
+  ts.gen_root     = root;
+  ts.gen_root_inv = rinv;
   return plan_build(out, device, N, q, root, ts, arith, 0);
 }
 
@@ -322,6 +464,20 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[5] = (uint64_t)make_passes(p->m, p->generic).n; /* HBM passes per transform (two-phase launches keep the second one on chip where they can) */
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
+  return NTT_OK;
+}
+
+extern "C" int ntt_plan_export_table(const ntt_plan *p, int which, void *h_dst, size_t bytes)
+{
+  if(!p || !h_dst) return fail(NTT_ERR_ARG, "null argument");
+  const void *src = which == 0 ? p->d_fwd : which == 1 ? p->d_inv : which == 2 ? p->d_fwd8 : which == 3 ? p->d_inv8 : nullptr;
+  if(!src) return fail(NTT_ERR_ARG, "the plan has no such table");
+  const size_t rec  = p->arith == NTT_ARITH_F64 ? sizeof(TwF64) : sizeof(TwU64);
+  const size_t have = which >= 2 ? p->N * sizeof(double)
+                                 : (p->arith == NTT_ARITH_U64_R4 ? 2 * p->N : p->N + (which == 1 ? 16 : 0)) * rec;
+  if(bytes > have) return fail(NTT_ERR_ARG, "table is smaller than the request");
+  USE_DEVICE(p->device);
+  HIP_TRY(hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost));
   return NTT_OK;
 }
 

@@ -745,3 +745,50 @@ def test_fused_product_kernel_large(lib, oracle, m):
     plan.negacyclic_mul(db.ptr, da.ptr, db.ptr, batch)           # c aliases b
     assert np.array_equal(db.download(), expect)
     plan.destroy()
+
+
+@pytest.mark.parametrize("i", [0, 4, 9, 12, 13, 17, 18])
+def test_device_built_tables(lib, oracle, kat, i):
+    """ntt_plan_create builds every table ON THE DEVICE: powers, 128-by-64-bit Shoup quotients, the
+    expanded radix-4 table and the folded N^-1 records equal the oracle's (= the reference's pre_compute.h) tables
+    bit for bit; the FP64 tables hold the balanced residues exactly and their quotients to within one rounding"""
+    c = kat["cases"][i]
+    m, q, w = c["m"], c["q"], c["w"]
+    n = 1 << m
+    cx = oracle.ctx(n, q, w)
+    pu = lib.Plan(n, q, w, arith=lib.ARITH_U64)
+    for which, tab, con in ((0, "w", "wcon"), (1, "winv", "winv_con")):
+        t = pu.export_table(which, n)
+        assert np.array_equal(t[:, 0], cx.table(tab)) and np.array_equal(t[:, 1], cx.table(con)), which
+    ext = pu.export_table(1, n + 16)[n:]
+    winv = cx.table("winv")
+    for k in range(min(16, n)):
+        v = (int(cx.c.ninv) * int(winv[k])) % q
+        assert int(ext[k, 0]) == v and int(ext[k, 1]) == (v << 64) // q
+    pu.destroy()
+    if 6 <= m <= 14:
+        pr = lib.Plan(n, q, w, arith=lib.ARITH_U64_R4)
+        for which, tab, con in ((0, "e", "econ"), (1, "einv", "einv_con")):
+            t = pr.export_table(which, 2 * n)
+            assert np.array_equal(t[:, 0], cx.table(tab)) and np.array_equal(t[:, 1], cx.table(con)), which
+        pr.destroy()
+    if q <= (1 << 51) + (1 << 41):
+        pf = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+        for which, tab in ((0, "w"), (1, "winv")):
+            t = pf.export_table(which, n, dtype=np.float64)
+            wt = cx.table(tab).astype(np.int64)
+            bal = np.where(wt > q // 2, wt - q, wt).astype(np.float64)
+            assert np.array_equal(t[:, 0], bal), which
+            assert np.all(np.abs(t[:, 1] - bal / q) <= np.abs(bal / q) * 2.3e-16), which
+            assert np.array_equal(pf.export_table(which + 2, n, dtype=np.float64), bal), which
+        pf.destroy()
+    # a plan built from caller tables (host route) behaves identically
+    a = oracle.fill_uniform(2 * n, q, 4)
+    p2 = lib.Plan.__new__(lib.Plan)
+    import ctypes as C
+    h = C.c_void_p()
+    tw, twi = cx.table("w"), cx.table("winv")
+    lib._check(lib._lib.ntt_plan_create_from_tables(C.byref(h), 0, n, q, tw.ctypes.data_as(lib.U64P), twi.ctypes.data_as(lib.U64P), 0))
+    p2.h, p2.N, p2.q, p2.root, p2.device = h.value, n, q, 0, 0
+    assert np.array_equal(p2.fwd_host(a), cx.fwd(a)) and np.array_equal(p2.inv_host(cx.fwd(a)), a)
+    p2.destroy()
