@@ -1090,16 +1090,23 @@ constexpr size_t        kCompatPlansMax = 32; /* least-recently-used plan is des
  * correctness. */
 uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
 {
-  uint64_t h[4] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL, 0x94d049bb133111ebULL, 0xcbf29ce484222325ULL};
+  /* eight independent rotate-xor-add lanes (no multiplies in the loop: the host compiler vectorises it), folded with
+   * multiplicative mixing at the end; every entry and its position influence the result */
+  uint64_t h[8] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL, 0x94d049bb133111ebULL, 0xcbf29ce484222325ULL,
+                   0x2545f4914f6cdd1dULL, 0xd6e8feb86659fd93ULL, 0xa0761d6478bd642fULL, 0xe7037ed1a0b428dbULL};
   uint64_t i    = 0;
-  for(; i + 4 <= n; i += 4) {
-    for(int l = 0; l < 4; l++) h[l] = (h[l] ^ w[(i + l) * stride]) * 0x100000001b3ULL + (i + l);
+  if(stride == 1) {
+    for(; i + 8 <= n; i += 8) {
+      for(int l = 0; l < 8; l++) h[l] = (((h[l] << 7) | (h[l] >> 57)) ^ w[i + l]) + h[l];
+    }
   }
-  for(; i < n; i++) h[0] = (h[0] ^ w[i * stride]) * 0x100000001b3ULL + i;
+  for(; i < n; i++) {
+    uint64_t &x = h[i & 7];
+    x           = (((x << 7) | (x >> 57)) ^ w[i * stride]) + x;
+  }
   uint64_t r = n;
-  for(int l = 0; l < 4; l++) {
-    r ^= h[l];
-    r *= 0xff51afd7ed558ccdULL;
+  for(int l = 0; l < 8; l++) {
+    r = (r ^ h[l]) * 0xff51afd7ed558ccdULL;
     r ^= r >> 33;
   }
   return r;
@@ -1201,16 +1208,19 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     }
     g_stage_bytes = bytes;
   }
-  bool ok = hipMemcpy(g_stage, a1, N * 8, hipMemcpyHostToDevice) == hipSuccess;
-  if(ok && a2) ok = hipMemcpy(g_stage + N, a2, N * 8, hipMemcpyHostToDevice) == hipSuccess;
+  /* copies and kernels queue on the null stream; ONE synchronisation at the end (the _dbl form's second polynomial
+   * rides in the same queue) */
+  bool ok = hipMemcpyAsync(g_stage, a1, N * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess;
+  if(ok && a2) ok = hipMemcpyAsync(g_stage + N, a2, N * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess;
   if(!ok) {
     g_err = "hipMemcpy H2D";
     die(fn);
   }
   /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
   if(run_transform(plan, g_stage, batch, inverse, true, nullptr, !inverse)) die(fn);
-  ok = hipMemcpy(a1, g_stage, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
-  if(ok && a2) ok = hipMemcpy(a2, g_stage + N, N * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  ok = hipMemcpyAsync(a1, g_stage, N * 8, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
+  if(ok && a2) ok = hipMemcpyAsync(a2, g_stage + N, N * 8, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
+  if(ok) ok = hipStreamSynchronize(nullptr) == hipSuccess;
   if(!ok) {
     g_err = std::string("hipMemcpy D2H / kernel execution: ") + hipGetErrorString(hipGetLastError());
     die(fn);
