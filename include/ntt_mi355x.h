@@ -51,9 +51,10 @@ typedef enum ntt_status {
 } ntt_status;
 
 typedef enum ntt_arith {
-  NTT_ARITH_AUTO = 0, /* FP64 path when q allows it, else 64-bit integer Shoup      */
+  NTT_ARITH_AUTO = 0, /* FP64 path when q allows it (q < 2^52), else 64-bit integer Shoup */
   NTT_ARITH_U64  = 1, /* reference-identical Harvey/Shoup lazy arithmetic, any q<2^61 */
-  NTT_ARITH_F64  = 2, /* balanced FP64 arithmetic, q <= 2^51(1+2^-10)                 */
+  NTT_ARITH_F64  = 2, /* balanced FP64 arithmetic: q <= 2^51(1+2^-10) with a compile-time reduction schedule,
+                       * up to q < 2^52 with both operands of every butterfly reduced (info[4] == 52)  */
   NTT_ARITH_U64_R4 = 3 /* the reference's radix-4 butterflies with the shared-quotient double
                         * product (include/internal/fast_mul_operators.h:62-70,108-149) on the 2N-entry
                         * expanded table (src/ntt_radix4.c:7-114); single-pass sizes 2^6..2^14, q < 2^60.

@@ -1,0 +1,9 @@
+/* inst_f64w.hip -- instantiates the kernels for ArithF64W, the FP64 policy for moduli between 2^51(1+2^-10) and 2^52
+ * (every butterfly reduces both operands; the headroom-class parameter is unused: class 0). */
+#include "ntt_kernels.h"
+
+namespace ntt {
+NTT_DEFINE_LAUNCH_PASS(ArithF64W, 0)
+/* (no fused product kernel for this policy: with six more instructions per butterfly it does not fit the register
+ * budget without scratch; products take the fwd, fwd, pointwise, inv chain) */
+} /* namespace ntt */

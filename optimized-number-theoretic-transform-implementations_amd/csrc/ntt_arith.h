@@ -445,6 +445,76 @@ struct ArithF64 {
 };
 
 /* ------------------------------------------------------------------ */
+/* ArithF64W: FP64 arithmetic for moduli up to 2^52                      */
+/* ------------------------------------------------------------------ */
+/*
+ * Above 2^51(1+2^-10) the balanced-double policy has less than two bits of headroom below 2^53: no value may
+ * exceed 2q.  Instead of a reduction schedule this policy reduces BOTH operands of every butterfly to |.| <= q/2
+ * (three exact instructions each), which keeps every intermediate below 2q without any bookkeeping:
+ *   forward  x~ = red(x), y~ = red(y), m = y~ * w mod q with |m| <= (1/2 + 1.5 * 0.5 * theta2) q <= 0.88 q,
+ *            outputs |x~ +- m| <= 1.38 q;  h - k*q is an integer with |.| <= (0.88 + 0.13) q < 2q <= 2^53: exact
+ *   inverse  s = x + y, d = x - y of values bounded by 1.38 q each (canonical inputs: < 2q): exact below 2^53 because
+ *            the pairs a stage combines are either both reduced sums (<= q/2) or both products (<= 0.88 q) or both
+ *            canonical inputs; s~ = red(s), y' = red(d) * w mod q
+ * 14 instead of 8 instructions per butterfly -- measured against the integer policy it replaces for 52-bit moduli
+ * in profiles/r02/ablations.txt.  The MASK / reduction-plan machinery of the kernels is simply ignored (RED is
+ * not looked at); lazy outputs do not exist below 2^53 (4q > 2^53) and fall back to canonical ones.
+ * Written as a mixin so that the emulator's checked policy can be run through the very same butterflies.
+ */
+template <class Base> struct WideF64 : Base {
+  using val    = typename Base::val;
+  using tw     = typename Base::tw;
+  using ctw    = typename Base::ctw;
+  using consts = typename Base::consts;
+
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const double xr = Base::reduce(x, c);
+    const double m  = Base::mulmod(t, Base::reduce(y, c), c);
+    x               = xr + m;
+    y               = xr - m;
+  }
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    const double xr = Base::reduce(x, c);
+    const double m  = Base::mulmod_c(w, Base::reduce(y, c), c);
+    x               = xr + m;
+    y               = xr - m;
+  }
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = Base::reduce(s, c);
+    y              = Base::mulmod(t, Base::reduce(d, c), c);
+  }
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, ctw w, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = Base::reduce(s, c);
+    y              = Base::mulmod_c(w, Base::reduce(d, c), c);
+  }
+  template <bool RED> static NTT_HD void inv_bfly_mirror(val &x, val &y, ctw wneg, const consts &c)
+  {
+    const double s = x + y;
+    const double d = y - x;
+    x              = Base::reduce(s, c);
+    y              = Base::mulmod_c(wneg, Base::reduce(d, c), c);
+  }
+  static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const double s = Base::reduce(x + y, c);
+    const double d = Base::reduce(x - y, c);
+    x              = Base::mulmod(c.ninv, s, c);
+    y              = Base::mulmod(c.wninv, d, c);
+  }
+  /* 4q exceeds 2^53: no lazy form; reduced outputs satisfy the lazy contract */
+  static NTT_HD uint64_t store_fwd_lazy(val v, const consts &c) { return Base::store_fwd(v, c); }
+};
+using ArithF64W = WideF64<ArithF64>;
+
+/* ------------------------------------------------------------------ */
 /* compile-time reduction schedule for ArithF64                        */
 /* ------------------------------------------------------------------ */
 /*

@@ -35,6 +35,7 @@ template <> hipError_t launch_pass<ArithU64R4, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 1>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 18>(const PassArgs &);
+template <> hipError_t launch_pass<ArithF64W, 0>(const PassArgs &);
 template <> hipError_t launch_product<ArithF64, 0>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 1>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 18>(const ProdArgs &);
@@ -198,6 +199,8 @@ __global__ void __launch_bounds__(256) records_r4_kernel(TwU64 *out, const uint6
 /* ------------------------------------------------------------------ */
 /* plan                                                                */
 /* ------------------------------------------------------------------ */
+constexpr int kWideClass = -1; /* ntt_plan::kcls of the FP64 policy for 2^51(1+2^-10) < q < 2^52 (ArithF64W) */
+
 struct ntt_plan {
   int      device  = 0;
   uint64_t N       = 0, q = 0, root = 0;
@@ -224,9 +227,10 @@ static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 
 static int resolve_arith(int requested, uint64_t q, int m, int *out)
 {
-  if(requested == NTT_ARITH_AUTO) requested = h_f64_eligible(q) ? NTT_ARITH_F64 : NTT_ARITH_U64;
-  if(requested == NTT_ARITH_F64 && !h_f64_eligible(q)) {
-    return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q <= 2^51(1+2^-10)");
+  /* FP64: the scheduled policy up to 2^51(1+2^-10), the reduce-both-operands policy (ArithF64W) up to 2^52 */
+  if(requested == NTT_ARITH_AUTO) requested = (h_f64_eligible(q) || h_f64w_eligible(q)) ? NTT_ARITH_F64 : NTT_ARITH_U64;
+  if(requested == NTT_ARITH_F64 && !h_f64_eligible(q) && !h_f64w_eligible(q)) {
+    return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q < 2^52");
   }
   if(requested == NTT_ARITH_U64_R4 && (m < kFusedMin || m > kFusedMax)) {
     return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers single-pass sizes 2^6..2^14");
@@ -359,7 +363,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
       p->cf.wninv = h_tw_f64(h_mulmod(ninv_override % q, inv_for_consts[1], q), q);
     }
     const int k = h_f64_ksh(q);
-    p->kcls     = k >= 18 ? 18 : (k >= 1 ? 1 : 0);
+    p->kcls     = !h_f64_eligible(q) ? kWideClass : (k >= 18 ? 18 : (k >= 1 ? 1 : 0));
   }
   rc = NTT_OK;
   if(gen) {
@@ -460,7 +464,7 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[1] = p->q;
   info[2] = (uint64_t)p->m;
   info[3] = (uint64_t)p->arith;
-  info[4] = (uint64_t)p->kcls;
+  info[4] = p->kcls == kWideClass ? 52u : (uint64_t)p->kcls; /* 52: the reduce-both-operands policy for q up to 2^52 */
   info[5] = (uint64_t)make_passes(p->m, p->generic).n; /* HBM passes per transform (two-phase launches keep the second one on chip where they can) */
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
@@ -509,7 +513,7 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       return NTT_OK;
     case NTT_OPT_F64_CLASS: {
       /* a coarser (smaller) headroom class than the modulus allows is always valid: it only reduces more often */
-      if(p->arith != NTT_ARITH_F64) return fail(NTT_ERR_ARG, "not an FP64 plan");
+      if(p->arith != NTT_ARITH_F64 || p->kcls == kWideClass) return fail(NTT_ERR_ARG, "not a plan of the scheduled FP64 policy");
       const int k = h_f64_ksh(p->q);
       if(value == 0 || (value == 1 && k >= 1) || (value == 18 && k >= 18)) {
         p->kcls = (int)value;
@@ -529,6 +533,7 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   if(p->arith == NTT_ARITH_U64) return launch_pass<ArithU64, 0>(pa);
   if(p->arith == NTT_ARITH_U64_R4) return launch_pass<ArithU64R4, 0>(pa);
   switch(p->kcls) {
+    case kWideClass: return launch_pass<ArithF64W, 0>(pa);
     case 18: return launch_pass<ArithF64, 18>(pa);
     case 1: return launch_pass<ArithF64, 1>(pa);
     default: return launch_pass<ArithF64, 0>(pa);
@@ -809,7 +814,7 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
-  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax && p->m <= kFusedMax + 3 && !p->generic &&
+  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->kcls != kWideClass && p->m >= kFusedMax && p->m <= kFusedMax + 3 && !p->generic &&
      p->has_fwd && p->has_inv && d_a != d_b && d_a && d_b && d_c && batch) {
     return fused_product(p, d_c, d_a, d_b, batch, stream);
   }

@@ -98,6 +98,9 @@ inline TwF64 h_tw_f64(uint64_t w, uint64_t q)
 /* largest modulus the FP64 policy accepts, and its headroom class */
 inline bool h_f64_eligible(uint64_t q) { return q <= ((1ULL << 51) + (1ULL << 41)); }
 
+/* moduli the wide FP64 policy (ArithF64W) takes over from there: everything below 2^52 */
+inline bool h_f64w_eligible(uint64_t q) { return q < (1ULL << 52); }
+
 /* class ksh <=> q <= 2^(51-ksh) * (1 + 2^-10) */
 inline int h_f64_ksh(uint64_t q)
 {

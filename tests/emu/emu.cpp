@@ -405,6 +405,23 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
     return inverse ? emu_run<ArithU64R4, true, 0>(a, batch, m, tab.data(), c, false, wide)
                    : emu_run<ArithU64R4, false, 0>(a, batch, m, tab.data(), c, false, wide);
   }
+  if(arith == 4 || arith == 5) { /* the FP64 policy for moduli up to 2^52 (ArithF64W); 5: checked */
+    if(!h_f64w_eligible(q)) return -2;
+    std::vector<TwF64>  tabw(src.size());
+    std::vector<double> tabw8(src.size());
+    for(uint64_t i = 0; i < src.size(); i++) {
+      tabw[i]  = h_tw_f64(src[i], q);
+      tabw8[i] = tabw[i].w;
+    }
+    const auto cw = h_consts_f64(q, N, wi);
+#ifndef EMU_SAN_BUILD
+    if(arith == 5)
+      return inverse ? emu_run<WideF64<ArithF64Chk>, true, 0>(a, batch, m, tabw.data(), cw, generic, wide, tabw8.data())
+                     : emu_run<WideF64<ArithF64Chk>, false, 0>(a, batch, m, tabw.data(), cw, generic, wide, tabw8.data());
+#endif
+    return inverse ? emu_run<ArithF64W, true, 0>(a, batch, m, tabw.data(), cw, generic, wide, tabw8.data())
+                   : emu_run<ArithF64W, false, 0>(a, batch, m, tabw.data(), cw, generic, wide, tabw8.data());
+  }
   if(!h_f64_eligible(q)) return -2;
 #ifndef EMU_SAN_BUILD
   if(arith == 2) { /* checked FP64 policy */

@@ -283,3 +283,36 @@ def test_fused_product_kernel_logic(oracle, emu, q):
             assert rc == 0 and np.array_equal(c, expect), (lazy, chk)
     fails, maxb, maxr = emu.chk_stats()
     assert fails == 0
+
+
+@pytest.mark.parametrize("m", [6, 9, 12, 13, 14, 15])
+def test_wide_fp64_policy_52_bit_moduli(oracle, emu, m):
+    """ArithF64W: moduli between 2^51(1+2^-10) and 2^52 (less than one bit below 2^53/2): both operands of every
+    butterfly are reduced; bit-exact against the oracle, every value an integer below 2^53 and every product exact
+    (checked policy), for the largest 52-bit primes and for a 51-bit one"""
+    n = 1 << m
+    for q in (oracle.find_prime(52, n, 0), oracle.find_prime(52, n, 3), 0x7fffffffe0001):
+        if (q - 1) % (2 * n):
+            continue
+        assert q < (1 << 52)
+        w = oracle.min_root(q, n)
+        cx = oracle.ctx(n, q, w)
+        a = oracle.fill_uniform(2 * n, q, 52 + m)
+        a[:6] = [0, 1, q - 1, q - 2, q // 2, q // 2 + 1]
+        expect = cx.fwd(a)
+        emu.chk_stats()
+        for arith in (4, 5):
+            rc, got = emu.transform(a, m, q, w, arith)
+            assert rc == 0 and np.array_equal(got, expect), (hex(q), arith)
+            rc, back = emu.transform(got, m, q, w, arith, inverse=True)
+            assert rc == 0 and np.array_equal(back, a), (hex(q), arith)
+            rc, lz = emu.transform(a, m, q, w, arith, lazy=True)                 # no lazy form: reduced values
+            assert rc == 0 and np.array_equal(lz, expect)
+            rc, back = emu.transform(expect + np.uint64(3 * q), m, q, w, arith, inverse=True, wide=True)
+            assert rc == 0 and np.array_equal(back, a)
+        if m <= 12:
+            rc, got = emu.transform(a, m, q, w, 5, generic=True)
+            assert rc == 0 and np.array_equal(got, expect)
+        fails, maxb, maxr = emu.chk_stats()
+        assert fails == 0 and maxb < 2.0 and maxr < 0.9, (hex(q), fails, maxb, maxr)
+    assert emu.transform(a, m, (1 << 52) + 1, 3, 4)[0] == -2

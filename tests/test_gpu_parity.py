@@ -249,6 +249,14 @@ def test_full_size_config3_n65536(lib, oracle, kat):
     _full_size_roundtrip(lib, oracle, 16, c["q"], c["w"], 8192, [0, 1, 4097, 8191])
 
 
+def test_full_size_config3_n65536_true_52_bit_prime(lib, oracle):
+    """BASELINE config 3 to the letter: N=65536, a 52-bit q (the largest prime below 2^52 with 2N | q-1), batch=8192,
+    fwd+inv round trip -- served by the FP64 policy for moduli up to 2^52"""
+    q = lib.find_prime(52, 65536)
+    assert q >> 51 == 1
+    _full_size_roundtrip(lib, oracle, 16, q, lib.min_root(q, 65536), 8192, [0, 1, 4097, 8191])
+
+
 def test_full_size_config4_share_n16384(lib, oracle, kat):
     """BASELINE config 4, one GPU's share: N=16384, 51-bit q (reference case 12), batch=131072"""
     c = kat["cases"][12]
@@ -792,3 +800,40 @@ def test_device_built_tables(lib, oracle, kat, i):
     p2.h, p2.N, p2.q, p2.root, p2.device = h.value, n, q, 0, 0
     assert np.array_equal(p2.fwd_host(a), cx.fwd(a)) and np.array_equal(p2.inv_host(cx.fwd(a)), a)
     p2.destroy()
+
+
+@pytest.mark.parametrize("m", [8, 11, 12, 13, 14, 15, 16, 17])
+def test_wide_fp64_policy_52_bit_moduli(lib, oracle, m):
+    """moduli between 2^51(1+2^-10) and 2^52 now run in FP64 (ArithF64W: both operands of every butterfly reduced)
+    instead of the integer policy: AUTO picks it, results equal the oracle's and the integer policy's; config 3's
+    literal wording -- N = 65536 with a true 52-bit prime -- is the m = 16 case"""
+    n = 1 << m
+    q = oracle.find_prime(52, n, 1)
+    assert (1 << 51) + (1 << 41) < q < (1 << 52)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    info = plan.info()
+    assert info["arith"] == lib.ARITH_F64 and info["f64_class"] == 52
+    batch = 3
+    a = oracle.fill_uniform(batch * n, q, 5200 + m)
+    a[:6] = [0, 1, q - 1, q - 2, q // 2, q // 2 + 1]
+    expect = cx.fwd(a)
+    assert np.array_equal(plan.fwd_host(a), expect)
+    assert np.array_equal(plan.inv_host(expect), a)
+    assert np.array_equal(plan.fwd_host(a, lazy=True), expect)          # no lazy form below 2^53: reduced values
+    assert np.array_equal(plan.inv_host(expect + np.uint64(5 * q), wide=True), a)
+    pu = lib.Plan(n, q, w, arith=lib.ARITH_U64)
+    assert np.array_equal(pu.fwd_host(a), expect)
+    b = oracle.fill_uniform(batch * n, q, 5300 + m)
+    da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+    plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
+    assert np.array_equal(dc.download(), cx.inv(oracle.pointwise(expect, cx.fwd(b), q)))
+    if m in (12, 16):
+        plan.set_generic(1)
+        assert np.array_equal(plan.fwd_host(a), expect)
+    with pytest.raises(lib.NttError):
+        plan.set_option(lib.OPT_F64_CLASS, 0)
+    with pytest.raises(lib.NttError):
+        lib.Plan(n, oracle.find_prime(53, n), 3, arith=lib.ARITH_F64)
+    plan.destroy(), pu.destroy()
