@@ -9,6 +9,13 @@
  *                (SURVEY 8d).  No MFMA: 53/64-bit modular butterflies are
  *                element-wise VALU work.
  * column_kernel: strided passes for the leading stages of N > 2^14 and for tiny N.
+ * fused_product_kernel: c = a * b in Z_q[X]/(X^N+1) with b never leaving the CU: forward transform of b, product
+ *                with a^ in registers, inverse transform (N = 2^14 whole polynomials; block by block for
+ *                N = 2^15..2^17); the inverse half reads the forward LDS twiddle table in mirrored order.
+ * twophase_kernel: both passes of a 2^16 / 2^17 transform inside one workgroup (optional; fabric-bound, see
+ *                DESIGN.md section 3).
+ * The same kernels serve four arithmetic policies (ntt_arith.h): FP64 with a reduction schedule, FP64 for moduli up
+ * to 2^52, the reference's integer radix-2 arithmetic and its radix-4 formulation.
  *
  * Launch geometry (wave64, 256 CUs): LOGN=14 -> one persistent 1024-thread
  * workgroup per CU (16 waves, 4 per SIMD, <=128 VGPRs, no scratch) using 158 KiB
@@ -18,7 +25,7 @@
  * persistent loops below (register prefetch of the next block); smaller blocks
  * pack several per 256-thread workgroup, share LDS twiddle tables from 2^8 up and
  * rely on multiple resident workgroups instead of a prefetch.
- * Tuning history and rejected variants: profiles/r01/ablations.txt.
+ * Tuning history and rejected variants: profiles/r01/ablations.txt, profiles/r02/ablations.txt.
  */
 #pragma once
 #include <hip/hip_runtime.h>

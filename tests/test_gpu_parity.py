@@ -837,3 +837,18 @@ def test_wide_fp64_policy_52_bit_moduli(lib, oracle, m):
     with pytest.raises(lib.NttError):
         lib.Plan(n, oracle.find_prime(53, n), 3, arith=lib.ARITH_F64)
     plan.destroy(), pu.destroy()
+
+
+def test_compat_device_selection_env():
+    """NTT_DEVICE (with NTT_COMPAT_ARITH the only environment the library reads): the reference-signature entry points
+    run on that device, and a device that does not exist makes them fail loudly (stderr + abort), never silently"""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, ontt\nfrom oracle_binding import Oracle\n"
+            "lib = ontt.load(); o = Oracle(); n, q = 256, 0x1e01; w = o.min_root(q, n); cx = o.ctx(n, q, w)\n"
+            "a = o.fill_uniform(n, q, 1); x = a.copy(); lib.fwd_ntt_ref_harvey(x, n, q, cx.table('w'), cx.table('wcon'))\n"
+            "assert np.array_equal(x, cx.fwd(a)); print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, NTT_DEVICE="0"))
+    assert ok.returncode == 0 and "ok" in ok.stdout, ok.stderr[-2000:]
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, NTT_DEVICE="63"))
+    assert bad.returncode != 0 and "libntt_mi355x" in bad.stderr and "ok" not in bad.stdout
