@@ -387,8 +387,12 @@ struct ArithF64 {
     union {
       double   d;
       uint64_t u;
-    } k, x;
-    k.u = (r < 0.0) ? c.qi : 0ULL;
+    } k, x, s;
+    /* q where r is negative, 0 elsewhere, from the sign bit by integer operations (an arithmetic shift and two ANDs
+     * with the scalar q: full-rate instructions, where a compare and two selects cost an FP64-rate compare more).
+     * r is never -0.0: an fma whose exact result is zero returns +0 in round-to-nearest. */
+    s.d = r;
+    k.u = c.qi & (uint64_t)((int64_t)s.u >> 63);
     x.d = fma_(r, 0x1p-1074, k.d);
     return x.u;
   }
