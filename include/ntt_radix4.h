@@ -3,11 +3,13 @@
  *
  * Drop-in replacement for reference include/ntt_radix4.h:10-35 /
  * src/ntt_radix4.c:27-114.  The tables are the reference's 2N-entry EXPANDED
- * tables (include/internal/pre_compute.h:85-105): slot 2k holds the radix-2
- * twiddle w[k], which is what the GPU butterfly network consumes; the merged
- * odd slots are the CPU radix-4 butterfly's private shortcut and are not needed
- * on the device (any exact evaluation gives identical reduced output, SURVEY
- * A.6).  Output of the lazy forward is in [0,q), inside the documented [0,8q).
+ * tables (include/internal/pre_compute.h:85-105) and their precomputation.  For
+ * 2^6 <= N <= 2^14 the device runs the reference's radix-4 butterflies with the
+ * shared-quotient double product on exactly these tables (collect_roots'
+ * five-twiddle pack = records 2s and 4s..4s+3; csrc/ntt_arith.h ArithU64R4), so
+ * the lazy forward output in [0,8q) equals the reference's bit for bit.  Other
+ * sizes are served by the radix-2 engine on the even slots (slot 2k = w[k]):
+ * values in [0,4q), congruent to the reference's.
  */
 #ifndef NTT_MI355X_NTT_RADIX4_H
 #define NTT_MI355X_NTT_RADIX4_H

@@ -5,7 +5,9 @@
  * src/ntt_radix4x4.c:41-114 (same expanded tables as ntt_radix4.h).  On the GPU
  * the "two radix-4 levels per block" idea is the native shape of every kernel:
  * each thread keeps a 16-coefficient tile in registers for four stages
- * (csrc/ntt_core.h), so this symbol shares the radix-4 engine.
+ * (csrc/ntt_core.h), so this symbol shares the radix-4 engine of ntt_radix4.h:
+ * the reference's radix-4x4 code applies the same radix-4 butterflies in a
+ * cache-blocked order and produces the same lazy values.
  */
 #ifndef NTT_MI355X_NTT_RADIX4X4_H
 #define NTT_MI355X_NTT_RADIX4X4_H

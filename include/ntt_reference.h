@@ -9,12 +9,14 @@
  * gfx950 kernels and copies the result back (a correctness/compatibility path;
  * the throughput path is the batched API in ntt_mi355x.h).
  *
- * Differences a caller can observe: none in values after the final reduction.
- * The *_lazy functions return values already reduced to [0,q), which is inside
- * the documented lazy range [0,4q) ("Returning already-reduced
- * values is legal"), so the header-inline wrappers below are unchanged in
- * effect.  If no HIP device is usable the functions print the error to stderr
- * and abort(): the signatures return void and there is no CPU fallback.
+ * Differences a caller can observe: none.  By default the kernels run the
+ * reference's own Harvey butterflies on the caller's w AND w_con, so the
+ * *_lazy functions return the reference's lazy values in [0,4q) bit for bit and
+ * the header-inline wrappers below do what they do in the reference.  (With
+ * NTT_COMPAT_ARITH=f64 the FP64 kernels serve the call and the lazy functions
+ * return values already reduced to [0,q) -- inside the documented lazy range.)
+ * If no HIP device is usable the functions print the error to stderr and
+ * abort(): the signatures return void and there is no CPU fallback.
  */
 #ifndef NTT_MI355X_NTT_REFERENCE_H
 #define NTT_MI355X_NTT_REFERENCE_H

@@ -19,8 +19,9 @@ timeout 900 python3 bench.py --scaling strong --steps 5 --warmup 2 --no-cpu-base
 timeout 600 python3 tools/sweep.py --logn 8 9 10 11 12 13 14 15 16 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 > $out/sweep_sizes.txt 2>&1
 timeout 600 python3 tools/sweep.py --logn 17 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 | tail -2 >> $out/sweep_sizes.txt 2>&1
 timeout 600 python3 tools/sweep.py --logn 16 17 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 --two-phase 1 > $out/sweep_two_phase.txt 2>&1
-timeout 900 python3 tools/sweep.py --logn 14 --ops fwd inv fwdlazy mul --arith f64 u64 r4 --qs 0x7fffffffe0001 0x80000001c0001 0x3ffffffdf0001 0x7ffe0001 --bytes 4e9 > $out/sweep_arith_moduli.txt 2>&1
+timeout 900 python3 tools/sweep.py --logn 14 --ops fwd inv fwdlazy mul --arith f64 u64 r4 --qs 0x7fffffffe0001 0x80000001c0001 0x3ffffffdf0001 0x7ffe0001 0xffffffff00001 --bytes 4e9 > $out/sweep_arith_moduli.txt 2>&1
 (timeout 300 python3 tools/pipeline_bench.py; timeout 300 python3 tools/pipeline_bench.py --logn 16 --batch 1024; timeout 300 python3 tools/pipeline_bench.py --logn 14 --batch 4096) > $out/pipeline_rns.txt 2>&1
+timeout 600 python3 tools/sweep.py --logn 12 14 16 --ops fwd inv mul --arith auto u64 --qs 0xffffffff00001 --bytes 8e9 > $out/sweep_52bit_modulus.txt 2>&1
 timeout 600 build/skel 16 16 > $out/skeleton.txt 2>&1
 if [ -x oracle/_ref/ntt-variants-bench-dropin ]; then timeout 600 oracle/_ref/ntt-variants-bench-dropin > $out/reference_bench_driver_dropin.txt 2>&1; fi
 tail -1 $out/bench.json; cat $out/pmc_summary.txt $out/pmc_traffic_two_pass.txt
