@@ -6,8 +6,10 @@
  * the "two radix-4 levels per block" idea is the native shape of every kernel:
  * each thread keeps a 16-coefficient tile in registers for four stages
  * (csrc/ntt_core.h), so this symbol shares the radix-4 engine of ntt_radix4.h:
- * the reference's radix-4x4 code applies the same radix-4 butterflies in a
- * cache-blocked order and produces the same lazy values.
+ * its lazy output is the one of fwd_ntt_radix4_lazy -- in [0,8q) and congruent to
+ * the reference's radix-4x4 output (which pairs the stages differently when
+ * log2 N is not a multiple of 4, src/ntt_radix4x4.c:81-113, and may then return
+ * other representatives); identical after the header-inline reduction below.
  */
 #ifndef NTT_MI355X_NTT_RADIX4X4_H
 #define NTT_MI355X_NTT_RADIX4X4_H

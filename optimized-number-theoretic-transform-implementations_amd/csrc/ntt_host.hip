@@ -1286,9 +1286,10 @@ void inv_ntt_radix4(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, const 
   compat_run("inv_ntt_radix4", a, nullptr, N, q, w, w_con, kCompatR4, true, (uint64_t)n_inv.op);
 }
 
-/* the radix-16 blocking of the reference (src/ntt_radix4x4.c:41-114) applies the same radix-4 butterflies
- * in a cache-friendlier order: values and lazy ranges are those of fwd_ntt_radix4_lazy; on the device the
- * register-resident stage groups play that role */
+/* the radix-16 blocking of the reference (src/ntt_radix4x4.c:41-114) is a cache-friendlier order of radix-4
+ * butterflies (with its own remainder handling when log2 N is not a multiple of 4); on the device the
+ * register-resident stage groups play that role: this symbol returns fwd_ntt_radix4_lazy's values -- same range,
+ * same residues */
 void fwd_ntt_radix4x4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
   compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, w_con, kCompatR4, false, 0);
