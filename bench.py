@@ -296,7 +296,10 @@ def main():
     ndev_mod = int(os.environ.get("NTT_BENCH_DEVICE_MOD", "0"))   # test hook: fold shards onto fewer GPUs
 
     dist = None
-    if world > 1:
+    # (test hook NTT_BENCH_FORCE_DIST: a single rank still goes through RCCL init, barrier, MAX-reduction and gather)
+    if world > 1 or os.environ.get("NTT_BENCH_FORCE_DIST"):
+        # torch BEFORE the library: the torch wheel bundles its own HIP runtime under the same SONAME, the library
+        # then binds to the copy torch loaded (profiles/r02/torch_runtime_coexistence.txt)
         import torch
         import torch.distributed as dist
         backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")      # "gloo" only for the folded test hook

@@ -150,6 +150,17 @@ def test_reference_drivers_compile_unchanged_against_our_headers(lib):
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", exe))
 
 
+def test_c_example_builds_against_the_public_header(lib):
+    """examples/batched_product.c: a plain-C caller (gcc, no HIP headers) compiles and links against
+    include/ntt_mi355x.h + libntt_mi355x.so; the GPU suite runs it (test_c_example_runs)"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "batched_product.c"), "-L" + os.path.dirname(lib.LIB_PATH),
+                           "-lntt_mi355x", "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH),
+                           "-o", os.path.join(ROOT, "build", "batched_product")])
+    assert os.path.exists(os.path.join(ROOT, "build", "batched_product"))
+
+
 def test_headline_kernels_do_not_spill():
     """persistent kernels for blocks >= 2^12 must be scratch-free (a spill reload is a vmcnt(0) wait queued
     behind the HBM prefetch: measured -40 %); read from the built objects' metadata, no GPU needed"""

@@ -852,3 +852,68 @@ def test_compat_device_selection_env():
     assert ok.returncode == 0 and "ok" in ok.stdout, ok.stderr[-2000:]
     bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, NTT_DEVICE="63"))
     assert bad.returncode != 0 and "libntt_mi355x" in bad.stderr and "ok" not in bad.stdout
+
+
+def test_c_example_runs():
+    """the plain-C caller of the batched API (examples/batched_product.c): built here if it did not travel, run on the
+    GPU, exit code 0 = its product coefficient equals the schoolbook value"""
+    exe = os.path.join(ROOT, "build", "batched_product")
+    libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "batched_product.c"), "-L" + libdir, "-lntt_mi355x",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "schoolbook" in out.stdout
+
+
+def test_torch_tensors_and_streams_interoperate():
+    """PyTorch is plumbing here (device memory, streams): a CUDA int64 tensor's data_ptr and a torch stream go straight
+    into the C ABI; the library leaves torch's current device alone.  Run in a fresh process with torch imported FIRST:
+    the torch wheel bundles its own HIP runtime under the same SONAME, and the library must bind to the copy torch
+    loaded (loaded the other way round the process holds two runtimes and the second one finds no device --
+    profiles/r02/torch_runtime_coexistence.txt).  This is also the order of bench.py's torch.distributed path."""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+assert torch.cuda.is_available()
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, q, w, batch = 1 << 14, 0x7fffffffe0001, 83051296654, 16
+a = orc.fill_uniform(batch * n, q, 2024)
+t = torch.from_numpy(a.view(np.int64)).to("cuda:0")
+plan = lib.Plan(n, q, w, device=0)
+s = torch.cuda.Stream(device=0)
+with torch.cuda.stream(s):
+    plan.fwd(t.data_ptr(), batch, stream=s.cuda_stream)
+    y = t.clone()                      # torch work queued behind the transform on the same stream
+    plan.inv(t.data_ptr(), batch, stream=s.cuda_stream)
+s.synchronize()
+assert torch.cuda.current_device() == 0
+assert np.array_equal(y.cpu().numpy().view(np.uint64), orc.ctx(n, q, w).fwd(a))
+assert np.array_equal(t.cpu().numpy().view(np.uint64), a)
+print("interop ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "interop ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_bench_rccl_control_plane_single_rank():
+    """bench.py's torch.distributed path with the real backend (nccl = RCCL): torch first, then the library, process group
+    on the GPU, barrier, MAX-reduction of the elapsed time and all_gather of the kernel times on device tensors -- with
+    the one rank a 1-GPU box allows (the 2-rank form runs folded with gloo: RCCL refuses two ranks on one device)"""
+    import json
+    import sys
+    env = dict(os.environ, NTT_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "8192", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1e5 and len(d["roofline"]["kernel_ms_per_gpu"]) == 1
