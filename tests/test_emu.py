@@ -316,3 +316,46 @@ def test_wide_fp64_policy_52_bit_moduli(oracle, emu, m):
         fails, maxb, maxr = emu.chk_stats()
         assert fails == 0 and maxb < 2.0 and maxr < 0.9, (hex(q), fails, maxb, maxr)
     assert emu.transform(a, m, (1 << 52) + 1, 3, 4)[0] == -2
+
+
+def _prime_near(oracle, bound, n, below=True):
+    """an NTT-friendly prime (q = 1 mod 2n) closest to `bound` from below / above"""
+    step = 2 * n
+    q = (bound // step) * step + 1
+    if below and q > bound:
+        q -= step
+    if not below and q <= bound:
+        q += step
+    while not oracle.lib.orc_is_prime(q):
+        q += -step if below else step
+    return q
+
+
+@pytest.mark.parametrize("m", [12, 14])
+def test_fp64_class_boundary_moduli(oracle, emu, m):
+    """moduli sitting right at the edges of the FP64 headroom classes (where the compile-time bounds are tightest):
+    just below and above 2^51(1+2^-10) (scheduled policy <-> reduce-both policy), 2^50(1+2^-10) (class 0 <-> 1),
+    2^33(1+2^-10) (class 1 <-> 18), just below 2^52; adversarial inputs (all q-1, alternating 0 / q-1); checked
+    policy: no value ever leaves the exactly representable range"""
+    n = 1 << m
+    edges = [((1 << 51) + (1 << 41), True), ((1 << 51) + (1 << 41), False), ((1 << 50) + (1 << 40), True),
+             ((1 << 50) + (1 << 40), False), ((1 << 33) + (1 << 23), True), ((1 << 33) + (1 << 23), False), ((1 << 52) - 1, True)]
+    for bound, below in edges:
+        q = _prime_near(oracle, bound, n, below)
+        w = oracle.min_root(q, n)
+        cx = oracle.ctx(n, q, w)
+        wide = q > (1 << 51) + (1 << 41)
+        a = oracle.fill_uniform(3 * n, q, bound & 0xffff)
+        a[n:2 * n] = q - 1
+        a[2 * n:3 * n:2] = 0
+        a[2 * n + 1:3 * n:2] = q - 1
+        expect = cx.fwd(a)
+        emu.chk_stats()
+        for arith in ((4, 5) if wide else (1, 2)):
+            rc, got = emu.transform(a, m, q, w, arith)
+            assert rc == 0 and np.array_equal(got, expect), (hex(q), arith)
+            rc, back = emu.transform(got, m, q, w, arith, inverse=True)
+            assert rc == 0 and np.array_equal(back, a), (hex(q), arith)
+        assert emu.chk_stats()[0] == 0, hex(q)
+        if not wide:
+            assert emu.transform(a, m, q, w, 4)[0] == 0          # the wide policy is valid for every q < 2^52 as well

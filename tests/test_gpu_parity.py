@@ -917,3 +917,27 @@ def test_bench_rccl_control_plane_single_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e5 and len(d["roofline"]["kernel_ms_per_gpu"]) == 1
+
+
+def test_fp64_class_boundary_moduli_on_device(lib, oracle):
+    """moduli at the edges of the FP64 headroom classes, adversarial inputs, every kernel family (2^9, 2^12, 2^14, 2^16):
+    FP64 result == integer-policy result == oracle"""
+    from test_emu import _prime_near
+    for m in (9, 12, 14, 16):
+        n = 1 << m
+        for bound, below in (((1 << 51) + (1 << 41), True), ((1 << 51) + (1 << 41), False), ((1 << 50) + (1 << 40), True),
+                             ((1 << 50) + (1 << 40), False), ((1 << 33) + (1 << 23), True), ((1 << 33) + (1 << 23), False),
+                             ((1 << 52) - 1, True)):
+            q = _prime_near(oracle, bound, n, below)
+            w = oracle.min_root(q, n)
+            a = oracle.fill_uniform(3 * n, q, m)
+            a[n:2 * n] = q - 1
+            a[2 * n:3 * n:2] = 0
+            a[2 * n + 1:3 * n:2] = q - 1
+            pf, pu = lib.Plan(n, q, w, arith=lib.ARITH_F64), lib.Plan(n, q, w, arith=lib.ARITH_U64)
+            f = pf.fwd_host(a)
+            assert np.array_equal(f, pu.fwd_host(a)), (m, hex(q))
+            if m <= 14:
+                assert np.array_equal(f, oracle.ctx(n, q, w).fwd(a)), (m, hex(q))
+            assert np.array_equal(pf.inv_host(f), a), (m, hex(q))
+            pf.destroy(), pu.destroy()
