@@ -205,6 +205,20 @@ class GpuShard:
     def kernel_ms(self, steps):
         return self.ev1.elapsed_ms_since(self.ev0) / max(steps, 1)
 
+    def copy_ceiling_gbs(self, reps=6):
+        """GB/s of a plain in-place read-modify-write (16 B per lane, no arithmetic) over this shard's buffer,
+        HIP events on the shard's stream, best of `reps` after one warm-up: the measured ceiling SURVEY 8d asks
+        for next to the 8 TB/s specification figure.  Runs after the timed region; mask 0 leaves the data alone."""
+        words, best = self.batch * self.n, None
+        for r in range(reps + 1):
+            self.ev0.record(self.stream)
+            self.lib.rmw_probe(self.buf.ptr, words, 0, device=self.device, stream=self.stream)
+            self.ev1.record(self.stream)
+            ms = self.ev1.elapsed_ms_since(self.ev0)
+            if r and (best is None or ms < best):
+                best = ms
+        return words * 16 / (best * 1e-3) / 1e9
+
     def polys(self, which):
         import numpy as np
         return np.concatenate([self.buf.download(self.n, p * self.n) for p in which])
@@ -245,7 +259,7 @@ def run_steps(shards, steps, warmup, barrier, after_first_warmup=None):
     return elapsed, [s.kernel_ms(steps) for s in shards]
 
 
-def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None):
+def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None):
     n = n or N
     bytes_per_ntt = 16 * n
     ms_per_step = elapsed * 1e3 / args.steps
@@ -271,7 +285,9 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(batch, kname) if n == N else None,
                      "kernel": kname, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
-                     "algorithmic_bytes_per_launch": batch * bytes_per_ntt},
+                     "algorithmic_bytes_per_launch": batch * bytes_per_ntt,
+                     # measured in this run: in-place read-modify-write of the same buffer without arithmetic
+                     "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None},
     }
 
 
@@ -367,7 +383,9 @@ def main():
         kernel_ms = [float(x.item()) for x in allk]
 
     if rank == 0:
-        out = make_report(args, n_gpus, batch, elapsed, kernel_ms, shards[0].arith(), shards[0].hbm_passes(), n=n)
+        copy_gbs = shards[0].copy_ceiling_gbs()     # after the timed region, on shard 0's resident buffer
+        out = make_report(args, n_gpus, batch, elapsed, kernel_ms, shards[0].arith(), shards[0].hbm_passes(), n=n,
+                          copy_gbs=copy_gbs)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

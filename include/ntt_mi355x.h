@@ -170,6 +170,11 @@ NTT_API int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, 
  * per-polynomial checksum for full-size parity checks */
 NTT_API int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, uint64_t N,
                               uint64_t batch, void *stream);
+/* measured ceiling of the transform's memory shape (SURVEY 8d "fraction of a measured copy-kernel ceiling"):
+ * every 16 bytes of d_a[0..n) are read, XORed with mask and written back in place by a plain grid-stride kernel
+ * -- no arithmetic, no LDS, the same 8 B in + 8 B out per coefficient as an in-place NTT.  mask = 0 leaves the
+ * data unchanged.  n must be even. */
+NTT_API int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream);
 
 /* ---- multi-GPU: one call drives every listed device (per-device streams, no
  * collective -- polynomials are independent).  plans[g], d_a[g] and

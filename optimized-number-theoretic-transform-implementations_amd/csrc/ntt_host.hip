@@ -888,6 +888,32 @@ extern "C" int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_
   return NTT_OK;
 }
 
+struct alignas(16) U64x2 {
+  uint64_t a, b;
+};
+__global__ void __launch_bounds__(256) rmw_probe_kernel(U64x2 *a, uint64_t n2, uint64_t mask)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) {
+    U64x2 v = a[i];
+    v.a ^= mask;
+    v.b ^= mask;
+    a[i] = v;
+  }
+}
+
+extern "C" int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream)
+{
+  int rc = check_device(device);
+  if(rc) return rc;
+  if(!d_a || (n & 1) || ((uintptr_t)d_a & 15)) return fail(NTT_ERR_ARG, "rmw probe: null, odd length or unaligned buffer");
+  if(n == 0) return NTT_OK;
+  USE_DEVICE(device);
+  /* one workgroup per 4 KiB up to 65536 workgroups: the fastest of the grids tried (profiles/r02/skeleton.txt) */
+  hipLaunchKernelGGL(rmw_probe_kernel, dim3(grid_for(n / 2, 65536)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_a, n / 2, mask);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* thin HIP wrappers                                                   */
 /* ------------------------------------------------------------------ */

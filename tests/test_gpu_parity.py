@@ -941,3 +941,25 @@ def test_fp64_class_boundary_moduli_on_device(lib, oracle):
                 assert np.array_equal(f, oracle.ctx(n, q, w).fwd(a)), (m, hex(q))
             assert np.array_equal(pf.inv_host(f), a), (m, hex(q))
             pf.destroy(), pu.destroy()
+
+
+def test_rmw_probe_touches_every_word_and_nothing_else(lib, oracle):
+    """bench.py's measured memory ceiling: read, XOR, write back in place -- mask 0 leaves the data alone, a mask
+    applied twice restores it, the words behind the range are not touched, bad arguments are refused"""
+    n, mask = (1 << 16) + 2, 0x0123456789abcdef
+    a = oracle.fill_uniform(n + 2, (1 << 61) - 1, 99)
+    d = lib.DeviceBuffer(a.size).upload(a)
+    lib.rmw_probe(d.ptr, n, 0)
+    assert np.array_equal(d.download(), a)
+    lib.rmw_probe(d.ptr, n, mask)
+    want = a.copy()
+    want[:n] ^= np.uint64(mask)
+    assert np.array_equal(d.download(), want)
+    lib.rmw_probe(d.ptr, n, mask)
+    assert np.array_equal(d.download(), a)
+    with pytest.raises(lib.NttError):
+        lib.rmw_probe(d.ptr, n + 1, 0)          # odd length
+    with pytest.raises(lib.NttError):
+        lib.rmw_probe(d.ptr + 8, n, 0)          # not 16-byte aligned
+    lib.rmw_probe(d.ptr, 0, 0)
+    d.free()
