@@ -164,9 +164,13 @@ constexpr int kLoadAux = 2; /* cache-policy bits of the coefficient loads: nt (m
  * 32-bit lane offset (t*8) and take the row offset as a scalar operand, instead of a
  * 64-bit per-lane address each (two carry-chained VALU adds per row in the hot loop).
  * blk is wave-uniform (derived from blockIdx and the loop counter only). */
-template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc(const uint64_t *blk)
+template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc(const uint64_t *blk, bool live = true)
 {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(blk), /*stride*/ 0, (int)(8u << LOGN), 0x00020000);
+  /* live = false: a descriptor of zero records -- every load through it is out of range, returns 0 and moves no
+   * data.  The persistent loops prefetch unconditionally (a branch around the prefetch costs registers); in a
+   * workgroup's last iteration the descriptor is dead instead of re-reading a block (1/8 of the reads of a
+   * 256 MiB chunk of a multi-pass transform, where a workgroup only sees 8 blocks per launch). */
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(blk), /*stride*/ 0, live ? (int)(8u << LOGN) : 0, 0x00020000);
 }
 __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
@@ -199,10 +203,10 @@ __device__ __forceinline__ void buffer_store_first_raw(const uint64_t (&u)[kE], 
 }
 
 /* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
-template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
 {
   using P = Plan<LOGN>;
-  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk, live);
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
     raw[E]          = buffer_load_u64(r, t * 8u, ((uint32_t)E << P::LT) * 8u);
@@ -211,12 +215,12 @@ template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&ra
 
 /* raw coefficients in the last-kind layout (runs of 2^RL consecutive indices, 16-byte loads):
  * what the inverse transform's first group consumes */
-template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
 {
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
   const uint32_t ib = P::IBASE(G, t);
-  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk, live);
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
     const u64x2   v = buffer_load_u64x2(r, ib * 8u, P::IOFF(G, E) * 8u);
@@ -393,8 +397,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
          * its HBM loads are then in flight for the whole iteration (measured best of
          * four placements: after the first exchange -4 %, inside the last group -3 %,
          * a quarter after every exchange -7 %; profiles/r01/ablations.txt) */
-        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-        prefetch_first<LOGN>(raw, tid, p.a + (nb << LOGN));
+        const bool     more = b + stride < p.nblocks;
+        const uint64_t nb   = more ? b + stride : b;
+        prefetch_first<LOGN>(raw, tid, p.a + (nb << LOGN), more);
       }
       STAMP(0); /* wait for prefetched coefficients + convert */
       run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
@@ -462,8 +467,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
       {
         /* (whole-line loads through the same lane swap as the forward stores: measured 17.74 vs 17.75 M, not kept) */
-        const uint64_t nb = b + stride < p.nblocks ? b + stride : b;
-        prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN));
+        const bool     more = b + stride < p.nblocks;
+        const uint64_t nb   = more ? b + stride : b;
+        prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN), more);
       }
       if constexpr(IPRE) {
         run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
@@ -907,8 +913,9 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
      * the scheduler, the two lived side by side and spilled) */
     __builtin_amdgcn_sched_barrier(0);
     {
-      const uint64_t nb = b + stride < pf.nblocks ? b + stride : b;
-      prefetch_first<LOGN>(raw, tl, pf.a + (nb << LOGN));
+      const bool     more = b + stride < pf.nblocks;
+      const uint64_t nb   = more ? b + stride : b;
+      prefetch_first<LOGN>(raw, tl, pf.a + (nb << LOGN), more);
     }
     run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
     static_for<0, P::NG - 1>([&](auto gg) {
