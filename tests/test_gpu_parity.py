@@ -963,3 +963,47 @@ def test_rmw_probe_touches_every_word_and_nothing_else(lib, oracle):
         lib.rmw_probe(d.ptr + 8, n, 0)          # not 16-byte aligned
     lib.rmw_probe(d.ptr, 0, 0)
     d.free()
+
+
+def test_product_pipeline_captured_in_a_hip_graph():
+    """Launch-bound use (small batches, serving): the whole fwd -> fused multiply+inverse chain of a 2-limb RNS product
+    is captured ONCE into a HIP graph (torch.cuda.graph on a side stream; the library only enqueues kernels on the
+    stream it is given -- no allocation, synchronisation or device query inside the batched entry points) and replayed
+    on new inputs; every replay equals the oracle's schoolbook-free product (fwd, pointwise, inv)."""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, batch = 1 << 14, 4
+qs = [0x7fffffffe0001, 0x3ffffffdf0001]
+ws = [lib.min_root(q, n) for q in qs]
+plans = [lib.Plan(n, q, w, device=0) for q, w in zip(qs, ws)]
+ta = torch.zeros(len(qs) * batch * n, dtype=torch.int64, device="cuda:0")
+tb, tc = torch.zeros_like(ta), torch.zeros_like(ta)
+sa, sb = ta.clone(), tb.clone()                      # static inputs the graph reads from (the chain works in place)
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.graph(g, stream=s):
+    ta.copy_(sa); tb.copy_(sb)
+    lib.rns_negacyclic_mul(plans, tc.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=torch.cuda.current_stream().cuda_stream)
+for seed in (1, 2, 3):
+    a = np.concatenate([orc.fill_uniform(batch * n, q, 100 * seed + i) for i, q in enumerate(qs)])
+    b = np.concatenate([orc.fill_uniform(batch * n, q, 200 * seed + i) for i, q in enumerate(qs)])
+    sa.copy_(torch.from_numpy(a.view(np.int64))); sb.copy_(torch.from_numpy(b.view(np.int64)))
+    g.replay()
+    torch.cuda.synchronize()
+    got = tc.cpu().numpy().view(np.uint64)
+    for i, (q, w) in enumerate(zip(qs, ws)):
+        cx, sl = orc.ctx(n, q, w), slice(i * batch * n, (i + 1) * batch * n)
+        want = cx.inv(orc.pointwise(cx.fwd(a[sl]), cx.fwd(b[sl]), q))
+        assert np.array_equal(got[sl], want), (seed, i)
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
