@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Randomised differential soak of the HIP library against the CPU oracle (GPU box; test infrastructure, like tests/).
+
+Every round draws a transform size 2^1..2^18, a prime of 20..60 bits with 2N | q-1, an arithmetic policy the
+library offers for it, a ragged batch (with a bias to the persistent grids' edges: 255, 256, 257, 511, ...), plan
+options (chunk size, grid cap, two-phase, column-only engine, fused product on/off) and checks, bit for bit against
+the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms.
+usage: python3 tools/soak.py [--seconds 300] [--seed 1] [--max-coeffs 2^22]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=300)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--max-coeffs", type=int, default=1 << 22)
+args = ap.parse_args()
+lib, orc = ontt.load(), Oracle()
+rng = np.random.default_rng(args.seed)
+EDGE = [1, 2, 3, 7, 8, 15, 16, 17, 31, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1025]
+t_end, rounds, checks = time.time() + args.seconds, 0, 0
+stats = {}
+
+
+def fail(what, **kw):
+    print("SOAK FAILURE:", what, kw, flush=True)
+    sys.exit(1)
+
+
+while time.time() < t_end:
+    m = int(rng.integers(1, 19))
+    n = 1 << m
+    bits = int(rng.choice([int(rng.integers(max(m + 2, 20), 61)), 50, 51, 52, 60]))
+    q = lib.find_prime(bits, n, int(rng.integers(0, 4)))
+    if q == 0 or q != orc.find_prime(bits, n, 0) and False:
+        continue
+    w = lib.min_root(q, n)
+    if w == 0:
+        fail("min_root", q=hex(q), n=n)
+    cap = max(1, args.max_coeffs // n)
+    batch = int(rng.choice(EDGE)) if rng.random() < 0.5 else int(rng.integers(1, 600))
+    batch = max(1, min(batch, cap))
+    policies = [lib.ARITH_AUTO, lib.ARITH_U64]
+    if q < (1 << 52):
+        policies.append(lib.ARITH_F64)
+    if 6 <= m <= 14 and q < (1 << 60):
+        policies.append(lib.ARITH_U64_R4)
+    arith = int(rng.choice(policies))
+    try:
+        plan = lib.Plan(n, q, w, arith=arith)
+    except lib.NttError as e:
+        fail("plan", q=hex(q), n=n, arith=arith, err=str(e))
+    info = plan.info()
+    opts = {}
+    if rng.random() < 0.3:
+        opts["chunk"] = int(rng.choice([1, 2, 8, 64, 256]))
+        plan.set_option(lib.OPT_CHUNK_MIB, opts["chunk"])
+    if rng.random() < 0.3:
+        opts["grid"] = int(rng.choice([1, 3, 64, 255, 256, 1000]))
+        plan.set_option(lib.OPT_MAX_GRID, opts["grid"])
+    if rng.random() < 0.3:
+        opts["two_phase"] = 1
+        plan.set_option(lib.OPT_TWO_PHASE, 1)
+    if rng.random() < 0.2 and arith != lib.ARITH_U64_R4:
+        opts["generic"] = 1
+        plan.set_generic(1)
+    if rng.random() < 0.3:
+        opts["fused_product"] = 0
+        plan.set_option(lib.OPT_FUSED_PRODUCT, 0)
+    cx = orc.ctx(n, q, w)
+    a = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
+    k = int(rng.integers(0, 5))
+    if k == 0:
+        a[:] = q - 1
+    elif k == 1:
+        a[: a.size // 2] = 0
+    key = (m, info["arith"], info["f64_class"])
+    stats[key] = stats.get(key, 0) + 1
+    ctxt = dict(m=m, q=hex(q), arith=arith, resolved=info["arith"], cls=info["f64_class"], batch=batch, opts=opts)
+    want = cx.fwd(a)
+    got = plan.fwd_host(a)
+    if not np.array_equal(got, want):
+        fail("fwd", **ctxt)
+    if not np.array_equal(plan.inv_host(want), a):
+        fail("inv", **ctxt)
+    lazy_mult = 8 if q < (1 << 60) else 4
+    lz = a + np.uint64(q) * rng.integers(0, lazy_mult, size=a.shape, dtype=np.uint64)
+    if not np.array_equal(plan.fwd_host(lz, wide=True), want):
+        fail("fwd wide", **ctxt)
+    lz = want + np.uint64(q) * rng.integers(0, lazy_mult, size=a.shape, dtype=np.uint64)
+    if not np.array_equal(plan.inv_host(lz, wide=True), a):
+        fail("inv wide", **ctxt)
+    out = plan.fwd_host(a, lazy=True)
+    bound = 8 if info["arith"] == lib.ARITH_U64_R4 else 4
+    if int(out.max()) >= bound * q or not np.array_equal(out % np.uint64(q), want):
+        fail("fwd lazy", **ctxt)
+    out = plan.inv_host(want, lazy=True)
+    if int(out.max()) >= 2 * q or not np.array_equal(out % np.uint64(q), a):
+        fail("inv lazy", **ctxt)
+    checks += 6
+    if info["arith"] != lib.ARITH_U64_R4:
+        b = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
+        prod = cx.inv(orc.pointwise(want, cx.fwd(b), q))
+        form = int(rng.integers(0, 4))
+        da, db = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b)
+        dc = lib.DeviceBuffer(a.size)
+        if form == 0:
+            plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch); res = dc.download()
+        elif form == 1:
+            plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, batch); res = da.download()
+        elif form == 2:
+            plan.negacyclic_mul(db.ptr, da.ptr, db.ptr, batch); res = db.download()
+        else:
+            plan.negacyclic_mul(dc.ptr, da.ptr, da.ptr, batch); res = dc.download()
+            prod = cx.inv(orc.pointwise(want, want, q))
+        if not np.array_equal(res, prod):
+            fail("product form %d" % form, **ctxt)
+        for d in (da, db, dc):
+            d.free()
+        checks += 1
+    plan.destroy()
+    rounds += 1
+
+print("soak ok: %d rounds, %d checks in %.0f s (seed %d)" % (rounds, checks, args.seconds, args.seed))
+by_arith = {}
+for (m, ar, cls), c in stats.items():
+    by_arith[(ar, cls)] = by_arith.get((ar, cls), 0) + c
+print("rounds per (resolved policy, FP64 class):", dict(sorted(by_arith.items())))
+print("sizes seen:", sorted({m for (m, _, _) in stats}))
