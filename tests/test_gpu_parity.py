@@ -1007,3 +1007,41 @@ print("graph ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_concurrent_host_threads_on_their_own_streams(lib, oracle, kat):
+    """the batched API is re-entrant like the reference's functions (no statics on that path, thread-local error
+    text): four host threads, each with its own plan, stream and buffers, transform concurrently"""
+    import ctypes as C
+    import threading
+    cases = [kat["cases"][i] for i in (4, 9, 12, 13)]
+    errors, results = [], {}
+
+    def work(idx, c):
+        try:
+            n, q, w = 1 << c["m"], c["q"], c["w"]
+            plan = lib.Plan(n, q, w)
+            h = C.c_void_p()
+            lib._check(lib._lib.ntt_stream_create(0, C.byref(h)))
+            a = oracle.fill_uniform(24 * n, q, 1000 + idx)
+            d = lib.DeviceBuffer(a.size).upload(a)
+            for _ in range(20):
+                plan.fwd(d.ptr, 24, stream=h.value)
+                plan.inv(d.ptr, 24, stream=h.value)
+            plan.fwd(d.ptr, 24, stream=h.value)
+            lib.stream_sync(0, h.value)
+            results[idx] = (d.download(), a, n, q, w)
+            d.free()
+            plan.destroy()
+            lib._lib.ntt_stream_destroy(0, h.value)
+        except Exception as e:                      # noqa: BLE001 -- reported by the main thread
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i, c)) for i, c in enumerate(cases)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for idx, (got, a, n, q, w) in results.items():
+        assert np.array_equal(got, oracle.ctx(n, q, w).fwd(a)), idx
