@@ -49,14 +49,21 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
    * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
    * and L2 latencies better.) */
-  static constexpr int WG  = P::T < 256 ? 256 : P::T;      /* threads per workgroup */
-  static constexpr int BPW = P::T < 256 ? 256 / P::T : 1;  /* blocks per workgroup  */
+  /* 2^13 (FP64 policies): TWO blocks per 1024-thread workgroup, each half running the persistent loop on its own
+   * exchange buffer and sharing the twiddle table -- the resource shape of the 2^14 kernel (16 waves per CU,
+   * 158 KB of LDS).  One 512-thread workgroup per CU with every table in LDS (round 1) left two waves per SIMD. */
+  static constexpr bool PERSIST2 = COMPACT && LOGN == 13 && !INV; /* (inverse: its first group's per-lane twiddles then fit neither the registers nor the LDS: measured 0.58 -> 0.48) */
+  static constexpr int WG  = PERSIST2 ? 1024 : (P::T < 256 ? 256 : P::T);      /* threads per workgroup */
+  static constexpr int BPW = PERSIST2 ? 2 : (P::T < 256 ? 256 / P::T : 1);    /* blocks per workgroup  */
+  static constexpr bool PERSISTENT = BPW == 1 || PERSIST2;                     /* persistent prefetching loops */
   /* Compact twiddles kept in LDS for the whole launch, one table per stage group whose stages
    * are all per-lane (entries; 0 = not used).  Which groups get one is a footprint decision:
    *   2^14: the second-to-last group (stages 8..11, 3840 doubles = 30 KB next to the 128.1 KB
    *         exchange buffer); the last group's 12288 entries do not fit and are preloaded;
-   *   2^13: every per-lane group (stages 4..7, 8..11 and 12: 2 + 30 + 32 KB): one 130 KB
-   *         workgroup per CU and no global twiddle loads at all;
+   *   2^13: inverse: every per-lane group (stages 4..7, 8..11 and 12: 2 + 30 + 32 KB): one 130 KB
+   *         workgroup per CU and no global twiddle loads at all; forward (two blocks per
+   *         workgroup, PERSIST2): as 2^14 -- the second-to-last group's table, the last group's
+   *         twiddles register-resident (measured +1.5 % over the inverse's scheme);
    *   2^12: the second-to-last group only (7.7 KB: 4 workgroups per CU, measured +10 %; the
    *         last group's 24 KB would halve the resident workgroups);
    *   2^8..2^11: every per-lane group (at most 16 KB per 256-thread workgroup of 2..64
@@ -72,9 +79,9 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   {
     if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
     bool on = false;
-    if(LOGN == 14 || LOGN == 12) on = (g == P::NG - 2);
+    if(LOGN == 14 || LOGN == 12 || (LOGN == 13 && !INV)) on = (g == P::NG - 2);
     if(LOGN >= 8 && LOGN <= 11) on = true; /* several blocks per workgroup share the tables (2^6, 2^7: measured no gain) */
-    if(LOGN == 13) on = true;
+    if(LOGN == 13 && INV) on = true;
     return on ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
   }
   /* first entry of group g's table behind the exchange buffer(s) */
@@ -352,17 +359,23 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
    * its twiddles from an LDS-resident table (lgkmcnt) and the first two groups
    * through the scalar cache.  So no twiddle wait ever sits behind HBM loads,
    * and the prefetched block lands during ~10 stages of butterflies. */
-  if constexpr(!INV && G::BPW == 1 && !A::kRadix4) {
+  if constexpr(!INV && G::PERSISTENT && !A::kRadix4) {
     constexpr int  GL     = P::NG - 1;          /* last group                      */
     /* the last group's 12 per-lane twiddles (8-byte form) are requested well
      * ahead of their use; for whole-polynomial blocks they do not depend on the
      * block at all and stay in 24 VGPRs for the entire launch (LOGN 14 only:
      * smaller blocks have several workgroups per CU hiding that latency) */
-    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == kPreAlso) && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
+    constexpr bool PRE    = A::kCompact && (LOGN == 14 || LOGN == 13 || LOGN == kPreAlso) && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
     constexpr bool LTW    = LDS_TW > 0;
-    const uint64_t stride = gridDim.x;
-    uint64_t       b      = blockIdx.x;
-    if(b >= p.nblocks) return;
+    /* BPW == 2 (2^13): each half of the workgroup owns the block b0 + sub; a half without a block (odd count)
+     * shadows the last one and never stores.  BPW == 1: tt, ll, b are tid, lds_all, b0 -- unchanged code. */
+    const uint32_t         tt     = G::BPW == 1 ? tid : t;
+    typename A::val *const ll     = G::BPW == 1 ? lds_all : lds;
+    const uint64_t         stride = (uint64_t)gridDim.x * G::BPW;
+    uint64_t               b0     = (uint64_t)blockIdx.x * G::BPW;
+    if(b0 >= p.nblocks) return;
+    const uint64_t lastb = p.nblocks - 1;
+    uint64_t       b     = G::BPW == 1 ? b0 : (b0 + sub < p.nblocks ? b0 + sub : lastb);
     /* twiddle tables of this workgroup, behind the exchange buffer */
     typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
     const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       __syncthreads();
     }
     uint64_t raw[kE];
-    prefetch_first<LOGN>(raw, tid, p.a + (b << LOGN));
+    prefetch_first<LOGN>(raw, tt, p.a + (b << LOGN));
     pin_raw(raw);
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
@@ -384,10 +397,12 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
      * loop -- the prefetched block now has the entire iteration to arrive (measured +2 %). */
     typename A::ctw pre[4][kE / 2];
     if constexpr(PRE) {
-      preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
+      preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
       pin_preloaded<A, LOGN, GL>(pre);
     }
-    for(; b < p.nblocks; b += stride) {
+    for(; b0 < p.nblocks; b0 += stride) {
+      const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
+      b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[kE];
@@ -397,23 +412,24 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
          * its HBM loads are then in flight for the whole iteration (measured best of
          * four placements: after the first exchange -4 %, inside the last group -3 %,
          * a quarter after every exchange -7 %; profiles/r01/ablations.txt) */
-        const bool     more = b + stride < p.nblocks;
-        const uint64_t nb   = more ? b + stride : b;
-        prefetch_first<LOGN>(raw, tid, p.a + (nb << LOGN), more);
+        const bool     more = b0 + stride < p.nblocks;
+        const uint64_t nb0  = more ? b0 + stride : b0;
+        const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
+        prefetch_first<LOGN>(raw, tt, p.a + (nb << LOGN), more);
       }
       STAMP(0); /* wait for prefetched coefficients + convert */
-      run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+      run_group<A, LOGN, 0, false, MASK>(x, tt, blk, p);
       STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
-        exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
+        exchange<A, LOGN, GI, GI + 1>(x, tt, ll);
         STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
-          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tt, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
-          run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+          run_group<A, LOGN, GI + 1, false, MASK>(x, tt, blk, p);
         }
         STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
@@ -421,7 +437,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       if constexpr(LOGN == 14) {
         store_last_whole_lines<A, LOGN, LAZY>(x, tid, base, p.c, p.lazy != 0);
       } else {
-        global_store_last<A, LOGN, false, LAZY>(x, tid, base, p.c, p.lazy != 0);
+        if(live) global_store_last<A, LOGN, false, LAZY>(x, tt, base, p.c, p.lazy != 0);
       }
       STAMP(10); /* final reduction + stores */
     }
@@ -434,12 +450,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
    * 8-byte stores. */
   /* (FP64 policy only: with the integer policy's larger temporaries this loop spills 6-10
    * VGPRs and the plain loop below is 2-13 % faster -- measured, profiles/r01/ablations.txt) */
-  if constexpr(INV && G::BPW == 1 && A::kCompact) {
+  if constexpr(INV && G::PERSISTENT && A::kCompact) {
     constexpr int  GL     = P::NG - 1;
     constexpr bool LTW    = LDS_TW > 0;
-    const uint64_t stride = gridDim.x;
-    uint64_t       b      = blockIdx.x;
-    if(b >= p.nblocks) return;
+    const uint32_t         tt     = G::BPW == 1 ? tid : t;
+    typename A::val *const ll     = G::BPW == 1 ? lds_all : lds;
+    const uint64_t         stride = (uint64_t)gridDim.x * G::BPW;
+    uint64_t               b0     = (uint64_t)blockIdx.x * G::BPW;
+    if(b0 >= p.nblocks) return;
+    const uint64_t lastb = p.nblocks - 1;
+    uint64_t       b     = G::BPW == 1 ? b0 : (b0 + sub < p.nblocks ? b0 + sub : lastb);
     /* twiddle tables of this workgroup, behind the exchange buffer */
     typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
     const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
@@ -455,41 +475,44 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     constexpr bool IPRE = A::kCompact && LOGN >= kIpreMin && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 &&
                           !(LOGN == 12 && KSH == 1);
     typename A::ctw pre[4][kE / 2];
-    if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, (uint32_t)b & bmask, p);
+    if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
     uint64_t raw[kE];
-    prefetch_last<LOGN>(raw, tid, p.a + (b << LOGN));
+    prefetch_last<LOGN>(raw, tt, p.a + (b << LOGN));
     pin_raw(raw);
     if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
-    for(; b < p.nblocks; b += stride) {
+    for(; b0 < p.nblocks; b0 += stride) {
+      const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
+      b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
       uint64_t *     base = p.a + (b << LOGN);
       typename A::val x[kE];
       convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
       {
         /* (whole-line loads through the same lane swap as the forward stores: measured 17.74 vs 17.75 M, not kept) */
-        const bool     more = b + stride < p.nblocks;
-        const uint64_t nb   = more ? b + stride : b;
-        prefetch_last<LOGN>(raw, tid, p.a + (nb << LOGN), more);
+        const bool     more = b0 + stride < p.nblocks;
+        const uint64_t nb0  = more ? b0 + stride : b0;
+        const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
+        prefetch_last<LOGN>(raw, tt, p.a + (nb << LOGN), more);
       }
       if constexpr(IPRE) {
         run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
       } else if constexpr(G::TBL(GL) > 0) {
-        run_group<A, LOGN, GL, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GL));
+        run_group<A, LOGN, GL, true, MASK, true>(x, tt, blk, p, ltw + G::TBL_OFF(GL));
       } else {
-        run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+        run_group<A, LOGN, GL, true, MASK>(x, tt, blk, p);
       }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
-        exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
+        exchange<A, LOGN, GI, GI - 1>(x, tt, ll);
         if constexpr(G::TBL(GI - 1) > 0) {
-          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
+          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tt, blk, p, ltw + G::TBL_OFF(GI - 1));
         } else {
-          run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+          run_group<A, LOGN, GI - 1, true, MASK>(x, tt, blk, p);
         }
       });
       uint64_t out[kE];
       static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], p.c); });
-      buffer_store_first_raw<LOGN>(out, tid, base);
+      if(live) buffer_store_first_raw<LOGN>(out, tt, base);
     }
     return;
   }
@@ -1014,7 +1037,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   p.nblocks = pa.batch << pa.s;
   uint64_t wgs = (p.nblocks + G::BPW - 1) / G::BPW;
   uint64_t cap = 1ull << 20;
-  if(G::BPW == 1) {
+  if(G::PERSISTENT) {
     /* persistent prefetching loop: exactly the resident workgroups (LDS- and
      * wave-limited), each striding over the blocks */
     constexpr int by_lds    = G::WG_PER_CU0;
@@ -1022,7 +1045,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
     cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
   }
-  if(G::BPW > 1 && G::LDS_TW > 0) {
+  if(!G::PERSISTENT && G::LDS_TW > 0) {
     /* tables are filled once per workgroup: a few workgroups per resident slot, each looping */
     if(pa.s != 0) return hipErrorInvalidValue;
     constexpr int per_cu = G::WG_PER_CU0 < 8 ? G::WG_PER_CU0 : 8;

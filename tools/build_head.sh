@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/build_head.sh [REV] : builds build/libntt_prev.so from the committed kernels of REV (default HEAD) -- the "before" side of a
+# same-box A/B against the working tree's library (NTT_LIB=build/libntt_prev.so selects it in tools/ and tests/)
+set -e
+rev=${1:-HEAD}
+rm -rf build/prevsrc build/prev; mkdir -p build/prevsrc build/prev
+git archive $rev optimized-number-theoretic-transform-implementations_amd/csrc include | tar -x -C build/prevsrc
+src=build/prevsrc/optimized-number-theoretic-transform-implementations_amd/csrc
+pids=()
+for f in ntt_host inst_u64 inst_u64r4 inst_f64k0 inst_f64k1 inst_f64k18 inst_f64w; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
+     -Ibuild/prevsrc/include -Ibuild/prevsrc/include/internal -I$src -c -o build/prev/$f.o $src/$f.hip &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libntt_prev.so build/prev/*.o
+echo built build/libntt_prev.so from $rev
