@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=0, help="polynomials per GPU (default: from --scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the side measurements (copy ceiling, literal 50-bit prime): profiler runs then see one kernel")
     ap.add_argument("--logn", type=int, default=LOGN, help="(experiments) other transform sizes; the metric is quoted on 14")
     args = ap.parse_args()
 
@@ -404,10 +406,11 @@ def main():
         kernel_ms = [float(x.item()) for x in allk]
 
     if rank == 0:
-        copy_gbs = shards[0].copy_ceiling_gbs()     # after the timed region, on shard 0's resident buffer
+        # after the timed region, on shard 0's resident buffer
+        copy_gbs = None if args.headline_only else shards[0].copy_ceiling_gbs()
         out = make_report(args, n_gpus, batch, elapsed, kernel_ms, shards[0].arith(), shards[0].hbm_passes(), n=n,
                           copy_gbs=copy_gbs)
-        if n_gpus == 1 and n == N:
+        if n_gpus == 1 and n == N and not args.headline_only:
             out["also_literal_50_bit_q"] = literal_50_bit(lib, shards[0], args.steps)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

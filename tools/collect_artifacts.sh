@@ -3,10 +3,10 @@
 # (kernel trace + stats, PMC passes one group per run, the plain bench line, the size and modulus sweeps).
 out=$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprofv3.json 2> $out/kt.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --headline-only > $out/bench_under_rocprofv3.json 2> $out/kt.log
 declare -A grp=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [sq]="SQ_INSTS_VALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" [ta]="TA_TA_BUSY GRBM_GUI_ACTIVE" [valu]="SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM" )
 for g in fetch write sq ta valu; do
-  timeout 600 rocprofv3 --kernel-trace --pmc ${grp[$g]} --output-format csv -d $out/pmc/$g/run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_$g.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc ${grp[$g]} --output-format csv -d $out/pmc/$g/run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > $out/pmc_$g.log 2>&1
 done
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt 2>&1
 # HBM-side traffic of the transforms larger than one block (N = 2^16, 2^17), one launch per pass and two-phase
