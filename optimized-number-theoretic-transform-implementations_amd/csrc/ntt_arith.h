@@ -1,21 +1,25 @@
 /*
  * ntt_arith.h -- modular arithmetic policies for the gfx950 NTT kernels.
  *
- * Two interchangeable policies drive the same butterfly network:
+ * Interchangeable policies drive the same butterfly network (ntt_core.h):
  *
- *  ArithU64  exact restatement of the reference's Harvey/Shoup lazy arithmetic
- *            (reference include/internal/fast_mul_operators.h:15-106) on 64-bit
- *            integers; valid for every q with 4q < 2^64.  On gfx950 one Shoup
- *            product costs ~10 quarter-rate 32-bit multiplies.
- *
- *  ArithF64  the MI355X fast path for q <= 2^51(1+2^-10): coefficients are kept
- *            as integer-valued doubles in balanced form, a product is
- *            h=t*w, l=fma(t,w,-h), k=rint(t*(w/q)), r=fma(-k,q,h)+l
- *            (6 FP64 ops, every step exact -- proof in DESIGN.md section 4), and the
- *            conditional subtracts of the Harvey butterfly become a
- *            compile-time schedule of rint-reductions.  Final outputs are
- *            reduced to [0,q), so results are bit-identical to the reference
- *            (SURVEY A.6).  No MFMA: this is element-wise 53-bit work.
+ *  ArithU64    exact restatement of the reference's Harvey/Shoup lazy arithmetic
+ *              (reference include/internal/fast_mul_operators.h:15-106) on 64-bit
+ *              integers; valid for every q with 4q < 2^64.  On gfx950 one butterfly is
+ *              28 VALU instructions, 10 of them 32-bit multiplies (profiles/r02/ablations.txt).
+ *  ArithU64R4  the reference's radix-4 butterflies with the shared-quotient double product
+ *              (:62-70, :108-149) on the 2N-entry expanded table: bit-identical lazy values
+ *              for the *_radix4 entry points.
+ *  ArithF64    the MI355X fast path for q <= 2^51(1+2^-10): coefficients are kept
+ *              as integer-valued doubles in balanced form, a product is
+ *              h=t*w, l=fma(t,w,-h), k=rint(t*(w/q)), r=fma(-k,q,h)+l
+ *              (6 FP64 ops, every step exact -- proof in DESIGN.md section 4), and the
+ *              conditional subtracts of the Harvey butterfly become a
+ *              compile-time schedule of rint-reductions.  Final outputs are
+ *              reduced to [0,q), so results are bit-identical to the reference
+ *              (SURVEY A.6).  No MFMA: this is element-wise 53-bit work.
+ *  ArithF64W   (= WideF64<ArithF64>) the same for q up to 2^52: both operands of every
+ *              butterfly are reduced first (14 instead of 8 FP64 instructions).
  *
  * Everything here is NTT_HD (host+device) so tests/emu can run the identical
  * code on the CPU against the oracle.
