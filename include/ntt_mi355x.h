@@ -67,7 +67,7 @@ typedef enum ntt_option {
   NTT_OPT_F64_CLASS = 3, /* force a coarser FP64 headroom class (0, 1 or 18) than q permits: tests  */
   NTT_OPT_TWO_PHASE = 4, /* N = 2^15..2^17: 1 = both passes of a polynomial in one workgroup (one launch),
                           * 0 = one launch per pass over the whole batch */
-  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^14, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
+  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^12..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes); 0 = fwd, fwd, pointwise, inv (72N bytes) */
 } ntt_option;
 

@@ -43,8 +43,10 @@ constexpr int kIpreMin = 12; /* inverse: first executed group's twiddles registe
  * workgroup size allows) */
 template <class A> constexpr int flavor_of() { return A::kCompact ? 1 : (A::kRadix4 ? 2 : 0); }
 
+/* FLAVOR: 0 integer radix-2, 1 FP64 (compact twiddles), 2 integer radix-4, 3 FP64 inside fused_product_kernel (one block
+ * per workgroup at every size: the two transforms of a product leave no registers for a second block's prefetch) */
 template <int LOGN, bool INV, int FLAVOR> struct Geom {
-  static constexpr bool COMPACT = FLAVOR == 1;
+  static constexpr bool COMPACT = FLAVOR == 1 || FLAVOR == 3;
   using P = Plan<LOGN>;
   /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
    * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
@@ -52,7 +54,7 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* 2^13 (FP64 policies): TWO blocks per 1024-thread workgroup, each half running the persistent loop on its own
    * exchange buffer and sharing the twiddle table -- the resource shape of the 2^14 kernel (16 waves per CU,
    * 158 KB of LDS).  One 512-thread workgroup per CU with every table in LDS (round 1) left two waves per SIMD. */
-  static constexpr bool PERSIST2 = COMPACT && LOGN == 13 && !INV; /* (inverse: its first group's per-lane twiddles then fit neither the registers nor the LDS: measured 0.58 -> 0.48) */
+  static constexpr bool PERSIST2 = FLAVOR == 1 && LOGN == 13 && !INV; /* (inverse: its first group's per-lane twiddles then fit neither the registers nor the LDS: measured 0.58 -> 0.48) */
   static constexpr int WG  = PERSIST2 ? 1024 : (P::T < 256 ? 256 : P::T);      /* threads per workgroup */
   static constexpr int BPW = PERSIST2 ? 2 : (P::T < 256 ? 256 / P::T : 1);    /* blocks per workgroup  */
   static constexpr bool PERSISTENT = BPW == 1 || PERSIST2;                     /* persistent prefetching loops */
@@ -310,11 +312,10 @@ __device__ __forceinline__ void pin_preloaded(const typename A::ctw (&pre)[4][kE
  * is valid because its stride over the blocks is a multiple of the blocks per polynomial
  * (launch_fused enforces it).  Stage J of group g is stored TRANSPOSED: slot
  * l = prefix * 2^J + u goes to (2^J - 1) * 2^S + u * 2^S + prefix (see load_stage_tw). */
-template <class A, int LOGN, bool INV>
+template <class A, int LOGN, bool INV, class G = Geom<LOGN, INV, flavor_of<A>()>>
 __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Params<A> &p, uint32_t blk0, uint32_t tid)
 {
   using P = Plan<LOGN>;
-  using G = Geom<LOGN, INV, flavor_of<A>()>;
   static_for<0, P::NG>([&](auto gg) {
     constexpr int GI = decltype(gg)::value;
     if constexpr(G::TBL(GI) > 0) {
@@ -865,16 +866,17 @@ template <class A> struct ProdParams {
  * blocks per polynomial), whose forward table slice it keeps in LDS; the mirrored read would need the slice of the
  * complementary position, so the inverse half takes that one group's twiddles from global memory instead. */
 template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE>
-__global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS))
+__global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_kernel(const ProdParams<A> pp)
 {
   using P = Plan<LOGN>;
-  using G = Geom<LOGN, false, flavor_of<A>()>;
-  static_assert(A::kCompact && G::BPW == 1 && LOGN == 14, "built for the FP64 policy on 2^14-point blocks");
+  using G = Geom<LOGN, false, 3>;
+  static_assert(A::kCompact && G::BPW == 1 && (LOGN == 14 || ((LOGN == 13 || LOGN == 12) && WHOLE)),
+                "built for the FP64 policy on 2^14-point blocks and whole 2^13- and 2^12-point polynomials");
   constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
   constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | (WHOLE ? kLastInvFlag : 0u);
   constexpr int      GL    = P::NG - 1;
-  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && P::R(GL) < 4, "twiddle placement this kernel assumes");
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0, "twiddle placement this kernel assumes");
   __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
   const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
@@ -896,7 +898,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
   uint64_t       b      = blockIdx.x;
   if(b >= pf.nblocks) return;
   const uint32_t blk = WHOLE ? 0u : ((uint32_t)b & ((1u << pf.s0) - 1u)); /* the same for every block of this workgroup */
-  fill_lds_tables<A, LOGN, false>(tabl, pf, blk, tid);
+  fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
   __syncthreads();
   uint64_t raw[kE];
   prefetch_first<LOGN>(raw, tid, pf.a + (b << LOGN));
@@ -1135,8 +1137,8 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.logn < 14 || pa.logn > 17) return hipErrorNotSupported;
-    const uint32_t s0 = pa.logn - 14; /* leading stages done by column passes around this launch */
+    if(pa.logn < 12 || pa.logn > 17) return hipErrorNotSupported;
+    const uint32_t s0 = pa.logn <= 14 ? 0 : pa.logn - 14; /* leading stages done by column passes around this launch */
     ProdParams<A>  pp{};
     pp.f.a       = pa.b;
     pp.f.tw      = static_cast<const typename A::tw *>(pa.tw_f);
@@ -1160,7 +1162,18 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(wgs == 0) return hipSuccess;
     /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
     if(!pa.a_lazy) return hipErrorNotSupported;
-    if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    if(pa.logn == 12) {
+      using G12 = Geom<12, false, 3>;
+      constexpr int per_cu = G12::WG_PER_CU0 < G12::WPS ? G12::WG_PER_CU0 : G12::WPS; /* 256-thread workgroups: one wave per SIMD each */
+      uint64_t      cap12  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * per_cu;
+      if(pa.max_grid > 0) cap12 = (uint64_t)pa.max_grid;
+      wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
+      hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+    } else if(pa.logn == 13) {
+      using G13 = Geom<13, false, 3>;
+      /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
+      hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
+    } else if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
     else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
     return hipGetLastError();
   }

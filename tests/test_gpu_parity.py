@@ -685,12 +685,13 @@ def test_full_batch_forward_cross_check(lib, oracle, kat, m, bits, batch):
     plan.destroy()
 
 
+@pytest.mark.parametrize("m", [14, 13, 12])
 @pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001])
-def test_fused_product_kernel(lib, oracle, q):
-    """N = 2^14, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
+def test_fused_product_kernel(lib, oracle, q, m):
+    """N = 2^14, 2^13 and 2^12, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
     equals the oracle's inv(fwd(a) . fwd(b)), the four-launch chain (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial,
     the schoolbook product; all aliasing forms; batches around the persistent grid"""
-    n = 1 << 14
+    n = 1 << m
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
     plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)

@@ -14,6 +14,7 @@ ap.add_argument("--qs", nargs="+", default=["0x7fffffffe0001"])
 ap.add_argument("--arith", nargs="+", default=["auto"])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--two-phase", type=int, default=0, help="N=2^15..2^17: 1 = one launch per transform (default), 0 = one launch per pass")
+ap.add_argument("--fused-product", type=int, default=1, help="ntt_negacyclic_mul_batch: 1 = fused product kernel where built (default), 0 = four transforms")
 a = ap.parse_args()
 ap2 = None
 AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64, "r4": lib.ARITH_U64_R4}
@@ -31,6 +32,7 @@ for qs in a.qs:
             except lib.NttError as e:
                 print(ln, qs, ar, "unsupported:", e); continue
             plan.set_option(lib.OPT_TWO_PHASE, a.two_phase)
+            plan.set_option(lib.OPT_FUSED_PRODUCT, a.fused_product)
             nb = 3 if "mul" in a.ops else 1
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
             for i, b in enumerate(bufs): lib.fill_uniform(b.ptr, batch * n, q, 77 + i)
