@@ -26,7 +26,7 @@ oracle:
 	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref; fi
 
 emu:
-	$(MAKE) -C tests/emu
+	$(MAKE) -C tests/emu -j8
 
 all-test: lib oracle emu
 

@@ -19,13 +19,21 @@
 
 using namespace ntt;
 
+/* The file is compiled several times (tests/emu/Makefile, -DEMU_PART=k, in parallel): part 0 holds the C interface,
+ * parts 1..6 each a share of the emu_run / emu_fused_product instantiations (explicit instantiation definitions);
+ * without EMU_PART everything lands in one translation unit (the sanitizer build). */
+#ifndef EMU_PART
+#  define EMU_PART (-1)
+#endif
+#define EMU_HAS(k) (EMU_PART == -1 || EMU_PART == (k))
+
 /* ------------------------------------------------------------------ */
 /* ArithF64Chk: the FP64 policy with every exactness claim of DESIGN.md */
 /* section 4 asserted at run time against 128-bit integer arithmetic.   */
 /* ------------------------------------------------------------------ */
-static uint64_t g_chk_fail  = 0;   /* number of violated claims          */
-static double   g_chk_maxb  = 0;   /* largest |value|/q seen             */
-static double   g_chk_maxr  = 0;   /* largest |product|/q seen           */
+inline uint64_t g_chk_fail  = 0;   /* number of violated claims          (inline: one copy for all parts) */
+inline double   g_chk_maxb  = 0;   /* largest |value|/q seen             */
+inline double   g_chk_maxr  = 0;   /* largest |product|/q seen           */
 
 struct ArithF64Chk : ArithF64 {
   static __int128 as_int(double v)
@@ -215,7 +223,7 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false>
  * with a^ in the last group's layout, inverse transform whose per-lane group reads the FORWARD twiddle table in the
  * LDS layout, mirrored (load_stage_tw MIRROR) */
 template <class A, int LOGN, int KSH, bool ALAZY>
-static void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, const Params<A> &pf,
+void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, const Params<A> &pf,
                               const Params<A> &pi)
 {
   using P                  = Plan<LOGN>;
@@ -297,11 +305,11 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
   }
 }
 
-static bool g_lazy = false; /* lazy outputs for the next emu_transform (set by emu_set_lazy) */
+inline bool g_lazy = false; /* lazy outputs for the next emu_transform (set by emu_set_lazy) */
 
 template <class A, bool INV, int KSH>
-static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
-                   const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
+int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
+            const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
 {
   const PassList L = make_passes(m, generic);
   const bool lazy  = g_lazy;
@@ -357,6 +365,42 @@ static int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab
   return 0;
 }
 
+/* ---- the parts: explicit instantiations (definitions in parts 1..6, declarations in part 0) ---- */
+#define EMU_RUN_ARGS(A) (uint64_t *, uint64_t, int, const typename A::tw *, const typename A::consts &, bool, bool, const typename A::ctw *)
+#define EMU_PROD_ARGS(A) (uint64_t *, const uint64_t *, const uint64_t *, uint64_t, const Params<A> &, const Params<A> &)
+#define EMU_RUN(KW, A, K)                               \
+  KW template int emu_run<A, true, K> EMU_RUN_ARGS(A);  \
+  KW template int emu_run<A, false, K> EMU_RUN_ARGS(A);
+#define EMU_PROD(KW, A, K)                                               \
+  KW template void emu_fused_product<A, 14, K, true> EMU_PROD_ARGS(A);   \
+  KW template void emu_fused_product<A, 14, K, false> EMU_PROD_ARGS(A);
+using WideChk = WideF64<ArithF64Chk>;
+#if EMU_PART >= 0
+#  define P1(KW) EMU_RUN(KW, ArithU64, 0) EMU_RUN(KW, ArithU64R4, 0) EMU_RUN(KW, ArithF64W, 0)
+#  define P2(KW) EMU_RUN(KW, ArithF64, 0) EMU_RUN(KW, ArithF64, 1)
+#  define P3(KW) EMU_RUN(KW, ArithF64, 18) EMU_RUN(KW, ArithF64Chk, 18)
+#  define P4(KW) EMU_RUN(KW, ArithF64Chk, 0)
+#  define P5(KW) EMU_RUN(KW, ArithF64Chk, 1) EMU_RUN(KW, WideChk, 0)
+#  define P6(KW) EMU_PROD(KW, ArithF64, 0) EMU_PROD(KW, ArithF64, 1) EMU_PROD(KW, ArithF64, 18) \
+                 EMU_PROD(KW, ArithF64Chk, 0) EMU_PROD(KW, ArithF64Chk, 1) EMU_PROD(KW, ArithF64Chk, 18)
+#  if EMU_PART == 0
+P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern)
+#  elif EMU_PART == 1
+P1()
+#  elif EMU_PART == 2
+P2()
+#  elif EMU_PART == 3
+P3()
+#  elif EMU_PART == 4
+P4()
+#  elif EMU_PART == 5
+P5()
+#  elif EMU_PART == 6
+P6()
+#  endif
+#endif
+
+#if EMU_HAS(0)
 /* plan introspection for the layout tests: returns LDS row pad, fills info[]:
  * {NG, R0, RL, T, ROW, LDS_ELEMS, wave_local bits, f64 fwd mask ksh0, f64 inv mask ksh0} */
 template <int LOGN> static void plan_info(uint64_t *info)
@@ -574,3 +618,4 @@ int emu_plan_info(int logn, uint64_t *info)
   }
 }
 }
+#endif /* EMU_HAS(0) */

@@ -15,7 +15,7 @@ class Emu:
     def __init__(self):
         path = os.path.join(EDIR, "libntt_emu.so")
         if not os.path.exists(path):
-            subprocess.check_call(["make", "-C", EDIR])
+            subprocess.check_call(["make", "-j8", "-C", EDIR])
         L = self.lib = C.CDLL(path)
         L.emu_transform.argtypes = [U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64] + [C.c_int] * 5
         L.emu_plan_info.argtypes = [C.c_int, U64P]
