@@ -4,6 +4,5 @@
 
 namespace ntt {
 NTT_DEFINE_LAUNCH_PASS(ArithF64W, 0)
-/* (no fused product kernel for this policy: with six more instructions per butterfly it does not fit the register
- * budget without scratch; products take the fwd, fwd, pointwise, inv chain) */
+NTT_DEFINE_LAUNCH_PRODUCT(ArithF64W, 0)
 } /* namespace ntt */

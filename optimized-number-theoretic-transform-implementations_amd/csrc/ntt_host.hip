@@ -39,6 +39,7 @@ template <> hipError_t launch_pass<ArithF64W, 0>(const PassArgs &);
 template <> hipError_t launch_product<ArithF64, 0>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 1>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 18>(const ProdArgs &);
+template <> hipError_t launch_product<ArithF64W, 0>(const ProdArgs &);
 } // namespace ntt
 
 /* ------------------------------------------------------------------ */
@@ -796,7 +797,10 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;
     pa.stream   = (hipStream_t)stream;
-    hipError_t e = p->kcls == 18 ? launch_product<ArithF64, 18>(pa) : (p->kcls == 1 ? launch_product<ArithF64, 1>(pa) : launch_product<ArithF64, 0>(pa));
+    hipError_t e = p->kcls == kWideClass ? launch_product<ArithF64W, 0>(pa)
+                   : p->kcls == 18       ? launch_product<ArithF64, 18>(pa)
+                   : p->kcls == 1        ? launch_product<ArithF64, 1>(pa)
+                                         : launch_product<ArithF64, 0>(pa);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     for(int k = L.n - 2; k >= 0; k--) { /* inverse column passes of c, the last one ends the transform (N^-1) */
       rc = launch_one_pass(p, L.p[k], d_c + off, nb, true, false, false, k == 0, stream);
@@ -814,7 +818,7 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
-  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->kcls != kWideClass && p->m >= kFusedMax - 2 && p->m <= kFusedMax + 3 && !p->generic &&
+  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax - 2 && p->m <= kFusedMax + 3 && !p->generic &&
      p->has_fwd && p->has_inv && d_a != d_b && d_a && d_b && d_c && batch) {
     return fused_product(p, d_c, d_a, d_b, batch, stream);
   }

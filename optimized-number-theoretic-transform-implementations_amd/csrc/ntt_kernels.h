@@ -1169,11 +1169,15 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       if(pa.max_grid > 0) cap12 = (uint64_t)pa.max_grid;
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
       hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
-    } else if(pa.logn == 13) {
+      return hipGetLastError();
+    }
+    if(pa.logn == 13) {
       using G13 = Geom<13, false, 3>;
       /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
       hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
-    } else if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      return hipGetLastError();
+    }
+    if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
     else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
     return hipGetLastError();
   }

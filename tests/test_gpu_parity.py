@@ -686,11 +686,12 @@ def test_full_batch_forward_cross_check(lib, oracle, kat, m, bits, batch):
 
 
 @pytest.mark.parametrize("m", [14, 13, 12])
-@pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001])
+@pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001, 0xffffffff00001])
 def test_fused_product_kernel(lib, oracle, q, m):
     """N = 2^14, 2^13 and 2^12, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
     equals the oracle's inv(fwd(a) . fwd(b)), the four-launch chain (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial,
-    the schoolbook product; all aliasing forms; batches around the persistent grid"""
+    the schoolbook product; all aliasing forms; batches around the persistent grid.  (0xffffffff00001: a 52-bit prime,
+    served by the reduce-both-operands FP64 policy.)"""
     n = 1 << m
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
@@ -729,15 +730,17 @@ def test_fused_product_kernel(lib, oracle, q, m):
     plan.destroy()
 
 
+@pytest.mark.parametrize("bits", [50, 52])
 @pytest.mark.parametrize("m", [15, 16, 17])
-def test_fused_product_kernel_large(lib, oracle, m):
+def test_fused_product_kernel_large(lib, oracle, m, bits):
     """N = 2^15..2^17: the product fuses block by block (column stages on b, ONE launch fwd block * a^ block -> inverse
     block, inverse column stages): equals the oracle and the four-transform chain, also chunk by chunk"""
     n = 1 << m
-    q = lib.find_prime(50, n, 1)
+    q = lib.find_prime(bits, n, 1)       # 52 bits: the reduce-both-operands FP64 policy
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
     plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    assert plan.info()["f64_class"] == (52 if bits == 52 else 1)
     batch = 5
     a = oracle.fill_uniform(batch * n, q, 81)
     b = oracle.fill_uniform(batch * n, q, 82)
