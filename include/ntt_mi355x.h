@@ -67,7 +67,7 @@ typedef enum ntt_option {
   NTT_OPT_F64_CLASS = 3, /* force a coarser FP64 headroom class (0, 1 or 18) than q permits: tests  */
   NTT_OPT_TWO_PHASE = 4, /* N = 2^15..2^17: 1 = both passes of a polynomial in one workgroup (one launch),
                           * 0 = one launch per pass over the whole batch */
-  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^12..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
+  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes); 0 = fwd, fwd, pointwise, inv (72N bytes) */
 } ntt_option;
 
@@ -132,7 +132,7 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
  * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
- * transform); d_b is overwritten likewise or -- when the fused product kernel serves the call (FP64, N = 2^12 .. 2^14) --
+ * transform); d_b is overwritten likewise or -- when the fused product kernel serves the call (FP64, N = 2^8 .. 2^14) --
  * left as it was; callers must not rely on either.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,

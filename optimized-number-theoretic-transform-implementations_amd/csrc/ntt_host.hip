@@ -757,7 +757,7 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
   return NTT_OK;
 }
 
-/* c = a * b with the fused product kernel (FP64, N = 2^12 .. 2^17).
+/* c = a * b with the fused product kernels (FP64, N = 2^8 .. 2^17).
  *   N <= 2^14: a^ = fwd(a) (lazy words); ONE launch: b -> fwd -> * a^ -> inv -> c.            40N bytes, 2 launches.
  *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14-point blocks (fwd block * a^ block
  *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
@@ -818,7 +818,7 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
-  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax - 2 && p->m <= kFusedMax + 3 && !p->generic &&
+  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= 8 && p->m <= kFusedMax + 3 && !p->generic &&
      p->has_fwd && p->has_inv && d_a != d_b && d_a && d_b && d_c && batch) {
     return fused_product(p, d_c, d_a, d_b, batch, stream);
   }

@@ -99,7 +99,9 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* waves per SIMD the register allocator may assume (VGPR budget 512/x): what
    * the LDS footprint lets be resident, at most 4 */
   static constexpr int WPS0 = (WG_PER_CU0 * (WG / 64)) / 4;
-  static constexpr int WPSC = FLAVOR == 2 ? (WG / 256 > 2 ? WG / 256 : 2) : 4;
+  /* (FLAVOR 3 below 2^12: the product kernel keeps a^ (32 VGPRs) beside the transform's registers -- three
+   * workgroups per CU, 170 VGPRs, as the LDS footprint dictates at 2^10 and 2^11 anyway; four would spill 2-5) */
+  static constexpr int WPSC = FLAVOR == 2 ? (WG / 256 > 2 ? WG / 256 : 2) : (FLAVOR == 3 && LOGN < 12 ? 3 : 4);
   static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > WPSC ? WPSC : WPS0);
 };
 
@@ -961,6 +963,64 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   }
 }
 
+/* The same product for whole polynomials of 2^8 .. 2^11 points, where a 256-thread workgroup holds several blocks
+ * (Geom::BPW) that share the LDS twiddle tables: the plain (non-persistent) loop of fused_kernel's small-block path with
+ * the product and the inverse half appended.  Every per-lane group has its forward table in LDS at these sizes, and the
+ * inverse half reads all of them mirrored, so the kernel issues no per-lane global twiddle load at all; a^ arrives in
+ * the last group's layout as 16-byte loads.  40N bytes per product instead of 72N. */
+template <class A, int LOGN, int KSH>
+__global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
+  fused_product_small_kernel(const ProdParams<A> pp)
+{
+  using P = Plan<LOGN>;
+  using G = Geom<LOGN, false, 3>;
+  static_assert(A::kCompact && G::BPW > 1 && LOGN >= 8 && LOGN <= 11, "whole polynomials of 2^8..2^11 points");
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | kLastInvFlag;
+  __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + G::LDS_TW];
+  const uint32_t         tid = threadIdx.x;
+  const uint32_t         sub = tid >> P::LT;
+  const uint32_t         t   = tid & (P::T - 1);
+  typename A::val *const lds = lds_all + sub * P::LDS_ELEMS;
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+  const lds_ctw_ptr<A>   gtw  = (lds_ctw_ptr<A>)tabl;
+  Params<A> pf = pp.f;
+  pf.s0        = 0;
+  pf.logn      = LOGN;
+  pf.wide      = 0;
+  pf.lazy      = 0;
+  Params<A> pi = pf;
+  pi.tw        = pp.tw_i;
+  pi.tw8       = pp.tw8_i;
+  pi.lastinv   = 1;
+  fill_lds_tables<A, LOGN, false, G>(tabl, pf, 0u, tid);
+  __syncthreads();
+  for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < pf.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
+    uint64_t   b    = b0 + sub;
+    const bool live = b < pf.nblocks;
+    if(!live) b = pf.nblocks - 1; /* idle sub-blocks shadow a real polynomial (barriers are workgroup-wide), never store */
+    typename A::val x[kE];
+    global_load_first<A, LOGN, false>(x, t, pf.a + (b << LOGN), false, pf.c);
+    uint64_t raw[kE];
+    prefetch_last<LOGN>(raw, t, pp.ahat + (b << LOGN));
+    run_group<A, LOGN, 0, false, MASKF, (G::TBL(0) > 0)>(x, t, 0u, pf, gtw);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, t, lds);
+      run_group<A, LOGN, GI + 1, false, MASKF, (G::TBL(GI + 1) > 0)>(x, t, 0u, pf, gtw + G::TBL_OFF(GI + 1));
+    });
+    static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    constexpr int GL = P::NG - 1;
+    run_group<A, LOGN, GL, true, MASKI, (G::TBL(GL) > 0), (G::TBL(GL) > 0)>(x, t, 0u, pi, gtw + G::TBL_OFF(GL));
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = P::NG - 1 - decltype(gg)::value;
+      exchange<A, LOGN, GI, GI - 1>(x, t, lds);
+      run_group<A, LOGN, GI - 1, true, MASKI, (G::TBL(GI - 1) > 0), (G::TBL(GI - 1) > 0)>(x, t, 0u, pi, gtw + G::TBL_OFF(GI - 1));
+    });
+    if(live) global_store_first<A, LOGN, true>(x, t, pp.out + (b << LOGN), pf.c, false);
+  }
+}
+
 template <class A, int R, bool INV, int KSH>
 __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S,
                                                      uint32_t wide, uint32_t lastinv, uint32_t lazy,
@@ -1137,7 +1197,7 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.logn < 12 || pa.logn > 17) return hipErrorNotSupported;
+    if(pa.logn < 8 || pa.logn > 17) return hipErrorNotSupported;
     const uint32_t s0 = pa.logn <= 14 ? 0 : pa.logn - 14; /* leading stages done by column passes around this launch */
     ProdParams<A>  pp{};
     pp.f.a       = pa.b;
@@ -1162,6 +1222,27 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(wgs == 0) return hipSuccess;
     /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
     if(!pa.a_lazy) return hipErrorNotSupported;
+    if(pa.logn < 12) {
+      switch(pa.logn) {
+#define NTT_SMALL_PRODUCT(LN)                                                                                       \
+  case LN: {                                                                                                        \
+    using GS = Geom<LN, false, 3>;                                                                                  \
+    constexpr int per_cu = GS::WG_PER_CU0 < 8 ? GS::WG_PER_CU0 : 8;                                                 \
+    uint64_t      g      = (pp.f.nblocks + GS::BPW - 1) / GS::BPW;                                                  \
+    uint64_t      gcap   = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;           \
+    if(pa.max_grid > 0) gcap = (uint64_t)pa.max_grid;                                                               \
+    if(g > gcap) g = gcap;                                                                                          \
+    hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
+    return hipGetLastError();                                                                                       \
+  }
+        NTT_SMALL_PRODUCT(8)
+        NTT_SMALL_PRODUCT(9)
+        NTT_SMALL_PRODUCT(10)
+        NTT_SMALL_PRODUCT(11)
+#undef NTT_SMALL_PRODUCT
+        default: return hipErrorNotSupported;
+      }
+    }
     if(pa.logn == 12) {
       using G12 = Geom<12, false, 3>;
       constexpr int per_cu = G12::WG_PER_CU0 < G12::WPS ? G12::WG_PER_CU0 : G12::WPS; /* 256-thread workgroups: one wave per SIMD each */

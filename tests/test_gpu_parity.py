@@ -685,10 +685,10 @@ def test_full_batch_forward_cross_check(lib, oracle, kat, m, bits, batch):
     plan.destroy()
 
 
-@pytest.mark.parametrize("m", [14, 13, 12])
+@pytest.mark.parametrize("m", [14, 13, 12, 11, 10, 9, 8])
 @pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001, 0xffffffff00001])
 def test_fused_product_kernel(lib, oracle, q, m):
-    """N = 2^14, 2^13 and 2^12, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
+    """N = 2^8 .. 2^14, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
     equals the oracle's inv(fwd(a) . fwd(b)), the four-launch chain (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial,
     the schoolbook product; all aliasing forms; batches around the persistent grid.  (0xffffffff00001: a 52-bit prime,
     served by the reduce-both-operands FP64 policy.)"""
