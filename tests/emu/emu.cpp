@@ -292,6 +292,86 @@ void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, u
   }
 }
 
+/* fused_product_small_kernel (2^8 .. 2^11): every per-lane group reads its forward table in the LDS layout -- the
+ * inverse half mirrored -- and the last group is an ordinary table group too */
+template <int LOGN> constexpr bool emu_group_per_lane(int g)
+{
+  using P = Plan<LOGN>;
+  for(int j = 0; j < P::R(g); j++)
+    if(P::TW_UNIFORM(g, j)) return false;
+  return true;
+}
+template <int LOGN> constexpr int emu_tbl(int g)
+{
+  using P = Plan<LOGN>;
+  return (g >= 0 && g < P::NG && emu_group_per_lane<LOGN>(g)) ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
+}
+template <int LOGN> constexpr int emu_tbl_off(int g)
+{
+  int o = 0;
+  for(int h = 0; h < g; h++) o += emu_tbl<LOGN>(h);
+  return o;
+}
+template <class A, int LOGN, int KSH>
+void emu_fused_product_small(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, const Params<A> &pf,
+                             const Params<A> &pi)
+{
+  using P                  = Plan<LOGN>;
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | kLastInvFlag;
+  constexpr int      GL    = P::NG - 1;
+  std::vector<typename A::ctw> table((size_t)emu_tbl_off<LOGN>(P::NG) + 1);
+  static_for<0, P::NG>([&](auto gg) {
+    constexpr int G = decltype(gg)::value;
+    if constexpr(emu_tbl<LOGN>(G) > 0) {
+      constexpr int SG = P::S(G);
+      for(int jj = 0; jj < P::R(G); jj++) {
+        const int              slj = SG + jj;
+        const typename A::ctw *src = pf.tw8 + ((size_t)1 << slj);
+        for(uint32_t l = 0; l < (1u << slj); l++) {
+          const uint32_t u = l & ((1u << jj) - 1u), prefix = l >> jj;
+          table[(size_t)emu_tbl_off<LOGN>(G) + (((1u << jj) - 1u) << SG) + (u << SG) + prefix] = src[l];
+        }
+      }
+    }
+  });
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         regs(P::T);
+  for(uint64_t pb = 0; pb < batch; pb++) {
+    const uint64_t *bb = b + (pb << LOGN);
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      global_load_first<A, LOGN, false>(regs[t].x, t, bb, false, pf.c);
+      run_group<A, LOGN, 0, false, MASKF, (emu_tbl<LOGN>(0) > 0)>(regs[t].x, t, 0u, pf, table.data());
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+        run_group<A, LOGN, G + 1, false, MASKF, (emu_tbl<LOGN>(G + 1) > 0)>(regs[t].x, t, 0u, pf, table.data() + emu_tbl_off<LOGN>(G + 1));
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      const uint32_t ib = P::IBASE(GL, t);
+      for(int e = 0; e < kE; e++) {
+        const uint64_t aw = ahat[(pb << LOGN) + ib + P::IOFF(GL, e)];
+        regs[t].x[e]      = A::template product_in_domain<true>(regs[t].x[e], aw, pf.c);
+      }
+      run_group<A, LOGN, GL, true, MASKI, (emu_tbl<LOGN>(GL) > 0), (emu_tbl<LOGN>(GL) > 0)>(regs[t].x, t, 0u, pi, table.data() + emu_tbl_off<LOGN>(GL));
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = P::NG - 1 - decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+        run_group<A, LOGN, G - 1, true, MASKI, (emu_tbl<LOGN>(G - 1) > 0), (emu_tbl<LOGN>(G - 1) > 0)>(regs[t].x, t, 0u, pi,
+                                                                                                      table.data() + emu_tbl_off<LOGN>(G - 1));
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, out + (pb << LOGN), pf.c);
+  }
+}
+
 template <class A, int R, bool INV, int KSH>
 static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, bool wide, bool lastinv,
                        const typename A::tw *tab, const typename A::consts &c, bool lazy_out)
@@ -374,6 +454,13 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
 #define EMU_PROD(KW, A, K)                                               \
   KW template void emu_fused_product<A, 14, K, true> EMU_PROD_ARGS(A);   \
   KW template void emu_fused_product<A, 14, K, false> EMU_PROD_ARGS(A);
+#define EMU_PROD_OTHER(KW, A, K)                                               \
+  KW template void emu_fused_product<A, 13, K, true> EMU_PROD_ARGS(A);         \
+  KW template void emu_fused_product<A, 12, K, true> EMU_PROD_ARGS(A);         \
+  KW template void emu_fused_product_small<A, 11, K> EMU_PROD_ARGS(A);         \
+  KW template void emu_fused_product_small<A, 10, K> EMU_PROD_ARGS(A);         \
+  KW template void emu_fused_product_small<A, 9, K> EMU_PROD_ARGS(A);          \
+  KW template void emu_fused_product_small<A, 8, K> EMU_PROD_ARGS(A);
 using WideChk = WideF64<ArithF64Chk>;
 #if EMU_PART >= 0
 #  define P1(KW) EMU_RUN(KW, ArithU64, 0) EMU_RUN(KW, ArithU64R4, 0) EMU_RUN(KW, ArithF64W, 0)
@@ -383,8 +470,9 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P5(KW) EMU_RUN(KW, ArithF64Chk, 1) EMU_RUN(KW, WideChk, 0)
 #  define P6(KW) EMU_PROD(KW, ArithF64, 0) EMU_PROD(KW, ArithF64, 1) EMU_PROD(KW, ArithF64, 18) \
                  EMU_PROD(KW, ArithF64Chk, 0) EMU_PROD(KW, ArithF64Chk, 1) EMU_PROD(KW, ArithF64Chk, 18)
+#  define P7(KW) EMU_PROD_OTHER(KW, ArithF64Chk, 0) EMU_PROD_OTHER(KW, ArithF64Chk, 1) EMU_PROD_OTHER(KW, WideChk, 0)
 #  if EMU_PART == 0
-P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern)
+P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern)
 #  elif EMU_PART == 1
 P1()
 #  elif EMU_PART == 2
@@ -397,6 +485,8 @@ P4()
 P5()
 #  elif EMU_PART == 6
 P6()
+#  elif EMU_PART == 7
+P7()
 #  endif
 #endif
 
@@ -555,6 +645,55 @@ int emu_fused_product14(uint64_t *out, const uint64_t *ahat, const uint64_t *b, 
   if(cls == 1) RUNP(ArithF64, 1)
   RUNP(ArithF64, 0)
 #undef RUNP
+}
+#endif
+
+#ifndef EMU_SAN_BUILD
+/* the same for the product kernels' other sizes (m = 8 .. 13), always with the CHECKED policy and a lazy-or-canonical a^
+ * as ntt_fwd_batch_lazy leaves it: fused_product_small_kernel (8..11), fused_product_kernel (12, 13).  Moduli above
+ * 2^51(1+2^-10) run the reduce-both-operands policy. */
+int emu_fused_product_chk(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root)
+{
+  if(m < 8 || m > 13) return -1;
+  const uint64_t N    = 1ull << m;
+  const bool     wide = !h_f64_eligible(q);
+  if(wide && !h_f64w_eligible(q)) return -2;
+  const uint64_t rinv = h_powmod(root, q - 2, q);
+  const auto     w    = h_power_table(root, N, q);
+  const auto     wi   = h_power_table(rinv, N, q);
+  const auto     wix  = h_with_folded_ninv(wi, h_powmod(N % q, q - 2, q), q);
+  std::vector<TwF64>  tf(w.size()), ti(wix.size());
+  std::vector<double> tf8(w.size()), ti8(wi.size());
+  for(size_t i = 0; i < w.size(); i++) {
+    tf[i]  = h_tw_f64(w[i], q);
+    tf8[i] = tf[i].w;
+  }
+  for(size_t i = 0; i < wix.size(); i++) ti[i] = h_tw_f64(wix[i], q);
+  for(size_t i = 0; i < wi.size(); i++) ti8[i] = h_tw_f64(wi[i], q).w;
+  const auto c   = h_consts_f64(q, N, wi);
+  const int  cls = wide ? 0 : (h_f64_ksh(q) >= 1 ? 1 : 0);
+#define RUNQ(POL, K, FN, LN)                                                                                 \
+  {                                                                                                         \
+    Params<POL> pf{}, pi{};                                                                                 \
+    pf.tw = tf.data(); pf.tw8 = tf8.data(); pf.c = c; pf.logn = LN;                                          \
+    pi = pf; pi.tw = ti.data(); pi.tw8 = ti8.data(); pi.lastinv = 1;                                         \
+    FN(out, ahat, b, batch, pf, pi);                                                                        \
+    return 0;                                                                                               \
+  }
+#define RUNM(POL, K)                                                                                        \
+  switch(m) {                                                                                               \
+    case 13: RUNQ(POL, K, (emu_fused_product<POL, 13, K, true>), 13)                                         \
+    case 12: RUNQ(POL, K, (emu_fused_product<POL, 12, K, true>), 12)                                         \
+    case 11: RUNQ(POL, K, (emu_fused_product_small<POL, 11, K>), 11)                                         \
+    case 10: RUNQ(POL, K, (emu_fused_product_small<POL, 10, K>), 10)                                         \
+    case 9: RUNQ(POL, K, (emu_fused_product_small<POL, 9, K>), 9)                                            \
+    default: RUNQ(POL, K, (emu_fused_product_small<POL, 8, K>), 8)                                           \
+  }
+  if(wide) { RUNM(WideChk, 0) }
+  if(cls == 1) { RUNM(ArithF64Chk, 1) }
+  RUNM(ArithF64Chk, 0)
+#undef RUNM
+#undef RUNQ
 }
 #endif
 

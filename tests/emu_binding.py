@@ -25,6 +25,7 @@ class Emu:
         L.emu_set_lazy.argtypes = [C.c_int]
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
+        L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
         """arith: 0 = integer radix-2, 1 = FP64, 2 = checked FP64, 3 = integer radix-4 (expanded table)"""
@@ -42,6 +43,15 @@ class Emu:
         out = np.zeros_like(b)
         rc = self.lib.emu_fused_product14(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
                                           b.size >> 14, q, root, int(a_lazy), int(chk))
+        return rc, out
+
+    def fused_product_chk(self, ahat, b, m, q, root):
+        """inv(fwd(b) * ahat) as the product kernels for N = 2^8 .. 2^13 compute it, checked policy"""
+        ahat = np.ascontiguousarray(ahat, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(b)
+        rc = self.lib.emu_fused_product_chk(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
+                                            b.size >> m, m, q, root)
         return rc, out
 
     def expand_radix4(self, w, q):

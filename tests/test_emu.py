@@ -285,6 +285,32 @@ def test_fused_product_kernel_logic(oracle, emu, q):
     assert fails == 0
 
 
+@pytest.mark.parametrize("m", [8, 9, 10, 11, 12, 13])
+def test_fused_product_kernels_other_sizes_logic(oracle, emu, m):
+    """the product kernels below 2^14 step by step on the CPU with the checked policy: fused_product_kernel at 2^12 and
+    2^13 (one LDS table, last group's twiddles preloaded), fused_product_small_kernel at 2^8..2^11 (EVERY per-lane group,
+    the last one included, from its forward table -- the inverse half mirrored); 51-, 50- and 52-bit moduli (scheduled
+    classes 0 and 1, reduce-both-operands policy); lazy a^ as the forward transform leaves it"""
+    n = 1 << m
+    for q in (0x7fffffffe0001, oracle.find_prime(50, n, 0), oracle.find_prime(52, n, 1)):
+        w = oracle.min_root(q, n)
+        cx = oracle.ctx(n, q, w)
+        a = oracle.fill_uniform(3 * n, q, 131 + m)
+        b = oracle.fill_uniform(3 * n, q, 132 + m)
+        b[:8] = [0, 1, q - 1, q - 2, 2, 3, q // 2, q // 2 + 1]
+        expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
+        if m <= 10:
+            assert np.array_equal(expect[:n], oracle.schoolbook(a[:n].copy(), b[:n].copy(), n, q))
+        emu.chk_stats()
+        arith = 4 if q > (1 << 51) + (1 << 41) else 1
+        rc, ahat = emu.transform(a, m, q, w, arith, lazy=True)
+        assert rc == 0
+        rc, c = emu.fused_product_chk(ahat, b, m, q, w)
+        assert rc == 0 and np.array_equal(c, expect), (m, hex(q))
+        fails, maxb, maxr = emu.chk_stats()
+        assert fails == 0, (m, hex(q))
+
+
 @pytest.mark.parametrize("m", [6, 9, 12, 13, 14, 15])
 def test_wide_fp64_policy_52_bit_moduli(oracle, emu, m):
     """ArithF64W: moduli between 2^51(1+2^-10) and 2^52 (less than one bit below 2^53/2): both operands of every
