@@ -65,8 +65,9 @@ typedef enum ntt_option {
   NTT_OPT_MAX_GRID  = 1, /* cap on workgroups per launch (0 = the kernels' own choice)             */
   NTT_OPT_CHUNK_MIB = 2, /* bytes of one chunk of a multi-pass transform, MiB (default 256)        */
   NTT_OPT_F64_CLASS = 3, /* force a coarser FP64 headroom class (0, 1 or 18) than q permits: tests  */
-  NTT_OPT_TWO_PHASE = 4, /* N = 2^15..2^17: 1 = both passes of a polynomial in one workgroup (one launch),
-                          * 0 = one launch per pass over the whole batch */
+  NTT_OPT_TWO_PHASE = 4, /* N = 2^16, 2^17 (FP64): 1 = both passes of a polynomial in one workgroup (one launch),
+                          * 0 = one launch per pass over the whole batch, -1 (default) = the faster of the two as
+                          * measured: one launch for the forward transform at 2^16, per pass elsewhere */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes); 0 = fwd, fwd, pointwise, inv (72N bytes) */
 } ntt_option;

@@ -221,7 +221,8 @@ struct ntt_plan {
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
   bool             fused_product = true; /* N = 2^14, FP64: ntt_negacyclic_mul_batch as fwd(a) + fused_product_kernel */
-  bool             two_phase  = false; /* 2^15..2^17: both passes of a polynomial inside one workgroup (twophase_kernel) */
+  int              two_phase  = -1;    /* 2^16, 2^17: both passes of a polynomial inside one workgroup (twophase_kernel):
+                                        * 1 on, 0 off, -1 where it measured faster (forward 2^16, scheduled FP64 policy: +3 %) */
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
@@ -507,7 +508,7 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       p->chunk_mib = (int)value;
       return NTT_OK;
     case NTT_OPT_TWO_PHASE:
-      p->two_phase = value != 0;
+      p->two_phase = value < 0 ? -1 : (value != 0);
       return NTT_OK;
     case NTT_OPT_FUSED_PRODUCT:
       p->fused_product = value != 0;
@@ -549,7 +550,8 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
   const PassList L = make_passes(p->m, p->generic);
-  if(p->two_phase && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3) {
+  const bool tp_auto = p->two_phase < 0 && !inverse && p->m == kFusedMax + 2 && p->kcls != kWideClass;
+  if((p->two_phase == 1 || tp_auto) && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3) {
     /* one launch, one workgroup per polynomial, both passes back to back (ntt_kernels.h: twophase_kernel) */
     PassArgs pa{};
     pa.a        = d_a;

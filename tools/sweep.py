@@ -13,7 +13,7 @@ ap.add_argument("--bytes", type=float, default=8e9)
 ap.add_argument("--qs", nargs="+", default=["0x7fffffffe0001"])
 ap.add_argument("--arith", nargs="+", default=["auto"])
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--two-phase", type=int, default=0, help="N=2^15..2^17: 1 = one launch per transform (default), 0 = one launch per pass")
+ap.add_argument("--two-phase", type=int, default=-1, help="N=2^16, 2^17: 1 = one launch per transform, 0 = one launch per pass, -1 = the library's choice (default)")
 ap.add_argument("--fused-product", type=int, default=1, help="ntt_negacyclic_mul_batch: 1 = fused product kernel where built (default), 0 = four transforms")
 a = ap.parse_args()
 ap2 = None
