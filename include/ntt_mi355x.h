@@ -68,6 +68,9 @@ typedef enum ntt_option {
   NTT_OPT_TWO_PHASE = 4, /* N = 2^16, 2^17 (FP64): 1 = both passes of a polynomial in one workgroup (one launch),
                           * 0 = one launch per pass over the whole batch, -1 (default) = the faster of the two as
                           * measured: one launch for the forward transform at 2^16, per pass elsewhere */
+  NTT_OPT_BLOCK_LOG = 6, /* N = 2^15, 2^16: log2 of the blocks the fused pass works on below the column pass: 12
+                          * (3 or 4 column stages), 14 (1 or 2), 0 (default) = the faster one as measured.  Results
+                          * are identical. */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes); 0 = fwd, fwd, pointwise, inv (72N bytes) */
 } ntt_option;

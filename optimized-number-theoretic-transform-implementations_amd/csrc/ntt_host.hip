@@ -220,6 +220,7 @@ struct ntt_plan {
   int              max_grid   = 0;
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
+  int              block_log  = 0;     /* multi-pass transforms: block size below the column passes (0 = multi_pass_block's choice) */
   bool             fused_product = true; /* N = 2^14, FP64: ntt_negacyclic_mul_batch as fwd(a) + fused_product_kernel */
   int              two_phase  = -1;    /* 2^16, 2^17: both passes of a polynomial inside one workgroup (twophase_kernel):
                                         * 1 on, 0 off, -1 where it measured faster (forward 2^16, scheduled FP64 policy: +3 %) */
@@ -513,6 +514,11 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
     case NTT_OPT_FUSED_PRODUCT:
       p->fused_product = value != 0;
       return NTT_OK;
+    case NTT_OPT_BLOCK_LOG:
+      if(value != 0 && value != kFusedSmallBlock && value != kFusedLarge) return fail(NTT_ERR_ARG, "block size must be 0 (automatic), 12 or 14");
+      if(value == kFusedSmallBlock && p->m > kFusedSmallBlock + 4) return fail(NTT_ERR_ARG, "2^12-point blocks need at most 4 leading stages");
+      p->block_log = (int)value;
+      return NTT_OK;
     case NTT_OPT_F64_CLASS: {
       /* a coarser (smaller) headroom class than the modulus allows is always valid: it only reduces more often */
       if(p->arith != NTT_ARITH_F64 || p->kcls == kWideClass) return fail(NTT_ERR_ARG, "not a plan of the scheduled FP64 policy");
@@ -549,7 +555,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
-  const PassList L = make_passes(p->m, p->generic);
+  const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
   const bool tp_auto = p->two_phase < 0 && !inverse && p->m == kFusedMax + 2 && p->kcls != kWideClass;
   if((p->two_phase == 1 || tp_auto) && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3) {
     /* one launch, one workgroup per polynomial, both passes back to back (ntt_kernels.h: twophase_kernel) */

@@ -1129,7 +1129,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
      * passes, not ending it */
     if(pa.lastinv) {
       hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
-    } else if constexpr(LOGN == kFusedLarge) {
+    } else if constexpr(LOGN == kFusedLarge || LOGN == kFusedSmallBlock) {
       hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
     } else {
       return hipErrorInvalidValue;

@@ -3,10 +3,14 @@
  *
  *   6 <= m <= 14 : one fused pass (block = whole polynomial, one HBM round trip)
  *   m  > 14      : strided column passes of <= 4 stages over the leading
- *                  m-14 stages, then one fused pass over 2^14-point blocks
- *                  (measured 2-6 % faster than 2^13-point blocks)
+ *                  stages, then one fused pass over 2^14- or 2^12-point blocks
  *                  (two or more HBM round trips; reference sizes m = 15,16,17,
- *                  tests/test_cases.h:184-203)
+ *                  tests/test_cases.h:184-203).  The column pass is memory-bound
+ *                  whatever its stage count, the block pass is bound by its FP64 work
+ *                  (board power): at m = 15, 16 a 3- or 4-stage column pass over
+ *                  2^12-point blocks measured 2-5 % faster than 1 or 2 stages over
+ *                  2^14-point blocks (profiles/r02/ablations.txt); m = 17 would need
+ *                  two column passes and keeps 2^14.
  *   m  < 6       : column passes only
  * The inverse runs the same passes in the opposite order.
  */
@@ -18,6 +22,7 @@ namespace ntt {
 constexpr int kFusedMin   = 6;
 constexpr int kFusedMax   = 14;
 constexpr int kFusedLarge = 14; /* block size used below column passes */
+constexpr int kFusedSmallBlock = 12; /* ... and the alternative: more stages in the memory-bound column pass */
 
 struct Pass {
   int fused; /* 1: fused block pass, 0: column pass            */
@@ -30,8 +35,16 @@ struct PassList {
   Pass p[16];
 };
 
+/* block size below the column passes for a transform of 2^m points (m > kFusedMax) */
+inline int multi_pass_block(int m, bool inverse, bool fp64)
+{
+  /* (integer policy: 2^12 blocks measured +5..7 % for the inverse, -3..-17 % for the forward transform) */
+  if((m == 15 || m == 16) && (fp64 || inverse)) return kFusedSmallBlock;
+  return kFusedLarge;
+}
+
 /* forward order; generic=true forces column passes only (cross-check path) */
-inline PassList make_passes(int m, bool generic)
+inline PassList make_passes(int m, bool generic, int block_log = kFusedLarge)
 {
   PassList L{};
   int      lead  = 0;
@@ -39,7 +52,7 @@ inline PassList make_passes(int m, bool generic)
   if(!generic && m >= kFusedMin && m <= kFusedMax) {
     block = m;
   } else if(!generic && m > kFusedMax) {
-    block = kFusedLarge;
+    block = block_log;
     lead  = m - block;
   } else {
     lead = m;

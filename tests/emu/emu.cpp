@@ -391,7 +391,7 @@ template <class A, bool INV, int KSH>
 int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
             const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
 {
-  const PassList L = make_passes(m, generic);
+  const PassList L = make_passes(m, generic, multi_pass_block(m, INV, A::kTracksBounds)); /* as the library's run_transform */
   const bool lazy  = g_lazy;
   for(int k = 0; k < L.n; k++) {
     const Pass &ps      = L.p[INV ? L.n - 1 - k : k];

@@ -1049,3 +1049,41 @@ def test_concurrent_host_threads_on_their_own_streams(lib, oracle, kat):
     assert not errors, errors
     for idx, (got, a, n, q, w) in results.items():
         assert np.array_equal(got, oracle.ctx(n, q, w).fwd(a)), idx
+
+
+@pytest.mark.parametrize("m", [15, 16])
+@pytest.mark.parametrize("arith", ["u64", "f64", "f64_52bit"])
+def test_block_sizes_below_the_column_pass_agree(lib, oracle, m, arith):
+    """N = 2^15, 2^16: 3 or 4 column stages over 2^12-point blocks (the default where it measured faster) and 1 or 2 over
+    2^14-point blocks (NTT_OPT_BLOCK_LOG) are the same transform: both equal the oracle, forward and inverse, lazy
+    outputs of the integer policy bit for bit, also chunk by chunk; 2^17 refuses the small blocks (5 leading stages)"""
+    n = 1 << m
+    q = lib.find_prime(52 if arith == "f64_52bit" else 50, n, 0)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    batch = 5
+    a = _inputs(oracle, n, q, batch, 900 + m)
+    want = cx.fwd(a)
+    plan = lib.Plan(n, q, w, arith=lib.ARITH_U64 if arith == "u64" else lib.ARITH_F64)
+    plan.set_option(lib.OPT_TWO_PHASE, 0)
+    lazies = []
+    for blk, chunk in ((0, 256), (12, 256), (14, 256), (12, 1), (14, 1)):
+        plan.set_option(lib.OPT_BLOCK_LOG, blk)
+        plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+        assert np.array_equal(plan.fwd_host(a), want), (blk, chunk, "fwd")
+        assert np.array_equal(plan.inv_host(want), a), (blk, chunk, "inv")
+        lz = plan.fwd_host(a, lazy=True)
+        assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), want)
+        lazies.append(lz)
+    if arith == "u64":
+        assert all(np.array_equal(lazies[0], x) for x in lazies) and np.array_equal(lazies[0], cx.fwd_lazy(a))
+    with pytest.raises(lib.NttError):
+        plan.set_option(lib.OPT_BLOCK_LOG, 13)
+    plan.destroy()
+    if m == 16:
+        n17 = 1 << 17
+        q17 = lib.find_prime(50, n17, 0)
+        p17 = lib.Plan(n17, q17, lib.min_root(q17, n17))
+        with pytest.raises(lib.NttError):
+            p17.set_option(lib.OPT_BLOCK_LOG, 12)
+        p17.destroy()

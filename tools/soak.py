@@ -67,6 +67,9 @@ while time.time() < t_end:
     if rng.random() < 0.2 and arith != lib.ARITH_U64_R4:
         opts["generic"] = 1
         plan.set_generic(1)
+    if rng.random() < 0.3 and m in (15, 16):
+        opts["block"] = int(rng.choice([12, 14]))
+        plan.set_option(lib.OPT_BLOCK_LOG, opts["block"])
     if rng.random() < 0.3:
         opts["fused_product"] = 0
         plan.set_option(lib.OPT_FUSED_PRODUCT, 0)

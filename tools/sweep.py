@@ -15,6 +15,7 @@ ap.add_argument("--arith", nargs="+", default=["auto"])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--two-phase", type=int, default=-1, help="N=2^16, 2^17: 1 = one launch per transform, 0 = one launch per pass, -1 = the library's choice (default)")
 ap.add_argument("--fused-product", type=int, default=1, help="ntt_negacyclic_mul_batch: 1 = fused product kernel where built (default), 0 = four transforms")
+ap.add_argument("--block-log", type=int, default=0, help="N=2^15, 2^16: block size below the column pass (12, 14, 0 = library's choice)")
 a = ap.parse_args()
 ap2 = None
 AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64, "r4": lib.ARITH_U64_R4}
@@ -33,6 +34,7 @@ for qs in a.qs:
                 print(ln, qs, ar, "unsupported:", e); continue
             plan.set_option(lib.OPT_TWO_PHASE, a.two_phase)
             plan.set_option(lib.OPT_FUSED_PRODUCT, a.fused_product)
+            if a.block_log and ln in (15, 16): plan.set_option(lib.OPT_BLOCK_LOG, a.block_log)
             nb = 3 if "mul" in a.ops else 1
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
             for i, b in enumerate(bufs): lib.fill_uniform(b.ptr, batch * n, q, 77 + i)
