@@ -767,7 +767,7 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
 
 /* c = a * b with the fused product kernels (FP64, N = 2^8 .. 2^17).
  *   N <= 2^14: a^ = fwd(a) (lazy words); ONE launch: b -> fwd -> * a^ -> inv -> c.            40N bytes, 2 launches.
- *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14-point blocks (fwd block * a^ block
+ *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14- or 2^12-point blocks (fwd block * a^ block
  *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
  *              inverse on c.                                                                   88N bytes, 5 launches
  *              (120N and 7 launches for fwd, fwd, pointwise, inv). */
@@ -776,7 +776,11 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(rc) return rc;
   USE_DEVICE(p->device);
-  const PassList L     = make_passes(p->m, false);
+  /* blocks of the fused launch for N > 2^14: as for the transforms, stages are cheaper in the memory-bound column
+   * passes than in the FP64-bound fused launch -- 2^12-point blocks where 4 column stages reach (measured +3..5 % at
+   * 2^15 and 2^16; 2^13-point blocks at 2^17: -1 %, not used) */
+  const int      pblk   = p->m > kFusedMax ? (p->block_log ? p->block_log : (p->m <= kFusedSmallBlock + 4 ? kFusedSmallBlock : kFusedLarge)) : p->m;
+  const PassList L     = make_passes(p->m, false, pblk);
   uint64_t       chunk = batch;
   if(L.n > 1) {
     chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t));
@@ -801,6 +805,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.consts   = &p->cf;
     pa.batch    = nb;
     pa.logn     = (uint32_t)p->m;
+    pa.block_log = (uint32_t)pblk;
     pa.a_lazy   = 1;
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;

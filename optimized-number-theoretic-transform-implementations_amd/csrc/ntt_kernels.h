@@ -873,8 +873,8 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
 {
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, 3>;
-  static_assert(A::kCompact && G::BPW == 1 && (LOGN == 14 || ((LOGN == 13 || LOGN == 12) && WHOLE)),
-                "built for the FP64 policy on 2^14-point blocks and whole 2^13- and 2^12-point polynomials");
+  static_assert(A::kCompact && G::BPW == 1 && (LOGN == 14 || LOGN == 12 || (LOGN == 13 && WHOLE)),
+                "built for the FP64 policy on blocks of 2^12 and 2^14 points and whole polynomials of 2^13");
   constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
   constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>() | (WHOLE ? kLastInvFlag : 0u);
   constexpr int      GL    = P::NG - 1;
@@ -1071,6 +1071,7 @@ struct ProdArgs {
   const void *    consts;
   uint64_t        batch;
   uint32_t        logn;
+  uint32_t        block_log; /* N > 2^14: log2 of the blocks (12, 13 or 14); the column passes around the launch cover logn - block_log stages */
   int             a_lazy;
   int             max_grid, num_cus;
   hipStream_t     stream;
@@ -1198,7 +1199,9 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     return hipErrorNotSupported;
   } else {
     if(pa.logn < 8 || pa.logn > 17) return hipErrorNotSupported;
-    const uint32_t s0 = pa.logn <= 14 ? 0 : pa.logn - 14; /* leading stages done by column passes around this launch */
+    const uint32_t blog = pa.logn <= 14 ? pa.logn : (pa.block_log ? pa.block_log : 14u);
+    if(blog < 12 && pa.logn > 14) return hipErrorInvalidValue;
+    const uint32_t s0 = pa.logn - blog; /* leading stages done by column passes around this launch */
     ProdParams<A>  pp{};
     pp.f.a       = pa.b;
     pp.f.tw      = static_cast<const typename A::tw *>(pa.tw_f);
@@ -1222,7 +1225,7 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(wgs == 0) return hipSuccess;
     /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
     if(!pa.a_lazy) return hipErrorNotSupported;
-    if(pa.logn < 12) {
+    if(blog < 12) {
       switch(pa.logn) {
 #define NTT_SMALL_PRODUCT(LN)                                                                                       \
   case LN: {                                                                                                        \
@@ -1243,18 +1246,22 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
         default: return hipErrorNotSupported;
       }
     }
-    if(pa.logn == 12) {
+    if(blog == 12) {
       using G12 = Geom<12, false, 3>;
       constexpr int per_cu = G12::WG_PER_CU0 < G12::WPS ? G12::WG_PER_CU0 : G12::WPS; /* 256-thread workgroups: one wave per SIMD each */
       uint64_t      cap12  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * per_cu;
       if(pa.max_grid > 0) cap12 = (uint64_t)pa.max_grid;
+      if(cap12 < (1ull << s0)) cap12 = 1ull << s0;
+      cap12 &= ~((1ull << s0) - 1);
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
-      hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
       return hipGetLastError();
     }
-    if(pa.logn == 13) {
+    if(blog == 13) {
       using G13 = Geom<13, false, 3>;
       /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
+      if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
       hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
       return hipGetLastError();
     }

@@ -746,12 +746,14 @@ def test_fused_product_kernel_large(lib, oracle, m, bits):
     b = oracle.fill_uniform(batch * n, q, 82)
     expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
     da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
-    for fused, chunk in ((1, 256), (1, 1), (0, 256)):
+    for fused, chunk, blk in ((1, 256, 0), (1, 1, 0), (0, 256, 0), (1, 256, 14), (1, 1, 12 if m < 17 else 14)):
         plan.set_option(lib.OPT_FUSED_PRODUCT, fused)
         plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+        plan.set_option(lib.OPT_BLOCK_LOG, blk)      # blocks of the fused launch (and of the transforms): 2^12 or 2^14
         da.upload(a), db.upload(b)
         plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
-        assert np.array_equal(dc.download(), expect), (fused, chunk)
+        assert np.array_equal(dc.download(), expect), (fused, chunk, blk)
+    plan.set_option(lib.OPT_BLOCK_LOG, 0)
     plan.set_option(lib.OPT_FUSED_PRODUCT, 1)
     da.upload(a), db.upload(b)
     plan.negacyclic_mul(db.ptr, da.ptr, db.ptr, batch)           # c aliases b
