@@ -55,3 +55,17 @@ build/skel: tools/skel.hip
 sanitize:
 	$(MAKE) -C tests/sanitize run
 .PHONY: sanitize
+
+# memory skeleton of the XCD-local four-step transform for N = 2^16 / 2^17 (run on the GPU box: build/skel4 [GiB] [reps] [filter])
+skel4: build/skel4
+build/skel4: tools/skel4.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -o $@ tools/skel4.hip
+.PHONY: skel4
+
+# second skeleton of the XCD-local two-pass transform: barrier-free items, class queues (build/skel5 [GiB] [reps] [filter])
+skel5: build/skel5
+build/skel5: tools/skel5.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -ffp-contract=off -o $@ tools/skel5.hip
+.PHONY: skel5

@@ -1,38 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- batched forward NTTs/s at N=2^14, ~50-bit q, on MI355X.
+"""bench.py -- batched forward NTTs/s at N=2^14, ~50-bit q, on MI355X (and BASELINE's other GPU configs).
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config 2|3|4|5]
 
-One "step" = one in-place forward negacyclic NTT (reduced output, the semantics of
-the reference's fwd_ntt_radix4 / fwd_ntt_ref_harvey) over every GPU's shard of
-independent polynomials, already resident in HBM.  Workload = BASELINE.json
-config 4 ("N=16384, 50-bit q, batch=2^20 sharded across 8 GPUs"): N = 2^14
-coefficients modulo q = 0x7fffffffe0001 (reference tests/test_cases.h case 12, the
-51-bit prime SURVEY 8d maps this config to).
+Default (= --config 4, the configuration BASELINE.json's metric is quoted on): one "step" = one in-place forward
+negacyclic NTT (reduced output, the semantics of the reference's fwd_ntt_radix4 / fwd_ntt_ref_harvey) over every
+GPU's shard of independent polynomials, already resident in HBM: N = 2^14 coefficients modulo q = 0x7fffffffe0001
+(reference tests/test_cases.h case 12, the 51-bit prime SURVEY 8d maps "50-bit q" to), batch 2^20 sharded over 8 GPUs.
 
-  --scaling weak   (default) every GPU holds 2^20/8 = 131072 polynomials (16 GiB)
-  --scaling strong the 2^20 polynomials (128 GiB) are split over the N GPUs
+  --scaling weak   (default) every GPU holds the config's per-GPU share (config 4: 2^20/8 = 131072 polynomials, 16 GiB)
+  --scaling strong the config's total batch is split over the N GPUs in use
 
-The path shards by independent polynomials: no collective on the data path
-(SURVEY 8e).  Two ways to run N > 1, same shard code either way:
+  --config 2   N=4096, 50-bit q, batch 65536, forward                      unit NTT/s,            16N bytes per unit
+  --config 3   N=65536, 52-bit q, batch 8192, forward + inverse round trip unit round trips/s,    32N bytes per unit
+  --config 4   (default, above)                                             unit NTT/s,            16N bytes per unit
+  --config 5   N=2^17, 4-prime RNS, batch 4096 over 8 GPUs: per limb fwd(a), fwd(b), pointwise, inv
+                                                                            unit RNS products/s,   4 x 56N bytes per unit
+  (config 1 is the reference's own CPU case: it is a parity test, tests/test_oracle_golden.py, not a bench line)
 
-  * `python bench.py --gpus N` alone: ONE process drives the N devices, one HIP
-    stream and one pair of HIP events per device, one host wall clock around all
-    of them (north_star: "per-GPU HIP streams only, no RCCL");
-  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-    (WORLD_SIZE set): one rank per GPU; torch.distributed (RCCL) is used for the
-    barrier and the MAX-reduction of the elapsed time only.
+The path shards by independent polynomials: no collective on the data path.  Two ways to run N > 1, same
+shard code either way:
 
-Rank 0 prints ONE JSON line: metric/value (whole-job NTT/s), roofline of the
-dominant kernel (algorithmic bytes 16*N per NTT / measured launch time, HIP events
-on the launch stream) and, at N=1, the CPU baseline timed on this box's host cores.
+  * `python bench.py --gpus N` alone: ONE process drives the N devices, one HIP stream and one set of HIP events per
+    device, one host wall clock around all of them (north_star: "per-GPU HIP streams only, no RCCL");
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set): one rank per
+    GPU; torch.distributed (RCCL) is used for the barrier and the MAX-reduction of the elapsed time only.
+
+Rank 0 prints ONE JSON line: metric/value (whole-job units/s), roofline (algorithmic bytes per step / device time of a
+step, HIP events on the launch stream, with mean, min and median over the K steps) and, at N=1, the CPU baseline:
+the reference's own radix-4 functions (oracle/_ref) timed on this box's host cores by a pthread harness.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -49,7 +52,61 @@ SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NTT = 16 * N       # one 8-byte read + one 8-byte write per coefficient
 METRIC = "batched forward NTTs/sec at N=2^14, 50-bit q; achieved HBM GB/s vs peak"
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# workloads = BASELINE.json configs 2..5 on one GPU's shard
+# --------------------------------------------------------------------------------------------------------------
+class Workload:
+    """What one step does, in which unit it is counted and how many algorithmic HBM bytes a unit moves."""
+
+    def __init__(self, config, logn, kind, total_batch, shards, unit, metric, bytes_per_unit, cpu_op, limbs=1, qbits=None,
+                 q=None, root=None, note=""):
+        self.config, self.logn, self.n, self.kind = config, logn, 1 << logn, kind
+        self.total_batch, self.shards, self.unit, self.metric = total_batch, shards, unit, metric
+        self.bytes_per_unit, self.cpu_op, self.limbs = bytes_per_unit, cpu_op, limbs
+        self.qbits, self.q, self.root, self.note = qbits, q, root, note
+        self.qs, self.roots = None, None
+
+    def resolve(self, lib):
+        """moduli and roots (generated ones: the library's prime finder / minimum-root rule)"""
+        if self.qs is None:
+            if self.q is not None:
+                self.qs = [self.q]
+                self.roots = [self.root if self.root and self.n == N else lib.min_root(self.q, self.n)]
+            else:
+                self.qs = [lib.find_prime(self.qbits, self.n, k) for k in range(self.limbs)]
+                self.roots = [lib.min_root(q, self.n) for q in self.qs]
+        return self
+
+    def per_gpu_batch(self, scaling, n_gpus):
+        if scaling == "strong":
+            return max(1, self.total_batch // n_gpus)
+        return max(1, self.total_batch // self.shards)
+
+
+def workload_for(config, logn=None):
+    if config == 4:
+        w = Workload(4, LOGN, "fwd", TOTAL_BATCH, SHARDS, "NTT/s", METRIC, 16 * N, 0, q=Q, root=ROOT_W)
+        if logn and logn != LOGN:   # (experiments: same bytes at another size, same prime)
+            scale = (1 << LOGN) / (1 << logn)
+            w = Workload(4, logn, "fwd", int(TOTAL_BATCH * scale), SHARDS, "NTT/s",
+                         METRIC.replace("2^14", "2^%d" % logn), 16 << logn, 0, q=Q)
+        return w
+    if config == 2:
+        return Workload(2, 12, "fwd", 65536, 1, "NTT/s",
+                        "batched forward NTTs/sec at N=2^12, 50-bit q, batch 65536; achieved HBM GB/s vs peak", 16 << 12, 0,
+                        qbits=50)
+    if config == 3:
+        return Workload(3, 16, "roundtrip", 8192, 1, "round trips/s",
+                        "forward+inverse NTT round trips/sec at N=2^16, 52-bit q, batch 8192; achieved HBM GB/s vs peak",
+                        32 << 16, 1, qbits=52)
+    if config == 5:
+        return Workload(5, 17, "rns_product", 4096, 8, "RNS products/s",
+                        "FHE-style RNS negacyclic products/sec (per limb: fwd a, fwd b, pointwise, inv) at N=2^17, 4 primes, "
+                        "batch 4096 over 8 GPUs; achieved HBM GB/s vs peak", 4 * (56 << 17), 2, limbs=4, qbits=50)
+    raise SystemExit("bench.py: --config must be 2, 3, 4 or 5")
 
 
 def cpu_model():
@@ -63,64 +120,78 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(budget_s=12.0):
-    """Reference radix-4 CPU path on all host cores (bounded sample).
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own functions under a pthread harness (oracle/cpu_bench.inc)
+# --------------------------------------------------------------------------------------------------------------
+def cpu_baseline(workload=None, lib=None, budget_s=10.0):
+    """The reference's radix-4 CPU path on this box's host cores (bounded sample).
 
-    kind "reference": oracle/_ref/libntt_ref.so = the reference's own
-    src/ntt_radix4.c compiled in the build container; falls back to the oracle's
-    restatement ("port") if that file did not travel."""
+    kind "reference": oracle/_ref/libntt_ref.so = the reference's own src/ntt_radix4.c compiled in the build
+    container; kind "port" (oracle/libntt_oracle.so, the restatement) only if that file did not travel -- the JSON
+    then says so in `kind` AND in `warning`.  Both legs run in C (oracle/cpu_bench.inc): the all-core leg is one
+    pthread per CPU of the process's affinity mask, pinned, each on its own slab; the single-core leg is the
+    reference's MEASURE() (tests/measurements.h:38-75: 10 warm-ups, 10 x 200 calls, minimum of the means)."""
     import numpy as np
     from oracle_binding import Oracle, ptr
+    w = workload or workload_for(4)
+    if w.qs is None:
+        if lib is None:
+            import ontt
+            lib = ontt.load()
+        w.resolve(lib)
+    n, q, root = w.n, w.qs[0], w.roots[0]      # RNS: every limb costs the same on the CPU; limb 0 is timed
     orc = Oracle()
-    cx = orc.ctx(N, Q, ROOT_W)
-    ref_path = os.path.join(ROOT, "oracle", "_ref", "libntt_ref.so")
-    kind = "port"
+    cx = orc.ctx(n, q, root)
     U64P = C.POINTER(C.c_uint64)
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libntt_ref.so")
     if os.path.exists(ref_path):
-        ref = C.CDLL(ref_path)
-        ref.ref_fwd_r4_batch.argtypes = [U64P, C.c_uint64, C.c_uint64, C.c_uint64, U64P, U64P]
-        e, econ = cx.table("e"), cx.table("econ")
-        kind = "reference"
-
-        def run(buf, nb):
-            ref.ref_fwd_r4_batch(ptr(buf), nb, N, Q, ptr(e), ptr(econ))
+        dll, pre, kind = C.CDLL(ref_path), "ref_", "reference"
     else:
-        def run(buf, nb):
-            orc.lib.orc_fwd_r4_batch(ptr(buf), nb, cx.h)
-    cores = os.cpu_count() or 1
-    per_thread = 16                       # polynomials per call (2 MiB, stays in L2)
-    bufs = [orc.fill_uniform(per_thread * N, Q, SEED, t * per_thread * N) for t in range(cores)]
-    # parity of the baseline itself against the oracle (first polynomial)
-    chk = bufs[0][:N].copy()
-    run(chk, 1)
-    assert np.array_equal(chk, cx.fwd(bufs[0][:N])), "CPU baseline disagrees with the oracle"
-    counts = [0] * cores
-    stop = time.perf_counter() + budget_s
-
-    def worker(t):
-        while time.perf_counter() < stop:
-            run(bufs[t], per_thread)      # ctypes releases the GIL
-            counts[t] += per_thread
-
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
-    total = sum(counts)
-    # single-core figure with the reference's own methodology (min of means, tests/measurements.h:57-75)
-    one = bufs[0][:N].copy()
-    best = 1e9
-    for _ in range(5):
-        s = time.perf_counter()
-        for _ in range(20):
-            run(one, 1)
-        best = min(best, (time.perf_counter() - s) / 20)
-    return {"value": total / dt, "unit": "NTT/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
-            "sample": "%d forward radix-4 NTTs (N=2^14, q=0x7fffffffe0001, reduced output) in %.1f s on %d threads "
-                      "of %s; single core %.1f us/NTT" % (total, dt, cores, cpu_model(), best * 1e6)}
+        dll, pre, kind = orc.lib, "orc_", "port"
+    single = getattr(dll, pre + "bench_single")
+    single.restype = C.c_double
+    single.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, U64P, U64P, U64P, U64P, C.c_int, C.c_int, C.c_int]
+    threads = getattr(dll, pre + "bench_threads")
+    threads.restype = C.c_int
+    threads.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, U64P, U64P, U64P, U64P, C.c_int, C.c_double, C.c_uint64,
+                        C.POINTER(C.c_double)]
+    e, econ, einv, einvcon = [cx.table(t) for t in ("e", "econ", "einv", "einv_con")]
+    tabs = (ptr(e), ptr(econ), ptr(einv), ptr(einvcon))
+    # parity of the baseline itself against the oracle (one polynomial through the same entry point the harness calls)
+    if kind == "reference":
+        dll.ref_fwd_r4_generic.argtypes = [U64P, C.c_uint64, C.c_uint64, U64P, U64P]
+        chk = orc.fill_uniform(n, q, SEED, 0)
+        exp = cx.fwd(chk)
+        dll.ref_fwd_r4_generic(ptr(chk), n, q, tabs[0], tabs[1])
+        assert np.array_equal(chk, exp), "CPU baseline disagrees with the oracle"
+    # all-core leg
+    slab_ops = max(1, (2 << 20) // (8 * n * (3 if w.cpu_op == 2 else 1)))     # about 2 MiB per thread: L2-sized
+    out = (C.c_double * 5)()
+    rc = threads(w.cpu_op, n, q, cx.c.ninv, *tabs, 0, budget_s, slab_ops, out)
+    if rc != 0:
+        raise RuntimeError("cpu baseline harness failed (%d)" % rc)
+    ops, secs, nthr, allowed, online = out[0], out[1], int(out[2]), int(out[3]), int(out[4])
+    # single-core leg: the reference's repetition counts where they fit the time budget (about 6 s), fewer inner
+    # calls for the long transforms -- the counts used are stated in `sample`
+    est_us = 6e-3 * n * w.logn / 14 * (1, 3, 5)[w.cpu_op]        # rough: 90 us per 2^14-point transform
+    inner = int(max(10, min(200, 6e6 / (10 * est_us))))
+    ns = single(w.cpu_op, n, q, cx.c.ninv, *tabs, 10, 10, inner)
+    per_limb = ops / secs
+    value = per_limb / w.limbs                                    # RNS product = `limbs` limb-products
+    what = {0: "forward radix-4 NTTs (fwd_ntt_radix4, reduced output)",
+            1: "forward+inverse radix-4 round trips (fwd_ntt_radix4 + inv_ntt_radix4)",
+            2: "limb-products (fwd_ntt_radix4 x2, 128-bit pointwise %, inv_ntt_radix4)"}[w.cpu_op]
+    res = {"value": value, "unit": w.unit, "cores": nthr, "threads": nthr, "cpus_allowed": allowed, "cpus_online": online,
+           "cpu_model": cpu_model(), "kind": kind, "single_core_us": ns / 1e3 * w.limbs,
+           "all_core_over_single_core": per_limb * ns * 1e-9,
+           "sample": "%d %s at N=2^%d, q=%s in %.1f s on %d pinned pthreads (sched_getaffinity: %d of %d online CPUs), "
+                     "%d-op slabs per thread; single core: %d warm-ups, 10 x %d calls, min of means = %.1f us per call"
+                     % (int(ops), what, w.logn, hex(q), secs, nthr, allowed, online, slab_ops, 10, inner, ns / 1e3)}
+    if w.limbs > 1:
+        res["sample"] += "; an RNS product = %d limb-products" % w.limbs
+    if kind != "reference":
+        res["warning"] = "oracle/_ref/libntt_ref.so did not travel: this is the oracle RESTATEMENT, not the compiled reference"
+    return res
 
 
 def kernel_name(arith):
@@ -152,7 +223,7 @@ def shard_of_rank(rank, per_gpu_batch, n):
 
 
 def per_gpu_batch(scaling, n_gpus, n=N):
-    """polynomials per GPU: weak = config 4's fixed 2^20/8 share, strong = 2^20 split over the GPUs in use
+    """config 4: polynomials per GPU: weak = the fixed 2^20/8 share, strong = 2^20 split over the GPUs in use
     (both scaled to the same bytes when --logn changes the transform size)"""
     scale = (1 << LOGN) / n
     if scaling == "strong":
@@ -170,46 +241,98 @@ def allreduce_max(dist, value, device=None):
     return float(t.item())
 
 
+# --------------------------------------------------------------------------------------------------------------
+# one GPU's shard
+# --------------------------------------------------------------------------------------------------------------
 class GpuShard:
-    """One GPU's shard: plan (replicated tables), resident coefficients, its own stream and events."""
+    """One GPU's shard: plans (replicated tables), resident coefficients, its own stream and events.
 
-    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None):
-        self.lib, self.device, self.index, self.batch = lib, device, index, batch
+    kind "fwd": one in-place forward transform per step (configs 2, 4); "roundtrip": forward then inverse in place
+    (config 3); "rns_product": c = a * b per limb over [limb][batch][N] slabs (config 5) -- the product overwrites
+    its operands, so every step (warm-ups included) gets its own operand pair, generated before the timed region."""
+
+    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None, kind="fwd", qs=None, roots=None, steps_total=1):
+        self.lib, self.device, self.index, self.batch, self.kind = lib, device, index, batch, kind
         self.n = n or N
-        self.plan = lib.Plan(self.n, q, root or ROOT_W, device=device)
-        self.buf = lib.DeviceBuffer(batch * self.n, device=device)
+        self.qs = qs or [q]
+        self.roots = roots or [root or ROOT_W]
+        self.plans = [lib.Plan(self.n, qq, rr, device=device) for qq, rr in zip(self.qs, self.roots)]
+        self.plan = self.plans[0]
+        self.q = self.qs[0]
+        self.limbs = len(self.qs)
+        self.slab = batch * self.n                     # words of one limb
+        words = self.limbs * self.slab
+        self.sets = steps_total if kind == "rns_product" else 1
+        need = words * 8 * (2 * self.sets + 1 if kind == "rns_product" else 1)
+        if need > 230 * 2**30:
+            raise SystemExit("bench.py: config needs %.0f GiB of operands on one GPU (reduce --steps)" % (need / 2**30))
+        self.buf = lib.DeviceBuffer(words * (2 * self.sets if kind == "rns_product" else 1), device=device)
+        self.out = lib.DeviceBuffer(words, device=device) if kind == "rns_product" else None
         h = C.c_void_p()
         lib._check(lib._lib.ntt_stream_create(device, C.byref(h)))
         self.stream = h.value
         self.ev0, self.ev1 = lib.Event(device), lib.Event(device)
-        self.q = q
+        self.step_events = []
+        self.step_no = 0
+
+    # ---- operands -----------------------------------------------------------------------------------------
+    def operand_ptr(self, s, which):
+        """rns_product: operand `which` (0 = a, 1 = b) of step s"""
+        return self.buf.ptr + 8 * (2 * s + which) * self.limbs * self.slab
 
     def fill(self):
         # synthetic, device-generated, shard-distinct inputs: a[p][i] = splitmix64(seed ^ (offset+i)) mod q
         _, offset = shard_of_rank(self.index, self.batch, self.n)
-        self.lib.fill_uniform(self.buf.ptr, self.batch * self.n, self.q, SEED, offset, device=self.device,
-                              stream=self.stream)
+        if self.kind != "rns_product":
+            self.lib.fill_uniform(self.buf.ptr, self.slab, self.q, SEED, offset, device=self.device, stream=self.stream)
+            return
+        for s in range(self.sets):
+            for which in (0, 1):
+                for l, q in enumerate(self.qs):
+                    self.lib.fill_uniform(self.operand_ptr(s, which) + 8 * l * self.slab, self.slab, q, SEED + 2 * s + which,
+                                          offset + l * self.slab, device=self.device, stream=self.stream)
+        self.step_no = 0
 
+    # ---- one step -------------------------------------------------------------------------------------------
     def launch(self):
-        self.plan.fwd(self.buf.ptr, self.batch, stream=self.stream)
+        if self.kind == "fwd":
+            self.plan.fwd(self.buf.ptr, self.batch, stream=self.stream)
+        elif self.kind == "roundtrip":
+            self.plan.fwd(self.buf.ptr, self.batch, stream=self.stream)
+            self.plan.inv(self.buf.ptr, self.batch, stream=self.stream)
+        else:
+            s = self.step_no % self.sets
+            self.lib.rns_negacyclic_mul(self.plans, self.out.ptr, self.operand_ptr(s, 0), self.operand_ptr(s, 1), self.batch,
+                                        stream=self.stream)
+            self.step_no += 1
 
     def sync(self):
         self.lib.stream_sync(self.device, self.stream)
 
     def mark_start(self):
-        self.ev0.record(self.stream)
+        self.step_events = [self.lib.Event(self.device)]
+        self.step_events[0].record(self.stream)
+
+    def mark_step(self):
+        e = self.lib.Event(self.device)
+        e.record(self.stream)
+        self.step_events.append(e)
 
     def mark_stop(self):
-        self.ev1.record(self.stream)
+        pass                                    # the last mark_step() is the stop event
 
     def kernel_ms(self, steps):
-        return self.ev1.elapsed_ms_since(self.ev0) / max(steps, 1)
+        return self.step_events[-1].elapsed_ms_since(self.step_events[0]) / max(steps, 1)
+
+    def step_ms(self):
+        ev = self.step_events
+        return [ev[i + 1].elapsed_ms_since(ev[i]) for i in range(len(ev) - 1)]
 
     def copy_ceiling_gbs(self, reps=6):
         """GB/s of a plain in-place read-modify-write (16 B per lane, no arithmetic) over this shard's buffer,
-        HIP events on the shard's stream, best of `reps` after one warm-up: the measured ceiling SURVEY 8d asks
-        for next to the 8 TB/s specification figure.  Runs after the timed region; mask 0 leaves the data alone."""
-        words, best = self.batch * self.n, None
+        HIP events on the shard's stream, best of `reps` after one warm-up: a measured reference point next to the
+        8 TB/s specification figure.  Runs after the timed region; mask 0 leaves the data alone."""
+        words, best = self.limbs * self.slab, None
         for r in range(reps + 1):
             self.ev0.record(self.stream)
             self.lib.rmw_probe(self.buf.ptr, words, 0, device=self.device, stream=self.stream)
@@ -219,25 +342,32 @@ class GpuShard:
                 best = ms
         return words * 16 / (best * 1e-3) / 1e9
 
-    def polys(self, which):
+    def polys(self, which, base=None, limb=0):
         import numpy as np
-        return np.concatenate([self.buf.download(self.n, p * self.n) for p in which])
+        buf = base if base is not None else self.buf
+        return np.concatenate([buf.download(self.n, limb * self.slab + p * self.n) for p in which])
 
     def arith(self):
         return self.plan.info()["arith"]
+
+    def f64_class(self):
+        return self.plan.info()["f64_class"]
 
     def hbm_passes(self):
         return self.plan.info()["hbm_passes"]
 
     def close(self):
         self.buf.free()
-        self.plan.destroy()
+        if self.out:
+            self.out.free()
+        for p in self.plans:
+            p.destroy()
         self.lib._lib.ntt_stream_destroy(self.device, self.stream)
 
 
 def run_steps(shards, steps, warmup, barrier, after_first_warmup=None):
     """W untimed steps, then exactly K timed steps on every shard, bracketed by barrier() on both sides.
-    Returns (host seconds for the K steps, [average launch ms per shard])."""
+    Returns (host seconds for the K steps, [average device ms per step and shard])."""
     for s in shards:
         s.fill()
     for i in range(warmup):
@@ -252,6 +382,8 @@ def run_steps(shards, steps, warmup, barrier, after_first_warmup=None):
     for _ in range(steps):
         for s in shards:
             s.launch()
+            if hasattr(s, "mark_step"):
+                s.mark_step()
     for s in shards:
         s.mark_stop()
     barrier()
@@ -259,14 +391,11 @@ def run_steps(shards, steps, warmup, barrier, after_first_warmup=None):
     return elapsed, [s.kernel_ms(steps) for s in shards]
 
 
-def literal_50_bit(lib, shard, steps):
-    """BASELINE.json's metric says "50-bit q"; SURVEY 8d maps it to the reference's case 12, a 51-bit prime, which is
-    what `value` is measured on.  For the record, the same launch on the largest prime BELOW 2^50 with 2N | q-1
-    (one more bit of FP64 headroom: a reduction schedule with fewer reducing stages), same buffer, same batch,
-    HIP events on the same stream, after the timed region.  Not the headline."""
-    q50 = lib.find_prime(50, shard.n)
-    plan = lib.Plan(shard.n, q50, lib.min_root(q50, shard.n), device=shard.device)
-    lib.fill_uniform(shard.buf.ptr, shard.batch * shard.n, q50, SEED, 0, device=shard.device, stream=shard.stream)
+def side_forward(lib, shard, q, steps, label):
+    """the same forward launch on another prime, same buffer, same batch, HIP events on the same stream, after the
+    timed region.  Not the headline."""
+    plan = lib.Plan(shard.n, q, lib.min_root(q, shard.n), device=shard.device)
+    lib.fill_uniform(shard.buf.ptr, shard.batch * shard.n, q, SEED, 0, device=shard.device, stream=shard.stream)
     for _ in range(2):
         plan.fwd(shard.buf.ptr, shard.batch, stream=shard.stream)
     shard.ev0.record(shard.stream)
@@ -276,39 +405,92 @@ def literal_50_bit(lib, shard, steps):
     ms = shard.ev1.elapsed_ms_since(shard.ev0) / steps
     plan.destroy()
     gbs = shard.batch * 16 * shard.n / (ms * 1e-3) / 1e9
-    return {"q": hex(q50), "value": shard.batch / (ms * 1e-3), "unit": "NTT/s", "kernel_ms": ms,
+    return {"q": hex(q), "what": label, "value": shard.batch / (ms * 1e-3), "unit": "NTT/s", "kernel_ms": ms,
             "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
 
 
-def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None):
+def literal_50_bit(lib, shard, steps):
+    """BASELINE.json's metric says "50-bit q"; SURVEY 8d maps it to the reference's case 12, a 51-bit prime, which is
+    what `value` is measured on.  For the record, the same launch on the largest prime BELOW 2^50 with 2N | q-1
+    (one more bit of FP64 headroom: a reduction schedule with fewer reducing stages)."""
+    return side_forward(lib, shard, lib.find_prime(50, shard.n), steps, "largest prime below 2^50")
+
+
+def kernel_chain(w, arith, f64_class):
+    """the device work of one step, for the report"""
+    pol = "ArithU64" if arith != 2 else ("ArithF64W" if f64_class == 52 else "ArithF64")
+    if w is None or (w.kind == "fwd" and w.logn == LOGN):
+        return kernel_name(arith), 1
+    if w.kind == "fwd":
+        return "fused_kernel<%s,%d,fwd>" % (pol, w.logn), 1
+    if w.kind == "roundtrip":
+        return ("column_kernel<%s,4,fwd> + fused_kernel<%s,12,fwd> + fused_kernel<%s,12,inv> + column_kernel<%s,4,inv>, "
+                "per 256 MiB chunk" % (pol, pol, pol, pol)), 4
+    return ("per limb: column + fused forward passes of a, column pass of b, fused_product_kernel<%s,14> over the "
+            "blocks, inverse column pass of c, per 256 MiB chunk" % pol), 5 * w.limbs
+
+
+def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,
+                step_ms=None, f64_class=0):
     n = n or N
-    bytes_per_ntt = 16 * n
+    w = workload
+    bytes_per_unit = w.bytes_per_unit if w else 16 * n
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_gpus * batch / (elapsed / args.steps)
     slowest = max(kernel_ms)
-    achieved = batch * bytes_per_ntt / (slowest * 1e-3) / 1e9
-    kname = kernel_name(arith)
-    if args.scaling == "strong":
-        share = "batch 2^20 (128 GiB) split over %d GPU%s = %d polynomials (%.0f GiB) per GPU" % (
-            n_gpus, "" if n_gpus == 1 else "s", batch, batch * n * 8 / 2**30)
+    achieved = batch * bytes_per_unit / (slowest * 1e-3) / 1e9
+    kname, launches = kernel_chain(w, arith, f64_class)
+    scaling = getattr(args, "scaling", "weak")
+    total = w.total_batch if w else TOTAL_BATCH
+    shards = w.shards if w else SHARDS
+    gib = batch * n * 8 * (w.limbs if w else 1) / 2**30
+    if scaling == "strong":
+        share = "batch %d (%.0f GiB) split over %d GPU%s = %d per GPU (%.1f GiB)" % (
+            total, total * n * 8 * (w.limbs if w else 1) / 2**30, n_gpus, "" if n_gpus == 1 else "s", batch, gib)
+    elif shards > 1:
+        share = "batch %d sharded over %d GPUs = %d per GPU (%.1f GiB)" % (total, shards, batch, gib)
     else:
-        share = "batch 2^20 sharded over 8 GPUs = %d polynomials (%.0f GiB) per GPU" % (batch, batch * n * 8 / 2**30)
+        share = "batch %d per GPU (%.1f GiB)" % (batch, gib)
+    qs = w.qs if (w and w.qs) else [Q]
+    cfg = w.config if w else 4
+    what = {"fwd": "forward negacyclic NTT, in place, reduced output",
+            "roundtrip": "forward then inverse negacyclic NTT, in place (bit-exact round trip)",
+            "rns_product": "RNS negacyclic product c = a*b over %d primes: per limb fwd(a), fwd(b), pointwise, inv"
+                           % (w.limbs if w else 1)}[w.kind if w else "fwd"]
+    qdesc = ", ".join(hex(q) for q in qs)
+    if cfg == 4:
+        qdesc += " (51-bit, reference test case 12)"
+    traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r03/pmc_traffic.json), "
+                              "not collected in this run" if traffic is not None else None,
+            "kernel": kname, "launches_per_step": launches, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
+            "algorithmic_bytes_per_step": batch * bytes_per_unit,
+            "algorithmic_bytes_per_unit": bytes_per_unit,
+            # measured in this run: in-place read-modify-write of the same buffer without arithmetic (a reference
+            # point, not the ceiling: memory-only skeletons of the kernel's own shape reach 0.67-0.72 of the peak,
+            # profiles/r02/skeleton.txt)
+            "copy_probe": copy_gbs, "frac_of_copy_probe": (achieved / copy_gbs) if copy_gbs else None,
+            "best_memory_only_skeleton_frac": 0.717,
+            "frac_of_best_memory_only_skeleton": achieved / HBM_PEAK_GBS / 0.717}
+    if step_ms:
+        roof["step_ms_min"] = min(step_ms)
+        roof["step_ms_median"] = statistics.median(step_ms)
+        roof["step_ms_mean"] = sum(step_ms) / len(step_ms)
+        roof["frac_at_min"] = batch * bytes_per_unit / (min(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["frac_at_median"] = batch * bytes_per_unit / (statistics.median(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
     return {
-        "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f64" if arith == 2 else "u64", "data": "synthetic",
-        "config": {"workload": "config4: forward negacyclic NTT, N=%d, q=0x7fffffffe0001 (51-bit, reference test "
-                               "case 12), %s, in place, reduced output" % (n, share),
-                   "N": n, "q": hex(Q), "batch_per_gpu": batch, "global_batch": n_gpus * batch,
+        "metric": w.metric if w else METRIC, "value": value, "unit": w.unit if w else "NTT/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64" if arith == 2 else "u64", "data": "synthetic",
+        "config": {"workload": "config%d: %s, N=%d, q=%s, %s" % (cfg, what, n, qdesc, share),
+                   "N": n, "q": hex(qs[0]) if len(qs) == 1 else [hex(q) for q in qs], "batch_per_gpu": batch,
+                   "global_batch": n_gpus * batch,
                    "parallelism": "batch-sharded x%d, no collective" % n_gpus,
-                   "arith": "f64-balanced" if arith == 2 else "u64-shoup", "hbm_passes": hbm_passes},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(batch, kname) if n == N else None,
-                     "kernel": kname, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
-                     "algorithmic_bytes_per_launch": batch * bytes_per_ntt,
-                     # measured in this run: in-place read-modify-write of the same buffer without arithmetic
-                     "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None},
+                   "arith": ("f64-balanced" if f64_class != 52 else "f64-balanced (both operands reduced: 2^51 < q < 2^52)")
+                   if arith == 2 else "u64-shoup", "hbm_passes": hbm_passes},
+        "roofline": roof,
     }
 
 
@@ -318,11 +500,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--batch", type=int, default=0, help="polynomials per GPU (default: from --scaling)")
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2, 3, 4 (default, the metric) or 5")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: from --config and --scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="skip the side measurements (copy ceiling, literal 50-bit prime): profiler runs then see one kernel")
-    ap.add_argument("--logn", type=int, default=LOGN, help="(experiments) other transform sizes; the metric is quoted on 14")
+                    help="skip the side measurements (copy probe, other primes): profiler runs then see the step's kernels only")
+    ap.add_argument("--logn", type=int, default=0, help="(experiments, config 4 only) other transform sizes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -352,11 +535,11 @@ def main():
     import ontt
     lib = ontt.load()
 
-    n, root = N, ROOT_W
-    if args.logn != LOGN:
-        n = 1 << args.logn
-        root = lib.min_root(Q, n)
-    batch = args.batch or per_gpu_batch(args.scaling, n_gpus, n)
+    w = workload_for(args.config, args.logn or None).resolve(lib)
+    n = w.n
+    batch = args.batch or w.per_gpu_batch(args.scaling, n_gpus)
+    if w.kind == "rns_product" and args.steps + args.warmup > 24 and not args.batch:
+        sys.exit("bench.py: config 5 keeps one operand pair per step resident: use --steps + --warmup <= 24")
 
     have = lib.device_count()
     shards = []
@@ -367,7 +550,8 @@ def main():
             device %= ndev_mod
         if device >= have:
             sys.exit("bench.py: --gpus %d but only %d HIP device(s) visible" % (n_gpus, have))
-        shards.append(GpuShard(lib, device, index, batch, n=n, root=root))
+        shards.append(GpuShard(lib, device, index, batch, n=n, kind=w.kind, qs=w.qs, roots=w.roots,
+                               steps_total=args.steps + max(args.warmup, 1)))
 
     def barrier():
         for s in shards:
@@ -375,9 +559,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # parity spot check on the benchmarked launch itself: the first warm-up step transforms the whole shard;
-    # polynomial 0 and the last one of shard 0 are compared with the oracle (no separate probe launch, so the
-    # profiler's per-kernel statistics contain full-size launches only)
+    # parity spot check on the benchmarked launches themselves: the first warm-up step runs on the whole shard; the first
+    # and the last polynomial of shard 0 are compared with the oracle (no separate probe launch, so the profiler's
+    # per-kernel statistics contain full-size launches only)
     check = rank == 0 and not os.environ.get("NTT_BENCH_NOCHECK")   # (ablation builds compute garbage on purpose)
     before = {}
 
@@ -385,14 +569,53 @@ def main():
         s = shards[0]
         s.sync()
         from oracle_binding import Oracle
-        cx = Oracle().ctx(n, Q, root)
-        got = s.polys([0, batch - 1])
-        assert np.array_equal(got, cx.fwd(before["a"])), "GPU forward NTT differs from the oracle"
+        orc = Oracle()
+        which = [0, batch - 1]
+        if w.kind == "fwd":
+            cx = orc.ctx(n, w.qs[0], w.roots[0])
+            assert np.array_equal(s.polys(which), cx.fwd(before["a"])), "GPU forward NTT differs from the oracle"
+        elif w.kind == "roundtrip":
+            assert np.array_equal(s.polys(which), before["a"]), "forward+inverse round trip is not the identity"
+        else:
+            for l in (0, w.limbs - 1):
+                cx = orc.ctx(n, w.qs[l], w.roots[l])
+                exp = cx.inv(orc.pointwise(cx.fwd(before["a%d" % l]), cx.fwd(before["b%d" % l]), w.qs[l]))
+                assert np.array_equal(s.polys(which, base=s.out, limb=l), exp), "GPU RNS product differs from the oracle"
+
+    mid = {}
+
+    def capture():
+        s = shards[0]
+        s.fill()
+        s.sync()
+        which = [0, batch - 1]
+        if w.kind == "rns_product":
+            words = s.limbs * s.slab
+
+            class View:      # operand set 0 inside the big buffer
+                def __init__(self, off):
+                    self.off = off
+
+                def download(self, cnt, offset):
+                    return s.buf.download(cnt, self.off + offset)
+            for l in (0, w.limbs - 1):
+                before["a%d" % l] = s.polys(which, base=View(0), limb=l)
+                before["b%d" % l] = s.polys(which, base=View(words), limb=l)
+        else:
+            before["a"] = s.polys(which)
+
+    def parity_roundtrip_forward():
+        """config 3: the forward half against the oracle, on a separate small launch after the timed region (the timed
+        steps are whole round trips)"""
+        s = shards[0]
+        from oracle_binding import Oracle
+        cx = Oracle().ctx(n, w.qs[0], w.roots[0])
+        a = before["a"]
+        assert np.array_equal(s.plan.fwd_host(a), cx.fwd(a)), "GPU forward NTT differs from the oracle"
+        mid["fwd_checked"] = True
 
     if check:
-        shards[0].fill()
-        shards[0].sync()
-        before["a"] = shards[0].polys([0, batch - 1])
+        capture()
     elapsed, kernel_ms = run_steps(shards, args.steps, max(args.warmup, 1 if check else 0), barrier,
                                    parity if check else None)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
@@ -406,14 +629,22 @@ def main():
         kernel_ms = [float(x.item()) for x in allk]
 
     if rank == 0:
+        s0 = shards[0]
+        if check and w.kind == "roundtrip":
+            parity_roundtrip_forward()
         # after the timed region, on shard 0's resident buffer
-        copy_gbs = None if args.headline_only else shards[0].copy_ceiling_gbs()
-        out = make_report(args, n_gpus, batch, elapsed, kernel_ms, shards[0].arith(), shards[0].hbm_passes(), n=n,
-                          copy_gbs=copy_gbs)
-        if n_gpus == 1 and n == N and not args.headline_only:
-            out["also_literal_50_bit_q"] = literal_50_bit(lib, shards[0], args.steps)
+        copy_gbs = None if args.headline_only else s0.copy_ceiling_gbs()
+        slow = max(range(len(shards)), key=lambda i: kernel_ms[i] if i < len(kernel_ms) else 0) if world == 1 else 0
+        out = make_report(args, n_gpus, batch, elapsed, kernel_ms, s0.arith(), s0.hbm_passes(), n=n, copy_gbs=copy_gbs,
+                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class())
+        if n_gpus == 1 and not args.headline_only:
+            if w.config == 4 and n == N:
+                out["also_literal_50_bit_q"] = literal_50_bit(lib, s0, args.steps)
+            if w.config == 3:
+                out["also_reference_case_17"] = side_forward(lib, s0, Q, max(args.steps // 2, 2),
+                                                             "forward only, 51-bit q of reference test case 17")
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(w, lib)
         print(json.dumps(out), flush=True)
     barrier()
     for s in shards:

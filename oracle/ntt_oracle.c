@@ -518,3 +518,15 @@ void orc_inv_r4_batch(uint64_t *a, uint64_t batch, const orc_ctx *c)
     orc_inv_r4(a + p * c->N, c->N, c->q, c->ninv, c->ninv_con, c->einv, c->einv_con);
   }
 }
+
+/* ---- CPU timing harness on the restatement (bench.py cpu_baseline, kind "port": used only when oracle/_ref did
+ * not travel) ---- */
+static inline void orc_cb_inv_r4(uint64_t *a, uint64_t N, uint64_t q, uint64_t ninv, const uint64_t *einv,
+                                 const uint64_t *einv_con)
+{
+  orc_inv_r4(a, N, q, ninv, orc_precon1(ninv, q, 64), einv, einv_con);
+}
+#define CB_PREFIX(name)                      orc_##name
+#define CB_FWD(a, N, q, e, econ)             orc_fwd_r4(a, N, q, e, econ)
+#define CB_INV(a, N, q, ninv, einv, einvcon) orc_cb_inv_r4(a, N, q, ninv, einv, einvcon)
+#include "cpu_bench.inc"

@@ -104,6 +104,14 @@ void orc_fwd_r2_batch(uint64_t *a, uint64_t batch, const orc_ctx *c);
 void orc_inv_r2_batch(uint64_t *a, uint64_t batch, const orc_ctx *c);
 void orc_inv_r4_batch(uint64_t *a, uint64_t batch, const orc_ctx *c);
 
+/* CPU timing harness for bench.py's cpu_baseline leg (oracle/cpu_bench.inc; the same code is compiled around the
+ * real reference in oracle/ref_shim.c as ref_bench_*).  op: 0 forward, 1 forward + inverse, 2 limb-product. */
+double orc_bench_single(int op, uint64_t N, uint64_t q, uint64_t ninv, const uint64_t *e, const uint64_t *econ,
+                        const uint64_t *einv, const uint64_t *einvcon, int warmup, int outer, int inner);
+int    orc_bench_threads(int op, uint64_t N, uint64_t q, uint64_t ninv, const uint64_t *e, const uint64_t *econ,
+                         const uint64_t *einv, const uint64_t *einvcon, int nthreads, double seconds, uint64_t slab_ops,
+                         double out[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,3 +173,17 @@ EXPORT void ref_inv_r4_generic(uint64_t *a, uint64_t N, uint64_t q, uint64_t nin
   n.con = calc_ninv_con(ninv, q, WORD_SIZE);
   inv_ntt_radix4(a, N, q, n, einv, einv_con);
 }
+
+/* ---- CPU timing harness on the reference's own functions (bench.py cpu_baseline, kind "reference") ---- */
+static inline void shim_inv_r4(uint64_t *a, uint64_t N, uint64_t q, uint64_t ninv, const uint64_t *einv,
+                               const uint64_t *einv_con)
+{
+  mul_op_t n;
+  n.op  = ninv;
+  n.con = calc_ninv_con(ninv, q, WORD_SIZE);
+  inv_ntt_radix4(a, N, q, n, einv, einv_con);
+}
+#define CB_PREFIX(name)                      ref_##name
+#define CB_FWD(a, N, q, e, econ)             fwd_ntt_radix4(a, N, q, e, econ)
+#define CB_INV(a, N, q, ninv, einv, einvcon) shim_inv_r4(a, N, q, ninv, einv, einvcon)
+#include "cpu_bench.inc"

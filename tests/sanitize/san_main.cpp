@@ -99,6 +99,16 @@ int main()
       CHECK(emu_pointwise_lazy(c2.data(), al.data(), bl.data(), n, q, arith) == 0);
       CHECK(c2 == c);
     }
+    /* the CPU timing harness of bench.py's cpu_baseline leg (oracle/cpu_bench.inc): a few milliseconds of each unit of
+     * work on two threads, and the single-thread method, under the sanitizers */
+    if(cs.m >= 10 && cs.m <= 12) {
+      for(int op = 0; op < 3; op++) {
+        double out[5] = {0, 0, 0, 0, 0};
+        CHECK(orc_bench_threads(op, n, q, cx->ninv, cx->e, cx->econ, cx->einv, cx->einv_con, 2, 0.02, 2, out) == 0);
+        CHECK(out[0] >= 2 && out[2] == 2 && out[3] >= 1);
+        CHECK(orc_bench_single(op, n, q, cx->ninv, cx->e, cx->econ, cx->einv, cx->einv_con, 1, 2, 2) > 0);
+      }
+    }
     orc_ctx_free(cx);
   }
   uint64_t info[10];

@@ -1,0 +1,413 @@
+/*
+ * skel4.hip -- memory skeleton of an XCD-local "four-step" transform for N = 2^16 / 2^17 (diagnostic tool, GPU box only).
+ *
+ * Question: can the intermediate of a two-pass transform stay inside ONE XCD's 4 MiB L2, so that
+ * only 16*N bytes per transform cross the fabric instead of 32*N?  Shape tried here:
+ *   - the polynomial is cut into 4096-element items for each pass: "column" items (16 adjacent columns x 256 rows, stride
+ *     N/256: the leading 8 stages) and "row" items (4096 consecutive elements: the remaining stages);
+ *   - 256-thread workgroups, 16 elements per thread, several workgroups per CU;
+ *   - a workgroup reads its XCD from HW_REG_XCC_ID and pulls items from THAT XCD's queue (one atomic counter per XCD), so
+ *     all items of a polynomial run on one XCD whatever the dispatcher does -- placement is read, never assumed;
+ *   - queue order: col(poly j), row(poly j - LAG), col(j + 1), ...; a row item waits on a per-polynomial counter that the
+ *     column items bump after their stores have completed (s_waitcnt vmcnt(0) + barrier + agent-scope atomic).  Column
+ *     items never wait, and every item a row item waits for was handed out earlier to a running workgroup: no deadlock
+ *     whatever the residency;
+ *   - column stores stay dirty in the L2 (plain stores); row loads bypass the L1 (nt / sc1).
+ * Pass 1 adds 1, pass 2 doubles: the result 2(x+1) is checked element by element, so an ordering or visibility error of
+ * the hand-off shows up as a mismatch count.
+ * Build: make skel4      Run: build/skel4 [GiB] [reps] [filter]
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                 \
+  do {                                                        \
+    hipError_t e_ = (x);                                      \
+    if(e_ != hipSuccess) {                                    \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); \
+      exit(1);                                                \
+    }                                                         \
+  } while(0)
+
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+struct alignas(16) d2 {
+  double a, b;
+};
+
+constexpr int T    = 256;
+constexpr int C    = 16;
+constexpr int TILE = T * C; /* elements per item */
+
+struct Ctl {
+  unsigned next[8][32];  /* per-XCD item counter, one 128-byte line each */
+  unsigned nwg[8][32];   /* census: workgroups that reported this XCD     */
+  unsigned spins[8][32]; /* poll iterations spent waiting, per XCD        */
+  unsigned done[1];      /* [polys] column items finished (flexible)      */
+};
+
+__device__ __forceinline__ unsigned xcc_id()
+{
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v & 7u;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, uint32_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+template <int AUX> __device__ __forceinline__ double ld8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX> __device__ __forceinline__ void st8(double x, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, (int)voff, (int)soff, AUX);
+}
+template <int AUX> __device__ __forceinline__ void st16(d2 x, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, x), r, (int)voff, (int)soff, AUX);
+}
+
+template <int F> __device__ __forceinline__ void fake_compute(double (&x)[C], double c1, double c2)
+{
+#pragma unroll
+  for(int f = 0; f < F; f++) {
+#pragma unroll
+    for(int e = 0; e < C; e++) x[e] = __builtin_fma(x[e], c1, c2);
+  }
+}
+
+/* column item: element (h, c) of the tile, h = 0..255, c = 0..15, lives at h * rowlen + 16 * tile + c.
+ * in : slot e <-> h = 16 e + (t >> 4)   (first stage group: top four bits of h in the thread)
+ * out: slot e <-> h = 16 (t >> 4) + e   (second stage group: low four bits of h in the thread) */
+template <int LA, int SA, int F, int X>
+__device__ __forceinline__ void col_item(double *poly, uint32_t nbytes, uint32_t rowlen, uint32_t tile, uint32_t t, double *lds,
+                                         double c1, double c2, double add)
+{
+  const __amdgpu_buffer_rsrc_t r = rsrc_of(poly, nbytes);
+  const uint32_t hl = t >> 4, c = t & 15u;
+  double         x[C];
+  const uint32_t vin = (hl * rowlen + c) * 8u;
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] = ld8<LA>(r, vin, ((uint32_t)e * 16u * rowlen + 16u * tile) * 8u);
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] += add;
+  fake_compute<F / 2>(x, c1, c2);
+  if constexpr(X) {
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < C; e++) lds[((uint32_t)e * 16u + hl) * 17u + c] = x[e];
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < C; e++) x[e] = lds[(hl * 16u + (uint32_t)e) * 17u + c];
+    fake_compute<F - F / 2>(x, c1, c2);
+    const uint32_t vout = (hl * 16u * rowlen + c) * 8u;
+#pragma unroll
+    for(int e = 0; e < C; e++) st8<SA>(x[e], r, vout, ((uint32_t)e * rowlen + 16u * tile) * 8u);
+  } else {
+    fake_compute<F - F / 2>(x, c1, c2);
+#pragma unroll
+    for(int e = 0; e < C; e++) st8<SA>(x[e], r, vin, ((uint32_t)e * 16u * rowlen + 16u * tile) * 8u);
+  }
+}
+
+/* row item: 4096 consecutive elements; 8-byte coalesced loads, 16-byte stores in runs of four per lane */
+template <int LA, int SA, int F, int X, int TW>
+__device__ __forceinline__ void row_item(double *poly, uint32_t nbytes, uint32_t tile, uint32_t t, double *lds, double c1, double c2,
+                                         double mul, const double *tw, double c0)
+{
+  const __amdgpu_buffer_rsrc_t r = rsrc_of(poly + (size_t)tile * TILE, TILE * 8u);
+  (void)nbytes;
+  double x[C];
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] = ld8<LA>(r, t * 8u, (uint32_t)e * T * 8u);
+  if constexpr(TW) {
+    /* as many per-lane 8-byte table reads as a transform's per-lane twiddles (cacheable: the table is shared by all polynomials) */
+    const double *w = tw + (size_t)tile * TILE + t;
+#pragma unroll
+    for(int e = 0; e < C; e++) x[e] = __builtin_fma(w[(size_t)e * T], c0, x[e]);
+  }
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] *= mul;
+  fake_compute<F / 2>(x, c1, c2);
+  if constexpr(X) {
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < C; e++) lds[e * (T + 1) + t] = x[e];
+    __syncthreads();
+    /* like the real kernels' last group: thread t then owns runs of four consecutive elements, 16-byte stores */
+#pragma unroll
+    for(int e = 0; e < C; e++) {
+      const uint32_t i = (((uint32_t)e >> 2) * T + t) * 4u + ((uint32_t)e & 3u);
+      x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)];
+    }
+    fake_compute<F - F / 2>(x, c1, c2);
+#pragma unroll
+    for(int h = 0; h < C / 2; h++) st16<SA>(d2{x[2 * h], x[2 * h + 1]}, r, t * 32u + (uint32_t)(h & 1) * 16u, (uint32_t)(h >> 1) * T * 32u);
+  } else {
+    fake_compute<F - F / 2>(x, c1, c2);
+#pragma unroll
+    for(int e = 0; e < C; e++) st8<SA>(x[e], r, t * 8u, (uint32_t)e * T * 8u);
+  }
+}
+
+/* mode 0: fused (both passes, XCD-local hand-off); 1: column items only; 2: row items only (no waiting) */
+template <int LA1, int SA1, int LA2, int SA2, int F, int X, int TW, int WPS>
+__global__ void __launch_bounds__(T, WPS) k_four(double *a, uint32_t logn, uint32_t batch, int lag, int mode, Ctl *ctl, double c1,
+                                                 double c2, const double *tw, double c0, int blocked)
+{
+  __shared__ double   lds[X ? 256 * 17 : 1]; /* column layout 256 x 17 (the row layout needs 16 x 257) */
+  __shared__ unsigned s_k;
+  const uint32_t      t      = threadIdx.x;
+  const uint32_t      xcc    = xcc_id();
+  const uint32_t      N      = 1u << logn;
+  const uint32_t      rowlen = N >> 8;
+  const uint32_t      NT     = N / TILE;                       /* items per pass and polynomial */
+  /* polynomials of this XCD: xcc, xcc + 8, ... (interleaved) or a contiguous eighth of the batch (blocked) */
+  const uint32_t      per    = (batch + 7u) / 8u;
+  const uint32_t      J      = blocked ? (xcc * per < batch ? (batch - xcc * per < per ? batch - xcc * per : per) : 0u)
+                                       : (batch > xcc ? (batch - xcc + 7u) / 8u : 0u);
+  if(t == 0) atomicAdd(&ctl->nwg[xcc][0], 1u);
+  const uint32_t per_step = mode == 0 ? 2u * NT : NT;
+  const uint32_t steps    = mode == 0 ? J + (uint32_t)lag : J;
+  unsigned       spins    = 0;
+  for(;;) {
+    if(t == 0) s_k = atomicAdd(&ctl->next[xcc][0], 1u);
+    __syncthreads();
+    const uint32_t k = s_k;
+    __syncthreads();
+    const uint32_t step = k / per_step, r = k % per_step;
+    if(step >= steps) break;
+    const bool     is_row = mode == 2 || (mode == 0 && r >= NT);
+    const uint32_t tile   = r >= NT ? r - NT : r;
+    const int64_t  j      = (mode == 0 && is_row) ? (int64_t)step - lag : (int64_t)step;
+    if(j < 0 || j >= (int64_t)J) continue;
+    const uint32_t p    = blocked ? xcc * ((batch + 7u) / 8u) + (uint32_t)j : xcc + 8u * (uint32_t)j;
+    double *       poly = a + ((size_t)p << logn);
+    if(!is_row) {
+      col_item<LA1, SA1, F, X>(poly, N * 8u, rowlen, tile, t, lds, c1, c2, 1.0);
+      if(mode == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if(t == 0) __hip_atomic_fetch_add(&ctl->done[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if(mode == 0) {
+        if(t == 0) {
+          while(__hip_atomic_load(&ctl->done[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NT) {
+            __builtin_amdgcn_s_sleep(8);
+            spins++;
+          }
+        }
+        __syncthreads();
+      }
+      row_item<LA2, SA2, F, X, TW>(poly, N * 8u, tile, t, lds, c1, c2, 2.0, tw, c0);
+    }
+  }
+  if(t == 0 && spins) atomicAdd(&ctl->spins[xcc][0], spins);
+}
+
+__global__ void __launch_bounds__(256) k_fill(double *a, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    a[i] = (double)((i * 2654435761ull) & 0xfffffull);
+  }
+}
+/* counts elements that are not 2 (x0 + 1) (fused / both passes) */
+__global__ void __launch_bounds__(256) k_check(const double *a, size_t n, unsigned long long *bad)
+{
+  unsigned long long b = 0;
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double x0 = (double)((i * 2654435761ull) & 0xfffffull);
+    b += a[i] != 2.0 * (x0 + 1.0);
+  }
+  if(b) atomicAdd(bad, b);
+}
+
+static double *            g_buf;
+static double *            g_tw;
+static size_t              g_n;
+static Ctl *               g_ctl;
+static size_t              g_ctl_bytes;
+static unsigned long long *g_bad;
+static hipEvent_t          g_e0, g_e1;
+static int                 g_reps = 16;
+static const char *        g_filter = nullptr;
+
+struct Cfg {
+  int logn, wpc, lag, mode, blocked = 0;
+};
+
+template <int LA1, int SA1, int LA2, int SA2, int F, int X, int TW, int WPS> static void run(Cfg cf, const char *note)
+{
+  char label[200];
+  snprintf(label, sizeof label, "m%d mode%d wpc%d lag%-2d blk%d la1 %2d sa1 %2d la2 %2d sa2 %2d F%-2d X%d TW%d %s", cf.logn, cf.mode, cf.wpc, cf.lag, cf.blocked,
+           LA1, SA1, LA2, SA2, F, X, TW, note);
+  if(g_filter && !strstr(label, g_filter)) return;
+  const uint32_t batch = (uint32_t)(g_n >> cf.logn);
+  auto           launch = [&](int mode) {
+    CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+    hipLaunchKernelGGL((k_four<LA1, SA1, LA2, SA2, F, X, TW, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch,
+                       cf.lag, mode, g_ctl, 1.0, 0.0, g_tw, 0.0, cf.blocked);
+  };
+  /* correctness of the hand-off first, on freshly filled data */
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n);
+  CK(hipMemset(g_bad, 0, 8));
+  if(cf.mode == 0) {
+    launch(0);
+  } else {
+    launch(1);
+    launch(2);
+  }
+  hipLaunchKernelGGL(k_check, dim3(8192), dim3(256), 0, 0, g_buf, g_n, g_bad);
+  unsigned long long bad = 0;
+  CK(hipMemcpy(&bad, g_bad, 8, hipMemcpyDeviceToHost));
+  Ctl census;
+  CK(hipMemcpy(&census, g_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n); /* keep values small: every timed launch doubles them */
+  std::vector<float> ms;
+  for(int rpt = 0; rpt < g_reps; rpt++) {
+    float m = 0;
+    if(cf.mode == 0) {
+      CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+      CK(hipEventRecord(g_e0));
+      hipLaunchKernelGGL((k_four<LA1, SA1, LA2, SA2, F, X, TW, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch,
+                         cf.lag, 0, g_ctl, 1.0, 0.0, g_tw, 0.0, cf.blocked);
+      CK(hipEventRecord(g_e1));
+    } else {
+      /* two launches, the memset between them inside the timed region (a few microseconds) */
+      CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+      CK(hipEventRecord(g_e0));
+      hipLaunchKernelGGL((k_four<LA1, SA1, LA2, SA2, F, X, TW, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch,
+                         cf.lag, 1, g_ctl, 1.0, 0.0, g_tw, 0.0, cf.blocked);
+      CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+      hipLaunchKernelGGL((k_four<LA1, SA1, LA2, SA2, F, X, TW, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch,
+                         cf.lag, 2, g_ctl, 1.0, 0.0, g_tw, 0.0, cf.blocked);
+      CK(hipEventRecord(g_e1));
+    }
+    CK(hipEventSynchronize(g_e1));
+    CK(hipEventElapsedTime(&m, g_e0, g_e1));
+    ms.push_back(m);
+    if((rpt & 7) == 7) hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n);
+  }
+  CK(hipGetLastError());
+  std::vector<float> tail(ms.begin() + g_reps / 2, ms.end());
+  std::sort(tail.begin(), tail.end());
+  const float  med = tail[tail.size() / 2], best = tail[0];
+  const double bytes = (double)g_n * 16.0;
+  unsigned     wmin = ~0u, wmax = 0, sp = 0;
+  for(int x = 0; x < 8; x++) {
+    wmin = std::min(wmin, census.nwg[x][0]);
+    wmax = std::max(wmax, census.nwg[x][0]);
+    sp += census.spins[x][0];
+  }
+  printf("%-78s med %7.3f ms best %7.3f  %5.2f TB/s frac %.3f  bad %llu  wg/xcd %u..%u spins %u\n", label, med, best, bytes / med * 1e-9,
+         bytes / med * 1e-9 / 8.0, bad, wmin, wmax, sp);
+  fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+  const double gib = argc > 1 ? atof(argv[1]) : 16.0;
+  if(argc > 2) g_reps = atoi(argv[2]);
+  if(argc > 3) g_filter = argv[3];
+  g_n = (size_t)(gib * 1024.0 * 1024.0 * 1024.0 / 8.0);
+  g_n &= ~((size_t)(1u << 17) * 8 - 1);
+  CK(hipMalloc(&g_buf, g_n * 8));
+  CK(hipMalloc(&g_tw, (size_t)8 << 17));
+  CK(hipMemset(g_tw, 0, (size_t)8 << 17));
+  g_ctl_bytes = sizeof(Ctl) + (g_n >> 16) * sizeof(unsigned);
+  CK(hipMalloc(&g_ctl, g_ctl_bytes));
+  CK(hipMalloc(&g_bad, 8));
+  CK(hipEventCreate(&g_e0));
+  CK(hipEventCreate(&g_e1));
+  printf("# %.1f GiB in place; algorithmic bytes = 16 per element per transform; %d launches per row (median of the second half)\n", gib,
+         g_reps);
+  constexpr int NTL = 2, SC1 = 16;
+  if(getenv("SKEL4_SWEEP3")) {
+    /* third sweep: lag in single steps, polynomial-to-XCD assignment, which cache-policy bit matters, then the
+     * LDS exchanges, table reads and FP64 work of a real transform on top of the best shapes */
+    constexpr int S01 = SC1 | 1;
+    for(int m : {16, 17}) {
+      printf("# N = 2^%d: lag and assignment (blk1 = each XCD owns a contiguous eighth of the batch)\n", m);
+      for(int blocked : {0, 1})
+        for(int lag : {2, 3, 4, 5, 6, 7, 8, 10, 12}) {
+          Cfg cf{m, 2, lag, 0};
+          cf.blocked = blocked;
+          run<S01, 0, NTL, SC1, 0, 0, 0, 4>(cf, "");
+        }
+      puts("# which bits: input loads sc1 only / sc0 only / sc0 sc1 nt; row loads plain / sc0 sc1; final stores sc0 sc1");
+      for(int blocked : {0, 1})
+        for(int lag : {3, 5, 6}) {
+          Cfg cf{m, 2, lag, 0};
+          cf.blocked = blocked;
+          run<SC1, 0, NTL, SC1, 0, 0, 0, 4>(cf, "");
+          run<1, 0, NTL, SC1, 0, 0, 0, 4>(cf, "");
+          run<S01 | NTL, 0, NTL, SC1, 0, 0, 0, 4>(cf, "");
+          run<S01, 0, 0, SC1, 0, 0, 0, 4>(cf, "");
+          run<S01, 0, S01, SC1, 0, 0, 0, 4>(cf, "");
+          run<S01, 0, NTL, S01, 0, 0, 0, 4>(cf, "");
+          run<S01, NTL, NTL, SC1, 0, 0, 0, 4>(cf, "");
+        }
+      puts("# + LDS exchange in both passes (X1), + per-lane table reads in the row pass (TW1), + F FP64 FMAs per element and pass");
+      for(int blocked : {0, 1})
+        for(int wpc : {2, 3})
+          for(int lag : {3, 5, 6, 7}) {
+            Cfg cf{m, wpc, lag, 0};
+            cf.blocked = blocked;
+            run<S01, 0, NTL, SC1, 0, 1, 0, 4>(cf, "");
+            run<S01, 0, NTL, SC1, 0, 1, 1, 4>(cf, "");
+            run<S01, 0, NTL, SC1, 40, 1, 1, 4>(cf, "");
+          }
+    }
+    return 0;
+  }
+  const bool sweep2 = getenv("SKEL4_SWEEP2") != nullptr;
+  if(sweep2) {
+    /* second sweep: fewer resident workgroups (smaller in-flight footprint), longer lags, cache-policy hints on the
+     * streaming sides (input loads, final stores) so that they do not displace the intermediate from the L2 */
+    for(int m : {16, 17}) {
+      printf("# N = 2^%d: fused; hints on the streaming sides\n", m);
+      for(int wpc : {1, 2, 3})
+        for(int lag : {2, 3, 4, 6, 8}) {
+          run<NTL, 0, NTL, 0, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+          run<NTL, 0, NTL, NTL, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+          run<NTL, 0, NTL, SC1, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+          run<NTL, 0, NTL, SC1 | NTL, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+          run<SC1 | 1, 0, NTL, SC1, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+          run<NTL | 1, 0, NTL, NTL, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+        }
+    }
+    return 0;
+  }
+  for(int m : {16, 17}) {
+    printf("# N = 2^%d: separate launches per pass (mode 1 then 2) -- the two-launch baseline of this tiling\n", m);
+    run<NTL, 0, NTL, 0, 0, 0, 0, 4>(Cfg{m, 4, 0, 1}, "two launches");
+    run<NTL, 0, NTL, 0, 0, 1, 0, 4>(Cfg{m, 4, 0, 1}, "two launches");
+    printf("# N = 2^%d: fused, XCD-local hand-off; memory only\n", m);
+    for(int wpc : {2, 3, 4})
+      for(int lag : {1, 2, 3, 4, 6}) run<NTL, 0, NTL, 0, 0, 0, 0, 4>(Cfg{m, wpc, lag, 0}, "");
+    puts("# final stores write-through (sc1: the line is dropped from the L2) / nt; row loads sc1");
+    for(int lag : {2, 3, 4}) {
+      run<NTL, 0, NTL, SC1, 0, 0, 0, 4>(Cfg{m, 4, lag, 0}, "");
+      run<NTL, 0, NTL, NTL, 0, 0, 0, 4>(Cfg{m, 4, lag, 0}, "");
+      run<NTL, 0, SC1, 0, 0, 0, 0, 4>(Cfg{m, 4, lag, 0}, "");
+      run<0, 0, SC1, 0, 0, 0, 0, 4>(Cfg{m, 4, lag, 0}, "");
+    }
+    puts("# + LDS exchange in both passes, + table reads in the row pass, + FP64 work (F FMAs per element and pass)");
+    for(int lag : {2, 3, 4}) {
+      run<NTL, 0, NTL, 0, 0, 1, 0, 4>(Cfg{m, 4, lag, 0}, "");
+      run<NTL, 0, NTL, 0, 0, 1, 1, 4>(Cfg{m, 4, lag, 0}, "");
+      run<NTL, 0, NTL, 0, 40, 1, 1, 4>(Cfg{m, 4, lag, 0}, "");
+      run<NTL, 0, NTL, 0, 40, 1, 1, 4>(Cfg{m, 3, lag, 0}, "");
+    }
+  }
+  return 0;
+}
