@@ -216,6 +216,7 @@ struct ntt_plan {
   void *   d_inv8  = nullptr; /* compact inverse twiddles (FP64 policy) */
   ArithU64::consts cu{};
   F64Consts        cf{};
+  std::vector<unsigned char> limbrec; /* this plan's LimbRec<A> (table pointers + constants): copied into the kernel arguments of every launch */
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              num_cus    = 256;
@@ -317,6 +318,33 @@ static int device_build_direction(ntt_plan *p, uint64_t base, bool inverse, uint
   return rc;
 }
 
+/* the plan's LimbRec as raw bytes (host copy): the layout the kernels read (ntt_kernels.h) */
+static std::vector<unsigned char> limbrec_bytes(const ntt_plan *p)
+{
+  std::vector<unsigned char> b;
+  if(p->arith == NTT_ARITH_F64) {
+    LimbRec<ArithF64> r{};
+    r.tw_f  = static_cast<const TwF64 *>(p->d_fwd);
+    r.tw8_f = static_cast<const double *>(p->d_fwd8);
+    r.tw_i  = static_cast<const TwF64 *>(p->d_inv);
+    r.tw8_i = static_cast<const double *>(p->d_inv8);
+    r.c     = p->cf;
+    b.resize(sizeof r);
+    memcpy(b.data(), &r, sizeof r);
+  } else {
+    LimbRec<ArithU64> r{};
+    r.tw_f = static_cast<const TwU64 *>(p->d_fwd);
+    r.tw_i = static_cast<const TwU64 *>(p->d_inv);
+    r.c    = p->cu;
+    b.resize(sizeof r);
+    memcpy(b.data(), &r, sizeof r);
+  }
+  return b;
+}
+static_assert(sizeof(LimbRec<ArithU64>) == sizeof(LimbRec<ArithU64R4>) && sizeof(LimbRec<ArithF64>) == sizeof(LimbRec<ArithF64W>),
+              "the policies of one family share a record layout");
+
+
 /* ninv_override: 0 = derive N^-1 */
 static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64_t root, const TableSet &ts, int arith,
                       uint64_t ninv_override)
@@ -398,6 +426,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
       if(!rc && p->has_inv) rc = upload_u64(&p->d_inv, inv_ext, ts.inv_con, q); /* caller precons cover the first N records */
     }
   }
+  if(!rc) p->limbrec = limbrec_bytes(p);
   if(rc) {
     ntt_plan_destroy(p);
     return rc;
@@ -548,22 +577,36 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   }
 }
 
+/* The limbs one launch serves: the plan's own record (every ordinary call), or an RNS set's records (host array, copied
+ * into the kernel arguments) with the word distance between the limbs' slabs ([limb][batch][N]). */
+struct LimbSet {
+  const void *d;
+  int         n;
+  uint64_t    stride;
+};
+
 static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream,
-                         bool lazy = false)
+                         bool lazy = false, const LimbSet *set = nullptr)
 {
   if(!p || (!d_a && batch)) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
-  const bool tp_auto = p->two_phase < 0 && !inverse && p->m == kFusedMax + 2 && p->kcls != kWideClass;
-  if((p->two_phase == 1 || tp_auto) && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3) {
+  /* the one-launch two-phase kernel owns a CU per polynomial: it only pays when the batch fills the chip (measured +3 % at
+   * batch ~30k; a batch below the CU count would leave CUs idle where the per-pass launches spread one polynomial
+   * over 16 workgroups) -- the automatic choice is gated on that, an explicit NTT_OPT_TWO_PHASE 1 is honoured as given */
+  const bool tp_auto = p->two_phase < 0 && !inverse && p->m == kFusedMax + 2 && p->kcls != kWideClass &&
+                       batch >= 2ull * (uint64_t)p->num_cus;
+  if((p->two_phase == 1 || tp_auto) && ls.n == 1 && !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 &&
+     p->m <= kFusedMax + 3) {
     /* one launch, one workgroup per polynomial, both passes back to back (ntt_kernels.h: twophase_kernel) */
     PassArgs pa{};
     pa.a        = d_a;
-    pa.tw       = inverse ? p->d_inv : p->d_fwd;
-    pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
-    pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+    pa.limbs    = ls.d;
+    pa.nlimbs   = ls.n;
+    pa.limb_stride = ls.stride;
     pa.batch    = batch;
     pa.logn     = (uint32_t)p->m;
     pa.fused    = 2;
@@ -587,7 +630,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   uint64_t chunk = batch;
   if(L.n > 1) {
     const uint64_t budget = (uint64_t)p->chunk_mib << 20;
-    chunk                 = budget / (p->N * sizeof(uint64_t));
+    chunk                 = budget / (p->N * sizeof(uint64_t) * (uint64_t)ls.n); /* a chunk holds this many polynomials of EVERY limb */
     if(chunk < 1) chunk = 1;
     if(chunk > batch) chunk = batch;
   }
@@ -597,9 +640,9 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
       const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
       PassArgs    pa{};
       pa.a        = d_a + first * p->N;
-      pa.tw       = inverse ? p->d_inv : p->d_fwd;
-      pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
-      pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+      pa.limbs    = ls.d;
+      pa.nlimbs   = ls.n;
+      pa.limb_stride = ls.stride;
       pa.lazy     = lazy;
       pa.ends     = k == L.n - 1;
       pa.batch    = nb;
@@ -740,13 +783,13 @@ extern "C" int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, co
 
 /* one pass of a transform on nb polynomials starting at d (shared by run_transform's loop and the fused product) */
 static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint64_t nb, bool inverse, bool wide, bool lazy,
-                           bool ends, void *stream)
+                           bool ends, void *stream, const LimbSet &ls)
 {
   PassArgs pa{};
   pa.a        = d;
-  pa.tw       = inverse ? p->d_inv : p->d_fwd;
-  pa.tw8      = inverse ? p->d_inv8 : p->d_fwd8;
-  pa.consts   = p->arith == NTT_ARITH_F64 ? (const void *)&p->cf : (const void *)&p->cu;
+  pa.limbs    = ls.d;
+  pa.nlimbs   = ls.n;
+  pa.limb_stride = ls.stride;
   pa.batch    = nb;
   pa.logn     = (uint32_t)p->m;
   pa.fused    = ps.fused;
@@ -771,9 +814,11 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
  *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
  *              inverse on c.                                                                   88N bytes, 5 launches
  *              (120N and 7 launches for fwd, fwd, pointwise, inv). */
-static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream)
+static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream,
+                         const LimbSet *set = nullptr)
 {
-  int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  int rc = run_transform(p, d_a, batch, false, false, stream, true, &ls);
   if(rc) return rc;
   USE_DEVICE(p->device);
   /* blocks of the fused launch for N > 2^14: as for the transforms, stages are cheaper in the memory-bound column
@@ -783,7 +828,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   const PassList L     = make_passes(p->m, false, pblk);
   uint64_t       chunk = batch;
   if(L.n > 1) {
-    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t));
+    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t) * (uint64_t)ls.n);
     if(chunk < 1) chunk = 1;
     if(chunk > batch) chunk = batch;
   }
@@ -791,18 +836,16 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
     const uint64_t off = first * p->N;
     for(int k = 0; k + 1 < L.n; k++) { /* forward column passes of b (every pass but the last, which is the block pass) */
-      rc = launch_one_pass(p, L.p[k], d_b + off, nb, false, false, false, false, stream);
+      rc = launch_one_pass(p, L.p[k], d_b + off, nb, false, false, false, false, stream, ls);
       if(rc) return rc;
     }
     ProdArgs pa{};
     pa.b        = d_b + off;
     pa.ahat     = d_a + off;
     pa.out      = d_c + off;
-    pa.tw_f     = p->d_fwd;
-    pa.tw8_f    = p->d_fwd8;
-    pa.tw_i     = p->d_inv;
-    pa.tw8_i    = p->d_inv8;
-    pa.consts   = &p->cf;
+    pa.limbs    = ls.d;
+    pa.nlimbs   = ls.n;
+    pa.limb_stride = ls.stride;
     pa.batch    = nb;
     pa.logn     = (uint32_t)p->m;
     pa.block_log = (uint32_t)pblk;
@@ -816,11 +859,17 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
                                          : launch_product<ArithF64, 0>(pa);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     for(int k = L.n - 2; k >= 0; k--) { /* inverse column passes of c, the last one ends the transform (N^-1) */
-      rc = launch_one_pass(p, L.p[k], d_c + off, nb, true, false, false, k == 0, stream);
+      rc = launch_one_pass(p, L.p[k], d_c + off, nb, true, false, false, k == 0, stream, ls);
       if(rc) return rc;
     }
   }
   return NTT_OK;
+}
+
+static bool fused_product_applies(const ntt_plan *p, const uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, uint64_t batch)
+{
+  return p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= 8 && p->m <= kFusedMax + 3 && !p->generic && p->has_fwd &&
+         p->has_inv && d_a != d_b && d_a && d_b && d_c && batch;
 }
 
 extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
@@ -831,10 +880,7 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
-  if(p && p->fused_product && p->arith == NTT_ARITH_F64 && p->m >= 8 && p->m <= kFusedMax + 3 && !p->generic &&
-     p->has_fwd && p->has_inv && d_a != d_b && d_a && d_b && d_c && batch) {
-    return fused_product(p, d_c, d_a, d_b, batch, stream);
-  }
+  if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c, d_a, d_b, batch, stream);
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);
   if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
@@ -853,24 +899,89 @@ static int rns_check(int nlimbs, ntt_plan *const *plans)
   return NTT_OK;
 }
 
-extern "C" int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
+/* One launch chain for all limbs (SURVEY 8e "split primes"): possible when the limbs' plans agree in
+ * everything a launch is shaped by -- size, device, arithmetic policy and headroom class (one kernel instantiation serves
+ * every limb), and the plan options.  Primes of the same bit size always do.  Otherwise the limbs are looped. */
+static bool rns_uniform(int nlimbs, ntt_plan *const *plans)
+{
+  const ntt_plan *a = plans[0];
+  if(a->arith != NTT_ARITH_F64) return false; /* the MULTI kernel variants are built for the FP64 policies */
+  for(int l = 1; l < nlimbs; l++) {
+    const ntt_plan *b = plans[l];
+    if(b->arith != a->arith || b->kcls != a->kcls || b->m != a->m || b->generic != a->generic || b->block_log != a->block_log ||
+       b->chunk_mib != a->chunk_mib || b->two_phase != a->two_phase || b->fused_product != a->fused_product ||
+       b->max_grid != a->max_grid || b->has_fwd != a->has_fwd || b->has_inv != a->has_inv) {
+      return false;
+    }
+  }
+  return nlimbs > 1;
+}
+
+/* One launch for all limbs pays when a single limb's share cannot fill the chip by itself (a ciphertext: a few
+ * polynomials x tens of primes); with thousands of polynomials per limb every per-limb launch fills it, and the
+ * single-set kernels are the faster ones (no run-time limb index: ntt_kernels.h, MULTI).  NTT_RNS_LOOP=1 / =0 forces
+ * either form (tests, measurements). */
+static bool rns_one_launch_pays(const ntt_plan *p, uint64_t batch)
+{
+  const char *env = getenv("NTT_RNS_LOOP");
+  if(env) return atoi(env) == 0;
+  const uint64_t wg_equivalents = (batch * p->N) >> 12; /* 256-thread workgroups' worth of coefficients per limb */
+  return wg_equivalents < 8ull * (uint64_t)p->num_cus;
+}
+
+/* the records of limbs [first, first + n) as one host array */
+static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first, int n)
+{
+  std::vector<unsigned char> all;
+  for(int l = first; l < first + n; l++) all.insert(all.end(), plans[l]->limbrec.begin(), plans[l]->limbrec.end());
+  return all;
+}
+
+static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, bool inverse, void *stream)
 {
   int rc = rns_check(nlimbs, plans);
-  for(int l = 0; !rc && l < nlimbs; l++) rc = ntt_fwd_batch(plans[l], d_a + (uint64_t)l * batch * plans[l]->N, batch, stream);
+  if(rc || batch == 0) return rc;
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch)) {
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet ls{recs.data(), n, batch * plans[0]->N};
+      rc = run_transform(plans[first], d_a + (uint64_t)first * batch * plans[0]->N, batch, inverse, false, stream, false, &ls);
+    }
+    return rc;
+  }
+  for(int l = 0; !rc && l < nlimbs; l++) {
+    uint64_t *d = d_a + (uint64_t)l * batch * plans[l]->N;
+    rc          = inverse ? ntt_inv_batch(plans[l], d, batch, stream) : ntt_fwd_batch(plans[l], d, batch, stream);
+  }
   return rc;
+}
+
+extern "C" int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
+{
+  return rns_transform(nlimbs, plans, d_a, batch, false, stream);
 }
 
 extern "C" int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
 {
-  int rc = rns_check(nlimbs, plans);
-  for(int l = 0; !rc && l < nlimbs; l++) rc = ntt_inv_batch(plans[l], d_a + (uint64_t)l * batch * plans[l]->N, batch, stream);
-  return rc;
+  return rns_transform(nlimbs, plans, d_a, batch, true, stream);
 }
 
 extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
                                             uint64_t *d_b, uint64_t batch, void *stream)
 {
   int rc = rns_check(nlimbs, plans);
+  if(rc || batch == 0) return rc;
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && fused_product_applies(plans[0], d_c, d_a, d_b, batch)) {
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet  ls{recs.data(), n, batch * plans[0]->N};
+      const uint64_t off = (uint64_t)first * batch * plans[0]->N;
+      rc                 = fused_product(plans[first], d_c + off, d_a + off, d_b + off, batch, stream, &ls);
+    }
+    return rc;
+  }
   for(int l = 0; !rc && l < nlimbs; l++) {
     const uint64_t off = (uint64_t)l * batch * plans[l]->N;
     rc                 = ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);

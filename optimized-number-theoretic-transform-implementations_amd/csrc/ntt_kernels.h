@@ -105,6 +105,72 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   static constexpr int WPS  = WPS0 < 1 ? 1 : (WPS0 > WPSC ? WPSC : WPS0);
 };
 
+/* ------------------------------------------------------------------ */
+/* kernel arguments: one launch may serve several RNS limbs             */
+/* ------------------------------------------------------------------ */
+/*
+ * A launch carries one LimbRec per limb in its kernel arguments: one for an ordinary call, up to kMaxLimbs for an RNS set
+ * (ntt_rns_*: limbs laid out [limb][batch][N], every limb its own prime, tables and constants -- SURVEY 8e).
+ * Workgroup g of a launch serves limb g / wgs_per_limb and is block-id g % wgs_per_limb of that limb's share of the grid,
+ * so a persistent workgroup never changes limb (its LDS tables and register-resident twiddles stay valid) and ONE launch
+ * fills the chip even when a single limb's batch is a handful of polynomials (a ciphertext: few polynomials x tens of
+ * primes).  The kernels below build their Params from their limb's record and are otherwise unchanged.
+ */
+template <class A> struct LimbRec {
+  const typename A::tw * tw_f;  /* forward records                                   */
+  const typename A::ctw *tw8_f; /* forward compact (FP64 policies; null otherwise)   */
+  const typename A::tw * tw_i;  /* inverse records (+16 folded N^-1 records)         */
+  const typename A::ctw *tw8_i;
+  typename A::consts     c;
+};
+
+constexpr int kMaxLimbs = 16; /* limbs of one launch (16 records of 112 bytes in the 4 KiB kernel-argument segment); larger sets take several launches */
+
+template <class A> struct KArgs {
+  uint64_t *        a;            /* limb 0's coefficients                                        */
+  uint64_t          limb_stride;  /* words between the slabs of consecutive limbs                 */
+  uint32_t          wgs_per_limb; /* grid = wgs_per_limb * limbs                                  */
+  uint32_t          logn, s0, wide, lastinv, lazy;
+  uint64_t          nblocks;      /* per limb                                                     */
+  /* one record per limb, IN the kernel-argument segment: its loads are kernarg-relative scalar loads like those of a
+   * single set of tables (the compiler re-loads them at will instead of holding or spilling them -- a table in global
+   * memory cost the 2^14 inverse kernel 3-4 spilled VGPRs) */
+  LimbRec<A>        limbs[kMaxLimbs];
+};
+
+/* the launch's Params for this workgroup's limb; bid = its block id inside the limb's share of the grid */
+/* MULTI is a compile-time property of the kernel: with it off the limb is 0, every record field sits at a fixed offset of
+ * the kernel-argument segment (the compiler re-loads such values at will instead of keeping them in registers) and the
+ * kernel is the single-set kernel it always was; a run-time limb index costs the register-tight kernels 2-4 spilled VGPRs
+ * (measured: the 2^14 inverse, the 2^13 forward), which is why the host only uses the MULTI variants when one limb's share
+ * alone cannot fill the chip. */
+template <class A, bool INV, bool MULTI>
+__device__ __forceinline__ Params<A> limb_params(const KArgs<A> &k, uint32_t &bid, uint32_t &gdim, uint32_t &limb)
+{
+  if constexpr(MULTI) {
+    limb = blockIdx.x / k.wgs_per_limb; /* wave-uniform: scalar arithmetic, once per workgroup */
+    bid  = blockIdx.x - limb * k.wgs_per_limb;
+    gdim = k.wgs_per_limb;
+  } else {
+    limb = 0;
+    bid  = blockIdx.x;
+    gdim = gridDim.x;
+  }
+  const LimbRec<A> &r = k.limbs[limb];
+  Params<A>         p;
+  p.a       = k.a + (uint64_t)limb * k.limb_stride;
+  p.tw      = INV ? r.tw_i : r.tw_f;
+  p.tw8     = INV ? r.tw8_i : r.tw8_f;
+  p.c       = r.c;
+  p.logn    = k.logn;
+  p.s0      = k.s0;
+  p.wide    = k.wide;
+  p.lastinv = k.lastinv;
+  p.lazy    = k.lazy;
+  p.nblocks = k.nblocks;
+  return p;
+}
+
 #ifdef NTT_STAMPS
 /* diagnostic build only: per-phase s_memtime stamps of every wave of the first
  * 256 workgroups (never compiled into the shipped library) */
@@ -339,9 +405,11 @@ __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Par
 /* LAZY (forward, FP64 policy): outputs in [0,4q) instead of [0,q) -- a kernel variant of its own because
  * the reduction schedule has to bound the last stage (fused_mask); the integer policies take the run-time
  * flag Params::lazy instead. */
-template <class A, int LOGN, bool INV, int KSH, bool LASTINV = false, bool LAZY = false>
-__global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<LOGN, INV, flavor_of<A>()>::WPS)) fused_kernel(const Params<A> p)
+template <class A, int LOGN, bool INV, int KSH, bool LASTINV = false, bool LAZY = false, bool MULTI = false>
+__global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<LOGN, INV, flavor_of<A>()>::WPS)) fused_kernel(const KArgs<A> k)
 {
+  uint32_t        bid, gdim, limb_;
+  const Params<A> p = limb_params<A, INV, MULTI>(k, bid, gdim, limb_);
   using P                 = Plan<LOGN>;
   using G                 = Geom<LOGN, INV, flavor_of<A>()>;
   static_assert(!LAZY || (!INV && A::kTracksBounds), "the LAZY variant exists for the FP64 forward kernels only");
@@ -374,8 +442,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
      * shadows the last one and never stores.  BPW == 1: tt, ll, b are tid, lds_all, b0 -- unchanged code. */
     const uint32_t         tt     = G::BPW == 1 ? tid : t;
     typename A::val *const ll     = G::BPW == 1 ? lds_all : lds;
-    const uint64_t         stride = (uint64_t)gridDim.x * G::BPW;
-    uint64_t               b0     = (uint64_t)blockIdx.x * G::BPW;
+    const uint64_t         stride = (uint64_t)gdim * G::BPW;
+    uint64_t               b0     = (uint64_t)bid * G::BPW;
     if(b0 >= p.nblocks) return;
     const uint64_t lastb = p.nblocks - 1;
     uint64_t       b     = G::BPW == 1 ? b0 : (b0 + sub < p.nblocks ? b0 + sub : lastb);
@@ -458,8 +526,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     constexpr bool LTW    = LDS_TW > 0;
     const uint32_t         tt     = G::BPW == 1 ? tid : t;
     typename A::val *const ll     = G::BPW == 1 ? lds_all : lds;
-    const uint64_t         stride = (uint64_t)gridDim.x * G::BPW;
-    uint64_t               b0     = (uint64_t)blockIdx.x * G::BPW;
+    const uint64_t         stride = (uint64_t)gdim * G::BPW;
+    uint64_t               b0     = (uint64_t)bid * G::BPW;
     if(b0 >= p.nblocks) return;
     const uint64_t lastb = p.nblocks - 1;
     uint64_t       b     = G::BPW == 1 ? b0 : (b0 + sub < p.nblocks ? b0 + sub : lastb);
@@ -528,7 +596,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     fill_lds_tables<A, LOGN, INV>(reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS), p, 0u, tid);
     __syncthreads();
   }
-  for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
+  for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gdim * G::BPW) {
     uint64_t   b    = b0 + sub;
     const bool live = b < p.nblocks;
     if(!live) b = p.nblocks - 1; /* idle lanes shadow a real block, never store */
@@ -706,8 +774,10 @@ template <class A, int LOGN, bool INV> struct TableRegs {
 constexpr int kTpPreAt = 1;
 constexpr int kTpPfAt  = 2;
 template <class A, int LEAD, bool INV, int KSH>
-__global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
+__global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
 {
+  uint32_t        bid, gdim, limb_;
+  const Params<A> pin = limb_params<A, INV, false>(k, bid, gdim, limb_);
   constexpr int LOGN = kFusedLarge;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, INV, flavor_of<A>()>;
@@ -728,7 +798,7 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const Params<A> pin)
    * policy canonical words (out_word ignores the flag for it) */
   constexpr bool MID_LAZY = !A::kTracksBounds;
 
-  for(uint64_t poly = blockIdx.x; poly < p.nblocks; poly += gridDim.x) {
+  for(uint64_t poly = bid; poly < p.nblocks; poly += gdim) {
     uint64_t *const base = p.a + (poly << (LOGN + LEAD));
     if constexpr(!INV) {
       twophase_columns<A, LEAD, false, KSH>(base, tid, p, p.wide != 0, MID_LAZY);
@@ -860,6 +930,25 @@ template <class A> struct ProdParams {
   uint64_t *             out;    /* c; may alias b or ahat */
   uint32_t               a_lazy;
 };
+/* kernel argument of the product kernels (limb 0's pointers; KArgs::limb_stride separates the limbs of all three slabs) */
+template <class A> struct KProd {
+  KArgs<A>        f;
+  const uint64_t *ahat;
+  uint64_t *      out;
+  uint32_t        a_lazy;
+};
+template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_prod_params(const KProd<A> &k, uint32_t &bid, uint32_t &gdim)
+{
+  uint32_t      limb;
+  ProdParams<A> pp;
+  pp.f = limb_params<A, false, MULTI>(k.f, bid, gdim, limb);
+  pp.tw_i   = k.f.limbs[limb].tw_i;
+  pp.tw8_i  = k.f.limbs[limb].tw8_i;
+  pp.ahat   = k.ahat + (uint64_t)limb * k.f.limb_stride;
+  pp.out    = k.out + (uint64_t)limb * k.f.limb_stride;
+  pp.a_lazy = k.a_lazy;
+  return pp;
+}
 
 /* WHOLE: the block is the whole polynomial (N = 2^14).  !WHOLE: the blocks of a larger transform (N = 2^15..2^17,
  * pp.f.s0 = log2 N - 14 leading stages done by column passes before and after this launch): the product is
@@ -867,10 +956,12 @@ template <class A> struct ProdParams {
  * 88N bytes instead of 120N.  A workgroup then always sees the same block position (its stride is a multiple of the
  * blocks per polynomial), whose forward table slice it keeps in LDS; the mirrored read would need the slice of the
  * complementary position, so the inverse half takes that one group's twiddles from global memory instead. */
-template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE>
+template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
-  fused_product_kernel(const ProdParams<A> pp)
+  fused_product_kernel(const KProd<A> kp)
 {
+  uint32_t            bid, gdim;
+  const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, 3>;
   static_assert(A::kCompact && G::BPW == 1 && (LOGN == 14 || LOGN == 12 || (LOGN == 13 && WHOLE)),
@@ -896,8 +987,8 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   pi.tw                       = pp.tw_i;
   pi.tw8                      = pp.tw8_i;
   pi.lastinv                  = WHOLE ? 1 : 0;
-  const uint64_t stride = gridDim.x;
-  uint64_t       b      = blockIdx.x;
+  const uint64_t stride = gdim;
+  uint64_t       b      = bid;
   if(b >= pf.nblocks) return;
   const uint32_t blk = WHOLE ? 0u : ((uint32_t)b & ((1u << pf.s0) - 1u)); /* the same for every block of this workgroup */
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
@@ -968,10 +1059,12 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
  * the product and the inverse half appended.  Every per-lane group has its forward table in LDS at these sizes, and the
  * inverse half reads all of them mirrored, so the kernel issues no per-lane global twiddle load at all; a^ arrives in
  * the last group's layout as 16-byte loads.  40N bytes per product instead of 72N. */
-template <class A, int LOGN, int KSH>
+template <class A, int LOGN, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
-  fused_product_small_kernel(const ProdParams<A> pp)
+  fused_product_small_kernel(const KProd<A> kp)
 {
+  uint32_t            bid, gdim;
+  const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, 3>;
   static_assert(A::kCompact && G::BPW > 1 && LOGN >= 8 && LOGN <= 11, "whole polynomials of 2^8..2^11 points");
@@ -995,7 +1088,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   pi.lastinv   = 1;
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, 0u, tid);
   __syncthreads();
-  for(uint64_t b0 = (uint64_t)blockIdx.x * G::BPW; b0 < pf.nblocks; b0 += (uint64_t)gridDim.x * G::BPW) {
+  for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < pf.nblocks; b0 += (uint64_t)gdim * G::BPW) {
     uint64_t   b    = b0 + sub;
     const bool live = b < pf.nblocks;
     if(!live) b = pf.nblocks - 1; /* idle sub-blocks shadow a real polynomial (barriers are workgroup-wide), never store */
@@ -1021,19 +1114,19 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   }
 }
 
-template <class A, int R, bool INV, int KSH>
-__global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S,
-                                                     uint32_t wide, uint32_t lastinv, uint32_t lazy,
-                                                     const typename A::tw *tab, const typename A::consts c)
+template <class A, int R, bool INV, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
 {
+  /* k.nblocks = polynomials per limb, k.s0 = first global stage of the pass */
+  uint32_t           bid, gdim, limb_;
+  const Params<A>    p     = limb_params<A, INV, MULTI>(k, bid, gdim, limb_);
   constexpr uint32_t MASK  = column_mask<A, R, INV, KSH>();
-  const uint32_t     lcols = logn - R;
-  const uint64_t     total = batch << lcols;
-  for(uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-      g += (uint64_t)gridDim.x * blockDim.x) {
+  const uint32_t     lcols = p.logn - R;
+  const uint64_t     total = p.nblocks << lcols;
+  for(uint64_t g = (uint64_t)bid * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gdim * blockDim.x) {
     const uint64_t poly = g >> lcols;
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
-    column_pass_thread<A, R, INV, MASK>(a + (poly << logn), col, logn, S, wide != 0, lastinv != 0, tab, c, lazy != 0);
+    column_pass_thread<A, R, INV, MASK>(p.a + (poly << p.logn), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
   }
 }
 
@@ -1042,10 +1135,10 @@ __global__ void __launch_bounds__(256) column_kernel(uint64_t *a, uint64_t batch
 /* ------------------------------------------------------------------ */
 struct PassArgs {
   uint64_t *  a;
-  const void *tw;     /* device table of A::tw             */
-  const void *tw8;    /* device table of A::ctw (may be null for policies without a compact form) */
-  const void *consts; /* host pointer to A::consts         */
-  uint64_t    batch;
+  const void *limbs;       /* HOST array of LimbRec<A>, one per limb (copied into the kernel arguments) */
+  int         nlimbs;      /* >= 1 */
+  uint64_t    limb_stride; /* words between consecutive limbs' slabs   */
+  uint64_t    batch;       /* polynomials per limb                     */
   uint32_t    logn;   /* whole transform                   */
   int         fused;  /* Pass::fused; 2 = both passes of a 2^15..2^17 transform in one launch (r = m - 14) */
   int         r;      /* Pass::r                           */
@@ -1067,9 +1160,10 @@ struct ProdArgs {
   uint64_t *      b;
   const uint64_t *ahat;
   uint64_t *      out;
-  const void *    tw_f, *tw8_f, *tw_i, *tw8_i;
-  const void *    consts;
-  uint64_t        batch;
+  const void *    limbs;       /* HOST array of LimbRec<A> */
+  int             nlimbs;
+  uint64_t        limb_stride;
+  uint64_t        batch;       /* per limb */
   uint32_t        logn;
   uint32_t        block_log; /* N > 2^14: log2 of the blocks (12, 13 or 14); the column passes around the launch cover logn - block_log stages */
   int             a_lazy;
@@ -1084,20 +1178,34 @@ template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
  * policy ignores the run-time flag (its passes exchange canonical words). */
 inline int pass_lazy(const PassArgs &pa) { return pa.ends ? pa.lazy : 1; }
 
+/* the MULTI kernel variants exist for the scheduled FP64 policy and its 52-bit form */
+template <class A> constexpr bool multi_limb_built() { return A::kCompact; }
+
+template <class A> KArgs<A> make_kargs(const PassArgs &pa)
+{
+  KArgs<A> k{};
+  k.a            = pa.a;
+  const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
+  for(int l = 0; l < (pa.nlimbs > 0 ? pa.nlimbs : 1) && l < kMaxLimbs; l++) k.limbs[l] = recs[l];
+  k.limb_stride  = pa.limb_stride;
+  k.wgs_per_limb = 1;
+  k.logn         = pa.logn;
+  k.s0           = 0;
+  k.wide         = (uint32_t)pa.wide;
+  k.lastinv      = (uint32_t)pa.lastinv;
+  k.lazy         = (uint32_t)pa.lazy;
+  k.nblocks      = pa.batch;
+  return k;
+}
+
 template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const PassArgs &pa)
 {
   using G = Geom<LOGN, INV, flavor_of<A>()>;
-  Params<A> p{};
-  p.a       = pa.a;
-  p.tw      = static_cast<const typename A::tw *>(pa.tw);
-  p.tw8     = static_cast<const typename A::ctw *>(pa.tw8);
-  p.c       = *static_cast<const typename A::consts *>(pa.consts);
-  p.logn    = pa.logn;
-  p.s0      = (uint32_t)pa.s;
-  p.wide    = (uint32_t)pa.wide;
-  p.lastinv = (uint32_t)pa.lastinv;
-  p.lazy    = (uint32_t)pass_lazy(pa);
-  p.nblocks = pa.batch << pa.s;
+  KArgs<A> p  = make_kargs<A>(pa);
+  p.s0        = (uint32_t)pa.s;
+  p.lazy      = (uint32_t)pass_lazy(pa);
+  p.nblocks   = pa.batch << pa.s;
+  const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
   uint64_t wgs = (p.nblocks + G::BPW - 1) / G::BPW;
   uint64_t cap = 1ull << 20;
   if(G::PERSISTENT) {
@@ -1115,6 +1223,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
   }
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+  cap = cap / nl > 0 ? cap / nl : 1; /* the limbs of one launch share the resident workgroups */
   /* a persistent workgroup must always see the same block position inside the
    * polynomial (its LDS twiddle table depends on it): the grid, which is its
    * stride, is a multiple of the 2^s blocks per polynomial (nblocks always is) */
@@ -1124,25 +1233,49 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   }
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
+  p.wgs_per_limb = (uint32_t)wgs;
+  wgs *= nl;
+  const dim3 grid((unsigned)wgs), wg(G::WG);
+  if(nl > 1) {
+    /* several limbs in one launch: the MULTI variants, built for the FP64 policies (the ones RNS bases use) */
+    if constexpr(multi_limb_built<A>()) {
+      if constexpr(INV) {
+        if(pa.lastinv) {
+          hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true, false, true>), grid, wg, 0, pa.stream, p);
+        } else if constexpr(LOGN == kFusedLarge || LOGN == kFusedSmallBlock) {
+          hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false, false, true>), grid, wg, 0, pa.stream, p);
+        } else {
+          return hipErrorInvalidValue;
+        }
+      } else if(pa.ends && pa.lazy) {
+        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true, true>), grid, wg, 0, pa.stream, p);
+      } else {
+        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, false, true>), grid, wg, 0, pa.stream, p);
+      }
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   if constexpr(INV) {
     /* the inverse kernel exists in two variants: ending a whole transform (N^-1 folded into
      * its last group) -- every block size -- and, for the block size used below column
      * passes, not ending it */
     if(pa.lastinv) {
-      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true>), grid, wg, 0, pa.stream, p);
     } else if constexpr(LOGN == kFusedLarge || LOGN == kFusedSmallBlock) {
-      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+      hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false>), grid, wg, 0, pa.stream, p);
     } else {
       return hipErrorInvalidValue;
     }
   } else {
     if constexpr(A::kTracksBounds) {
       if(pa.ends && pa.lazy) {
-        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true>), grid, wg, 0, pa.stream, p);
         return hipGetLastError();
       }
     }
-    hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, false>), dim3((unsigned)wgs), dim3(G::WG), 0, pa.stream, p);
+    hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, false>), grid, wg, 0, pa.stream, p);
   }
   return hipGetLastError();
 }
@@ -1158,22 +1291,17 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
   if constexpr(!two_phase_built<A, LEAD>()) {
     return hipErrorNotSupported;
   } else {
-  Params<A> p{};
-  p.a       = pa.a;
-  p.tw      = static_cast<const typename A::tw *>(pa.tw);
-  p.tw8     = static_cast<const typename A::ctw *>(pa.tw8);
-  p.c       = *static_cast<const typename A::consts *>(pa.consts);
-  p.logn    = pa.logn;
-  p.s0      = (uint32_t)LEAD;
-  p.wide    = (uint32_t)pa.wide;
-  p.lastinv = (uint32_t)pa.inverse;
-  p.lazy    = (uint32_t)pa.lazy;
-  p.nblocks = pa.batch;
+  if(pa.nlimbs > 1) return hipErrorNotSupported; /* (RNS sets take the per-pass launches) */
+  KArgs<A> p = make_kargs<A>(pa);
+  p.s0       = (uint32_t)LEAD;
+  p.lastinv  = (uint32_t)pa.inverse;
+  p.nblocks  = pa.batch;
   uint64_t wgs = pa.batch;
   uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
+  p.wgs_per_limb = (uint32_t)wgs;
   hipLaunchKernelGGL((twophase_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, p);
   return hipGetLastError();
   }
@@ -1181,15 +1309,27 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
 
 template <class A, int R, bool INV, int KSH> hipError_t launch_column(const PassArgs &pa)
 {
+  KArgs<A> p = make_kargs<A>(pa);
+  p.s0       = (uint32_t)pa.s;
+  p.lazy     = (uint32_t)pass_lazy(pa);
+  p.nblocks  = pa.batch;
+  const uint64_t nl    = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
   const uint64_t total = pa.batch << (pa.logn - R);
   uint64_t       wgs   = (total + 255) / 256;
-  const uint64_t cap   = pa.max_grid > 0 ? (uint64_t)pa.max_grid : (1ull << 22);
+  uint64_t       cap   = pa.max_grid > 0 ? (uint64_t)pa.max_grid : (1ull << 22);
+  cap                  = cap / nl > 0 ? cap / nl : 1;
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
-  hipLaunchKernelGGL((column_kernel<A, R, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, pa.a,
-                     pa.batch, pa.logn, (uint32_t)pa.s, (uint32_t)pa.wide, (uint32_t)pa.lastinv, (uint32_t)pass_lazy(pa),
-                     static_cast<const typename A::tw *>(pa.tw),
-                     *static_cast<const typename A::consts *>(pa.consts));
+  p.wgs_per_limb = (uint32_t)wgs;
+  if(nl > 1) {
+    if constexpr(multi_limb_built<A>()) {
+      hipLaunchKernelGGL((column_kernel<A, R, INV, KSH, true>), dim3((unsigned)(wgs * nl)), dim3(256), 0, pa.stream, p);
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
+  hipLaunchKernelGGL((column_kernel<A, R, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, p);
   return hipGetLastError();
 }
 
@@ -1202,22 +1342,23 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     const uint32_t blog = pa.logn <= 14 ? pa.logn : (pa.block_log ? pa.block_log : 14u);
     if(blog < 12 && pa.logn > 14) return hipErrorInvalidValue;
     const uint32_t s0 = pa.logn - blog; /* leading stages done by column passes around this launch */
-    ProdParams<A>  pp{};
-    pp.f.a       = pa.b;
-    pp.f.tw      = static_cast<const typename A::tw *>(pa.tw_f);
-    pp.f.tw8     = static_cast<const typename A::ctw *>(pa.tw8_f);
-    pp.f.c       = *static_cast<const typename A::consts *>(pa.consts);
-    pp.f.logn    = pa.logn;
-    pp.f.s0      = s0;
-    pp.f.nblocks = pa.batch << s0;
-    pp.tw_i      = static_cast<const typename A::tw *>(pa.tw_i);
-    pp.tw8_i     = static_cast<const typename A::ctw *>(pa.tw8_i);
-    pp.ahat      = pa.ahat;
-    pp.out       = pa.out;
-    pp.a_lazy    = (uint32_t)pa.a_lazy;
+    KProd<A> pp{};
+    pp.f.a            = pa.b;
+    const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
+    for(int l = 0; l < (pa.nlimbs > 0 ? pa.nlimbs : 1) && l < kMaxLimbs; l++) pp.f.limbs[l] = recs[l];
+    pp.f.limb_stride  = pa.limb_stride;
+    pp.f.wgs_per_limb = 1;
+    pp.f.logn         = pa.logn;
+    pp.f.s0           = s0;
+    pp.f.nblocks      = pa.batch << s0;
+    pp.ahat           = pa.ahat;
+    pp.out            = pa.out;
+    pp.a_lazy         = (uint32_t)pa.a_lazy;
+    const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
     uint64_t wgs = pp.f.nblocks;
     uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
     if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+    cap = cap / nl > 0 ? cap / nl : 1;
     /* a workgroup keeps the tables of ONE block position: its stride is a multiple of the blocks per polynomial */
     if(cap < (1ull << s0)) cap = 1ull << s0;
     cap &= ~((1ull << s0) - 1);
@@ -1234,8 +1375,11 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     uint64_t      g      = (pp.f.nblocks + GS::BPW - 1) / GS::BPW;                                                  \
     uint64_t      gcap   = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;           \
     if(pa.max_grid > 0) gcap = (uint64_t)pa.max_grid;                                                               \
+    gcap = gcap / nl > 0 ? gcap / nl : 1;                                                                           \
     if(g > gcap) g = gcap;                                                                                          \
-    hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
+    pp.f.wgs_per_limb = (unsigned)g;                                                                                \
+    if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true>), dim3((unsigned)(g * nl)), dim3(GS::WG), 0, pa.stream, pp); \
+    else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
     return hipGetLastError();                                                                                       \
   }
         NTT_SMALL_PRODUCT(8)
@@ -1251,22 +1395,37 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       constexpr int per_cu = G12::WG_PER_CU0 < G12::WPS ? G12::WG_PER_CU0 : G12::WPS; /* 256-thread workgroups: one wave per SIMD each */
       uint64_t      cap12  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * per_cu;
       if(pa.max_grid > 0) cap12 = (uint64_t)pa.max_grid;
+      cap12 = cap12 / nl > 0 ? cap12 / nl : 1;
       if(cap12 < (1ull << s0)) cap12 = 1ull << s0;
       cap12 &= ~((1ull << s0) - 1);
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
-      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
-      else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+      pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(nl > 1) {
+        if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+      } else {
+        if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+      }
       return hipGetLastError();
     }
     if(blog == 13) {
       using G13 = Geom<13, false, 3>;
       /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
       if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
-      hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
+      pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G13::WG), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
       return hipGetLastError();
     }
-    if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
-    else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    pp.f.wgs_per_limb = (uint32_t)wgs;
+    if(nl > 1) {
+      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+    } else {
+      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+    }
     return hipGetLastError();
   }
 }

@@ -161,14 +161,39 @@ def test_c_example_builds_against_the_public_header(lib):
     assert os.path.exists(os.path.join(ROOT, "build", "batched_product"))
 
 
+def _last_template_bool_is_multi(name):
+    """mangled kernel names: fused_kernel<A, LOGN, INV, KSH, LASTINV, LAZY, MULTI> has three trailing bools,
+    column_kernel<A, R, INV, KSH, MULTI> an int before the last one, fused_product_kernel<A, LOGN, KSH, ALAZY, WHOLE, MULTI>
+    three trailing bools, fused_product_small_kernel<A, LOGN, KSH, MULTI> one bool after an int"""
+    import re
+    head = name.split("EEEvNS_")[0] + "E"
+    args = re.findall(r"(Lb[01]E|Li\d+E)", head)
+    if "fused_kernel" in name:
+        return len(args) >= 6 and args[-1] == "Lb1E" and args[-3].startswith("Lb")
+    if "column_kernel" in name:
+        return args[-1] == "Lb1E" and args[-2].startswith("Li")
+    if "fused_product_small" in name:
+        return args[-1] == "Lb1E" and args[-2].startswith("Li")
+    if "fused_product_kernel" in name:
+        return args[-1] == "Lb1E" and args[-2].startswith("Lb") and args[-3].startswith("Lb")
+    return False
+
+
 def test_headline_kernels_do_not_spill():
     """persistent kernels for blocks >= 2^12 must be scratch-free (a spill reload is a vmcnt(0) wait queued
     behind the HBM prefetch: measured -40 %); read from the built objects' metadata, no GPU needed"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_spills
-    ks = check_spills.all_kernels()
-    assert len(ks) >= 80
+    every = check_spills.all_kernels()
+    # the MULTI variants (several RNS limbs in one launch: the limb's tables are picked at run time from an array in the
+    # kernel arguments) are exempt: a run-time limb index costs the register-tight ones 2-6 spilled VGPRs, which is why
+    # the host only takes them when one limb's share alone cannot fill the chip (ntt_host.hip rns_one_launch_pays)
+    multi = [k for k in every if _last_template_bool_is_multi(k["name"])]
+    ks = [k for k in every if k not in multi]
+    assert len(ks) >= 80 and len(multi) >= 40
+    for k in multi:
+        assert k["vgpr_spill_count"] <= 8, k
     fused = [k for k in ks if "fused_kernel" in k["name"] and "ArithF64" in k["name"]]
     big = [k for k in fused if any(("ELi%dE" % ln) in k["name"] for ln in (12, 13, 14))]
     # 3 block sizes x (3 headroom classes + the wide policy for q up to 2^52) x {fwd, fwd with lazy outputs, inv},

@@ -302,6 +302,84 @@ def test_rns_pipeline_small(lib, oracle):
     assert np.array_equal(got[s0:s0 + n], oracle.schoolbook(a[s0:s0 + n].copy(), b[s0:s0 + n].copy(), n, q))
 
 
+@pytest.mark.parametrize("logn", [14, 16])
+@pytest.mark.parametrize("nlimbs", [4, 16])
+@pytest.mark.parametrize("batch", [1, 2, 8])
+def test_rns_one_launch_over_all_limbs(lib, oracle, logn, nlimbs, batch, monkeypatch):
+    """ntt_rns_{fwd,inv,negacyclic_mul}_batch with a small per-limb batch: ONE launch (per pass) serves every limb
+    (kernel variants MULTI: the workgroup picks its limb's tables and constants from an array in the kernel arguments).
+    Every limb of every polynomial against the oracle; the same calls with NTT_RNS_LOOP=1 (one launch chain per prime,
+    the single-set kernels) must give the same words."""
+    n = 1 << logn
+    qs = [lib.find_prime(50, n, k) for k in range(nlimbs)]
+    assert len(set(qs)) == nlimbs
+    roots = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    assert len({p.info()["f64_class"] for p in plans}) == 1
+    a = np.concatenate([_inputs(oracle, n, q, batch, 900 + l) for l, q in enumerate(qs)])
+    b = np.concatenate([_inputs(oracle, n, q, batch, 950 + l) for l, q in enumerate(qs)])
+    ctxs = [oracle.ctx(n, q, w) for q, w in zip(qs, roots)]
+    sl = [slice(l * batch * n, (l + 1) * batch * n) for l in range(nlimbs)]
+    exp_f = np.concatenate([cx.fwd(a[s]) for cx, s in zip(ctxs, sl)])
+    exp_p = np.concatenate([cx.inv(oracle.pointwise(cx.fwd(a[s]), cx.fwd(b[s]), q)) for cx, s, q in zip(ctxs, sl, qs)])
+    results = {}
+    for loop in ("0", "1"):
+        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+        lib.rns_fwd(plans, da.ptr, batch)
+        f = da.download()
+        lib.rns_inv(plans, da.ptr, batch)
+        back = da.download()
+        lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+        results[loop] = (f, back, dc.download())
+        for x in (da, db, dc):
+            x.free()
+    for loop, (f, back, prod) in results.items():
+        assert np.array_equal(f, exp_f), loop
+        assert np.array_equal(back, a), loop
+        assert np.array_equal(prod, exp_p), loop
+    for p in plans:
+        p.destroy()
+
+
+def test_rns_one_launch_more_limbs_than_one_launch_holds(lib, oracle, monkeypatch):
+    """20 limbs: the kernel arguments hold 16 records, the set is served by two launches (16 + 4)"""
+    n, nlimbs, batch = 1 << 12, 20, 3
+    qs = [lib.find_prime(49, n, k) for k in range(nlimbs)]
+    roots = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    a = np.concatenate([_inputs(oracle, n, q, batch, 700 + l) for l, q in enumerate(qs)])
+    b = np.concatenate([_inputs(oracle, n, q, batch, 750 + l) for l, q in enumerate(qs)])
+    monkeypatch.setenv("NTT_RNS_LOOP", "0")
+    da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+    lib.rns_fwd(plans, da.ptr, batch)
+    got_f = da.download()
+    da.upload(a)
+    lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+    got_p = dc.download()
+    for l, (q, w) in enumerate(zip(qs, roots)):
+        cx = oracle.ctx(n, q, w)
+        s = slice(l * batch * n, (l + 1) * batch * n)
+        assert np.array_equal(got_f[s], cx.fwd(a[s])), l
+        assert np.array_equal(got_p[s], cx.inv(oracle.pointwise(cx.fwd(a[s]), cx.fwd(b[s]), q))), l
+
+
+def test_rns_mixed_classes_fall_back_to_the_loop(lib, oracle):
+    """limbs whose primes need different kernel instantiations (a 30-bit and a 51-bit prime: different FP64 headroom
+    classes) cannot share a launch: served one by one, same results"""
+    n, batch = 1 << 10, 2
+    qs = [lib.find_prime(30, n), lib.find_prime(51, n), lib.find_prime(45, n)]
+    roots = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    a = np.concatenate([_inputs(oracle, n, q, batch, 600 + l) for l, q in enumerate(qs)])
+    da = lib.DeviceBuffer(a.size).upload(a)
+    lib.rns_fwd(plans, da.ptr, batch)
+    got = da.download()
+    for l, (q, w) in enumerate(zip(qs, roots)):
+        s = slice(l * batch * n, (l + 1) * batch * n)
+        assert np.array_equal(got[s], oracle.ctx(n, q, w).fwd(a[s])), l
+
+
 def test_full_size_config5_share_rns_n131072(lib, oracle):
     """BASELINE config 5, one GPU's share: N=2^17, 4-prime RNS, 512 polynomials per GPU
     (2 GiB per operand): fwd/pointwise/inv pipeline, sampled polynomials vs the oracle,
