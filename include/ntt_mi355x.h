@@ -72,7 +72,8 @@ typedef enum ntt_option {
                           * (3 or 4 column stages), 14 (1 or 2), 0 (default) = the faster one as measured.  Results
                           * are identical. */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
-                          * fwd(b)*a^ -> inverse kernel (40N bytes); 0 = fwd, fwd, pointwise, inv (72N bytes) */
+                          * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14; block by block between column passes, 88N
+                          * bytes, above); 0 = fwd, fwd, pointwise, inv (72N / 120N bytes) */
 } ntt_option;
 
 typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
@@ -136,8 +137,8 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
  * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
- * transform); d_b is overwritten likewise or -- when the fused product kernel serves the call (FP64, N = 2^8 .. 2^14) --
- * left as it was; callers must not rely on either.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
+ * transform); d_b is overwritten likewise (four-launch chain), overwritten by the column passes of its forward transform
+ * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
@@ -146,7 +147,11 @@ NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t 
  * prime q_l (same N, same device); data layout is [limb][batch][N], i.e. limb l of
  * every polynomial is the contiguous [batch][N] slab at d_x + l*batch*N.  Each limb is
  * an independent transform -- the reference has no counterpart; its closest
- * primitive is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60). ---- */
+ * primitive is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
+ * When one limb's share alone cannot fill the GPU (a ciphertext: a few polynomials x tens of primes) and the limbs'
+ * plans agree in policy and options (primes of one bit size always do), ONE launch per pass serves up to 16 limbs: a
+ * workgroup picks its limb's tables and constants from an array in the kernel arguments.  Large per-limb batches and
+ * mixed sets are served limb by limb.  Results are identical either way (environment NTT_RNS_LOOP=1 / 0 forces a form). ---- */
 NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,

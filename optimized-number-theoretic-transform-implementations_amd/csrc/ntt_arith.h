@@ -268,10 +268,12 @@ struct ArithF64 {
 
   static NTT_HD double magic52() { return 4503599627370496.0; } /* 2^52 */
 
-  /* u64 in [0,2^52) -> double, exact, in ONE instruction: the bit pattern of
+  /* u64 in [0,2^53) -> double, exact, in ONE instruction: the bit pattern of
    * u < 2^52 read as a double is the subnormal u * 2^-1074, and ldexp by 1074
-   * (v_ldexp_f64, exact) scales it back to the integer u.  FP64 subnormals are
-   * never flushed on gfx9 (and not on the CPU emulation either). */
+   * (v_ldexp_f64, exact) scales it back to the integer u; for 2^52 <= u < 2^53 the pattern is a number of the first
+   * normal binade, (1 + (u - 2^52) 2^-52) 2^-1022 = u * 2^-1074 just the same (lazy words up to 4q arrive here).
+   * FP64 subnormals are never flushed on gfx9 (and not on the CPU emulation either).  (The name keeps its history:
+   * canonical inputs are below 2^52.) */
   static NTT_HD double u64_to_f64_lt52(uint64_t u)
   {
     union {
@@ -403,8 +405,9 @@ struct ArithF64 {
   static NTT_HD uint64_t store_fwd(val v, const consts &c) { return to_canonical(v, c); }
   static NTT_HD uint64_t store_inv(val v, const consts &c) { return to_canonical(v, c); }
   /* lazy forward output in [0,4q) (the reference's radix-2 lazy range, include/ntt_reference.h:13-17):
-   * v + 2q for |v| < 2q -- ONE exact fma instead of the seven instructions of to_canonical.  (v + 2q) is
-   * an integer below 4q <= 2^53, and an integer u < 2^53 scaled by 2^-1074 is the double whose bit
+   * v + 2q for |v| <= kLazyBound * q -- ONE exact fma instead of the seven instructions of to_canonical.  (v + 2q) is
+   * an integer below (2 + kLazyBound) q < 2^53 for every modulus of the policy (q <= 2^51(1+2^-10): 3.99 q < 2^53; note
+   * 4q itself may exceed 2^53 just above 2^51), and an integer u < 2^53 scaled by 2^-1074 is the double whose bit
    * pattern is u (subnormal below 2^52, first binade above).  The kernel's reduction schedule
    * guarantees the bound (fused_mask with LAZY). */
   static NTT_HD uint64_t store_fwd_lazy(val v, const consts &c)

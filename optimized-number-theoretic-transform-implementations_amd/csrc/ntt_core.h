@@ -947,6 +947,19 @@ NTT_HD void global_store_last(const typename A::val (&x)[kE], uint32_t t, uint64
 /* |value|/q a lazy forward output may have: v + 2q must stay in [0,4q) */
 constexpr double kLazyBound = 1.99;
 
+/* forward stages whose twiddles are compact (bit = local stage) */
+template <class A, int LOGN> constexpr uint32_t fused_cmask()
+{
+  using P        = Plan<LOGN>;
+  uint32_t cmask = 0;
+  for(int g = 0; g < P::NG; g++) {
+    for(int j = 0; j < P::R(g); j++) {
+      if(stage_is_compact<A, LOGN, false>(g, j)) cmask |= 1u << (P::S(g) + j);
+    }
+  }
+  return cmask;
+}
+
 template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uint32_t fused_mask()
 {
   if constexpr(!A::kTracksBounds) {
@@ -957,15 +970,12 @@ template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uin
     /* stages whose twiddles are compact estimate the quotient from the rounded
      * product (ArithF64::mulmod_c): 1.5x the error term at those positions */
     if constexpr(INV) return kRedPlanFlag | (uint32_t)KSH; /* per-butterfly plan (bfly_reduces) */
-    using P        = Plan<LOGN>;
-    uint32_t cmask = 0;
-    for(int g = 0; g < P::NG; g++) {
-      for(int j = 0; j < P::R(g); j++) {
-        const int sl = P::S(g) + j;
-        if(stage_is_compact<A, LOGN, INV>(g, j)) cmask |= 1u << (INV ? LOGN - 1 - sl : sl);
-      }
-    }
-    return f64_schedule(INV, LOGN, KSH, 1.0, cmask, LAZY ? kLazyBound : 1e30).mask;
+    constexpr F64Sched sc = f64_schedule(false, LOGN, KSH, 1.0, fused_cmask<A, LOGN>(), LAZY ? kLazyBound : 1e30);
+    /* store_fwd_lazy builds the bit pattern of v + 2q with one fma: only correct while |v| <= kLazyBound * q.  The
+     * schedule forces reductions from the last stage backwards until the bound holds; if a future plan or twiddle
+     * layout made that impossible the loop would simply end -- fail the build instead of emitting corrupt words */
+    static_assert(!LAZY || sc.bout <= kLazyBound, "lazy forward output: the reduction schedule cannot bound the last stage");
+    return sc.mask;
   }
 }
 

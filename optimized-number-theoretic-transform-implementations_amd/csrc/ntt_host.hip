@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -222,12 +223,13 @@ struct ntt_plan {
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
   int              block_log  = 0;     /* multi-pass transforms: block size below the column passes (0 = multi_pass_block's choice) */
-  bool             fused_product = true; /* N = 2^14, FP64: ntt_negacyclic_mul_batch as fwd(a) + fused_product_kernel */
+  bool             fused_product = true; /* N = 2^8..2^17, FP64: ntt_negacyclic_mul_batch as fwd(a) + the fused product kernels */
   int              two_phase  = -1;    /* 2^16, 2^17: both passes of a polynomial inside one workgroup (twophase_kernel):
                                         * 1 on, 0 off, -1 where it measured faster (forward 2^16, scheduled FP64 policy: +3 %) */
 };
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+static bool h_is_prime(uint64_t n); /* deterministic Miller-Rabin (below) */
 
 static int resolve_arith(int requested, uint64_t q, int m, int *out)
 {
@@ -288,31 +290,46 @@ static int device_build_direction(ntt_plan *p, uint64_t base, bool inverse, uint
     basis.p[j] = sq;
     sq         = h_mulmod(sq, sq, q);
   }
+  /* a private non-blocking stream: the build neither waits for nor stalls the caller's streams (the legacy NULL stream
+   * + hipDeviceSynchronize of round 2 did both).  Plans must still be created outside stream capture: hipMalloc and
+   * the synchronisation below are not capturable. */
+  hipStream_t bs = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
   uint64_t *d_w = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_w, N * sizeof(uint64_t)));
+  {
+    hipError_t em = hipMalloc((void **)&d_w, N * sizeof(uint64_t));
+    if(em != hipSuccess) {
+      (void)hipStreamDestroy(bs);
+      return fail(em == hipErrorOutOfMemory ? NTT_ERR_NOMEM : NTT_ERR_HIP, std::string("device table build: ") + hipGetErrorString(em));
+    }
+  }
   const unsigned g = (unsigned)((N + 255) / 256 > 4096 ? 4096 : (N + 255) / 256);
-  hipLaunchKernelGGL(power_table_kernel, dim3(g), dim3(256), 0, 0, d_w, N, (unsigned)p->m, basis, p->cu);
+  hipLaunchKernelGGL(power_table_kernel, dim3(g), dim3(256), 0, bs, d_w, N, (unsigned)p->m, basis, p->cu);
   int         rc    = NTT_OK;
   void **     d_rec = inverse ? &p->d_inv : &p->d_fwd;
   void **     d_cmp = inverse ? &p->d_inv8 : &p->d_fwd8;
   hipError_t  e     = hipSuccess;
   if(p->arith == NTT_ARITH_U64_R4) {
     e = hipMalloc(d_rec, 2 * N * sizeof(TwU64));
-    if(e == hipSuccess) hipLaunchKernelGGL(records_r4_kernel, dim3(g), dim3(256), 0, 0, (TwU64 *)*d_rec, d_w, N, p->cu);
+    if(e == hipSuccess) hipLaunchKernelGGL(records_r4_kernel, dim3(g), dim3(256), 0, bs, (TwU64 *)*d_rec, d_w, N, p->cu);
   } else {
     const uint64_t total = inverse ? N + 16 : N;
     if(p->arith == NTT_ARITH_F64) {
       e = hipMalloc(d_rec, total * sizeof(TwF64));
       if(e == hipSuccess) e = hipMalloc(d_cmp, N * sizeof(double));
       if(e == hipSuccess)
-        hipLaunchKernelGGL(records_f64_kernel, dim3(g), dim3(256), 0, 0, (TwF64 *)*d_rec, (double *)*d_cmp, d_w, N, total, ninv, p->cu);
+        hipLaunchKernelGGL(records_f64_kernel, dim3(g), dim3(256), 0, bs, (TwF64 *)*d_rec, (double *)*d_cmp, d_w, N, total, ninv, p->cu);
     } else {
       e = hipMalloc(d_rec, total * sizeof(TwU64));
-      if(e == hipSuccess) hipLaunchKernelGGL(records_u64_kernel, dim3(g), dim3(256), 0, 0, (TwU64 *)*d_rec, d_w, N, total, ninv, p->cu);
+      if(e == hipSuccess) hipLaunchKernelGGL(records_u64_kernel, dim3(g), dim3(256), 0, bs, (TwU64 *)*d_rec, d_w, N, total, ninv, p->cu);
     }
   }
   if(e == hipSuccess) e = hipGetLastError();
-  if(e == hipSuccess) e = hipDeviceSynchronize();
+  {
+    const hipError_t es = hipStreamSynchronize(bs); /* always: d_w is freed below */
+    if(e == hipSuccess) e = es;
+  }
+  (void)hipStreamDestroy(bs);
   (void)hipFree(d_w);
   if(e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? NTT_ERR_NOMEM : NTT_ERR_HIP, std::string("device table build: ") + hipGetErrorString(e));
   return rc;
@@ -439,8 +456,10 @@ extern "C" int ntt_plan_create(ntt_plan **out, int device, uint64_t N, uint64_t 
 {
   if(!is_pow2(N) || q < 3 || root == 0 || root >= q) return fail(NTT_ERR_ARG, "bad N, q or root");
   if(h_powmod(root, N, q) != q - 1) return fail(NTT_ERR_ARG, "root is not a primitive 2N-th root of unity mod q");
-  /* root^-1 and N^-1 come from Fermat's little theorem, which holds only for a prime q: verify them
-   * instead of trusting the caller (a composite q can pass 2N | q-1 and root^N == -1) */
+  /* root^-1 and N^-1 come from Fermat's little theorem, which holds only for a prime q (a composite q can pass
+   * 2N | q-1 and root^N == -1, and Carmichael-type composites even pass a Fermat test): deterministic Miller-Rabin
+   * for 64-bit integers, then the two inverses are checked for what they are */
+  if(!h_is_prime(q)) return fail(NTT_ERR_ARG, "q is not prime");
   const uint64_t rinv = h_powmod(root, q - 2, q);
   if(h_mulmod(root, rinv, q) != 1 || h_mulmod(N % q, h_powmod(N % q, q - 2, q), q) != 1) {
     return fail(NTT_ERR_ARG, "q is not prime (root^(q-2) is not the inverse of root)");
@@ -497,7 +516,13 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[2] = (uint64_t)p->m;
   info[3] = (uint64_t)p->arith;
   info[4] = p->kcls == kWideClass ? 52u : (uint64_t)p->kcls; /* 52: the reduce-both-operands policy for q up to 2^52 */
-  info[5] = (uint64_t)make_passes(p->m, p->generic).n; /* HBM passes per transform (two-phase launches keep the second one on chip where they can) */
+  /* launches (= passes over the data) of one forward transform of a large batch: 1 where the two-phase kernel is the
+   * default (2^16 forward, scheduled FP64 policy) or forced, else the pass list's length */
+  {
+    const bool tp = !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3 &&
+                    (p->two_phase == 1 || (p->two_phase < 0 && p->m == kFusedMax + 2 && p->kcls != kWideClass));
+    info[5] = tp ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
+  }
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
   return NTT_OK;
@@ -1141,22 +1166,44 @@ extern "C" int ntt_event_elapsed_ms(int device, void *start, void *stop, float *
 /* ------------------------------------------------------------------ */
 /* multi-GPU                                                           */
 /* ------------------------------------------------------------------ */
+static std::mutex g_own_stream_mu; /* lazy creation of ntt_plan::own_stream */
+
 extern "C" int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const *d_a, const uint64_t *batch,
                                int inverse)
 {
   if(ndev <= 0 || !plans || !d_a || !batch) return fail(NTT_ERR_ARG, "bad argument");
   for(int g = 0; g < ndev; g++) {
+    if(!plans[g]) return fail(NTT_ERR_ARG, "null plan");
+  }
+  int launched = 0, rc = NTT_OK;
+  for(int g = 0; g < ndev && !rc; g++) {
     ntt_plan *p = plans[g];
-    if(!p) return fail(NTT_ERR_ARG, "null plan");
-    USE_DEVICE(p->device);
-    if(!p->own_stream) HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
-    int rc = run_transform(p, d_a[g], batch[g], inverse != 0, false, (void *)p->own_stream);
-    if(rc) return rc;
+    {
+      std::lock_guard<std::mutex> lock(g_own_stream_mu);
+      if(!p->own_stream) {
+        DeviceGuard guard(p->device);
+        if(!guard.ok || hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) {
+          rc = fail(NTT_ERR_HIP, "ntt_batch_multi: stream creation failed");
+          break;
+        }
+      }
+    }
+    rc = run_transform(p, d_a[g], batch[g], inverse != 0, false, (void *)p->own_stream);
+    if(!rc) launched = g + 1;
   }
-  for(int g = 0; g < ndev; g++) {
-    USE_DEVICE(plans[g]->device);
-    HIP_TRY(hipStreamSynchronize(plans[g]->own_stream));
+  /* join every stream that received work -- also when a later device failed: the caller must not get control back
+   * while transforms it did not ask to abandon are still writing into its buffers */
+  std::string first_error = rc ? g_err : std::string();
+  for(int g = 0; g < launched; g++) {
+    DeviceGuard guard(plans[g]->device);
+    if(!guard.ok || hipStreamSynchronize(plans[g]->own_stream) != hipSuccess) {
+      if(!rc) {
+        rc          = NTT_ERR_HIP;
+        first_error = "ntt_batch_multi: hipStreamSynchronize failed";
+      }
+    }
   }
+  if(rc) return fail(rc, first_error);
   return NTT_OK;
 }
 
@@ -1227,22 +1274,39 @@ extern "C" uint64_t ntt_find_prime(unsigned bits, uint64_t N, unsigned skip)
 /* ------------------------------------------------------------------ */
 namespace {
 
+/* One cached plan of the reference-signature entry points, with everything a call needs privately: its staging buffer,
+ * its stream and its lock.  The reference's functions are re-entrant and may be called from several threads at once
+ * (they only touch their arguments); here callers that use DIFFERENT tables run concurrently (each on its entry's
+ * stream), callers that share a table queue on that entry's lock.  The cache itself is guarded by g_mu only while it
+ * is searched or changed, never across a transform. */
 struct CompatPlan {
-  uint64_t  N, q, key, ninv, stride;
-  bool      inverse;
-  ntt_plan *plan;
-  uint64_t  last_use;
+  uint64_t  N = 0, q = 0, key = 0, ninv = 0, stride = 0;
+  uint64_t  first[2] = {0, 0}, last = 0; /* table entries 0, 1 and the last one: compared besides the hash */
+  bool      inverse = false;
+  int       device = 0, arith = 0;
+  ntt_plan *plan = nullptr;
+  uint64_t  last_use = 0;
+  std::mutex  mu;
+  uint64_t *  stage       = nullptr;
+  size_t      stage_bytes = 0;
+  hipStream_t stream      = nullptr;
+  ~CompatPlan()
+  {
+    if(plan) {
+      DeviceGuard guard(device);
+      if(stage) (void)hipFree(stage);
+      if(stream) (void)hipStreamDestroy(stream);
+      ntt_plan_destroy(plan);
+    }
+  }
 };
 
-std::mutex              g_mu;
-std::vector<CompatPlan> g_plans;
-uint64_t                g_use_clock   = 0;
-uint64_t *              g_stage       = nullptr;
-size_t                  g_stage_bytes = 0;
-int                     g_stage_dev   = -1;
-constexpr size_t        kCompatPlansMax = 32; /* least-recently-used plan is destroyed beyond this */
+std::mutex                               g_mu;
+std::vector<std::shared_ptr<CompatPlan>> g_plans;
+uint64_t                                 g_use_clock = 0;
+constexpr size_t                         kCompatPlansMax = 32; /* least-recently-used plan is dropped beyond this */
 
-/* Identifies a caller table by ALL of its entries (position-sensitive multiply-add hash, four
+/* Identifies a caller table by ALL of its entries (position-sensitive rotate-xor-add hash over eight
  * independent lanes so the host compiler vectorises it: ~0.1 ms at N = 2^17, a fraction of the two PCIe
  * copies of the same call).  A sampled digest would hand a stale plan to a table that was edited in place
  * or that differs only in unsampled slots -- silently wrong results on a path whose only job is
@@ -1301,21 +1365,27 @@ int compat_arith(uint64_t q, uint64_t N, CompatKind kind)
 void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t q, const uint64_t *w,
                 const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv)
 {
-  std::lock_guard<std::mutex> lock(g_mu);
-  const int                   device = env_int("NTT_DEVICE", 0);
-  const int                   arith  = compat_arith(q, N, kind);
-  const uint64_t              entries = kind == kCompatR4 ? 2 * N : N;
-  /* the integer policies use the caller's precomputation too: it is part of the key */
+  const int      device  = env_int("NTT_DEVICE", 0);
+  const int      arith   = compat_arith(q, N, kind);
+  const uint64_t entries = kind == kCompatR4 ? 2 * N : N;
+  /* the integer policies use the caller's precomputation too: it is part of the key.  (Hashing happens outside any lock.) */
   const uint64_t key = table_key(w, entries, 1) ^ (arith != NTT_ARITH_F64 && w_con ? table_key(w_con, entries, 1) * 3 : 0);
-  ntt_plan *     plan = nullptr;
-  for(CompatPlan &c : g_plans) {
-    if(c.N == N && c.q == q && c.key == key && c.stride == (uint64_t)kind && c.inverse == inverse && c.ninv == ninv &&
-       c.plan->device == device && c.plan->arith == arith) {
-      plan       = c.plan;
-      c.last_use = ++g_use_clock;
+  std::shared_ptr<CompatPlan> ent;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for(const std::shared_ptr<CompatPlan> &c : g_plans) {
+      /* the 64-bit hash AND the parameters AND three entries of the table itself: a hash collision alone cannot hand a
+       * caller somebody else's tables */
+      if(c->N == N && c->q == q && c->key == key && c->stride == (uint64_t)kind && c->inverse == inverse && c->ninv == ninv &&
+         c->device == device && c->arith == arith && c->first[0] == w[0] && c->first[1] == w[1] && c->last == w[entries - 1]) {
+        ent           = c;
+        c->last_use   = ++g_use_clock;
+      }
     }
   }
-  if(!plan) {
+  if(!ent) {
+    /* built outside the cache lock (table conversion + upload take a while); two threads that miss on the same table
+     * both build, the second insert wins the lookup from then on and the first entry ages out */
     TableSet              ts;
     std::vector<uint64_t> tab, con;
     if(arith == NTT_ARITH_U64_R4) {
@@ -1334,18 +1404,33 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
       (inverse ? ts.inv : ts.fwd)         = tab;
       (inverse ? ts.inv_con : ts.fwd_con) = con;
     }
-    int rc = plan_build(&plan, device, N, q, 0, ts, arith, inverse ? ninv : 0);
-    if(rc) die(fn);
+    ntt_plan *plan = nullptr;
+    if(plan_build(&plan, device, N, q, 0, ts, arith, inverse ? ninv : 0)) die(fn);
+    ent           = std::make_shared<CompatPlan>();
+    ent->N        = N;
+    ent->q        = q;
+    ent->key      = key;
+    ent->ninv     = ninv;
+    ent->stride   = (uint64_t)kind;
+    ent->first[0] = w[0];
+    ent->first[1] = w[1];
+    ent->last     = w[entries - 1];
+    ent->inverse  = inverse;
+    ent->device   = device;
+    ent->arith    = arith;
+    ent->plan     = plan;
+    std::lock_guard<std::mutex> lock(g_mu);
+    ent->last_use = ++g_use_clock;
     if(g_plans.size() >= kCompatPlansMax) {
       size_t lru = 0;
       for(size_t k = 1; k < g_plans.size(); k++) {
-        if(g_plans[k].last_use < g_plans[lru].last_use) lru = k;
+        if(g_plans[k]->last_use < g_plans[lru]->last_use) lru = k;
       }
-      ntt_plan_destroy(g_plans[lru].plan);
-      g_plans.erase(g_plans.begin() + (long)lru);
+      g_plans.erase(g_plans.begin() + (long)lru); /* destroyed when its last user lets go of it */
     }
-    g_plans.push_back(CompatPlan{N, q, key, ninv, (uint64_t)kind, inverse, plan, ++g_use_clock});
+    g_plans.push_back(ent);
   }
+  std::lock_guard<std::mutex> run_lock(ent->mu);
   const uint64_t batch = a2 ? 2 : 1;
   const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
   DeviceGuard guard(device);
@@ -1353,33 +1438,35 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     g_err = "hipSetDevice";
     die(fn);
   }
-  if(bytes > g_stage_bytes || g_stage_dev != device) {
-    if(g_stage) {
-      DeviceGuard old(g_stage_dev);
-      (void)hipFree(g_stage);
-      g_stage       = nullptr;
-      g_stage_bytes = 0;
-    }
-    g_stage_dev = device;
-    if(hipMalloc((void **)&g_stage, bytes) != hipSuccess) {
+  if(!ent->stream && hipStreamCreateWithFlags(&ent->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_err = "hipStreamCreate";
+    die(fn);
+  }
+  if(bytes > ent->stage_bytes) {
+    if(ent->stage) (void)hipFree(ent->stage);
+    ent->stage       = nullptr;
+    ent->stage_bytes = 0;
+    if(hipMalloc((void **)&ent->stage, bytes) != hipSuccess) {
       g_err = "hipMalloc staging buffer";
       die(fn);
     }
-    g_stage_bytes = bytes;
+    ent->stage_bytes = bytes;
   }
-  /* copies and kernels queue on the null stream; ONE synchronisation at the end (the _dbl form's second polynomial
+  /* copies and kernels queue on the entry's stream; ONE synchronisation at the end (the _dbl form's second polynomial
    * rides in the same queue) */
-  bool ok = hipMemcpyAsync(g_stage, a1, N * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess;
-  if(ok && a2) ok = hipMemcpyAsync(g_stage + N, a2, N * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess;
+  uint64_t *const   stage = ent->stage;
+  const hipStream_t st    = ent->stream;
+  bool ok = hipMemcpyAsync(stage, a1, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+  if(ok && a2) ok = hipMemcpyAsync(stage + N, a2, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
   if(!ok) {
     g_err = "hipMemcpy H2D";
     die(fn);
   }
   /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
-  if(run_transform(plan, g_stage, batch, inverse, true, nullptr, !inverse)) die(fn);
-  ok = hipMemcpyAsync(a1, g_stage, N * 8, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
-  if(ok && a2) ok = hipMemcpyAsync(a2, g_stage + N, N * 8, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
-  if(ok) ok = hipStreamSynchronize(nullptr) == hipSuccess;
+  if(run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
+  ok = hipMemcpyAsync(a1, stage, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if(ok && a2) ok = hipMemcpyAsync(a2, stage + N, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if(ok) ok = hipStreamSynchronize(st) == hipSuccess;
   if(!ok) {
     g_err = std::string("hipMemcpy D2H / kernel execution: ") + hipGetErrorString(hipGetLastError());
     die(fn);
@@ -1392,16 +1479,12 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
  * tables, the staging buffer).  Safe to call at any time; the next call rebuilds what it needs. */
 extern "C" void ntt_compat_release(void)
 {
-  std::lock_guard<std::mutex> lock(g_mu);
-  for(CompatPlan &c : g_plans) ntt_plan_destroy(c.plan);
-  g_plans.clear();
-  if(g_stage) {
-    DeviceGuard guard(g_stage_dev);
-    (void)hipFree(g_stage);
+  std::vector<std::shared_ptr<CompatPlan>> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    drop.swap(g_plans);
   }
-  g_stage       = nullptr;
-  g_stage_bytes = 0;
-  g_stage_dev   = -1;
+  drop.clear(); /* entries still in use by another thread are destroyed when that call returns */
 }
 extern "C" int ntt_compat_cached_plans(void)
 {

@@ -407,6 +407,26 @@ def test_full_size_config5_share_rns_n131072(lib, oracle):
         ib = oracle.fill_uniform(n, q, UNI_SEED + 1, l * slab + p * n)
         expect = cx.inv(oracle.pointwise(cx.fwd(ia), cx.fwd(ib), q))
         assert np.array_equal(da.download(n, l * slab + p * n), expect), (l, p)
+    # the WHOLE slab, not only the three sampled polynomials: per-polynomial checksums of the fused product path against
+    # two independent routes through the library -- the four-transform chain (NTT_OPT_FUSED_PRODUCT 0: forward, forward,
+    # pointwise, inverse launches) and the generic column-pass implementation (no fused block kernel at all)
+    lib.poly_checksum(cs0.ptr, da.ptr, n, 4 * batch)
+    fused_sums = cs0.download()
+
+    def refill():
+        for l, q in enumerate(qs):
+            lib.fill_uniform(da.ptr + 8 * l * slab, slab, q, UNI_SEED, l * slab)
+            lib.fill_uniform(db.ptr + 8 * l * slab, slab, q, UNI_SEED + 1, l * slab)
+    for route in ("chain", "generic"):
+        refill()
+        for p in plans:
+            p.set_option(lib.OPT_FUSED_PRODUCT, 0)
+            p.set_generic(route == "generic")
+        lib.rns_negacyclic_mul(plans, da.ptr, da.ptr, db.ptr, batch)
+        lib.poly_checksum(cs1.ptr, da.ptr, n, 4 * batch)
+        assert np.array_equal(cs1.download(), fused_sums), route
+    for p in plans:
+        p.destroy()
 
 
 def test_multi_device_call(lib, oracle, kat):
@@ -779,7 +799,11 @@ def test_fused_product_kernel(lib, oracle, q, m):
         b = oracle.fill_uniform(batch * n, q, 62)
         if batch == 3:
             b[:8] = [0, 1, q - 1, q - 2, 2, 3, q // 2, q // 2 + 1]
-        expect = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q)) if batch < 300 else None
+        # the oracle on every polynomial of the small batches and on a sample of the large one (first, last, and the
+        # polynomials either side of the persistent grid's wrap-around at 256 workgroups)
+        sample = list(range(batch)) if batch < 300 else [0, 1, 127, 255, 256, 257, 298, 299]
+        pick = np.concatenate([np.arange(p * n, (p + 1) * n) for p in sample])
+        expect = cx.inv(oracle.pointwise(cx.fwd(a[pick]), cx.fwd(b[pick]), q))
         da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
         outs = []
         for fused in (1, 0):
@@ -788,8 +812,7 @@ def test_fused_product_kernel(lib, oracle, q, m):
             plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
             outs.append(dc.download())
         assert np.array_equal(outs[0], outs[1]), batch
-        if expect is not None:
-            assert np.array_equal(outs[0], expect), batch
+        assert np.array_equal(outs[0][pick], expect), batch
         plan.set_option(lib.OPT_FUSED_PRODUCT, 1)
         for alias in ("a", "b"):
             da.upload(a), db.upload(b)
@@ -836,6 +859,11 @@ def test_fused_product_kernel_large(lib, oracle, m, bits):
     da.upload(a), db.upload(b)
     plan.negacyclic_mul(db.ptr, da.ptr, db.ptr, batch)           # c aliases b
     assert np.array_equal(db.download(), expect)
+    for chunk in (256, 1):                                       # c aliases a: whole batch in one chunk, and chunk by chunk
+        plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+        da.upload(a), db.upload(b)
+        plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(da.download(), expect), chunk
     plan.destroy()
 
 
