@@ -54,7 +54,12 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* 2^13 (FP64 policies): TWO blocks per 1024-thread workgroup, each half running the persistent loop on its own
    * exchange buffer and sharing the twiddle table -- the resource shape of the 2^14 kernel (16 waves per CU,
    * 158 KB of LDS).  One 512-thread workgroup per CU with every table in LDS (round 1) left two waves per SIMD. */
-  static constexpr bool PERSIST2 = FLAVOR == 1 && LOGN == 13 && !INV; /* (inverse: its first group's per-lane twiddles then fit neither the registers nor the LDS: measured 0.58 -> 0.48) */
+  static constexpr bool PERSIST2 = FLAVOR == 1 && LOGN == 13 && !INV;
+  /* (inverse: measured 0.584 -> 0.48 in round 2 and again in round 3 (profiles/r03/ablations.txt) -- with the stage-12
+   * twiddles register-resident the kernel needs 133 VGPRs (5 spilled); requested per block it fits in 122 without a
+   * spill and is still 18 % slower: the two exchange buffers leave 1.8 KB of LDS, 128 bytes short of even the 1.9 KB
+   * table of stages 4..7, so 23 per-lane twiddles per thread and block come from global memory where the one-block
+   * shape reads all three tables (2 + 30 + 32 KB) from LDS) */
   static constexpr int WG  = PERSIST2 ? 1024 : (P::T < 256 ? 256 : P::T);      /* threads per workgroup */
   static constexpr int BPW = PERSIST2 ? 2 : (P::T < 256 ? 256 / P::T : 1);    /* blocks per workgroup  */
   static constexpr bool PERSISTENT = BPW == 1 || PERSIST2;                     /* persistent prefetching loops */

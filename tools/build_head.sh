@@ -3,15 +3,17 @@
 # same-box A/B against the working tree's library (NTT_LIB=build/libntt_prev.so selects it in tools/ and tests/)
 set -e
 rev=${1:-HEAD}
-rm -rf build/prevsrc build/prev; mkdir -p build/prevsrc build/prev
-git archive $rev optimized-number-theoretic-transform-implementations_amd/csrc include | tar -x -C build/prevsrc
-src=build/prevsrc/optimized-number-theoretic-transform-implementations_amd/csrc
+tmp=$(mktemp -d /tmp/ntt_prev.XXXXXX)   # scratch copies of the old sources live outside the repository and are removed below
+rm -rf build/prev; mkdir -p build/prev
+git archive $rev optimized-number-theoretic-transform-implementations_amd/csrc include | tar -x -C $tmp
+src=$tmp/optimized-number-theoretic-transform-implementations_amd/csrc
 pids=()
 for f in ntt_host inst_u64 inst_u64r4 inst_f64k0 inst_f64k1 inst_f64k18 inst_f64w; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
-     -Ibuild/prevsrc/include -Ibuild/prevsrc/include/internal -I$src -c -o build/prev/$f.o $src/$f.hip &
+     -I$tmp/include -I$tmp/include/internal -I$src -c -o build/prev/$f.o $src/$f.hip &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libntt_prev.so build/prev/*.o
+rm -rf $tmp build/prev
 echo built build/libntt_prev.so from $rev
