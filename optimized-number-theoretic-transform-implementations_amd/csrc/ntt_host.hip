@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -218,6 +219,17 @@ struct ntt_plan {
   ArithU64::consts cu{};
   F64Consts        cf{};
   std::vector<unsigned char> limbrec; /* this plan's LimbRec<A> (table pointers + constants): copied into the kernel arguments of every launch */
+  /* XCD-local two-pass launches (team_kernel, N = 2^15..2^17): queue heads and per-polynomial counters in device memory,
+   * one buffer per stream the plan is used on (launches on one stream are ordered; two streams must not share counters) */
+  int        xcd_local = -1; /* 1 on, 0 off, -1 automatic */
+  int        team_lag = 0, team_wpc = 0; /* 0 = the kernel's defaults */
+  struct TeamBuf {
+    void * stream;
+    void * d;
+    size_t bytes;
+  };
+  std::vector<TeamBuf> team_bufs;
+  std::mutex           team_mu;
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              num_cus    = 256;
@@ -504,6 +516,7 @@ extern "C" void ntt_plan_destroy(ntt_plan *p)
   if(p->d_inv) (void)hipFree(p->d_inv);
   if(p->d_fwd8) (void)hipFree(p->d_fwd8);
   if(p->d_inv8) (void)hipFree(p->d_inv8);
+  for(const ntt_plan::TeamBuf &tb : p->team_bufs) (void)hipFree(tb.d);
   if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
@@ -568,6 +581,17 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
     case NTT_OPT_FUSED_PRODUCT:
       p->fused_product = value != 0;
       return NTT_OK;
+    case NTT_OPT_XCD_LOCAL:
+      p->xcd_local = value < 0 ? -1 : (value != 0);
+      return NTT_OK;
+    case NTT_OPT_XCD_LOCAL_LAG:
+      if(value < 0 || value > 64) return fail(NTT_ERR_ARG, "lag must be 0 (default) .. 64 polynomials");
+      p->team_lag = (int)value;
+      return NTT_OK;
+    case NTT_OPT_XCD_LOCAL_WGS_PER_CU:
+      if(value < 0 || value > 3) return fail(NTT_ERR_ARG, "workgroups per CU: 0 (default) .. 3");
+      p->team_wpc = (int)value;
+      return NTT_OK;
     case NTT_OPT_BLOCK_LOG:
       if(value != 0 && value != kFusedSmallBlock && value != kFusedLarge) return fail(NTT_ERR_ARG, "block size must be 0 (automatic), 12 or 14");
       if(value == kFusedSmallBlock && p->m > kFusedSmallBlock + 4) return fail(NTT_ERR_ARG, "2^12-point blocks need at most 4 leading stages");
@@ -602,6 +626,41 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   }
 }
 
+/* XCD-local two-pass launches: FP64 policies, N = 2^15..2^17, plain calls (canonical in, canonical out) of a batch large
+ * enough to keep every XCD's queue busy.  -1 (automatic) currently means off: the path is selected with
+ * NTT_OPT_XCD_LOCAL 1 (or NTT_XCD_LOCAL=1 in the environment) until its measurements say otherwise. */
+static bool team_applies(const ntt_plan *p, uint64_t batch, bool wide, bool lazy, int nlimbs)
+{
+  int on = p->xcd_local;
+  if(on < 0) on = env_int("NTT_XCD_LOCAL", 0);
+  return on == 1 && p->arith == NTT_ARITH_F64 && !p->generic && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && !wide && !lazy &&
+         nlimbs == 1 && batch >= 64 && batch < (1ull << 31);
+}
+
+/* the stream's control block, at least sizeof(TeamCtl) + batch counters */
+static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
+{
+  const size_t need = sizeof(TeamCtl) + (size_t)batch * sizeof(unsigned);
+  std::lock_guard<std::mutex> lock(p->team_mu);
+  for(ntt_plan::TeamBuf &tb : p->team_bufs) {
+    if(tb.stream != stream) continue;
+    if(tb.bytes < need) {
+      HIP_TRY(hipFree(tb.d)); /* (waits for the launches that still use it) */
+      tb.d     = nullptr;
+      tb.bytes = 0;
+      HIP_TRY(hipMalloc(&tb.d, need * 2));
+      tb.bytes = need * 2;
+    }
+    *out = tb.d;
+    return NTT_OK;
+  }
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, need * 2));
+  p->team_bufs.push_back(ntt_plan::TeamBuf{stream, d, need * 2});
+  *out = d;
+  return NTT_OK;
+}
+
 /* The limbs one launch serves: the plan's own record (every ordinary call), or an RNS set's records (host array, copied
  * into the kernel arguments) with the word distance between the limbs' slabs ([limb][batch][N]). */
 struct LimbSet {
@@ -619,6 +678,57 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   USE_DEVICE(p->device);
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
+  /* both passes as items of ONE launch with the intermediate kept in each XCD's L2 (ntt_kernels.h: team_kernel) */
+  if(team_applies(p, batch, wide, lazy, ls.n)) {
+    void *ctl = nullptr;
+    int   rc  = team_buffer(const_cast<ntt_plan *>(p), stream, batch, &ctl);
+    if(rc) return rc;
+    PassArgs pa{};
+    pa.a           = d_a;
+    pa.limbs       = ls.d;
+    pa.nlimbs      = 1;
+    pa.limb_stride = 0;
+    pa.batch       = batch;
+    pa.logn        = (uint32_t)p->m;
+    pa.fused       = 3;
+    pa.r           = p->m - kTeamBlock;
+    pa.s           = 0;
+    pa.inverse     = inverse;
+    pa.lastinv     = inverse;
+    pa.ends        = 1;
+    pa.max_grid    = p->max_grid;
+    pa.num_cus     = p->num_cus;
+    pa.team_ctl    = ctl;
+    pa.team_lag    = p->team_lag ? p->team_lag : env_int("NTT_TEAM_LAG", 0);
+    pa.team_wpc    = p->team_wpc ? p->team_wpc : env_int("NTT_TEAM_WPC", 0);
+    pa.stream      = (hipStream_t)stream;
+    if(env_int("NTT_TEAM_DEBUG", 0)) fprintf(stderr, "team launch: m %d batch %llu inverse %d ctl %p\n", p->m, (unsigned long long)batch, (int)inverse, ctl);
+    hipError_t e   = dispatch_pass(p, pa);
+    if(env_int("NTT_TEAM_DEBUG", 0)) fprintf(stderr, "team launch returned %d\n", (int)e);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if(env_int("NTT_TEAM_DEBUG", 0)) {
+      /* development aid: watch the queue heads while the launch runs (side stream), then print the final state */
+      TeamCtl h;
+      hipStream_t side;
+      HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for(int it = 0; it < env_int("NTT_TEAM_DEBUG", 0) - 1; it++) {
+        struct timespec ts = {0, 300000000};
+        nanosleep(&ts, nullptr);
+        HIP_TRY(hipMemcpyAsync(&h, ctl, sizeof h, hipMemcpyDeviceToHost, side));
+        HIP_TRY(hipStreamSynchronize(side));
+        fprintf(stderr, "live:");
+        for(int q = 0; q < 8; q++) fprintf(stderr, " q%d next %u own %u items %u wd %u/%u/%u |", q, h.next[q][0], h.owner[q][0], h.owner[q][4], h.owner[q][1], h.owner[q][2], h.owner[q][3]);
+        fprintf(stderr, "\n");
+      }
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      HIP_TRY(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
+      for(int q = 0; q < 8; q++) {
+        fprintf(stderr, "team queue %d: next %u owner %u watchdog poly+1 %u done %u item %u\n", q, h.next[q][0], h.owner[q][0], h.owner[q][1],
+                h.owner[q][2], h.owner[q][3]);
+      }
+    }
+    return NTT_OK;
+  }
   /* the one-launch two-phase kernel owns a CU per polynomial: it only pays when the batch fills the chip (measured +3 % at
    * batch ~30k; a batch below the CU count would leave CUs idle where the per-pass launches spread one polynomial
    * over 16 workgroups) -- the automatic choice is gated on that, an explicit NTT_OPT_TWO_PHASE 1 is honoured as given */

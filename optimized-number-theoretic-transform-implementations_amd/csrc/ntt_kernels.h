@@ -254,22 +254,24 @@ template <int LOGN> __device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc
    * 256 MiB chunk of a multi-pass transform, where a workgroup only sees 8 blocks per launch). */
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(blk), /*stride*/ 0, live ? (int)(8u << LOGN) : 0, 0x00020000);
 }
-__device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+/* cache-policy bits of the buffer instructions (gfx940+): 1 = sc0, 2 = nt, 16 = sc1 */
+constexpr int kAuxNt = 2, kAuxSc1 = 16, kAuxSc0Sc1 = 17;
+template <int AUX = kLoadAux> __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kLoadAux);
+  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX);
   return (uint64_t)v.x | ((uint64_t)v.y << 32);
 }
-__device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+template <int AUX = kLoadAux> __device__ __forceinline__ u64x2 buffer_load_u64x2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kLoadAux);
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX);
   return u64x2{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
 }
 
 /* the inverse loop's final stores (slot e <-> index (e << LT) + t, 8 bytes per lane) through
  * the block descriptor: one lane offset, the row offset as a scalar operand */
-template <int LOGN>
+template <int LOGN, int AUX = 0>
 __device__ __forceinline__ void buffer_store_first_raw(const uint64_t (&u)[kE], uint32_t t, uint64_t *blk)
 {
   using P                        = Plan<LOGN>;
@@ -280,24 +282,26 @@ __device__ __forceinline__ void buffer_store_first_raw(const uint64_t (&u)[kE], 
     v2u32         v;
     v.x = (unsigned)u[E];
     v.y = (unsigned)(u[E] >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(t * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(t * 8u), (int)(((uint32_t)E << P::LT) * 8u), AUX);
   });
 }
 
 /* raw (unconverted) coefficients of the first-kind group: slot e <-> (e << LT) + t */
-template <int LOGN> __device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
+template <int LOGN, int AUX = kLoadAux>
+__device__ __forceinline__ void prefetch_first(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
 {
   using P = Plan<LOGN>;
   const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk, live);
   static_for<0, kE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    raw[E]          = buffer_load_u64(r, t * 8u, ((uint32_t)E << P::LT) * 8u);
+    raw[E]          = buffer_load_u64<AUX>(r, t * 8u, ((uint32_t)E << P::LT) * 8u);
   });
 }
 
 /* raw coefficients in the last-kind layout (runs of 2^RL consecutive indices, 16-byte loads):
  * what the inverse transform's first group consumes */
-template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
+template <int LOGN, int AUX = kLoadAux>
+__device__ __forceinline__ void prefetch_last(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
 {
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
@@ -305,7 +309,7 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
   const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk, live);
   static_for<0, kE / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = buffer_load_u64x2(r, ib * 8u, P::IOFF(G, E) * 8u);
+    const u64x2   v = buffer_load_u64x2<AUX>(r, ib * 8u, P::IOFF(G, E) * 8u);
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });
@@ -318,7 +322,7 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last(uint64_t (&raw
  * instruction of the wave covers one contiguous KiB (tools/skel.hip: 0.674 -> 0.694 of the HBM peak for the
  * memory skeleton).  This is the one place where a cross-lane move (north star: "wave64 shuffles") pays:
  * 16 single-issue VALU instructions per thread against 32 LDS operations for an LDS transpose. */
-template <class A, int LOGN, bool LAZYT>
+template <class A, int LOGN, bool LAZYT, int AUX = 0>
 __device__ __forceinline__ void store_last_whole_lines(const typename A::val (&x)[kE], uint32_t t, uint64_t *blk,
                                                        const typename A::consts &c, bool lazy_rt)
 {
@@ -350,7 +354,7 @@ __device__ __forceinline__ void store_last_whole_lines(const typename A::val (&x
     v.y = (unsigned)(u[E] >> 32);
     v.z = (unsigned)u[E + 1];
     v.w = (unsigned)(u[E + 1] >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(OFF * 8u), 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(OFF * 8u), AUX);
   });
 }
 
@@ -910,6 +914,282 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
 }
 
 /* ------------------------------------------------------------------ */
+/* N = 2^15 .. 2^17: both passes in one launch, intermediate kept in the XCD's L2 */
+/* ------------------------------------------------------------------ */
+/*
+ * The two passes of a large transform -- LEAD = m - 12 strided column stages, then the 2^12-point blocks -- as ITEMS of
+ * one persistent launch instead of two launches per 256 MiB chunk.  A column item is 256 adjacent columns of one
+ * polynomial (column_pass_thread's work: 2^LEAD values per thread in registers, no exchange, every access a contiguous
+ * 2 KiB row segment), a row item one 2^12-point block (the fused block kernel's work).  What makes it worth a kernel:
+ *   - a workgroup reads which XCD it runs on (HW_REG_XCC_ID) and pulls items from THAT XCD's queue, so all items of a
+ *     polynomial run on one XCD whatever the dispatcher does: the intermediate is written by plain stores into that
+ *     XCD's 4 MiB L2 and read back from it -- measured FETCH_SIZE 1.0x the data instead of 2.0x (profiles/r03,
+ *     skel_pmc_fabric_traffic.txt).  Final stores are write-through (sc1: the line leaves the L2 at once) and input loads
+ *     sc0 sc1, so the streaming sides do not push the waiting intermediates out of the L2;
+ *   - queue order per XCD: first-pass items of polynomial j, then second-pass items of polynomial j - LAG (forward:
+ *     columns then rows; inverse: rows then columns).  A second-pass item waits on a per-polynomial counter that the
+ *     first-pass items bump once their stores have completed (s_waitcnt vmcnt(0), workgroup barrier, agent-scope
+ *     atomic).  First-pass items never wait and items are handed out in order, so every item somebody waits for is
+ *     already in the hands of a running workgroup: no deadlock whatever the residency;
+ *   - polynomials are dealt to the eight queues statically (p mod 8); a queue is processed only by the XCD that owns it
+ *     (compare-and-swap on first touch: normally its namesake; an XCD that finds its own queue finished or foreign
+ *     adopts queues nobody has claimed), so exactly one L2 sees all items of a polynomial even on a device that exposes
+ *     fewer XCDs than eight.
+ * Correctness never rests on placement assumptions: the XCD is read, and a hand-off only happens inside one XCD.
+ * Reference precedent for finishing a sub-transform while its data is close: third_party/hexl/fwd-ntt-avx512.c:311-329.
+ */
+struct TeamCtl {
+  unsigned next[8][32];  /* per queue: next item; one 128-byte line each */
+  unsigned owner[8][32]; /* per queue: 0 = unclaimed, else 1 + the XCD that processes it */
+  unsigned done[1];      /* [polynomials] first-pass items finished (flexible) */
+};
+
+template <class A> struct KTeam {
+  KArgs<A> k;   /* a, limbs[0], logn; nblocks = polynomials */
+  TeamCtl *ctl; /* zeroed before the launch */
+  uint32_t lag; /* polynomials between a first-pass item and the second-pass items of the same queue */
+};
+
+__device__ __forceinline__ uint32_t xcc_id()
+{
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v & 7u;
+}
+
+constexpr int kTeamBlock = 12;  /* log2 of the row items (the block size below the column stages) */
+constexpr int kTeamCols  = 256; /* adjacent columns of a column item = threads of a workgroup */
+
+/* column item: leading stages [0, R) of a 2^logn-point polynomial on columns col of the 2^R x 2^(logn-R) view; the
+ * thread's 2^R values sit 2^(logn-R) apart.  column_pass_thread (ntt_core.h) with S = 0, through a buffer descriptor so
+ * that loads and stores carry a cache policy, twiddles through the scalar cache (their slots are compile-time here). */
+template <class A, int R, bool INV, uint32_t MASK, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_column_item(uint64_t *poly, uint32_t col, uint32_t logn, const Params<A> &p, bool lazy_out)
+{
+  constexpr int  NE  = 1 << R;
+  const uint32_t lsp = logn - R;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(poly, 0, (int)(8u << logn), 0x00020000);
+  typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+  uint64_t raw[NE];
+  static_for<0, NE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    raw[E]          = buffer_load_u64<LDAUX>(r, col * 8u, ((uint32_t)E << lsp) * 8u);
+  });
+  typename A::val x[NE];
+  static_for<0, NE>([&](auto ee) { x[decltype(ee)::value] = A::template load<INV, false>(raw[decltype(ee)::value], p.c); });
+  static_for<0, R>([&](auto jj) {
+    constexpr int  J   = INV ? (R - 1 - decltype(jj)::value) : decltype(jj)::value;
+    constexpr int  AB  = R - 1 - J;
+    constexpr int  POS = INV ? (R - 1 - J) : J;
+    constexpr bool RED = (MASK >> POS) & 1u;
+    static_for<0, NE>([&](auto ee) {
+      constexpr int E0 = decltype(ee)::value;
+      if constexpr(((E0 >> AB) & 1) == 0) {
+        constexpr int E1 = E0 | (1 << AB);
+        if constexpr(INV && J == 0) {
+          A::inv_bfly_last(x[E0], x[E1], p.c); /* global stage 0 ends the inverse transform: N^-1 folded in */
+        } else {
+          const typename A::tw w = load_tw<A, true>(p.tw, (1u << J) + (uint32_t)(E0 >> (R - J)));
+          if constexpr(INV) {
+            A::template inv_bfly<RED>(x[E0], x[E1], w, p.c);
+          } else {
+            A::template fwd_bfly<RED>(x[E0], x[E1], w, p.c);
+          }
+        }
+      }
+    });
+  });
+  static_for<0, NE>([&](auto ee) {
+    constexpr int  E = decltype(ee)::value;
+    const uint64_t u = out_word<A, INV, false>(x[E], lazy_out, p.c);
+    v2u32          w2;
+    w2.x = (unsigned)u;
+    w2.y = (unsigned)(u >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(w2, r, (int)(col * 8u), (int)(((uint32_t)E << lsp) * 8u), STAUX);
+  });
+}
+
+/* row item, forward: one 2^12-point block at position blk of its polynomial (the body of fused_kernel's persistent
+ * loop without the prefetch: the table of the second-to-last group and the last group's twiddles are per position,
+ * so they are fetched per item -- from the L2, the whole batch shares them) */
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_row_item_fwd(uint64_t *base, uint32_t blk, uint32_t tid, const Params<A> &p,
+                                                  typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, flavor_of<A>()>;
+  constexpr int GL   = P::NG - 1;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, false, KSH>();
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0, "twiddle placement this item assumes");
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX>(raw, tid, base);
+  typename A::ctw pre[4][kE / 2];
+  preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+  fill_lds_tables<A, LOGN, false>(tabl, p, blk, tid);
+  __syncthreads(); /* the table is complete before any wave reaches its group */
+  typename A::val x[kE];
+  convert_inputs<A, false>(x, raw, false, p.c);
+  run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = decltype(gg)::value;
+    exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+    if constexpr(GI + 1 == GL) {
+      run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+    } else if constexpr(G::TBL(GI + 1) > 0) {
+      run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
+    } else {
+      run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+    }
+  });
+  /* whole 128-byte lines per store instruction: a write-through store of half a line costs a full line's write */
+  store_last_whole_lines<A, LOGN, false, STAUX>(x, tid, base, p.c, p.lazy != 0);
+}
+
+/* row item, inverse: the mirror image (the block pass comes first in the inverse transform) */
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, uint32_t tid, const Params<A> &p,
+                                                  typename A::val *lds, typename A::ctw *tabl, bool mid_lazy)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, true, flavor_of<A>()>;
+  constexpr int GL   = P::NG - 1;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>(); /* not the pass that ends the transform */
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  uint64_t raw[kE];
+  prefetch_last<LOGN, LDAUX>(raw, tid, base);
+  constexpr bool IPRE = stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 && KSH != 1;
+  typename A::ctw pre[4][kE / 2];
+  if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+  fill_lds_tables<A, LOGN, true>(tabl, p, blk, tid);
+  __syncthreads();
+  typename A::val x[kE];
+  convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
+  if constexpr(IPRE) {
+    run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+  } else {
+    run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+  }
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    if constexpr(G::TBL(GI - 1) > 0) {
+      run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
+    } else {
+      run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+    }
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = out_word<A, true, false>(x[decltype(ee)::value], mid_lazy, p.c); });
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, base);
+}
+
+template <class A, int LEAD, bool INV, int KSH>
+__global__ void __launch_bounds__(256, 3) team_kernel(const KTeam<A> kt)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, INV, flavor_of<A>()>;
+  static_assert(A::kCompact && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5, "built for the FP64 policies on 2^12-point blocks, N = 2^15..2^17");
+  __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
+  __shared__ unsigned        s_k;
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
+  const uint32_t         tid  = threadIdx.x;
+  uint32_t               bid_, gdim_, limb_;
+  Params<A>              p = limb_params<A, INV, false>(kt.k, bid_, gdim_, limb_);
+  p.s0                     = LEAD;
+  constexpr uint32_t CMASK = column_mask<A, LEAD, INV, KSH>();
+  constexpr bool     MID_LAZY = !A::kTracksBounds; /* words between the passes: canonical for the FP64 policies */
+  const uint32_t logn  = LOGN + LEAD;
+  const uint32_t batch = (uint32_t)p.nblocks;
+  constexpr uint32_t NCOL = 1u << (LOGN - 8);      /* column items per polynomial: 2^(m - LEAD) columns / 256 */
+  constexpr uint32_t NROW = 1u << LEAD;            /* row items per polynomial */
+  constexpr uint32_t NA   = INV ? NROW : NCOL;     /* first-pass items */
+  constexpr uint32_t NB   = INV ? NCOL : NROW;
+  TeamCtl *const ctl = kt.ctl;
+  const uint32_t lag = kt.lag;
+  const uint32_t my  = xcc_id();
+  for(uint32_t qq = 0; qq < 8; qq++) {
+    const uint32_t q = (my + qq) & 7u; /* own queue first, then whatever nobody claimed */
+    if(tid == 0) {
+      const unsigned prev = atomicCAS(&ctl->owner[q][0], 0u, my + 1u);
+      s_k                 = (prev == 0u || prev == my + 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = s_k != 0;
+    __syncthreads();
+    if(!mine) continue;
+    const uint32_t J = batch > q ? (batch - q + 7u) / 8u : 0u; /* polynomials of this queue: q, q + 8, ... */
+    const uint32_t steps = J + lag;
+    /* Every lane-0 block of this loop is followed at once by a workgroup barrier.  A lane-0 block at the END of the body
+     * (the completion signal used to sit there) ends up next to the loop's back edge, and the compiler then lets lane 0
+     * leave the loop "early" while lanes 1-63 of its wave wait at the next iteration's barrier for the item only lane 0
+     * can fetch: the first version of this kernel hung on its first items exactly like that.  So the signal of a finished
+     * first-pass item is carried into the next iteration and issued by the same lane-0 block that fetches the next item. */
+    constexpr uint32_t kNoSignal = 0xffffffffu;
+    uint32_t           sig       = kNoSignal;
+    for(;;) {
+      if(tid == 0) {
+        if(sig != kNoSignal) __hip_atomic_fetch_add(&ctl->done[sig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_k = atomicAdd(&ctl->next[q][0], 1u);
+      }
+      sig = kNoSignal;
+      __syncthreads();
+      const uint32_t k = s_k;
+      __syncthreads();
+      const uint32_t step = k / (NA + NB), r = k % (NA + NB);
+      if(step >= steps) break;
+      const bool     second = r >= NA;
+      const uint32_t item   = second ? r - NA : r;
+      const int64_t  j      = second ? (int64_t)step - (int64_t)lag : (int64_t)step;
+      if(j < 0 || j >= (int64_t)J) continue;
+      const uint32_t pidx = q + 8u * (uint32_t)j;
+      uint64_t *     poly = p.a + ((uint64_t)pidx << logn);
+      if(second) {
+        if(tid == 0) {
+#ifdef NTT_TEAM_WATCHDOG
+          /* development builds: a wait that lasts longer than about a second is recorded (owner[q][1..3]) and abandoned,
+           * so that a protocol error shows up as a wrong result with a diagnosis instead of a hung GPU */
+          unsigned spins = 0;
+          while(__hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NA) {
+            __builtin_amdgcn_s_sleep(8);
+            if(++spins > (1u << 15)) {
+              ctl->owner[q][1] = pidx + 1u;
+              ctl->owner[q][2] = __hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ctl->owner[q][3] = k;
+              break;
+            }
+          }
+#else
+          while(__hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NA) __builtin_amdgcn_s_sleep(8);
+#endif
+        }
+        __syncthreads(); /* (also keeps every later load of the workgroup behind the poll) */
+      }
+      const bool row = second != INV;
+      if(!row) {
+        /* forward: inputs -> intermediate (kept dirty in the L2); inverse: intermediate -> final (write-through) */
+        if constexpr(INV) team_column_item<A, LEAD, true, CMASK, kAuxNt, kAuxSc1>(poly, item * kTeamCols + tid, logn, p, p.lazy != 0);
+        else team_column_item<A, LEAD, false, CMASK, kAuxSc0Sc1, 0>(poly, item * kTeamCols + tid, logn, p, MID_LAZY);
+      } else {
+        uint64_t *base = poly + ((uint64_t)item << LOGN);
+        if constexpr(INV) team_row_item_inv<A, KSH, kAuxSc0Sc1, 0>(base, item, tid, p, lds, tabl, MID_LAZY);
+        else team_row_item_fwd<A, KSH, kAuxNt, kAuxSc1>(base, item, tid, p, lds, tabl);
+      }
+      if(!second) {
+        /* the item's stores have completed (every wave waits for its own, the barrier collects the waves) before the
+         * counter moves -- at the top of the next iteration */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sig = pidx;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
 /* fused product: c = a * b in Z_q[X]/(X^N+1), b never leaves the CU     */
 /* ------------------------------------------------------------------ */
 /*
@@ -1145,7 +1425,8 @@ struct PassArgs {
   uint64_t    limb_stride; /* words between consecutive limbs' slabs   */
   uint64_t    batch;       /* polynomials per limb                     */
   uint32_t    logn;   /* whole transform                   */
-  int         fused;  /* Pass::fused; 2 = both passes of a 2^15..2^17 transform in one launch (r = m - 14) */
+  int         fused;  /* Pass::fused; 2 = both passes of a 2^16 / 2^17 transform in one workgroup (r = m - 14); 3 = both passes as
+                       * items of one launch with the intermediate kept in the XCD's L2 (team_kernel, r = m - 12) */
   int         r;      /* Pass::r                           */
   int         s;      /* Pass::s                           */
   int         inverse;
@@ -1155,6 +1436,8 @@ struct PassArgs {
   int         ends;     /* this pass is the last one of the transform */
   int         max_grid; /* cap on workgroups (0 = default) */
   int         num_cus;  /* compute units of the device     */
+  void *      team_ctl; /* fused == 3: device memory for the queues and counters (TeamCtl + batch counters) */
+  int         team_lag, team_wpc;
   hipStream_t stream;
 };
 
@@ -1312,6 +1595,31 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
   }
 }
 
+/* pa.r = LEAD (3..5), pa.batch polynomials of 2^(12 + LEAD) points; pa.team_ctl: TeamCtl with batch counters, zeroed here */
+template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const PassArgs &pa)
+{
+  if constexpr(!A::kCompact) {
+    return hipErrorNotSupported;
+  } else {
+    if(pa.nlimbs > 1 || !pa.team_ctl || pa.wide || pa.lazy) return hipErrorNotSupported;
+    KTeam<A> kt{};
+    kt.k         = make_kargs<A>(pa);
+    kt.k.lastinv = (uint32_t)pa.inverse;
+    kt.k.nblocks = pa.batch;
+    kt.ctl       = static_cast<TeamCtl *>(pa.team_ctl);
+    kt.lag       = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 6);
+    const size_t bytes = sizeof(TeamCtl) + (size_t)pa.batch * sizeof(unsigned);
+    hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
+    if(e != hipSuccess) return e;
+    /* three workgroups per CU (LDS: 32.9 KB exchange buffer + 7.5 KB table each) */
+    uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 3);
+    if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
+    kt.k.wgs_per_limb = (uint32_t)wgs;
+    hipLaunchKernelGGL((team_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt);
+    return hipGetLastError();
+  }
+}
+
 template <class A, int R, bool INV, int KSH> hipError_t launch_column(const PassArgs &pa)
 {
   KArgs<A> p = make_kargs<A>(pa);
@@ -1442,6 +1750,14 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
 #define NTT_DEFINE_LAUNCH_PASS(A, KSH)                                                   \
   template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
   {                                                                                      \
+    if(pa.fused == 3) {                                                                  \
+      switch(pa.r) {                                                                     \
+        case 3: return pa.inverse ? launch_team<A, 3, true, KSH>(pa) : launch_team<A, 3, false, KSH>(pa); \
+        case 4: return pa.inverse ? launch_team<A, 4, true, KSH>(pa) : launch_team<A, 4, false, KSH>(pa); \
+        case 5: return pa.inverse ? launch_team<A, 5, true, KSH>(pa) : launch_team<A, 5, false, KSH>(pa); \
+        default: return hipErrorInvalidValue;                                            \
+      }                                                                                  \
+    }                                                                                    \
     if(pa.fused == 2) {                                                                  \
       switch(pa.r) {                                                                     \
         case 1: return pa.inverse ? launch_twophase<A, 1, true, KSH>(pa) : launch_twophase<A, 1, false, KSH>(pa); \

@@ -302,6 +302,71 @@ def test_rns_pipeline_small(lib, oracle):
     assert np.array_equal(got[s0:s0 + n], oracle.schoolbook(a[s0:s0 + n].copy(), b[s0:s0 + n].copy(), n, q))
 
 
+@pytest.mark.parametrize("bits", [50, 52, 31])
+@pytest.mark.parametrize("m", [15, 16, 17])
+def test_xcd_local_two_pass_kernel(lib, oracle, m, bits):
+    """NTT_OPT_XCD_LOCAL 1: both passes of a 2^15..2^17 transform as items of ONE launch, every polynomial handled by the
+    workgroups of one XCD (per-XCD queues, per-polynomial hand-off counters, intermediate kept in that XCD's L2).
+    Forward and inverse against the oracle on every polynomial, for batches that leave queues ragged (batch mod 8 != 0),
+    for every lag / residency setting, and word for word against the one-launch-per-pass path."""
+    n = 1 << m
+    q = lib.find_prime(bits, n, 1)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    ref = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    ref.set_option(lib.OPT_XCD_LOCAL, 0)
+    plan.set_option(lib.OPT_XCD_LOCAL, 1)
+    for batch, lag, wpc in ((64, 0, 0), (67, 1, 1), (100, 2, 3), (131, 9, 2)):
+        plan.set_option(lib.OPT_XCD_LOCAL_LAG, lag)
+        plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, wpc)
+        a = _inputs(oracle, n, q, batch, 1200 + batch)
+        buf = lib.DeviceBuffer(a.size).upload(a)
+        plan.fwd(buf.ptr, batch)
+        f = buf.download()
+        check = [0, 1, 7, 8, batch // 2, batch - 2, batch - 1]
+        pick = np.concatenate([np.arange(p * n, (p + 1) * n) for p in check])
+        assert np.array_equal(f[pick], cx.fwd(a[pick])), (batch, lag, wpc)
+        assert np.array_equal(f, ref.fwd_host(a)), (batch, lag, wpc)      # every polynomial, against the per-pass path
+        plan.inv(buf.ptr, batch)
+        assert np.array_equal(buf.download(), a), (batch, lag, wpc)
+        # the inverse alone, from oracle-made inputs
+        fo = cx.fwd(a[pick])
+        b2 = lib.DeviceBuffer(batch * n).upload(f)
+        plan.inv(b2.ptr, batch)
+        assert np.array_equal(b2.download()[pick], cx.inv(fo)), (batch, lag, wpc)
+        buf.free(), b2.free()
+    plan.destroy(), ref.destroy()
+
+
+def test_xcd_local_full_size_round_trip_and_cross_check(lib, oracle):
+    """BASELINE config 3's shape (N = 2^16, batch 8192) through the XCD-local kernel: per-polynomial checksums equal the
+    per-pass path's after the forward transform, and the inverse restores the input exactly"""
+    n, batch = 1 << 16, 8192
+    q = lib.find_prime(52, n)
+    w = lib.min_root(q, n)
+    plan, ref = lib.Plan(n, q, w), lib.Plan(n, q, w)
+    plan.set_option(lib.OPT_XCD_LOCAL, 1)
+    ref.set_option(lib.OPT_XCD_LOCAL, 0)
+    da, db = lib.DeviceBuffer(batch * n), lib.DeviceBuffer(batch * n)
+    cs = [lib.DeviceBuffer(batch) for _ in range(3)]
+    lib.fill_uniform(da.ptr, batch * n, q, UNI_SEED)
+    lib.fill_uniform(db.ptr, batch * n, q, UNI_SEED)
+    lib.poly_checksum(cs[0].ptr, da.ptr, n, batch)
+    plan.fwd(da.ptr, batch)
+    ref.fwd(db.ptr, batch)
+    lib.poly_checksum(cs[1].ptr, da.ptr, n, batch)
+    lib.poly_checksum(cs[2].ptr, db.ptr, n, batch)
+    assert np.array_equal(cs[1].download(), cs[2].download())
+    cx = oracle.ctx(n, q, w)
+    for p in (0, 4097, 8191):
+        assert np.array_equal(da.download(n, p * n), cx.fwd(oracle.fill_uniform(n, q, UNI_SEED, p * n))), p
+    plan.inv(da.ptr, batch)
+    lib.poly_checksum(cs[1].ptr, da.ptr, n, batch)
+    assert np.array_equal(cs[1].download(), cs[0].download())
+    plan.destroy(), ref.destroy()
+
+
 @pytest.mark.parametrize("logn", [14, 16])
 @pytest.mark.parametrize("nlimbs", [4, 16])
 @pytest.mark.parametrize("batch", [1, 2, 8])

@@ -118,6 +118,114 @@ __device__ __forceinline__ void col_item(double *poly, uint32_t nbytes, uint32_t
   }
 }
 
+/* column item of the library's existing first pass (column_pass_thread, four stages held in registers, no exchange):
+ * 256 consecutive columns x 16 rows at stride N/16; every access is a contiguous 2 KiB row segment */
+template <int LA, int SA, int F>
+__device__ __forceinline__ void col16_item(double *poly, uint32_t nbytes, uint32_t n, uint32_t tile, uint32_t t, double c1, double c2)
+{
+  const __amdgpu_buffer_rsrc_t r = rsrc_of(poly, nbytes);
+  const uint32_t span = n >> 4;
+  double         x[C];
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] = ld8<LA>(r, t * 8u, ((uint32_t)e * span + 256u * tile) * 8u);
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] += 1.0;
+  fake_compute<F>(x, c1, c2);
+#pragma unroll
+  for(int e = 0; e < C; e++) st8<SA>(x[e], r, t * 8u, ((uint32_t)e * span + 256u * tile) * 8u);
+}
+
+__device__ __forceinline__ void wave_sync4()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* row item shaped like the library's 2^12-point block (fused_kernel<., 12>: stage groups 2,4,4,2): one cross-wave exchange
+ * (two barriers), two wave-local ones, a 7.5 KiB twiddle table copied into LDS per item (coalesced reads of a table the
+ * whole batch shares), 12 per-lane table reads for the last group, whole-line final stores */
+template <int LA, int SA, int F>
+__device__ __forceinline__ void row12_item(double *poly, uint32_t tile, uint32_t t, double *lds, double *tab, double c1, double c2,
+                                           const double *tw, double c0)
+{
+  const __amdgpu_buffer_rsrc_t r = rsrc_of(poly + (size_t)tile * TILE, TILE * 8u);
+  double x[C];
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] = ld8<LA>(r, t * 8u, (uint32_t)e * T * 8u);
+  /* this block position's table slice: 960 words */
+  const double *w = tw + (size_t)tile * TILE;
+  double tl[4];
+#pragma unroll
+  for(int k = 0; k < 4; k++) tl[k] = (t + 256u * k) < 960u ? w[t + 256u * k] : 0.0;
+  double pl[12];
+#pragma unroll
+  for(int k = 0; k < 12; k++) pl[k] = w[1024u + (uint32_t)k * 256u + t];
+#pragma unroll
+  for(int e = 0; e < C; e++) x[e] *= 2.0;
+  fake_compute<F / 6>(x, c1, c2); /* 2 of 12 stages */
+  __syncthreads();
+#pragma unroll
+  for(int e = 0; e < C; e++) lds[e * (T + 1) + t] = x[e];
+#pragma unroll
+  for(int k = 0; k < 4; k++)
+    if((t + 256u * k) < 960u) tab[t + 256u * k] = tl[k];
+  __syncthreads();
+#pragma unroll
+  for(int e = 0; e < C; e++) {
+    const uint32_t i = (t >> 4) * 256u + (uint32_t)e * 16u + (t & 15u);
+    x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)];
+  }
+  fake_compute<F / 3>(x, c1, c2); /* 4 stages */
+  wave_sync4();
+  /* (wave-local exchanges: every wave owns 1024 consecutive elements from here on) */
+#pragma unroll
+  for(int e = 0; e < C; e++) {
+    const uint32_t i                    = (t >> 4) * 256u + (uint32_t)e * 16u + (t & 15u);
+    lds[(i >> 8) * (T + 1) + (i & 255u)] = x[e];
+  }
+  wave_sync4();
+#pragma unroll
+  for(int e = 0; e < C; e++) {
+    const uint32_t i = (t >> 6) * 1024u + (uint32_t)e * 64u + (t & 63u);
+    x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)] + tab[(e * 60 + (t & 63u)) % 960u] * c0;
+  }
+  fake_compute<F / 3>(x, c1, c2); /* 4 stages */
+  wave_sync4();
+#pragma unroll
+  for(int e = 0; e < C; e++) {
+    const uint32_t i                    = (t >> 6) * 1024u + (uint32_t)e * 64u + (t & 63u);
+    lds[(i >> 8) * (T + 1) + (i & 255u)] = x[e];
+  }
+  wave_sync4();
+#pragma unroll
+  for(int e = 0; e < C; e++) {
+    const uint32_t i = (t >> 6) * 1024u + (((uint32_t)e >> 2) * 64u + (t & 63u)) * 4u + ((uint32_t)e & 3u);
+    x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)] + pl[e % 12] * c0;
+  }
+  fake_compute<F - F / 6 - 2 * (F / 3)>(x, c1, c2); /* 2 stages */
+  {
+    const uint32_t lane = t & 63u, wv = t >> 6;
+#pragma unroll
+    for(int e = 0; e < C; e++) {
+      if((e & 2) == 0) {
+        const v2u32 a = __builtin_bit_cast(v2u32, x[e]), b = __builtin_bit_cast(v2u32, x[e | 2]);
+        const auto  lo = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        const auto  hi = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        x[e]           = __builtin_bit_cast(double, v2u32{lo[0], hi[0]});
+        x[e | 2]       = __builtin_bit_cast(double, v2u32{lo[1], hi[1]});
+      }
+    }
+#pragma unroll
+    for(int h = 0; h < C / 2; h++) {
+      const uint32_t e0 = 2u * (uint32_t)h, q = e0 >> 2, b1 = (e0 >> 1) & 1u;
+      const uint32_t ql = lane < 32u ? (b1 ? lane + 32u : lane) : (b1 ? lane : lane - 32u);
+      const uint32_t i  = wv * 1024u + (q * 64u + ql) * 4u + (lane < 32u ? 0u : 2u);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, d2{x[e0], x[e0 + 1]}), r, (int)(i * 8u), 0, SA);
+    }
+  }
+}
+
 /* row item: 4096 consecutive elements; 8-byte coalesced loads, 16-byte stores in runs of four per lane */
 template <int LA, int SA, int F, int X, int TW>
 __device__ __forceinline__ void row_item(double *poly, uint32_t nbytes, uint32_t tile, uint32_t t, double *lds, double c1, double c2,
@@ -164,6 +272,7 @@ __global__ void __launch_bounds__(T, WPS) k_four(double *a, uint32_t logn, uint3
                                                  double c2, const double *tw, double c0, int blocked)
 {
   __shared__ double   lds[X ? 256 * 17 : 1]; /* column layout 256 x 17 (the row layout needs 16 x 257) */
+  __shared__ double   tab[X == 2 ? 960 : 1];
   __shared__ unsigned s_k;
   const uint32_t      t      = threadIdx.x;
   const uint32_t      xcc    = xcc_id();
@@ -192,7 +301,8 @@ __global__ void __launch_bounds__(T, WPS) k_four(double *a, uint32_t logn, uint3
     const uint32_t p    = blocked ? xcc * ((batch + 7u) / 8u) + (uint32_t)j : xcc + 8u * (uint32_t)j;
     double *       poly = a + ((size_t)p << logn);
     if(!is_row) {
-      col_item<LA1, SA1, F, X>(poly, N * 8u, rowlen, tile, t, lds, c1, c2, 1.0);
+      if constexpr(X == 2) col16_item<LA1, SA1, F / 4>(poly, N * 8u, N, tile, t, c1, c2); /* 4 of 16 stages */
+      else col_item<LA1, SA1, F, X>(poly, N * 8u, rowlen, tile, t, lds, c1, c2, 1.0);
       if(mode == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -208,7 +318,8 @@ __global__ void __launch_bounds__(T, WPS) k_four(double *a, uint32_t logn, uint3
         }
         __syncthreads();
       }
-      row_item<LA2, SA2, F, X, TW>(poly, N * 8u, tile, t, lds, c1, c2, 2.0, tw, c0);
+      if constexpr(X == 2) row12_item<LA2, SA2, F - F / 4>(poly, tile, t, lds, tab, c1, c2, tw, c0);
+      else row_item<LA2, SA2, F, X, TW>(poly, N * 8u, tile, t, lds, c1, c2, 2.0, tw, c0);
     }
   }
   if(t == 0 && spins) atomicAdd(&ctl->spins[xcc][0], spins);
@@ -331,6 +442,29 @@ int main(int argc, char **argv)
   printf("# %.1f GiB in place; algorithmic bytes = 16 per element per transform; %d launches per row (median of the second half)\n", gib,
          g_reps);
   constexpr int NTL = 2, SC1 = 16;
+  if(getenv("SKEL4_SWEEP4")) {
+    /* fourth sweep: items shaped like the library's existing passes at 2^16 -- column item = column_pass_thread with four
+     * stages (no exchange, 2 KiB row segments), row item = a 2^12-point block (one barrier pair, LDS table per item,
+     * per-lane reads for the last group, whole-line stores).  F = FMAs per element over BOTH passes (split 1:3). */
+    constexpr int S01 = SC1 | 1;
+    puts("# two launches of the same items (the library's per-pass structure, unchunked)");
+    run<NTL, 0, NTL, 0, 0, 2, 0, 4>(Cfg{16, 4, 0, 1}, "two launches");
+    run<NTL, 0, NTL, 0, 72, 2, 0, 4>(Cfg{16, 4, 0, 1}, "two launches");
+    run<NTL, 0, NTL, 0, 72, 2, 0, 4>(Cfg{16, 2, 0, 1}, "two launches");
+    puts("# fused, XCD-local");
+    for(int wpc : {2, 3, 4})
+      for(int lag : {3, 4, 5, 6, 7, 8, 10}) {
+        run<S01, 0, NTL, SC1, 0, 2, 0, 4>(Cfg{16, wpc, lag, 0}, "");
+        run<S01, 0, NTL, SC1, 72, 2, 0, 4>(Cfg{16, wpc, lag, 0}, "");
+      }
+    for(int lag : {4, 5, 6, 7})
+      for(int wpc : {2, 3}) {
+        run<S01, 0, NTL, 0, 72, 2, 0, 4>(Cfg{16, wpc, lag, 0}, "plain final stores");
+        run<NTL, 0, NTL, SC1, 72, 2, 0, 4>(Cfg{16, wpc, lag, 0}, "nt input loads");
+        run<S01, 0, NTL, SC1, 96, 2, 0, 4>(Cfg{16, wpc, lag, 0}, "");
+      }
+    return 0;
+  }
   if(getenv("SKEL4_SWEEP3")) {
     /* third sweep: lag in single steps, polynomial-to-XCD assignment, which cache-policy bit matters, then the
      * LDS exchanges, table reads and FP64 work of a real transform on top of the best shapes */

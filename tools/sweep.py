@@ -15,6 +15,9 @@ ap.add_argument("--arith", nargs="+", default=["auto"])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--two-phase", type=int, default=-1, help="N=2^16, 2^17: 1 = one launch per transform, 0 = one launch per pass, -1 = the library's choice (default)")
 ap.add_argument("--fused-product", type=int, default=1, help="ntt_negacyclic_mul_batch: 1 = fused product kernel where built (default), 0 = four transforms")
+ap.add_argument("--xcd-local", type=int, default=-1, help="N=2^15..2^17: 1 = both passes as items of one launch, intermediate kept in the XCD's L2; 0 = per-pass launches")
+ap.add_argument("--lag", type=int, default=0, help="--xcd-local 1: polynomials between the two passes (0 = default)")
+ap.add_argument("--wpc", type=int, default=0, help="--xcd-local 1: workgroups per CU (0 = default)")
 ap.add_argument("--block-log", type=int, default=0, help="N=2^15, 2^16: block size below the column pass (12, 14, 0 = library's choice)")
 a = ap.parse_args()
 ap2 = None
@@ -34,6 +37,9 @@ for qs in a.qs:
                 print(ln, qs, ar, "unsupported:", e); continue
             plan.set_option(lib.OPT_TWO_PHASE, a.two_phase)
             plan.set_option(lib.OPT_FUSED_PRODUCT, a.fused_product)
+            plan.set_option(lib.OPT_XCD_LOCAL, a.xcd_local)
+            plan.set_option(lib.OPT_XCD_LOCAL_LAG, a.lag)
+            plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, a.wpc)
             if a.block_log and ln in (15, 16): plan.set_option(lib.OPT_BLOCK_LOG, a.block_log)
             nb = 3 if "mul" in a.ops else 1
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
