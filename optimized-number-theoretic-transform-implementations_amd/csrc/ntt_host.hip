@@ -626,15 +626,22 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   }
 }
 
-/* XCD-local two-pass launches: FP64 policies, N = 2^15..2^17, plain calls (canonical in, canonical out) of a batch large
- * enough to keep every XCD's queue busy.  -1 (automatic) currently means off: the path is selected with
- * NTT_OPT_XCD_LOCAL 1 (or NTT_XCD_LOCAL=1 in the environment) until its measurements say otherwise. */
-static bool team_applies(const ntt_plan *p, uint64_t batch, bool wide, bool lazy, int nlimbs)
+/* XCD-local two-pass launches: FP64 policies, N = 2^15..2^17, plain calls (canonical in, canonical out).
+ * Automatic choice (-1), as measured (profiles/r03/sweep_xcd_local.txt): the FORWARD transform of a batch that keeps all
+ * eight queues busy for several lags (+8..14 % over one launch per pass); the inverse does not gain (its first pass is
+ * the heavy one: the column items wait longer than the L2 can hold their polynomials) and keeps the per-pass launches.
+ * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it; NTT_XCD_LOCAL in the
+ * environment overrides the automatic choice the same way. */
+static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool wide, bool lazy, int nlimbs)
 {
+  if(p->arith != NTT_ARITH_F64 || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy || nlimbs != 1 ||
+     batch < 64 || batch >= (1ull << 31)) {
+    return false;
+  }
   int on = p->xcd_local;
-  if(on < 0) on = env_int("NTT_XCD_LOCAL", 0);
-  return on == 1 && p->arith == NTT_ARITH_F64 && !p->generic && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && !wide && !lazy &&
-         nlimbs == 1 && batch >= 64 && batch < (1ull << 31);
+  if(on < 0) on = env_int("NTT_XCD_LOCAL", -1);
+  if(on >= 0) return on == 1;
+  return !inverse && batch >= 512;
 }
 
 /* the stream's control block, at least sizeof(TeamCtl) + batch counters */
@@ -679,7 +686,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
   /* both passes as items of ONE launch with the intermediate kept in each XCD's L2 (ntt_kernels.h: team_kernel) */
-  if(team_applies(p, batch, wide, lazy, ls.n)) {
+  if(team_applies(p, batch, inverse, wide, lazy, ls.n)) {
     void *ctl = nullptr;
     int   rc  = team_buffer(const_cast<ntt_plan *>(p), stream, batch, &ctl);
     if(rc) return rc;
@@ -699,7 +706,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.max_grid    = p->max_grid;
     pa.num_cus     = p->num_cus;
     pa.team_ctl    = ctl;
-    pa.team_lag    = p->team_lag ? p->team_lag : env_int("NTT_TEAM_LAG", 0);
+    pa.team_lag    = p->team_lag ? p->team_lag : env_int("NTT_TEAM_LAG", 8);
     pa.team_wpc    = p->team_wpc ? p->team_wpc : env_int("NTT_TEAM_WPC", 0);
     pa.stream      = (hipStream_t)stream;
     if(env_int("NTT_TEAM_DEBUG", 0)) fprintf(stderr, "team launch: m %d batch %llu inverse %d ctl %p\n", p->m, (unsigned long long)batch, (int)inverse, ctl);

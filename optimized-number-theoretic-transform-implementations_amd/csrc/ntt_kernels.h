@@ -1175,7 +1175,10 @@ __global__ void __launch_bounds__(256, 3) team_kernel(const KTeam<A> kt)
         else team_column_item<A, LEAD, false, CMASK, kAuxSc0Sc1, 0>(poly, item * kTeamCols + tid, logn, p, MID_LAZY);
       } else {
         uint64_t *base = poly + ((uint64_t)item << LOGN);
-        if constexpr(INV) team_row_item_inv<A, KSH, kAuxSc0Sc1, 0>(base, item, tid, p, lds, tabl, MID_LAZY);
+        /* (inverse inputs arrive as 16-byte loads in runs of four coefficients per lane: two instructions share every 128-byte
+         * line, so these loads must be allowed to hit the L2 -- nt; with the cache-bypassing policy of the forward
+         * inputs every line crossed the fabric twice) */
+        if constexpr(INV) team_row_item_inv<A, KSH, kAuxNt, 0>(base, item, tid, p, lds, tabl, MID_LAZY);
         else team_row_item_fwd<A, KSH, kAuxNt, kAuxSc1>(base, item, tid, p, lds, tabl);
       }
       if(!second) {

@@ -325,6 +325,181 @@ __global__ void __launch_bounds__(T, WPS) k_four(double *a, uint32_t logn, uint3
   if(t == 0 && spins) atomicAdd(&ctl->spins[xcc][0], spins);
 }
 
+/* X2 items with the NEXT item's 16 data loads in flight while the current item is computed and stored (register double
+ * buffer, as in the library's persistent single-pass kernels).  A second-pass item is prefetched only if its polynomial is
+ * ready when asked; otherwise the workgroup waits for it after finishing the current item. */
+template <int LA1, int SA1, int LA2, int SA2, int F, int WPS>
+__global__ void __launch_bounds__(T, WPS) k_four_pipe(double *a, uint32_t logn, uint32_t batch, int lag, Ctl *ctl, double c1, double c2,
+                                                      const double *tw, double c0)
+{
+  __shared__ double   lds[256 * 17];
+  __shared__ double   tab[960];
+  __shared__ unsigned s_k, s_rdy;
+  const uint32_t      t   = threadIdx.x;
+  const uint32_t      xcc = xcc_id();
+  const uint32_t      N   = 1u << logn;
+  const uint32_t      NT  = N / TILE;
+  const uint32_t      J   = batch > xcc ? (batch - xcc + 7u) / 8u : 0u;
+  const uint32_t      steps = J + (uint32_t)lag;
+  const uint32_t      span = N >> 4;
+  if(t == 0) atomicAdd(&ctl->nwg[xcc][0], 1u);
+  struct Item {
+    bool     valid, row;
+    uint32_t tile, p;
+  };
+  auto decode = [&](uint32_t k, bool &end) {
+    Item it{false, false, 0, 0};
+    const uint32_t step = k / (2u * NT), r = k % (2u * NT);
+    end = step >= steps;
+    if(end) return it;
+    it.row           = r >= NT;
+    it.tile          = it.row ? r - NT : r;
+    const int64_t j  = it.row ? (int64_t)step - lag : (int64_t)step;
+    it.valid         = j >= 0 && j < (int64_t)J;
+    it.p             = it.valid ? xcc + 8u * (uint32_t)j : 0u;
+    return it;
+  };
+  auto issue = [&](const Item &it, double (&raw)[C]) {
+    double *poly = a + ((size_t)it.p << logn);
+    if(it.row) {
+      const __amdgpu_buffer_rsrc_t r = rsrc_of(poly + (size_t)it.tile * TILE, TILE * 8u);
+#pragma unroll
+      for(int e = 0; e < C; e++) raw[e] = ld8<LA2>(r, t * 8u, (uint32_t)e * T * 8u);
+    } else {
+      const __amdgpu_buffer_rsrc_t r = rsrc_of(poly, N * 8u);
+#pragma unroll
+      for(int e = 0; e < C; e++) raw[e] = ld8<LA1>(r, t * 8u, ((uint32_t)e * span + 256u * it.tile) * 8u);
+    }
+  };
+  unsigned spins = 0;
+  double   raw[C];
+  bool     end = false, cur_loaded = false;
+  if(t == 0) s_k = atomicAdd(&ctl->next[xcc][0], 1u);
+  __syncthreads();
+  Item cur = decode(s_k, end);
+  __syncthreads();
+  while(!end) {
+    /* next index */
+    if(t == 0) s_k = atomicAdd(&ctl->next[xcc][0], 1u);
+    /* make sure the current item is loaded (blocking poll if it is a second-pass item that was not ready before) */
+    if(cur.valid && !cur_loaded) {
+      if(cur.row) {
+        if(t == 0) {
+          while(__hip_atomic_load(&ctl->done[cur.p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NT) {
+            __builtin_amdgcn_s_sleep(8);
+            spins++;
+          }
+        }
+        __syncthreads();
+      }
+      issue(cur, raw);
+      cur_loaded = true;
+    }
+    __syncthreads();
+    bool       nend = false;
+    const Item nxt  = decode(s_k, nend);
+    if(t == 0) s_rdy = (nxt.valid && nxt.row) ? (__hip_atomic_load(&ctl->done[nxt.p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= NT) : 1u;
+    __syncthreads();
+    const bool nready = nxt.valid && s_rdy != 0;
+    __syncthreads();
+    if(cur.valid) {
+      double *poly = a + ((size_t)cur.p << logn);
+      double  x[C];
+#pragma unroll
+      for(int e = 0; e < C; e++) x[e] = raw[e];
+      if(nready) issue(nxt, raw); /* the next item's loads are in flight from here on */
+      if(!cur.row) {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(poly, N * 8u);
+#pragma unroll
+        for(int e = 0; e < C; e++) x[e] += 1.0;
+        fake_compute<F / 4>(x, c1, c2);
+#pragma unroll
+        for(int e = 0; e < C; e++) st8<SA1>(x[e], r, t * 8u, ((uint32_t)e * span + 256u * cur.tile) * 8u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if(t == 0) __hip_atomic_fetch_add(&ctl->done[cur.p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      } else {
+        /* the row item's work on x (as row12_item, minus its loads) */
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(poly + (size_t)cur.tile * TILE, TILE * 8u);
+        const double *w = tw + (size_t)cur.tile * TILE;
+        double tl[4];
+#pragma unroll
+        for(int k2 = 0; k2 < 4; k2++) tl[k2] = (t + 256u * k2) < 960u ? w[t + 256u * k2] : 0.0;
+        double pl[12];
+#pragma unroll
+        for(int k2 = 0; k2 < 12; k2++) pl[k2] = w[1024u + (uint32_t)k2 * 256u + t];
+#pragma unroll
+        for(int e = 0; e < C; e++) x[e] *= 2.0;
+        constexpr int FR = F - F / 4;
+        fake_compute<FR / 6>(x, c1, c2);
+        __syncthreads();
+#pragma unroll
+        for(int e = 0; e < C; e++) lds[e * (T + 1) + t] = x[e];
+#pragma unroll
+        for(int k2 = 0; k2 < 4; k2++)
+          if((t + 256u * k2) < 960u) tab[t + 256u * k2] = tl[k2];
+        __syncthreads();
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          const uint32_t i = (t >> 4) * 256u + (uint32_t)e * 16u + (t & 15u);
+          x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)];
+        }
+        fake_compute<FR / 3>(x, c1, c2);
+        wave_sync4();
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          const uint32_t i                    = (t >> 4) * 256u + (uint32_t)e * 16u + (t & 15u);
+          lds[(i >> 8) * (T + 1) + (i & 255u)] = x[e];
+        }
+        wave_sync4();
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          const uint32_t i = (t >> 6) * 1024u + (uint32_t)e * 64u + (t & 63u);
+          x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)] + tab[(e * 60 + (t & 63u)) % 960u] * c0;
+        }
+        fake_compute<FR / 3>(x, c1, c2);
+        wave_sync4();
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          const uint32_t i                    = (t >> 6) * 1024u + (uint32_t)e * 64u + (t & 63u);
+          lds[(i >> 8) * (T + 1) + (i & 255u)] = x[e];
+        }
+        wave_sync4();
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          const uint32_t i = (t >> 6) * 1024u + (((uint32_t)e >> 2) * 64u + (t & 63u)) * 4u + ((uint32_t)e & 3u);
+          x[e]             = lds[(i >> 8) * (T + 1) + (i & 255u)] + pl[e % 12] * c0;
+        }
+        fake_compute<FR - FR / 6 - 2 * (FR / 3)>(x, c1, c2);
+        const uint32_t lane = t & 63u, wv = t >> 6;
+#pragma unroll
+        for(int e = 0; e < C; e++) {
+          if((e & 2) == 0) {
+            const v2u32 aa = __builtin_bit_cast(v2u32, x[e]), bb = __builtin_bit_cast(v2u32, x[e | 2]);
+            const auto  lo = __builtin_amdgcn_permlane32_swap(aa.x, bb.x, false, false);
+            const auto  hi = __builtin_amdgcn_permlane32_swap(aa.y, bb.y, false, false);
+            x[e]           = __builtin_bit_cast(double, v2u32{lo[0], hi[0]});
+            x[e | 2]       = __builtin_bit_cast(double, v2u32{lo[1], hi[1]});
+          }
+        }
+#pragma unroll
+        for(int h = 0; h < C / 2; h++) {
+          const uint32_t e0 = 2u * (uint32_t)h, qd = e0 >> 2, b1 = (e0 >> 1) & 1u;
+          const uint32_t ql = lane < 32u ? (b1 ? lane + 32u : lane) : (b1 ? lane : lane - 32u);
+          const uint32_t i  = wv * 1024u + (qd * 64u + ql) * 4u + (lane < 32u ? 0u : 2u);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, d2{x[e0], x[e0 + 1]}), r, (int)(i * 8u), 0, SA2);
+        }
+        __syncthreads();
+      }
+    }
+    cur        = nxt;
+    cur_loaded = nready;
+    end        = nend;
+  }
+  if(t == 0 && spins) atomicAdd(&ctl->spins[xcc][0], spins);
+}
+
 __global__ void __launch_bounds__(256) k_fill(double *a, size_t n)
 {
   for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -424,6 +599,52 @@ template <int LA1, int SA1, int LA2, int SA2, int F, int X, int TW, int WPS> sta
   fflush(stdout);
 }
 
+template <int LA1, int SA1, int LA2, int SA2, int F, int WPS> static void run_pipe(Cfg cf, const char *note)
+{
+  char label[200];
+  snprintf(label, sizeof label, "m%d mode%d wpc%d lag%-2d blk%d la1 %2d sa1 %2d la2 %2d sa2 %2d F%-2d X%d TW%d %s", cf.logn, 0, cf.wpc, cf.lag, 0,
+           LA1, SA1, LA2, SA2, F, 3, 0, note);
+  if(g_filter && !strstr(label, g_filter)) return;
+  const uint32_t batch = (uint32_t)(g_n >> cf.logn);
+  auto           go    = [&] {
+    CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+    hipLaunchKernelGGL((k_four_pipe<LA1, SA1, LA2, SA2, F, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch, cf.lag,
+                       g_ctl, 1.0, 0.0, g_tw, 0.0);
+  };
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n);
+  CK(hipMemset(g_bad, 0, 8));
+  go();
+  hipLaunchKernelGGL(k_check, dim3(8192), dim3(256), 0, 0, g_buf, g_n, g_bad);
+  unsigned long long bad = 0;
+  CK(hipMemcpy(&bad, g_bad, 8, hipMemcpyDeviceToHost));
+  Ctl census;
+  CK(hipMemcpy(&census, g_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n);
+  std::vector<float> ms;
+  for(int rpt = 0; rpt < g_reps; rpt++) {
+    float m = 0;
+    CK(hipMemsetAsync(g_ctl, 0, g_ctl_bytes));
+    CK(hipEventRecord(g_e0));
+    hipLaunchKernelGGL((k_four_pipe<LA1, SA1, LA2, SA2, F, WPS>), dim3(256 * cf.wpc), dim3(T), 0, 0, g_buf, (uint32_t)cf.logn, batch, cf.lag,
+                       g_ctl, 1.0, 0.0, g_tw, 0.0);
+    CK(hipEventRecord(g_e1));
+    CK(hipEventSynchronize(g_e1));
+    CK(hipEventElapsedTime(&m, g_e0, g_e1));
+    ms.push_back(m);
+    if((rpt & 7) == 7) hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, g_buf, g_n);
+  }
+  CK(hipGetLastError());
+  std::vector<float> tail(ms.begin() + g_reps / 2, ms.end());
+  std::sort(tail.begin(), tail.end());
+  const float  med = tail[tail.size() / 2], best = tail[0];
+  const double bytes = (double)g_n * 16.0;
+  unsigned     sp = 0;
+  for(int x = 0; x < 8; x++) sp += census.spins[x][0];
+  printf("%-78s med %7.3f ms best %7.3f  %5.2f TB/s frac %.3f  bad %llu  wg/xcd %u..%u spins %u\n", label, med, best, bytes / med * 1e-9,
+         bytes / med * 1e-9 / 8.0, bad, census.nwg[0][0], census.nwg[7][0], sp);
+  fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
   const double gib = argc > 1 ? atof(argv[1]) : 16.0;
@@ -442,6 +663,17 @@ int main(int argc, char **argv)
   printf("# %.1f GiB in place; algorithmic bytes = 16 per element per transform; %d launches per row (median of the second half)\n", gib,
          g_reps);
   constexpr int NTL = 2, SC1 = 16;
+  if(getenv("SKEL4_SWEEP5")) {
+    /* fifth sweep: the library-shaped items with the next item's data loads in flight during the current item (X3) */
+    constexpr int S01 = SC1 | 1;
+    for(int wpc : {1, 2, 3})
+      for(int lag : {4, 6, 8, 10, 12, 16}) {
+        run_pipe<S01, 0, NTL, SC1, 0, 4>(Cfg{16, wpc, lag, 0}, "pipelined");
+        run_pipe<S01, 0, NTL, SC1, 72, 4>(Cfg{16, wpc, lag, 0}, "pipelined");
+        run_pipe<S01, 0, NTL, SC1, 96, 4>(Cfg{16, wpc, lag, 0}, "pipelined");
+      }
+    return 0;
+  }
   if(getenv("SKEL4_SWEEP4")) {
     /* fourth sweep: items shaped like the library's existing passes at 2^16 -- column item = column_pass_thread with four
      * stages (no exchange, 2 KiB row segments), row item = a 2^12-point block (one barrier pair, LDS table per item,
