@@ -75,8 +75,8 @@ typedef enum ntt_option {
                            * handled by the workgroups of one XCD so that the intermediate stays in that XCD's L2 (fabric
                            * traffic 24N instead of 32N bytes per transform); 0 = one launch per pass; -1 (default) = where
                            * it measured faster: forward transforms of 512 polynomials or more.  Results are identical. */
-  NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default 8) */
-  NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..3 (0 = default 3) */
+  NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: 10, 8, 10 at 2^15, 2^16, 2^17) */
+  NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14; block by block between column passes, 88N
                           * bytes, above); 0 = fwd, fwd, pointwise, inv (72N / 120N bytes) */

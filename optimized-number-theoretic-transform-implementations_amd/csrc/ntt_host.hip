@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
-#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -589,7 +588,7 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       p->team_lag = (int)value;
       return NTT_OK;
     case NTT_OPT_XCD_LOCAL_WGS_PER_CU:
-      if(value < 0 || value > 3) return fail(NTT_ERR_ARG, "workgroups per CU: 0 (default) .. 3");
+      if(value < 0 || value > 4) return fail(NTT_ERR_ARG, "workgroups per CU: 0 (default) .. 4");
       p->team_wpc = (int)value;
       return NTT_OK;
     case NTT_OPT_BLOCK_LOG:
@@ -649,9 +648,13 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
 {
   const size_t need = sizeof(TeamCtl) + (size_t)batch * sizeof(unsigned);
   std::lock_guard<std::mutex> lock(p->team_mu);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  *out = nullptr;
   for(ntt_plan::TeamBuf &tb : p->team_bufs) {
     if(tb.stream != stream) continue;
     if(tb.bytes < need) {
+      if(capturing) return NTT_OK; /* (no buffer: the caller takes the other path) */
       HIP_TRY(hipFree(tb.d)); /* (waits for the launches that still use it) */
       tb.d     = nullptr;
       tb.bytes = 0;
@@ -661,6 +664,7 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
     *out = tb.d;
     return NTT_OK;
   }
+  if(capturing) return NTT_OK;
   void *d = nullptr;
   HIP_TRY(hipMalloc(&d, need * 2));
   p->team_bufs.push_back(ntt_plan::TeamBuf{stream, d, need * 2});
@@ -686,10 +690,15 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
   /* both passes as items of ONE launch with the intermediate kept in each XCD's L2 (ntt_kernels.h: team_kernel) */
+  void *ctl = nullptr;
   if(team_applies(p, batch, inverse, wide, lazy, ls.n)) {
-    void *ctl = nullptr;
-    int   rc  = team_buffer(const_cast<ntt_plan *>(p), stream, batch, &ctl);
+    /* the queue heads and counters live in a buffer the plan keeps per stream; it is allocated on first use -- except
+     * while the stream is being captured into a HIP graph (allocation is not capturable): the call then takes the
+     * per-pass launches, which need no memory of their own */
+    int rc = team_buffer(const_cast<ntt_plan *>(p), stream, batch, &ctl);
     if(rc) return rc;
+  }
+  if(ctl) {
     PassArgs pa{};
     pa.a           = d_a;
     pa.limbs       = ls.d;
@@ -706,34 +715,16 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.max_grid    = p->max_grid;
     pa.num_cus     = p->num_cus;
     pa.team_ctl    = ctl;
-    pa.team_lag    = p->team_lag ? p->team_lag : env_int("NTT_TEAM_LAG", 8);
-    pa.team_wpc    = p->team_wpc ? p->team_wpc : env_int("NTT_TEAM_WPC", 0);
+    /* polynomials between the two passes of a queue.  The L2 keeps the intermediate while lag x polynomial size stays
+     * below about 2.5 MiB (measured, FETCH_SIZE 1.0x the data: 2^15 up to lag 10, 2^16 up to 5, 2^17 not even at 2;
+     * profiles/r03/team_kernel_l2_retention.txt), but with four workgroups per CU a lag below 8 makes second-pass items
+     * wait: 2^15 gets both (lag 10: 0.43 of the roofline against 0.40-0.41 beyond), 2^16 and 2^17 run fastest at 8-10
+     * with the second pass served by the Infinity Cache (profiles/r03/sweep_xcd_local_lag.txt) */
+    pa.team_lag    = p->team_lag ? p->team_lag : (p->m == kTeamBlock + 4 ? 8 : 10);
+    pa.team_wpc    = p->team_wpc;
     pa.stream      = (hipStream_t)stream;
-    if(env_int("NTT_TEAM_DEBUG", 0)) fprintf(stderr, "team launch: m %d batch %llu inverse %d ctl %p\n", p->m, (unsigned long long)batch, (int)inverse, ctl);
     hipError_t e   = dispatch_pass(p, pa);
-    if(env_int("NTT_TEAM_DEBUG", 0)) fprintf(stderr, "team launch returned %d\n", (int)e);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if(env_int("NTT_TEAM_DEBUG", 0)) {
-      /* development aid: watch the queue heads while the launch runs (side stream), then print the final state */
-      TeamCtl h;
-      hipStream_t side;
-      HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      for(int it = 0; it < env_int("NTT_TEAM_DEBUG", 0) - 1; it++) {
-        struct timespec ts = {0, 300000000};
-        nanosleep(&ts, nullptr);
-        HIP_TRY(hipMemcpyAsync(&h, ctl, sizeof h, hipMemcpyDeviceToHost, side));
-        HIP_TRY(hipStreamSynchronize(side));
-        fprintf(stderr, "live:");
-        for(int q = 0; q < 8; q++) fprintf(stderr, " q%d next %u own %u items %u wd %u/%u/%u |", q, h.next[q][0], h.owner[q][0], h.owner[q][4], h.owner[q][1], h.owner[q][2], h.owner[q][3]);
-        fprintf(stderr, "\n");
-      }
-      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-      HIP_TRY(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
-      for(int q = 0; q < 8; q++) {
-        fprintf(stderr, "team queue %d: next %u owner %u watchdog poly+1 %u done %u item %u\n", q, h.next[q][0], h.owner[q][0], h.owner[q][1],
-                h.owner[q][2], h.owner[q][3]);
-      }
-    }
     return NTT_OK;
   }
   /* the one-launch two-phase kernel owns a CU per polynomial: it only pays when the batch fills the chip (measured +3 % at

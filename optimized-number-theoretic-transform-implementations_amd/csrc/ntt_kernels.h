@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, 
 }
 
 template <class A, int LEAD, bool INV, int KSH>
-__global__ void __launch_bounds__(256, 3) team_kernel(const KTeam<A> kt)
+__global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
 {
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
@@ -1614,8 +1614,8 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const Pas
     const size_t bytes = sizeof(TeamCtl) + (size_t)pa.batch * sizeof(unsigned);
     hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
     if(e != hipSuccess) return e;
-    /* three workgroups per CU (LDS: 32.9 KB exchange buffer + 7.5 KB table each) */
-    uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 3);
+    /* four workgroups per CU: 40,580 bytes of LDS each (32.9 KB exchange buffer + 7.5 KB table), at most 128 VGPRs */
+    uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
     if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
     kt.k.wgs_per_limb = (uint32_t)wgs;
     hipLaunchKernelGGL((team_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt);

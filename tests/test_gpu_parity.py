@@ -317,7 +317,7 @@ def test_xcd_local_two_pass_kernel(lib, oracle, m, bits):
     ref = lib.Plan(n, q, w, arith=lib.ARITH_F64)
     ref.set_option(lib.OPT_XCD_LOCAL, 0)
     plan.set_option(lib.OPT_XCD_LOCAL, 1)
-    for batch, lag, wpc in ((64, 0, 0), (67, 1, 1), (100, 2, 3), (131, 9, 2)):
+    for batch, lag, wpc in ((64, 0, 0), (67, 1, 1), (100, 2, 3), (131, 9, 2), (77, 3, 4)):
         plan.set_option(lib.OPT_XCD_LOCAL_LAG, lag)
         plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, wpc)
         a = _inputs(oracle, n, q, batch, 1200 + batch)
