@@ -10,6 +10,13 @@
  * the lazy forward output in [0,8q) equals the reference's bit for bit.  Other
  * sizes are served by the radix-2 engine on the even slots (slot 2k = w[k]):
  * values in [0,4q), congruent to the reference's.
+ * Known limit (deliberate): for N = 2^15 .. 2^17 (reference cases 14-18) the LAZY words
+ * are therefore a different member of the residue class than src/ntt_radix4.c's; after
+ * the reduction this header's fwd_ntt_radix4 applies -- the only thing the reference's
+ * own tests compare (tests/test_correctness.c:256-285) -- they are identical.  A
+ * device radix-4 formulation for the multi-pass sizes would need radix-4 pairs inside
+ * the strided column passes as well; the policy is 25-30 % slower than radix-2 on this
+ * hardware and serves a PCIe-bound compatibility path, so it was not built.
  */
 #ifndef NTT_MI355X_NTT_RADIX4_H
 #define NTT_MI355X_NTT_RADIX4_H

@@ -1028,7 +1028,8 @@ __device__ __forceinline__ void team_row_item_fwd(uint64_t *base, uint32_t blk, 
   typename A::ctw pre[4][kE / 2];
   preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
   fill_lds_tables<A, LOGN, false>(tabl, p, blk, tid);
-  __syncthreads(); /* the table is complete before any wave reaches its group */
+  /* (the table is read in the second-to-last group; the cross-wave exchange in front of it has two workgroup barriers) */
+  static_assert(!P::WAVE_LOCAL(0, 1), "the first exchange must cross waves: its barriers publish the LDS table");
   typename A::val x[kE];
   convert_inputs<A, false>(x, raw, false, p.c);
   run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
@@ -1064,6 +1065,7 @@ __device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, 
   typename A::ctw pre[4][kE / 2];
   if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
   fill_lds_tables<A, LOGN, true>(tabl, p, blk, tid);
+  /* (read after the exchange between the last two groups -- wave-local -- so the table needs its own barrier here) */
   __syncthreads();
   typename A::val x[kE];
   convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
@@ -1094,7 +1096,7 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
   using G            = Geom<LOGN, INV, flavor_of<A>()>;
   static_assert(A::kCompact && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5, "built for the FP64 policies on 2^12-point blocks, N = 2^15..2^17");
   __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
-  __shared__ unsigned        s_k;
+  __shared__ unsigned        s_k, s_k2[2];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
   const uint32_t         tid  = threadIdx.x;
   uint32_t               bid_, gdim_, limb_;
@@ -1130,15 +1132,16 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
      * first-pass item is carried into the next iteration and issued by the same lane-0 block that fetches the next item. */
     constexpr uint32_t kNoSignal = 0xffffffffu;
     uint32_t           sig       = kNoSignal;
-    for(;;) {
+    for(uint32_t it = 0;; it ^= 1u) {
+      /* the item index travels through one of two LDS words in turn, so that one barrier per fetch is enough (lane 0
+       * writes the other word next time: nobody can still be reading it, everybody has passed this barrier since) */
       if(tid == 0) {
         if(sig != kNoSignal) __hip_atomic_fetch_add(&ctl->done[sig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_k = atomicAdd(&ctl->next[q][0], 1u);
+        s_k2[it] = atomicAdd(&ctl->next[q][0], 1u);
       }
       sig = kNoSignal;
       __syncthreads();
-      const uint32_t k = s_k;
-      __syncthreads();
+      const uint32_t k = s_k2[it];
       const uint32_t step = k / (NA + NB), r = k % (NA + NB);
       if(step >= steps) break;
       const bool     second = r >= NA;

@@ -3,7 +3,8 @@
 
 Every round draws a transform size 2^1..2^18, a prime of 20..60 bits with 2N | q-1, an arithmetic policy the
 library offers for it, a ragged batch (with a bias to the persistent grids' edges: 255, 256, 257, 511, ...), plan
-options (chunk size, grid cap, two-phase, column-only engine, fused product on/off) and checks, bit for bit against
+options (chunk size, grid cap, two-phase, XCD-local launch with random lag and residency, column-only engine, fused
+product on/off), now and then an RNS set (one launch over all limbs or the per-prime loop) and checks, bit for bit against
 the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms.
 usage: python3 tools/soak.py [--seconds 300] [--seed 1] [--max-coeffs 2^22]"""
 import argparse, os, sys, time
@@ -73,6 +74,15 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         opts["fused_product"] = 0
         plan.set_option(lib.OPT_FUSED_PRODUCT, 0)
+    if m in (15, 16, 17) and rng.random() < 0.6:
+        # both passes as items of one launch (needs batch >= 64; forced on for both directions, random lag / residency)
+        opts["xcd_local"] = int(rng.choice([1, 1, 0]))
+        plan.set_option(lib.OPT_XCD_LOCAL, opts["xcd_local"])
+        opts["lag"], opts["wpc"] = int(rng.integers(0, 13)), int(rng.integers(0, 5))
+        plan.set_option(lib.OPT_XCD_LOCAL_LAG, opts["lag"])
+        plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, opts["wpc"])
+        if opts["xcd_local"] == 1:
+            batch = max(batch, int(rng.choice([64, 65, 71, 96, 129])))
     cx = orc.ctx(n, q, w)
     a = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
     k = int(rng.integers(0, 5))
@@ -142,11 +152,47 @@ while time.time() < t_end:
         checks += 2
         if rng.random() < 0.3:
             lib.compat_release()
+    # RNS sets: one launch over all limbs against the per-prime loop's semantics (every limb against the oracle)
+    if rng.random() < 0.12 and 8 <= m <= 16:
+        nl = int(rng.choice([2, 3, 4, 7, 16, 17]))
+        rb = int(rng.choice([1, 2, 3, 8]))
+        if nl * rb * n <= args.max_coeffs:
+            rbits = int(rng.choice([45, 49, 50]))
+            qs = [lib.find_prime(rbits, n, i) for i in range(nl)]
+            if all(qs) and len(set(qs)) == nl:
+                ws = [lib.min_root(x, n) for x in qs]
+                plans = [lib.Plan(n, x, y) for x, y in zip(qs, ws)]
+                ra = np.concatenate([orc.fill_uniform(rb * n, x, int(rng.integers(1, 1 << 40))) for x in qs])
+                rbv = np.concatenate([orc.fill_uniform(rb * n, x, int(rng.integers(1, 1 << 40))) for x in qs])
+                os.environ["NTT_RNS_LOOP"] = str(int(rng.integers(0, 2)))
+                da, db, dc = lib.DeviceBuffer(ra.size).upload(ra), lib.DeviceBuffer(ra.size).upload(rbv), lib.DeviceBuffer(ra.size)
+                lib.rns_fwd(plans, da.ptr, rb)
+                f = da.download()
+                lib.rns_inv(plans, da.ptr, rb)
+                back = da.download()
+                lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, rb)
+                pr = dc.download()
+                for l, (x, y) in enumerate(zip(qs, ws)):
+                    c2 = orc.ctx(n, x, y)
+                    sl = slice(l * rb * n, (l + 1) * rb * n)
+                    if not np.array_equal(f[sl], c2.fwd(ra[sl])) or not np.array_equal(back[sl], ra[sl]) or \
+                       not np.array_equal(pr[sl], c2.inv(orc.pointwise(c2.fwd(ra[sl]), c2.fwd(rbv[sl]), x))):
+                        fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=os.environ["NTT_RNS_LOOP"], q=hex(x))
+                del os.environ["NTT_RNS_LOOP"]
+                for d in (da, db, dc):
+                    d.free()
+                for pl in plans:
+                    pl.destroy()
+                checks += 3 * nl
+                stats_rns = stats.setdefault(("rns", 0, 0), 0)
+                stats[("rns", 0, 0)] = stats_rns + 1
     rounds += 1
 
 print("soak ok: %d rounds, %d checks in %.0f s (seed %d)" % (rounds, checks, args.seconds, args.seed))
 by_arith = {}
+rns_rounds = stats.pop(("rns", 0, 0), 0)
 for (m, ar, cls), c in stats.items():
     by_arith[(ar, cls)] = by_arith.get((ar, cls), 0) + c
+print("RNS rounds:", rns_rounds)
 print("rounds per (resolved policy, FP64 class):", dict(sorted(by_arith.items())))
 print("sizes seen:", sorted({m for (m, _, _) in stats}))
