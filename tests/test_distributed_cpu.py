@@ -131,3 +131,66 @@ def test_shard_helpers():
     assert bench.shard_of_rank(0, 131072, 1 << 14) == (0, 0)
     assert bench.shard_of_rank(7, 131072, 1 << 14) == (7 * 131072, 7 * 131072 << 14)
     assert bench.allreduce_max(None, 3.5) == 3.5
+
+
+def test_bench_config_workloads():
+    """bench.py --config 2|3|4|5: units, algorithmic bytes per unit and per-GPU shares of every BASELINE config"""
+    import bench
+    w4 = bench.workload_for(4)
+    assert (w4.n, w4.kind, w4.unit, w4.bytes_per_unit, w4.metric) == (1 << 14, "fwd", "NTT/s", 16 << 14, bench.METRIC)
+    assert w4.per_gpu_batch("weak", 1) == w4.per_gpu_batch("weak", 8) == 131072 and w4.per_gpu_batch("strong", 4) == 1 << 18
+    w2 = bench.workload_for(2)
+    assert (w2.n, w2.kind, w2.bytes_per_unit, w2.per_gpu_batch("weak", 1)) == (4096, "fwd", 16 * 4096, 65536)
+    w3 = bench.workload_for(3)
+    assert (w3.n, w3.kind, w3.unit, w3.bytes_per_unit, w3.per_gpu_batch("weak", 1)) == (65536, "roundtrip", "round trips/s", 32 * 65536, 8192)
+    w5 = bench.workload_for(5)
+    assert (w5.n, w5.kind, w5.limbs, w5.unit) == (1 << 17, "rns_product", 4, "RNS products/s")
+    assert w5.bytes_per_unit == 4 * 56 * (1 << 17)                     # 56N per limb-product, four limbs
+    assert w5.per_gpu_batch("weak", 8) == 512 and w5.per_gpu_batch("strong", 2) == 2048
+    with pytest.raises(SystemExit):
+        bench.workload_for(1)                                          # config 1 is the CPU plumbing case: a parity test, not a bench line
+
+
+def test_bench_report_for_other_configs():
+    """make_report on config 3 / 5 workloads: metric, unit, roofline bytes, min/median step times, no stale traffic figure"""
+    import argparse
+    import bench
+    args = argparse.Namespace(steps=4, warmup=1, scaling="weak")
+    w3 = bench.workload_for(3)
+    w3.qs, w3.roots = [0xffffffff00001], [3]
+    rep = bench.make_report(args, 1, 8192, 0.02, [5.0], 2, 2, n=w3.n, workload=w3, step_ms=[5.2, 4.9, 5.0, 5.1], f64_class=52)
+    assert rep["unit"] == "round trips/s" and rep["metric"] == w3.metric and rep["config"]["workload"].startswith("config3")
+    assert rep["value"] == pytest.approx(8192 / (0.02 / 4))
+    r = rep["roofline"]
+    assert r["algorithmic_bytes_per_step"] == 8192 * 32 * 65536 and r["traffic"] is None and r["traffic_source"] is None
+    assert r["step_ms_min"] == 4.9 and r["step_ms_median"] == pytest.approx(5.05) and r["launches_per_step"] == 4
+    assert r["frac"] == pytest.approx(8192 * 32 * 65536 / 5.0e-3 / 1e9 / 8000.0)
+    assert "reduced" in rep["config"]["arith"]
+    w5 = bench.workload_for(5)
+    w5.qs, w5.roots = [11, 13, 17, 19], [1, 1, 1, 1]
+    rep = bench.make_report(args, 8, 512, 0.04, [9.0] * 8, 2, 2, n=w5.n, workload=w5, step_ms=[9.0] * 4)
+    assert rep["n_gpus"] == 8 and rep["unit"] == "RNS products/s" and rep["config"]["global_batch"] == 4096
+    assert rep["roofline"]["algorithmic_bytes_per_unit"] == 4 * 56 * (1 << 17) and len(rep["config"]["q"]) == 4
+
+
+def test_cpu_quota_parsing(tmp_path, monkeypatch):
+    """cpu_baseline sizes its thread count by the container's CPU-time quota when there is one"""
+    import bench
+    q = bench.cpu_quota()
+    assert q is None or q > 0
+
+
+def test_cpu_baseline_harness_runs_on_the_reference():
+    """bench.py's CPU leg: the pthread harness around the compiled reference (oracle/_ref; the oracle restatement where
+    that file did not travel): plausible numbers, the fields the judge reads, and a thread count the box can serve"""
+    import os
+    import bench
+    r = bench.cpu_baseline(budget_s=0.4)
+    assert r["kind"] in ("reference", "port") and (r["kind"] == "reference") == os.path.exists(
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libntt_ref.so"))
+    assert r["unit"] == "NTT/s" and r["value"] > 1000 and r["single_core_us"] > 10
+    assert 1 <= r["threads"] == r["cores"] <= r["cpus_allowed"] <= max(r["cpus_online"], r["cpus_allowed"])
+    assert 0.3 < r["all_core_over_single_core"] < 1.5 * r["threads"]
+    assert "pthreads" in r["sample"] and "min of means" in r["sample"]
+    if r["kind"] != "reference":
+        assert "warning" in r
