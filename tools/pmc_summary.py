@@ -16,6 +16,6 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
     key = names[0]
     mx = max(d[key] for d in by_disp.values())
     full = [d for d in by_disp.values() if d[key] > 0.5 * mx]
-    print("# %s : %d full dispatches, grid %s vgpr %s lds %s" % ([x for x in f.split("/") if x not in ("run","runc")][-2], len(full), full[0]["_grid"], full[0]["_vgpr"], full[0]["_lds"]))
+    print("# %s : %d full dispatches, grid %s rocprofv3-VGPR_Count %s (= half the code object's vgpr_count for these wave64 kernels; tools/check_spills.py prints the ELF value) lds %s" % ([x for x in f.split("/") if x not in ("run","runc")][-2], len(full), full[0]["_grid"], full[0]["_vgpr"], full[0]["_lds"]))
     for n in names:
         print("  %-34s %16.0f" % (n, sum(d[n] for d in full) / len(full)))
