@@ -41,6 +41,10 @@ template <> hipError_t launch_product<ArithF64, 0>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 1>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64, 18>(const ProdArgs &);
 template <> hipError_t launch_product<ArithF64W, 0>(const ProdArgs &);
+template <> hipError_t launch_team_product<ArithF64, 0>(const ProdArgs &);
+template <> hipError_t launch_team_product<ArithF64, 1>(const ProdArgs &);
+template <> hipError_t launch_team_product<ArithF64, 18>(const ProdArgs &);
+template <> hipError_t launch_team_product<ArithF64W, 0>(const ProdArgs &);
 } // namespace ntt
 
 /* ------------------------------------------------------------------ */
@@ -958,6 +962,39 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   int rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
   if(rc) return rc;
   USE_DEVICE(p->device);
+  /* N >= 2^15, large batches: the rest of the chain (column stages of b, block products, inverse column stages of c) as
+   * the three item kinds of ONE launch (ntt_kernels.h: team_product_kernel) */
+  if(canonical_a && !p->block_log) {
+    void *ctl = nullptr;
+    rc        = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch, &ctl);
+    if(rc) return rc;
+    if(ctl) {
+      ProdArgs pa{};
+      pa.b           = d_b;
+      pa.ahat        = d_a;
+      pa.out         = d_c;
+      pa.limbs       = ls.d;
+      pa.nlimbs      = 1;
+      pa.limb_stride = 0;
+      pa.batch       = batch;
+      pa.logn        = (uint32_t)p->m;
+      pa.a_lazy      = 1;
+      pa.max_grid    = p->max_grid;
+      pa.num_cus     = p->num_cus;
+      pa.team_ctl    = ctl;
+      /* three passes, four workgroups per CU: the lag that keeps second- and third-pass items from waiting is larger than
+       * the transform's (measured, profiles/r03/sweep_product_lag.txt: flat optimum 12-14 at 2^17, 12-20 at 2^16, 20-24 at 2^15) */
+      pa.team_lag    = p->team_lag ? p->team_lag : (p->m == kTeamBlock + 3 ? 20 : (p->m == kTeamBlock + 4 ? 14 : 12));
+      pa.team_wpc    = p->team_wpc;
+      pa.stream      = (hipStream_t)stream;
+      hipError_t e = p->kcls == kWideClass ? launch_team_product<ArithF64W, 0>(pa)
+                     : p->kcls == 18       ? launch_team_product<ArithF64, 18>(pa)
+                     : p->kcls == 1        ? launch_team_product<ArithF64, 1>(pa)
+                                           : launch_team_product<ArithF64, 0>(pa);
+      if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+      return NTT_OK;
+    }
+  }
   /* blocks of the fused launch for N > 2^14: as for the transforms, stages are cheaper in the memory-bound column
    * passes than in the FP64-bound fused launch -- 2^12-point blocks where 4 column stages reach (measured +3..5 % at
    * 2^15 and 2^16; 2^13-point blocks at 2^17: -1 %, not used) */

@@ -1345,6 +1345,174 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* products at N = 2^15 .. 2^17: three passes as items of one launch    */
+/* ------------------------------------------------------------------ */
+/*
+ * c = a * b with a^ = fwd(a) already in HBM: the remaining chain -- column stages of b, per block forward x a^ -> inverse,
+ * inverse column stages of c -- as the three item kinds of ONE launch in team_kernel's scheme (per-XCD in-order queues,
+ * per-polynomial hand-off counters, intermediates kept in the XCD's L2 / Infinity Cache): first-pass items of polynomial j,
+ * second-pass items of polynomial j - lag, third-pass items of polynomial j - 2 lag.  An item only ever waits for items
+ * handed out earlier in its queue, and first-pass items never wait: no deadlock whatever the residency.  Five launches per
+ * 256 MiB chunk become one launch per batch; the fabric carries 40N bytes for this chain instead of 56N while the
+ * intermediates stay on chip.  The blocks are 2^12 points at every size (2^17: five column stages in one item, where the
+ * per-pass path needs 2^14-point blocks to get by with one column launch).
+ * c may alias a or b exactly as in fused_product_kernel: a block's a^ and b words are read by the item that overwrites them.
+ */
+template <class A, int KSH, int LDAUX_B, int LDAUX_A, int STAUX>
+__device__ __forceinline__ void team_product_item(uint64_t *bblk, const uint64_t *ablk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
+                                                  const Params<A> &pf, const Params<A> &pi, typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, 3>;
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>();
+  constexpr int      GL    = P::NG - 1;
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && !P::WAVE_LOCAL(0, 1), "twiddle placement / barrier this item assumes");
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  /* (an opaque copy of the thread id ties every lane-dependent address of the item to the item: hoisted out of the item
+   * loop they live in registers -- or scratch -- for the whole launch; fused_product_kernel does the same) */
+  uint32_t tl = tid0;
+  asm volatile("" : "+v"(tl));
+  const uint32_t tid = tl;
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX_B>(raw, tid, bblk);
+  typename A::ctw pre[4][kE / 2];
+  preload_group_tw<A, LOGN, GL>(pre, tid, blk, pf);
+  fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid); /* (published by the first exchange's barriers) */
+  typename A::val x[kE];
+  convert_inputs<A, false>(x, raw, false, pf.c);
+  prefetch_last<LOGN, LDAUX_A>(raw, tid, ablk); /* a^ in the last group's layout: used after the twelve forward stages */
+  run_group<A, LOGN, 0, false, MASKF>(x, tid, blk, pf);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = decltype(gg)::value;
+    exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+    if constexpr(GI + 1 == GL) {
+      run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
+    } else if constexpr(G::TBL(GI + 1) > 0) {
+      run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tid, blk, pf, ltw + G::TBL_OFF(GI + 1));
+    } else {
+      run_group<A, LOGN, GI + 1, false, MASKF>(x, tid, blk, pf);
+    }
+  });
+  uint32_t t2 = tid;
+  asm volatile("" : "+v"(t2));
+  preload_group_tw<A, LOGN, GL>(pre, t2, blk, pi); /* the inverse's first group: lands while the product is computed */
+  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+  run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    if constexpr(G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0); /* (as in fused_product_kernel: keep the global twiddle requests behind the exchange) */
+    run_group<A, LOGN, GI - 1, true, MASKI>(x, tid, blk, pi);
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, cblk);
+}
+
+struct TeamProdCtl {
+  unsigned next[8][32];
+  unsigned owner[8][32];
+  unsigned done[1]; /* [2][polynomials]: first- and second-pass items finished */
+};
+
+template <class A> struct KTeamProd {
+  KProd<A>     k;   /* f.a = b, ahat, out = c; f.nblocks = polynomials */
+  TeamProdCtl *ctl; /* zeroed before the launch */
+  uint32_t     lag;
+};
+
+template <class A, int LEAD, int KSH>
+__global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A> kt)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, 3>;
+  static_assert(A::kCompact && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5, "FP64 policies, N = 2^15..2^17");
+  __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
+  __shared__ unsigned        s_k, s_k2[2];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
+  const uint32_t         tid  = threadIdx.x;
+  uint32_t               bid_, gdim_;
+  const ProdParams<A>    pp = limb_prod_params<A, false>(kt.k, bid_, gdim_);
+  Params<A>              pf = pp.f;
+  pf.s0   = LEAD;
+  pf.wide = 0;
+  pf.lazy = 0;
+  Params<A> pi = pf;
+  pi.tw        = pp.tw_i;
+  pi.tw8       = pp.tw8_i;
+  pi.lastinv   = 1;
+  constexpr uint32_t CMASKF = column_mask<A, LEAD, false, KSH>();
+  constexpr uint32_t CMASKI = column_mask<A, LEAD, true, KSH>();
+  constexpr bool     MID_LAZY = !A::kTracksBounds;
+  const uint32_t logn  = LOGN + LEAD;
+  const uint32_t batch = (uint32_t)pf.nblocks;
+  constexpr uint32_t NCOL = 1u << (LOGN - 8), NROW = 1u << LEAD;
+  constexpr uint32_t PER = NCOL + NROW + NCOL; /* items per step */
+  TeamProdCtl *const ctl = kt.ctl;
+  const uint32_t lag = kt.lag;
+  const uint32_t my  = xcc_id();
+  for(uint32_t qq = 0; qq < 8; qq++) {
+    const uint32_t q = (my + qq) & 7u;
+    if(tid == 0) {
+      const unsigned prev = atomicCAS(&ctl->owner[q][0], 0u, my + 1u);
+      s_k                 = (prev == 0u || prev == my + 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = s_k != 0;
+    __syncthreads();
+    if(!mine) continue;
+    const uint32_t J     = batch > q ? (batch - q + 7u) / 8u : 0u;
+    const uint32_t steps = J + 2u * lag;
+    constexpr uint32_t kNoSignal = 0xffffffffu;
+    uint32_t           sig       = kNoSignal; /* index into done[]: polynomial, or batch + polynomial for the second pass */
+    for(uint32_t it = 0;; it ^= 1u) {
+      /* (lane-0 blocks are followed at once by a workgroup barrier: see team_kernel) */
+      if(tid == 0) {
+        if(sig != kNoSignal) __hip_atomic_fetch_add(&ctl->done[sig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_k2[it] = atomicAdd(&ctl->next[q][0], 1u);
+      }
+      sig = kNoSignal;
+      __syncthreads();
+      const uint32_t k    = s_k2[it];
+      const uint32_t step = k / PER, r = k % PER;
+      if(step >= steps) break;
+      const uint32_t pass = r < NCOL ? 0u : (r < NCOL + NROW ? 1u : 2u);
+      const uint32_t item = pass == 0 ? r : (pass == 1 ? r - NCOL : r - NCOL - NROW);
+      const int64_t  j    = (int64_t)step - (int64_t)(pass * lag);
+      if(j < 0 || j >= (int64_t)J) continue;
+      const uint32_t pidx = q + 8u * (uint32_t)j;
+      if(pass > 0) {
+        const uint32_t need = pass == 1 ? NCOL : NROW;
+        const uint32_t slot = pass == 1 ? pidx : batch + pidx;
+        if(tid == 0) {
+          while(__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+      }
+      uint64_t *      bpoly = pf.a + ((uint64_t)pidx << logn);
+      const uint64_t *apoly = pp.ahat + ((uint64_t)pidx << logn);
+      uint64_t *      cpoly = pp.out + ((uint64_t)pidx << logn);
+      if(pass == 0) {
+        team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(bpoly, item * kTeamCols + tid, logn, pf, MID_LAZY);
+      } else if(pass == 1) {
+        team_product_item<A, KSH, kAuxNt, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
+                                                       cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
+      } else {
+        team_column_item<A, LEAD, true, CMASKI, kAuxNt, kAuxSc1>(cpoly, item * kTeamCols + tid, logn, pi, false);
+      }
+      if(pass < 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sig = pass == 0 ? pidx : batch + pidx;
+      }
+    }
+  }
+}
+
 /* The same product for whole polynomials of 2^8 .. 2^11 points, where a 256-thread workgroup holds several blocks
  * (Geom::BPW) that share the LDS twiddle tables: the plain (non-persistent) loop of fused_kernel's small-block path with
  * the product and the inverse half appended.  Every per-lane group has its forward table in LDS at these sizes, and the
@@ -1462,9 +1630,12 @@ struct ProdArgs {
   uint32_t        block_log; /* N > 2^14: log2 of the blocks (12, 13 or 14); the column passes around the launch cover logn - block_log stages */
   int             a_lazy;
   int             max_grid, num_cus;
+  void *          team_ctl; /* launch_team_product: device memory for the queues and 2 * batch counters */
+  int             team_lag, team_wpc;
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
+template <class A, int KSH> hipError_t launch_team_product(const ProdArgs &pa);
 
 /* What a pass stores: the last pass of a transform honours the caller's lazy flag; every earlier pass of an
  * integer policy keeps the reference's lazy ranges in HBM (no reduction between stages, as in
@@ -1749,7 +1920,44 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
   }
 }
 
+/* the b-chain of a product at N = 2^15..2^17 as one launch (team_product_kernel); pa.team_ctl: TeamProdCtl + 2 * batch counters */
+template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &pa)
+{
+  if constexpr(!A::kCompact) {
+    return hipErrorNotSupported;
+  } else {
+    if(pa.nlimbs > 1 || !pa.team_ctl || !pa.a_lazy || pa.logn < kTeamBlock + 3 || pa.logn > kTeamBlock + 5) return hipErrorNotSupported;
+    KTeamProd<A> kt{};
+    kt.k.f.a            = pa.b;
+    const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
+    kt.k.f.limbs[0]     = recs[0];
+    kt.k.f.limb_stride  = 0;
+    kt.k.f.logn         = pa.logn;
+    kt.k.f.s0           = pa.logn - kTeamBlock;
+    kt.k.f.nblocks      = pa.batch;
+    kt.k.ahat           = pa.ahat;
+    kt.k.out            = pa.out;
+    kt.k.a_lazy         = 1;
+    kt.ctl              = static_cast<TeamProdCtl *>(pa.team_ctl);
+    kt.lag              = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 8);
+    const size_t bytes = sizeof(TeamProdCtl) + 2 * (size_t)pa.batch * sizeof(unsigned);
+    hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
+    if(e != hipSuccess) return e;
+    /* four workgroups per CU (121 VGPRs, 40.6 KB of LDS each) */
+    uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
+    if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
+    kt.k.f.wgs_per_limb = (uint32_t)wgs;
+    switch(pa.logn - kTeamBlock) {
+      case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+      case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+      default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+    }
+    return hipGetLastError();
+  }
+}
+
 #define NTT_DEFINE_LAUNCH_PRODUCT(A, KSH) \
+  template <> hipError_t launch_team_product<A, KSH>(const ProdArgs &pa) { return launch_team_product_impl<A, KSH>(pa); } \
   template <> hipError_t launch_product<A, KSH>(const ProdArgs &pa) { return launch_product_impl<A, KSH>(pa); }
 
 /* body of launch_pass<A,KSH>; each instantiating .hip file expands this once */

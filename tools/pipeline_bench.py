@@ -12,10 +12,15 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--limbs", type=int, default=4)
 ap.add_argument("--bits", type=int, default=50)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--lag", type=int, default=0, help="XCD-local launches: polynomials between passes (0 = default)")
+ap.add_argument("--wpc", type=int, default=0, help="XCD-local launches: workgroups per CU (0 = default)")
+ap.add_argument("--xcd-local", type=int, default=-1)
 a = ap.parse_args()
 n = 1 << a.logn
 qs = [lib.find_prime(a.bits, n, k) for k in range(a.limbs)]
 plans = [lib.Plan(n, q, lib.min_root(q, n)) for q in qs]
+for p in plans:
+    p.set_option(lib.OPT_XCD_LOCAL, a.xcd_local); p.set_option(lib.OPT_XCD_LOCAL_LAG, a.lag); p.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, a.wpc)
 per = a.batch * n
 bufs = [lib.DeviceBuffer(a.limbs * per) for _ in range(3)]
 def fill():
