@@ -482,10 +482,11 @@ def kernel_chain(w, arith, f64_class):
     if w.kind == "fwd":
         return "fused_kernel<%s,%d,fwd>" % (pol, w.logn), 1
     if w.kind == "roundtrip":
-        return ("column_kernel<%s,4,fwd> + fused_kernel<%s,12,fwd> + fused_kernel<%s,12,inv> + column_kernel<%s,4,inv>, "
-                "per 256 MiB chunk" % (pol, pol, pol, pol)), 4
-    return ("per limb: column + fused forward passes of a, column pass of b, fused_product_kernel<%s,14> over the "
-            "blocks, inverse column pass of c, per 256 MiB chunk" % pol), 5 * w.limbs
+        return ("team_kernel<%s,4,fwd> (both forward passes as items of one launch) + per 256 MiB chunk "
+                "fused_kernel<%s,12,inv> + column_kernel<%s,4,inv>" % (pol, pol, pol)), 33
+    return ("per limb: team_kernel<%s,5,fwd> (a^: both passes of the forward transform as items of one launch) + "
+            "team_product_kernel<%s,5> (column stages of b, block products with a^, inverse column stages of c as items "
+            "of one launch)" % (pol, pol)), 2 * w.limbs
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,

@@ -163,7 +163,7 @@ def test_bench_report_for_other_configs():
     assert rep["value"] == pytest.approx(8192 / (0.02 / 4))
     r = rep["roofline"]
     assert r["algorithmic_bytes_per_step"] == 8192 * 32 * 65536 and r["traffic"] is None and r["traffic_source"] is None
-    assert r["step_ms_min"] == 4.9 and r["step_ms_median"] == pytest.approx(5.05) and r["launches_per_step"] == 4
+    assert r["step_ms_min"] == 4.9 and r["step_ms_median"] == pytest.approx(5.05) and r["launches_per_step"] == 33
     assert r["frac"] == pytest.approx(8192 * 32 * 65536 / 5.0e-3 / 1e9 / 8000.0)
     assert "reduced" in rep["config"]["arith"]
     w5 = bench.workload_for(5)

@@ -83,6 +83,8 @@ while time.time() < t_end:
         plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, opts["wpc"])
         if opts["xcd_local"] == 1:
             batch = max(batch, int(rng.choice([64, 65, 71, 96, 129])))
+            if rng.random() < 0.25:
+                batch = int(rng.choice([512, 513, 519, 530]))      # large enough for the three-pass product launch
     cx = orc.ctx(n, q, w)
     a = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
     k = int(rng.integers(0, 5))
