@@ -14,6 +14,11 @@
  *                N = 2^15..2^17); the inverse half reads the forward LDS twiddle table in mirrored order.
  * twophase_kernel: both passes of a 2^16 / 2^17 transform inside one workgroup (optional; fabric-bound, see
  *                DESIGN.md section 3).
+ * team_kernel  : both passes of a 2^15 .. 2^17 transform as ITEMS of one persistent launch: per-XCD in-order queues
+ *                (the XCD is read from HW_REG_XCC_ID), per-polynomial hand-off counters, the intermediate kept in the
+ *                XCD's L2 / the Infinity Cache; team_product_kernel: the same scheme with three item kinds for the
+ *                b-chain of a product (column stages, block products with a^, inverse column stages).
+ * MULTI        : kernel variants that serve several RNS limbs in one launch (a LimbRec per limb in the kernel arguments).
  * The same kernels serve four arithmetic policies (ntt_arith.h): FP64 with a reduction schedule, FP64 for moduli up
  * to 2^52, the reference's integer radix-2 arithmetic and its radix-4 formulation.
  *

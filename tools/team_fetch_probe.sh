@@ -6,7 +6,4 @@ for lg in 16 17; do for wpc in 2 3; do for lag in 2 3 4 5 6 8; do
   d=$out/m${lg}_wpc${wpc}_lag${lag}
   timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $d -- python3 tools/sweep.py --logn $lg --ops fwd --qs 0x80000001c0001 --bytes 4e9 --steps 3 --xcd-local 1 --lag $lag --wpc $wpc > $d.log 2>&1
 done; done; done
-python3 - <<'PY'
-import csv, glob, os, sys
-out = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("OUT", ".")
-PY
+python3 tools/team_fetch_summary.py $out
