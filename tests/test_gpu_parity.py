@@ -1218,6 +1218,64 @@ print("graph ok")
     assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
+def test_single_launch_two_pass_transform_captured_in_a_hip_graph():
+    """The single-launch two-pass transform (N = 2^15, 512 polynomials: its default range) keeps queue heads and counters
+    in a buffer the plan allocates per stream on first use.  Allocation cannot be captured, so (cold) a capture on a stream
+    the plan has not seen takes the per-pass launches, and (warm) a capture on a stream that already owns a buffer records
+    the memset + the one launch.  Both graphs, replayed on fresh inputs, equal the oracle on sampled polynomials and each
+    other on all of them; so does the product chain."""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, batch, q = 1 << 15, 512, 0x7fffffffe0001
+w = lib.min_root(q, n)
+cx = orc.ctx(n, q, w)
+outs = {}
+for mode in ("cold", "warm"):
+    plan = lib.Plan(n, q, w, device=0)
+    ta = torch.zeros(batch * n, dtype=torch.int64, device="cuda:0")
+    tb, tc, sa, sb = torch.zeros_like(ta), torch.zeros_like(ta), torch.zeros_like(ta), torch.zeros_like(ta)
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+    s.wait_stream(torch.cuda.current_stream())
+    if mode == "warm":
+        with torch.cuda.stream(s):
+            plan.fwd(ta.data_ptr(), batch, stream=s.cuda_stream)
+            plan.negacyclic_mul(tc.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=s.cuda_stream)
+        s.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        st = torch.cuda.current_stream().cuda_stream
+        ta.copy_(sa); tb.copy_(sb)
+        plan.fwd(ta.data_ptr(), batch, stream=st)          # ta = fwd(a)
+        tc.copy_(ta)
+        plan.inv(tc.data_ptr(), batch, stream=st)          # tc = a again
+        ta.copy_(sa)
+        plan.negacyclic_mul(tb.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=st)   # tb = a * b (aliases b)
+    for seed in (1, 2):
+        a = orc.fill_uniform(batch * n, q, 10 * seed); b = orc.fill_uniform(batch * n, q, 10 * seed + 1)
+        sa.copy_(torch.from_numpy(a.view(np.int64))); sb.copy_(torch.from_numpy(b.view(np.int64)))
+        g.replay(); torch.cuda.synchronize()
+        back, prod = tc.cpu().numpy().view(np.uint64), tb.cpu().numpy().view(np.uint64)
+        assert np.array_equal(back, a), (mode, seed)
+        for j in (0, 1, 255, 256, 511):
+            sl = slice(j * n, (j + 1) * n)
+            want = cx.inv(orc.pointwise(cx.fwd(a[sl]), cx.fwd(b[sl]), q))
+            assert np.array_equal(prod[sl], want), (mode, seed, j)
+        outs[(mode, seed)] = prod.copy()
+for seed in (1, 2):
+    assert np.array_equal(outs[("cold", seed)], outs[("warm", seed)]), seed
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_concurrent_host_threads_on_their_own_streams(lib, oracle, kat):
     """the batched API is re-entrant like the reference's functions (no statics on that path, thread-local error
     text): four host threads, each with its own plan, stream and buffers, transform concurrently"""
