@@ -57,8 +57,8 @@ typedef enum ntt_arith {
                        * up to q < 2^52 with both operands of every butterfly reduced (info[4] == 52)  */
   NTT_ARITH_U64_R4 = 3 /* the reference's radix-4 butterflies with the shared-quotient double
                         * product (include/internal/fast_mul_operators.h:62-70,108-149) on the 2N-entry
-                        * expanded table (src/ntt_radix4.c:7-114); single-pass sizes 2^6..2^14, q < 2^60.
-                        * Never chosen by AUTO. */
+                        * expanded table (src/ntt_radix4.c:7-114); q < 2^60; forward 2^6..2^18 (two passes above
+                        * 2^14), inverse 2^6..2^14.  Never chosen by AUTO. */
 } ntt_arith;
 
 typedef enum ntt_option {

@@ -4,19 +4,17 @@
  * Drop-in replacement for reference include/ntt_radix4.h:10-35 /
  * src/ntt_radix4.c:27-114.  The tables are the reference's 2N-entry EXPANDED
  * tables (include/internal/pre_compute.h:85-105) and their precomputation.  For
- * 2^6 <= N <= 2^14 the device runs the reference's radix-4 butterflies with the
+ * 2^6 <= N <= 2^18 the device runs the reference's radix-4 butterflies with the
  * shared-quotient double product on exactly these tables (collect_roots'
  * five-twiddle pack = records 2s and 4s..4s+3; csrc/ntt_arith.h ArithU64R4), so
- * the lazy forward output in [0,8q) equals the reference's bit for bit.  Other
- * sizes are served by the radix-2 engine on the even slots (slot 2k = w[k]):
- * values in [0,4q), congruent to the reference's.
- * Known limit (deliberate): for N = 2^15 .. 2^17 (reference cases 14-18) the LAZY words
- * are therefore a different member of the residue class than src/ntt_radix4.c's; after
- * the reduction this header's fwd_ntt_radix4 applies -- the only thing the reference's
- * own tests compare (tests/test_correctness.c:256-285) -- they are identical.  A
- * device radix-4 formulation for the multi-pass sizes would need radix-4 pairs inside
- * the strided column passes as well; the policy is 25-30 % slower than radix-2 on this
- * hardware and serves a PCIe-bound compatibility path, so it was not built.
+ * the lazy forward output ([0,8q), [0,4q) for odd log2 N) equals the reference's bit
+ * for bit -- for N = 2^15 .. 2^17 too (reference cases 14-18: one or two radix-4
+ * levels as a strided column pass, then 2^13- or 2^14-point blocks that end with the
+ * reference's radix-2 stage when log2 N is odd; csrc/ntt_passplan.h make_passes_r4,
+ * csrc/ntt_core.h column_pass_thread_r4; round 3).  N < 2^6 is served by the radix-2
+ * engine on the even slots (slot 2k = w[k]): values in [0,4q), congruent to the
+ * reference's.  inv_ntt_radix4 returns canonical values at every size
+ * (radix-4 butterflies up to 2^14, the radix-2 engine on the even slots beyond).
  */
 #ifndef NTT_MI355X_NTT_RADIX4_H
 #define NTT_MI355X_NTT_RADIX4_H

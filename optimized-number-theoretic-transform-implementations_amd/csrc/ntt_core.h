@@ -1033,6 +1033,50 @@ NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint
   });
 }
 
+/* The same pass in the reference's radix-4 formulation (forward): local stages (J, J+1) form one radix-4 level whose
+ * five-twiddle pack is collect_roots' (src/ntt_radix4.c:7-25) for radix-2 slot s of stage S + J: expanded records 2s and
+ * 4s .. 4s+3.  Values stay in the butterfly's lazy range [0,8q) from load to store, as they do in the reference's array
+ * between its passes (src/ntt_radix4.c:33-48). */
+template <class A, int R>
+NTT_HD void column_pass_thread_r4(uint64_t *poly, uint32_t col, uint32_t logn, uint32_t S, const typename A::tw *tab,
+                                  const typename A::consts &c)
+{
+  static_assert(A::kRadix4 && R % 2 == 0, "radix-4 levels come in stage pairs");
+  constexpr int  NE   = 1 << R;
+  const uint32_t lsp  = logn - S - R; /* log2 span */
+  const uint32_t lo   = col & ((1u << lsp) - 1);
+  const uint32_t hi   = col >> lsp;
+  uint64_t *     base = poly + ((uint64_t)hi << (lsp + R)) + lo;
+  typename A::val x[NE];
+  static_for<0, NE>([&](auto ee) {
+    constexpr int E = decltype(ee)::value;
+    x[E]            = A::template load<false, false>(base[(uint64_t)E << lsp], c);
+  });
+  static_for<0, R / 2>([&](auto ll) {
+    constexpr int  J  = 2 * decltype(ll)::value;
+    constexpr int  BA = R - 1 - J; /* slot bit of the upper stage: a[i] <-> a[i+2t] */
+    constexpr int  BB = R - 2 - J; /* slot bit of the lower stage: a[i] <-> a[i+t]  */
+    const uint32_t tb = (1u << (S + J)) + (hi << J);
+    static_for<0, NE>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      if constexpr(((E >> BA) & 1) == 0 && ((E >> BB) & 1) == 0) {
+        const uint32_t   s = tb + (uint32_t)(E >> (R - J));
+        typename A::pack w;
+        w.w1   = tab[2u * s];
+        w.w2   = tab[4u * s];
+        w.w12  = tab[4u * s + 1u];
+        w.w3   = tab[4u * s + 2u];
+        w.nw13 = tab[4u * s + 3u];
+        A::r4_fwd(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, c);
+      }
+    });
+  });
+  static_for<0, NE>([&](auto ee) {
+    constexpr int E          = decltype(ee)::value;
+    base[(uint64_t)E << lsp] = A::store_fwd_lazy(x[E], c);
+  });
+}
+
 template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
 {
   if constexpr(!A::kTracksBounds) {

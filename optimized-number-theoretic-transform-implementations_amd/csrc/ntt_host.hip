@@ -253,8 +253,8 @@ static int resolve_arith(int requested, uint64_t q, int m, int *out)
   if(requested == NTT_ARITH_F64 && !h_f64_eligible(q) && !h_f64w_eligible(q)) {
     return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q < 2^52");
   }
-  if(requested == NTT_ARITH_U64_R4 && (m < kFusedMin || m > kFusedMax)) {
-    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers single-pass sizes 2^6..2^14");
+  if(requested == NTT_ARITH_U64_R4 && (m < kFusedMin || m > kRadix4Max)) {
+    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers 2^6..2^18 (the inverse: 2^6..2^14)");
   }
   if(requested == NTT_ARITH_U64_R4 && q >= (1ull << 60)) return fail(NTT_ERR_UNSUPPORTED, "radix-4 lazy range needs 16q < 2^64");
   if(requested != NTT_ARITH_F64 && requested != NTT_ARITH_U64 && requested != NTT_ARITH_U64_R4) return fail(NTT_ERR_ARG, "bad arith");
@@ -692,7 +692,14 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
-  const PassList L = make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
+  if(p->arith == NTT_ARITH_U64_R4 && inverse && p->m > kFusedMax) {
+    /* (its outputs are canonical, i.e. those of any other policy: nothing of the reference's radix-4 inverse would be
+     * visible in them; ntt_passplan.h) */
+    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy's inverse covers 2^6..2^14: use a radix-2 or FP64 plan");
+  }
+  const PassList L = p->arith == NTT_ARITH_U64_R4
+                         ? make_passes_r4(p->m)
+                         : make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
   /* both passes as items of ONE launch with the intermediate kept in each XCD's L2 (ntt_kernels.h: team_kernel) */
   void *ctl = nullptr;
   if(team_applies(p, batch, inverse, wide, lazy, ls.n)) {
@@ -1500,12 +1507,14 @@ uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
  *            lets the reference's own drivers exercise the throughput kernels. */
 enum CompatKind { kCompatR2 = 0, kCompatR4 = 1 };
 
-int compat_arith(uint64_t q, uint64_t N, CompatKind kind)
+int compat_arith(uint64_t q, uint64_t N, CompatKind kind, bool inverse)
 {
   const char *env = getenv("NTT_COMPAT_ARITH");
   if(env && !strcmp(env, "f64") && h_f64_eligible(q)) return NTT_ARITH_F64;
   const int m = (int)h_log2(N);
-  if(kind == kCompatR4 && m >= kFusedMin && m <= kFusedMax && q < (1ull << 60)) return NTT_ARITH_U64_R4;
+  /* the reference's radix-4 butterflies wherever their lazy values can be seen: every forward size (two passes above 2^14),
+   * the inverse up to 2^14 (beyond: canonical outputs from the radix-2 engine on the even slots) */
+  if(kind == kCompatR4 && m >= kFusedMin && m <= (inverse ? kFusedMax : kRadix4Max) && q < (1ull << 60)) return NTT_ARITH_U64_R4;
   return NTT_ARITH_U64;
 }
 
@@ -1515,7 +1524,7 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
                 const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv)
 {
   const int      device  = env_int("NTT_DEVICE", 0);
-  const int      arith   = compat_arith(q, N, kind);
+  const int      arith   = compat_arith(q, N, kind, inverse);
   const uint64_t entries = kind == kCompatR4 ? 2 * N : N;
   /* the integer policies use the caller's precomputation too: it is part of the key.  (Hashing happens outside any lock.) */
   const uint64_t key = table_key(w, entries, 1) ^ (arith != NTT_ARITH_F64 && w_con ? table_key(w_con, entries, 1) * 3 : 0);

@@ -1590,7 +1590,12 @@ __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
   for(uint64_t g = (uint64_t)bid * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gdim * blockDim.x) {
     const uint64_t poly = g >> lcols;
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
-    column_pass_thread<A, R, INV, MASK>(p.a + (poly << p.logn), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
+    if constexpr(A::kRadix4) {
+      /* (forward, even stage count: launch_pass refuses anything else for this policy) */
+      if constexpr(!INV && R % 2 == 0) column_pass_thread_r4<A, R>(p.a + (poly << p.logn), col, p.logn, p.s0, p.tw, p.c);
+    } else {
+      column_pass_thread<A, R, INV, MASK>(p.a + (poly << p.logn), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
+    }
   }
 }
 
@@ -2000,13 +2005,21 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     }                                                                                    \
   }
 
-/* policies without a column-pass form (ArithU64R4) */
-#define NTT_DEFINE_LAUNCH_PASS_FUSED_ONLY(A, KSH)                                        \
+/* the radix-4 formulation (ArithU64R4): block passes, and forward column passes of one or two radix-4 levels in front
+ * of them (ntt_passplan.h: make_passes_r4) */
+#define NTT_DEFINE_LAUNCH_PASS_RADIX4(A, KSH)                                            \
   template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
   {                                                                                      \
-    if(!pa.fused) return hipErrorInvalidValue;                                           \
+    if(pa.fused == 1) {                                                                  \
+      switch(pa.r) {                                                                     \
+        NTT_FUSED_CASES(A, KSH)                                                          \
+        default: return hipErrorInvalidValue;                                            \
+      }                                                                                  \
+    }                                                                                    \
+    if(pa.fused || pa.inverse || pa.s != 0) return hipErrorInvalidValue;                 \
     switch(pa.r) {                                                                       \
-      NTT_FUSED_CASES(A, KSH)                                                            \
+      case 2: return launch_column<A, 2, false, KSH>(pa);                                \
+      case 4: return launch_column<A, 4, false, KSH>(pa);                                \
       default: return hipErrorInvalidValue;                                              \
     }                                                                                    \
   }

@@ -385,13 +385,24 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
   }
 }
 
+template <class A, int R>
+static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, const typename A::tw *tab, const typename A::consts &c)
+{
+  const uint64_t cols = (1ull << logn) >> R;
+  for(uint64_t pidx = 0; pidx < batch; pidx++) {
+    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R>(a + (pidx << logn), (uint32_t)col, logn, S, tab, c);
+  }
+}
+
 inline bool g_lazy = false; /* lazy outputs for the next emu_transform (set by emu_set_lazy) */
 
 template <class A, bool INV, int KSH>
 int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
             const typename A::consts &c, bool generic, bool wide, const typename A::ctw *tab8 = nullptr)
 {
-  const PassList L = make_passes(m, generic, multi_pass_block(m, INV, A::kTracksBounds)); /* as the library's run_transform */
+  /* as the library's run_transform */
+  const PassList L = A::kRadix4 ? make_passes_r4(m) : make_passes(m, generic, multi_pass_block(m, INV, A::kTracksBounds));
+  if(A::kRadix4 && (generic || (INV && m > kFusedMax) || m > kRadix4Max)) return -4; /* the library refuses these too */
   const bool lazy  = g_lazy;
   for(int k = 0; k < L.n; k++) {
     const Pass &ps      = L.p[INV ? L.n - 1 - k : k];
@@ -431,7 +442,15 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
         default: return -1;
       }
     } else if constexpr(A::kRadix4) {
-      return -4; /* no column-pass form */
+      if constexpr(INV) {
+        return -4;
+      } else {
+        switch(ps.r) {
+          case 2: emu_column_r4<A, 2>(a, batch, m, ps.s, tab, c); break;
+          case 4: emu_column_r4<A, 4>(a, batch, m, ps.s, tab, c); break;
+          default: return -4; /* (sizes below the block range: no radix-4 form) */
+        }
+      }
     } else {
       switch(ps.r) {
         case 1: emu_column<A, 1, INV, KSH>(a, batch, m, ps.s, w, lastinv, tab, c, plazy); break;
@@ -531,7 +550,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
   if(arith == 3) { /* the reference's radix-4 formulation on the expanded table */
-    if(m < kFusedMin || m > kFusedMax || generic) return -4;
+    if(m < kFusedMin || m > kRadix4Max || (inverse && m > kFusedMax) || generic) return -4;
     const auto         e = h_expand_radix4(inverse ? wi : w, q);
     std::vector<TwU64> tab(e.size());
     for(uint64_t i = 0; i < e.size(); i++) tab[i] = h_tw_u64(e[i], q);

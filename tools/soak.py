@@ -47,8 +47,8 @@ while time.time() < t_end:
     policies = [lib.ARITH_AUTO, lib.ARITH_U64]
     if q < (1 << 52):
         policies.append(lib.ARITH_F64)
-    if 6 <= m <= 14 and q < (1 << 60):
-        policies.append(lib.ARITH_U64_R4)
+    if 6 <= m <= 18 and q < (1 << 60):
+        policies.append(lib.ARITH_U64_R4)      # (above 2^14: forward only, two passes)
     arith = int(rng.choice(policies))
     try:
         plan = lib.Plan(n, q, w, arith=arith)
@@ -99,6 +99,17 @@ while time.time() < t_end:
     got = plan.fwd_host(a)
     if not np.array_equal(got, want):
         fail("fwd", **ctxt)
+    r4_fwd_only = info["arith"] == lib.ARITH_U64_R4 and m > 14
+    if r4_fwd_only:
+        out = plan.fwd_host(a, lazy=True)
+        if not np.array_equal(out, cx.fwd_r4_lazy(a)):
+            fail("fwd lazy (radix-4, two passes)", **ctxt)
+        lz = a + np.uint64(q) * rng.integers(0, 8, size=a.shape, dtype=np.uint64)
+        if not np.array_equal(plan.fwd_host(lz, wide=True), want):
+            fail("fwd wide (radix-4, two passes)", **ctxt)
+        checks += 3
+        plan.destroy()
+        continue
     if not np.array_equal(plan.inv_host(want), a):
         fail("inv", **ctxt)
     lazy_mult = 8 if q < (1 << 60) else 4
@@ -148,7 +159,7 @@ while time.time() < t_end:
             fail("shim fwd_ntt_ref_harvey_lazy", **ctxt)
         x = one.copy()
         lib._lib.fwd_ntt_radix4_lazy(x.ctypes.data_as(U64P), n, q, e.ctypes.data_as(U64P), ec.ctypes.data_as(U64P))
-        ok = np.array_equal(x, cx.fwd_r4_lazy(one)) if 6 <= m <= 14 else (int(x.max()) < 8 * q and np.array_equal(x % np.uint64(q), want[:n]))
+        ok = np.array_equal(x, cx.fwd_r4_lazy(one)) if 6 <= m <= 18 else (int(x.max()) < 8 * q and np.array_equal(x % np.uint64(q), want[:n]))
         if not ok:
             fail("shim fwd_ntt_radix4_lazy", **ctxt)
         checks += 2
