@@ -145,7 +145,9 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
  * transform); d_b is overwritten likewise (four-launch chain), overwritten by the column passes of its forward transform
  * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
- * a*a (the shared operand is transformed once); any other overlap is undefined. */
+ * a*a (the shared operand is transformed once); any other overlap is undefined.
+ * NTT_ARITH_U64_R4 plans run the reference's radix-4 formulation end to end (fwd_ntt_radix4 on both operands, the
+ * pointwise product, inv_ntt_radix4; N <= 2^14, the sizes with a radix-4 inverse): d_a and d_b are left canonical there. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
 

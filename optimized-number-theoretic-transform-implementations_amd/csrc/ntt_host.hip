@@ -1060,7 +1060,16 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * the pointwise product takes [0,4q) operands, only the inverse's output is reduced.
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
-  if(p && p->arith == NTT_ARITH_U64_R4) return fail(NTT_ERR_UNSUPPORTED, "use a radix-2 or FP64 plan for products");
+  if(p && p->arith == NTT_ARITH_U64_R4) {
+    /* the reference's radix-4 formulation end to end: fwd_ntt_radix4 on both operands (canonical outputs), the pointwise
+     * product, inv_ntt_radix4 -- sizes that have the radix-4 inverse */
+    if(p->m > kFusedMax) return fail(NTT_ERR_UNSUPPORTED, "radix-4 products cover 2^6..2^14: use a radix-2 or FP64 plan");
+    int rc4 = ntt_fwd_batch(p, d_a, batch, stream);
+    if(!rc4 && d_b != d_a) rc4 = ntt_fwd_batch(p, d_b, batch, stream);
+    if(!rc4) rc4 = pointwise_launch(p, d_c, d_a, d_b, batch, stream, false);
+    if(!rc4) rc4 = ntt_inv_batch(p, d_c, batch, stream);
+    return rc4;
+  }
   if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c, d_a, d_b, batch, stream);
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);

@@ -734,6 +734,13 @@ def test_radix4_device_policy(lib, oracle, kat, i):
     assert np.array_equal(plan.inv_host(lazy, wide=True), a)
     lz = plan.inv_host(cx.fwd(a), lazy=True)
     assert int(lz.max()) < 2 * q and np.array_equal(lz % np.uint64(q), a)
+    # products through the radix-4 formulation end to end (fwd_ntt_radix4 x 2, pointwise, inv_ntt_radix4); c aliasing a
+    b = oracle.fill_uniform(batch * n, q, 1350 + i)
+    want = cx.inv(oracle.pointwise(cx.fwd(a), cx.fwd(b), q))
+    da, db = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b)
+    plan.negacyclic_mul(da.ptr, da.ptr, db.ptr, batch)
+    assert np.array_equal(da.download(), want)
+    da.free(); db.free()
     plan.destroy()
 
 
