@@ -57,8 +57,8 @@ typedef enum ntt_arith {
                        * up to q < 2^52 with both operands of every butterfly reduced (info[4] == 52)  */
   NTT_ARITH_U64_R4 = 3 /* the reference's radix-4 butterflies with the shared-quotient double
                         * product (include/internal/fast_mul_operators.h:62-70,108-149) on the 2N-entry
-                        * expanded table (src/ntt_radix4.c:7-114); q < 2^60; forward 2^6..2^18 (two passes above
-                        * 2^14), inverse 2^6..2^14.  Never chosen by AUTO. */
+                        * expanded table (src/ntt_radix4.c:7-114); q < 2^60; 2^6..2^18 (two passes above 2^14).
+                        * Never chosen by AUTO. */
 } ntt_arith;
 
 typedef enum ntt_option {
@@ -147,7 +147,7 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
  * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined.
  * NTT_ARITH_U64_R4 plans run the reference's radix-4 formulation end to end (fwd_ntt_radix4 on both operands, the
- * pointwise product, inv_ntt_radix4; N <= 2^14, the sizes with a radix-4 inverse): d_a and d_b are left canonical there. */
+ * pointwise product, inv_ntt_radix4): d_a and d_b are left canonical there. */
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
 

@@ -11,10 +11,9 @@
  * for bit -- for N = 2^15 .. 2^17 too (reference cases 14-18: one or two radix-4
  * levels as a strided column pass, then 2^13- or 2^14-point blocks that end with the
  * reference's radix-2 stage when log2 N is odd; csrc/ntt_passplan.h make_passes_r4,
- * csrc/ntt_core.h column_pass_thread_r4; round 3).  N < 2^6 is served by the radix-2
- * engine on the even slots (slot 2k = w[k]): values in [0,4q), congruent to the
- * reference's.  inv_ntt_radix4 returns canonical values at every size
- * (radix-4 butterflies up to 2^14, the radix-2 engine on the even slots beyond).
+ * csrc/ntt_core.h column_pass_thread_r4; round 3); inv_ntt_radix4 runs the same two
+ * passes in the opposite order.  N < 2^6 is served by the radix-2 engine on the even
+ * slots (slot 2k = w[k]): values in [0,4q), congruent to the reference's.
  */
 #ifndef NTT_MI355X_NTT_RADIX4_H
 #define NTT_MI355X_NTT_RADIX4_H

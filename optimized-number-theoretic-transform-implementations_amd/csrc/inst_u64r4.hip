@@ -1,5 +1,5 @@
 /* inst_u64r4.hip -- instantiates the kernels of ArithU64R4 (the reference's radix-4 butterflies): the fused block kernels
- * and the forward column passes of one or two radix-4 levels that precede them for N > 2^14. */
+ * and the column passes of one or two radix-4 levels that precede (forward) / follow (inverse) them for N > 2^14. */
 #include "ntt_kernels.h"
 
 namespace ntt {

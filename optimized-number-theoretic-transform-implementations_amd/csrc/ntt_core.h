@@ -1033,13 +1033,15 @@ NTT_HD void column_pass_thread(uint64_t *poly, uint32_t col, uint32_t logn, uint
   });
 }
 
-/* The same pass in the reference's radix-4 formulation (forward): local stages (J, J+1) form one radix-4 level whose
- * five-twiddle pack is collect_roots' (src/ntt_radix4.c:7-25) for radix-2 slot s of stage S + J: expanded records 2s and
- * 4s .. 4s+3.  Values stay in the butterfly's lazy range [0,8q) from load to store, as they do in the reference's array
- * between its passes (src/ntt_radix4.c:33-48). */
-template <class A, int R>
+/* The same pass in the reference's radix-4 formulation: local stages (J, J+1) form one radix-4 level whose five-twiddle
+ * pack is collect_roots' (src/ntt_radix4.c:7-25) for radix-2 slot s of stage S + J: expanded records 2s and 4s .. 4s+3.
+ * Forward (the FIRST pass of a transform larger than a block): values stay in the butterfly's lazy range [0,8q) from load
+ * to store, as they do in the reference's array between its levels (src/ntt_radix4.c:33-48).  Inverse (the LAST pass,
+ * S = 0): words in [0,2q) from the block pass, the levels in the opposite order (:95-109), and the reference's final
+ * N^-1 pass (:111-113) fused into the store. */
+template <class A, int R, bool INV>
 NTT_HD void column_pass_thread_r4(uint64_t *poly, uint32_t col, uint32_t logn, uint32_t S, const typename A::tw *tab,
-                                  const typename A::consts &c)
+                                  const typename A::consts &c, bool lazy_out)
 {
   static_assert(A::kRadix4 && R % 2 == 0, "radix-4 levels come in stage pairs");
   constexpr int  NE   = 1 << R;
@@ -1050,10 +1052,11 @@ NTT_HD void column_pass_thread_r4(uint64_t *poly, uint32_t col, uint32_t logn, u
   typename A::val x[NE];
   static_for<0, NE>([&](auto ee) {
     constexpr int E = decltype(ee)::value;
-    x[E]            = A::template load<false, false>(base[(uint64_t)E << lsp], c);
+    x[E]            = A::template load<INV, false>(base[(uint64_t)E << lsp], c);
   });
   static_for<0, R / 2>([&](auto ll) {
-    constexpr int  J  = 2 * decltype(ll)::value;
+    constexpr int  L  = INV ? (R / 2 - 1 - decltype(ll)::value) : decltype(ll)::value;
+    constexpr int  J  = 2 * L;
     constexpr int  BA = R - 1 - J; /* slot bit of the upper stage: a[i] <-> a[i+2t] */
     constexpr int  BB = R - 2 - J; /* slot bit of the lower stage: a[i] <-> a[i+t]  */
     const uint32_t tb = (1u << (S + J)) + (hi << J);
@@ -1067,13 +1070,21 @@ NTT_HD void column_pass_thread_r4(uint64_t *poly, uint32_t col, uint32_t logn, u
         w.w12  = tab[4u * s + 1u];
         w.w3   = tab[4u * s + 2u];
         w.nw13 = tab[4u * s + 3u];
-        A::r4_fwd(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, c);
+        if constexpr(INV) {
+          A::r4_inv(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, c);
+        } else {
+          A::r4_fwd(x[E], x[E | (1 << BB)], x[E | (1 << BA)], x[E | (1 << BA) | (1 << BB)], w, c);
+        }
       }
     });
   });
   static_for<0, NE>([&](auto ee) {
-    constexpr int E          = decltype(ee)::value;
-    base[(uint64_t)E << lsp] = A::store_fwd_lazy(x[E], c);
+    constexpr int E = decltype(ee)::value;
+    if constexpr(INV) {
+      base[(uint64_t)E << lsp] = lazy_out ? A::store_inv_lazy(x[E], c) : A::store_inv(x[E], c);
+    } else {
+      base[(uint64_t)E << lsp] = A::store_fwd_lazy(x[E], c);
+    }
   });
 }
 

@@ -222,6 +222,9 @@ struct ntt_plan {
   ArithU64::consts cu{};
   F64Consts        cf{};
   std::vector<unsigned char> limbrec; /* this plan's LimbRec<A> (table pointers + constants): copied into the kernel arguments of every launch */
+  std::vector<unsigned char> limbrec_mid; /* radix-4 policy: the same with the record of 1 in place of N^-1 -- what the block pass of a
+                                           * two-pass INVERSE multiplies by (the reference's N^-1 pass, src/ntt_radix4.c:111-113, comes
+                                           * once, after the last level: in the column pass's store) */
   /* XCD-local two-pass launches (team_kernel, N = 2^15..2^17): queue heads and per-polynomial counters in device memory,
    * one buffer per stream the plan is used on (launches on one stream are ordered; two streams must not share counters) */
   int        xcd_local = -1; /* 1 on, 0 off, -1 automatic */
@@ -254,7 +257,7 @@ static int resolve_arith(int requested, uint64_t q, int m, int *out)
     return fail(NTT_ERR_UNSUPPORTED, "FP64 arithmetic needs q < 2^52");
   }
   if(requested == NTT_ARITH_U64_R4 && (m < kFusedMin || m > kRadix4Max)) {
-    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers 2^6..2^18 (the inverse: 2^6..2^14)");
+    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy covers 2^6..2^18");
   }
   if(requested == NTT_ARITH_U64_R4 && q >= (1ull << 60)) return fail(NTT_ERR_UNSUPPORTED, "radix-4 lazy range needs 16q < 2^64");
   if(requested != NTT_ARITH_F64 && requested != NTT_ARITH_U64 && requested != NTT_ARITH_U64_R4) return fail(NTT_ERR_ARG, "bad arith");
@@ -459,6 +462,13 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
     }
   }
   if(!rc) p->limbrec = limbrec_bytes(p);
+  if(!rc && p->arith == NTT_ARITH_U64_R4) {
+    LimbRec<ArithU64> r{};
+    memcpy(&r, p->limbrec.data(), sizeof r);
+    r.c.ninv = h_tw_u64(1, p->q);
+    p->limbrec_mid.resize(sizeof r);
+    memcpy(p->limbrec_mid.data(), &r, sizeof r);
+  }
   if(rc) {
     ntt_plan_destroy(p);
     return rc;
@@ -692,11 +702,6 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
-  if(p->arith == NTT_ARITH_U64_R4 && inverse && p->m > kFusedMax) {
-    /* (its outputs are canonical, i.e. those of any other policy: nothing of the reference's radix-4 inverse would be
-     * visible in them; ntt_passplan.h) */
-    return fail(NTT_ERR_UNSUPPORTED, "the radix-4 policy's inverse covers 2^6..2^14: use a radix-2 or FP64 plan");
-  }
   const PassList L = p->arith == NTT_ARITH_U64_R4
                          ? make_passes_r4(p->m)
                          : make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
@@ -784,7 +789,8 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
       const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
       PassArgs    pa{};
       pa.a        = d_a + first * p->N;
-      pa.limbs    = ls.d;
+      /* (radix-4 inverse: a pass that does not end the transform multiplies by 1, not by N^-1) */
+      pa.limbs    = p->arith == NTT_ARITH_U64_R4 && inverse && ps.s != 0 ? (const void *)p->limbrec_mid.data() : ls.d;
       pa.nlimbs   = ls.n;
       pa.limb_stride = ls.stride;
       pa.lazy     = lazy;
@@ -1062,8 +1068,7 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
    * would multiply fwd(fwd(a)) with itself) */
   if(p && p->arith == NTT_ARITH_U64_R4) {
     /* the reference's radix-4 formulation end to end: fwd_ntt_radix4 on both operands (canonical outputs), the pointwise
-     * product, inv_ntt_radix4 -- sizes that have the radix-4 inverse */
-    if(p->m > kFusedMax) return fail(NTT_ERR_UNSUPPORTED, "radix-4 products cover 2^6..2^14: use a radix-2 or FP64 plan");
+     * product, inv_ntt_radix4 */
     int rc4 = ntt_fwd_batch(p, d_a, batch, stream);
     if(!rc4 && d_b != d_a) rc4 = ntt_fwd_batch(p, d_b, batch, stream);
     if(!rc4) rc4 = pointwise_launch(p, d_c, d_a, d_b, batch, stream, false);
@@ -1521,9 +1526,9 @@ int compat_arith(uint64_t q, uint64_t N, CompatKind kind, bool inverse)
   const char *env = getenv("NTT_COMPAT_ARITH");
   if(env && !strcmp(env, "f64") && h_f64_eligible(q)) return NTT_ARITH_F64;
   const int m = (int)h_log2(N);
-  /* the reference's radix-4 butterflies wherever their lazy values can be seen: every forward size (two passes above 2^14),
-   * the inverse up to 2^14 (beyond: canonical outputs from the radix-2 engine on the even slots) */
-  if(kind == kCompatR4 && m >= kFusedMin && m <= (inverse ? kFusedMax : kRadix4Max) && q < (1ull << 60)) return NTT_ARITH_U64_R4;
+  /* the reference's radix-4 butterflies at every size that has them (two passes above 2^14) */
+  (void)inverse;
+  if(kind == kCompatR4 && m >= kFusedMin && m <= kRadix4Max && q < (1ull << 60)) return NTT_ARITH_U64_R4;
   return NTT_ARITH_U64;
 }
 

@@ -1591,8 +1591,8 @@ __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
     const uint64_t poly = g >> lcols;
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
     if constexpr(A::kRadix4) {
-      /* (forward, even stage count: launch_pass refuses anything else for this policy) */
-      if constexpr(!INV && R % 2 == 0) column_pass_thread_r4<A, R>(p.a + (poly << p.logn), col, p.logn, p.s0, p.tw, p.c);
+      /* (even stage count: launch_pass refuses anything else for this policy) */
+      if constexpr(R % 2 == 0) column_pass_thread_r4<A, R, INV>(p.a + (poly << p.logn), col, p.logn, p.s0, p.tw, p.c, p.lazy != 0);
     } else {
       column_pass_thread<A, R, INV, MASK>(p.a + (poly << p.logn), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
     }
@@ -1736,7 +1736,9 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     /* the inverse kernel exists in two variants: ending a whole transform (N^-1 folded into
      * its last group) -- every block size -- and, for the block size used below column
      * passes, not ending it */
-    if(pa.lastinv) {
+    if(pa.lastinv || A::kRadix4) {
+      /* (radix-4 formulation: N^-1 is a pass of its own, fused into the LAST pass's store -- the blocks of a larger
+       * transform run the same kernel with the multiplier record of 1: ntt_host.hip, limbrec_mid) */
       hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, true>), grid, wg, 0, pa.stream, p);
     } else if constexpr(LOGN == kFusedLarge || LOGN == kFusedSmallBlock) {
       hipLaunchKernelGGL((fused_kernel<A, LOGN, true, KSH, false>), grid, wg, 0, pa.stream, p);
@@ -2005,8 +2007,8 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     }                                                                                    \
   }
 
-/* the radix-4 formulation (ArithU64R4): block passes, and forward column passes of one or two radix-4 levels in front
- * of them (ntt_passplan.h: make_passes_r4) */
+/* the radix-4 formulation (ArithU64R4): block passes, and column passes of one or two radix-4 levels before (forward) or
+ * after (inverse) them (ntt_passplan.h: make_passes_r4) */
 #define NTT_DEFINE_LAUNCH_PASS_RADIX4(A, KSH)                                            \
   template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
   {                                                                                      \
@@ -2016,10 +2018,10 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
         default: return hipErrorInvalidValue;                                            \
       }                                                                                  \
     }                                                                                    \
-    if(pa.fused || pa.inverse || pa.s != 0) return hipErrorInvalidValue;                 \
+    if(pa.fused || pa.s != 0) return hipErrorInvalidValue;                               \
     switch(pa.r) {                                                                       \
-      case 2: return launch_column<A, 2, false, KSH>(pa);                                \
-      case 4: return launch_column<A, 4, false, KSH>(pa);                                \
+      case 2: return pa.inverse ? launch_column<A, 2, true, KSH>(pa) : launch_column<A, 2, false, KSH>(pa); \
+      case 4: return pa.inverse ? launch_column<A, 4, true, KSH>(pa) : launch_column<A, 4, false, KSH>(pa); \
       default: return hipErrorInvalidValue;                                              \
     }                                                                                    \
   }

@@ -72,8 +72,8 @@ inline PassList make_passes(int m, bool generic, int block_log = kFusedLarge)
 /* Radix-4 formulation (ArithU64R4) beyond one block: the reference pairs global stages (0,1), (2,3), ... and ends an odd
  * size with one radix-2 stage (src/ntt_radix4.c:33-61), so the column pass takes an EVEN number of leading stages (one or
  * two radix-4 levels) and the block pass -- which already ends odd-sized blocks with that radix-2 stage -- the rest:
- * m = 15: 2 + 13, m = 16: 2 + 14, m = 17: 4 + 13, m = 18: 4 + 14.  Forward only (the inverse's outputs are canonical:
- * nothing distinguishes a radix-4 inverse from the radix-2 one). */
+ * m = 15: 2 + 13, m = 16: 2 + 14, m = 17: 4 + 13, m = 18: 4 + 14.  The inverse runs the same two passes in the opposite
+ * order (:64-114: the blocks with the leading radix-2 stage of an odd size first, the column levels and the N^-1 pass last). */
 constexpr int kRadix4Max = 18;
 inline PassList make_passes_r4(int m)
 {

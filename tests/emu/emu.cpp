@@ -385,12 +385,13 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
   }
 }
 
-template <class A, int R>
-static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, const typename A::tw *tab, const typename A::consts &c)
+template <class A, int R, bool INV>
+static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, const typename A::tw *tab, const typename A::consts &c,
+                          bool lazy_out)
 {
   const uint64_t cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
-    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R>(a + (pidx << logn), (uint32_t)col, logn, S, tab, c);
+    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R, INV>(a + (pidx << logn), (uint32_t)col, logn, S, tab, c, lazy_out);
   }
 }
 
@@ -402,7 +403,7 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
 {
   /* as the library's run_transform */
   const PassList L = A::kRadix4 ? make_passes_r4(m) : make_passes(m, generic, multi_pass_block(m, INV, A::kTracksBounds));
-  if(A::kRadix4 && (generic || (INV && m > kFusedMax) || m > kRadix4Max)) return -4; /* the library refuses these too */
+  if(A::kRadix4 && (generic || m > kRadix4Max)) return -4; /* the library refuses these too */
   const bool lazy  = g_lazy;
   for(int k = 0; k < L.n; k++) {
     const Pass &ps      = L.p[INV ? L.n - 1 - k : k];
@@ -418,6 +419,10 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
       p.tw      = tab;
       p.tw8     = tab8;
       p.c       = c;
+      if constexpr(A::kRadix4) {
+        /* as the library (ntt_host.hip, limbrec_mid): a block pass that does not end the inverse multiplies by 1 */
+        if(INV && ps.s != 0) p.c.ninv = h_tw_u64(1, c.q);
+      }
       p.logn    = (uint32_t)m;
       p.s0      = (uint32_t)ps.s;
       p.wide    = w;
@@ -442,14 +447,10 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
         default: return -1;
       }
     } else if constexpr(A::kRadix4) {
-      if constexpr(INV) {
-        return -4;
-      } else {
-        switch(ps.r) {
-          case 2: emu_column_r4<A, 2>(a, batch, m, ps.s, tab, c); break;
-          case 4: emu_column_r4<A, 4>(a, batch, m, ps.s, tab, c); break;
-          default: return -4; /* (sizes below the block range: no radix-4 form) */
-        }
+      switch(ps.r) {
+        case 2: emu_column_r4<A, 2, INV>(a, batch, m, ps.s, tab, c, plazy); break;
+        case 4: emu_column_r4<A, 4, INV>(a, batch, m, ps.s, tab, c, plazy); break;
+        default: return -4; /* (sizes below the block range: no radix-4 form) */
       }
     } else {
       switch(ps.r) {
@@ -550,7 +551,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
   }
   if(arith == 3) { /* the reference's radix-4 formulation on the expanded table */
-    if(m < kFusedMin || m > kRadix4Max || (inverse && m > kFusedMax) || generic) return -4;
+    if(m < kFusedMin || m > kRadix4Max || generic) return -4;
     const auto         e = h_expand_radix4(inverse ? wi : w, q);
     std::vector<TwU64> tab(e.size());
     for(uint64_t i = 0; i < e.size(); i++) tab[i] = h_tw_u64(e[i], q);
