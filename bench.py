@@ -484,9 +484,9 @@ def kernel_chain(w, arith, f64_class):
     if w.kind == "roundtrip":
         return ("team_kernel<%s,4,fwd> (both forward passes as items of one launch) + per 256 MiB chunk "
                 "fused_kernel<%s,12,inv> + column_kernel<%s,4,inv>" % (pol, pol, pol)), 33
-    return ("per limb: team_kernel<%s,5,fwd> (a^: both passes of the forward transform as items of one launch) + "
-            "team_product_kernel<%s,5> (column stages of b, block products with a^, inverse column stages of c as items "
-            "of one launch)" % (pol, pol)), 2 * w.limbs
+    return ("per limb ONE launch: team_product_kernel<%s,5,four> (column stages of b and a, block products -- both blocks "
+            "through their twelve stages, product, inverse stages --, inverse column stages of c as items of one launch; "
+            "a^ never exists in memory)" % pol), w.limbs
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,

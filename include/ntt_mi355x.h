@@ -79,7 +79,9 @@ typedef enum ntt_option {
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14; block by block between column passes, 88N
-                          * bytes, above); 0 = fwd, fwd, pointwise, inv (72N / 120N bytes) */
+                          * bytes, above -- and for 512 polynomials or more of N >= 2^15 the WHOLE chain, both forward
+                          * transforms included, as one launch); 2 = as 1, but a's forward transform always as a launch of
+                          * its own; 0 = fwd, fwd, pointwise, inv (72N / 120N bytes).  Results are identical. */
 } ntt_option;
 
 typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
@@ -143,7 +145,8 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
  * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
- * transform); d_b is overwritten likewise (four-launch chain), overwritten by the column passes of its forward transform
+ * transform -- or, large batches of N >= 2^15, holding only the column stages of it); d_b is overwritten likewise
+ * (four-launch chain), overwritten by the column passes of its forward transform
  * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined.
  * NTT_ARITH_U64_R4 plans run the reference's radix-4 formulation end to end (fwd_ntt_radix4 on both operands, the

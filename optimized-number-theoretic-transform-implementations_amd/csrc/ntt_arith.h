@@ -381,6 +381,9 @@ struct ArithF64 {
     const double y  = reduce(LAZY ? y0 - (c.q + c.q) : y0, c);
     return mulmod_c(y, xr, c);
   }
+  /* the same with BOTH factors still in registers (two forward transforms of one work item): each is reduced to |.| <= q/2
+   * first, so the bound above holds unchanged */
+  static NTT_HD val product_rr(val x, val y, const consts &c) { return mulmod_c(reduce(y, c), reduce(x, c), c); }
   /* balanced |v| < 2^53 -> canonical [0,q) as u64 */
   static NTT_HD uint64_t to_canonical(double v, const consts &c)
   {

@@ -241,7 +241,8 @@ struct ntt_plan {
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
   int              block_log  = 0;     /* multi-pass transforms: block size below the column passes (0 = multi_pass_block's choice) */
-  bool             fused_product = true; /* N = 2^8..2^17, FP64: ntt_negacyclic_mul_batch as fwd(a) + the fused product kernels */
+  int              fused_product = 1; /* N = 2^8..2^17, FP64: ntt_negacyclic_mul_batch through the fused product kernels (0: four-launch
+                                       * chain; 2: as 1, but a's forward transform always as a launch of its own) */
   int              two_phase  = -1;    /* 2^16, 2^17: both passes of a polynomial inside one workgroup (twophase_kernel):
                                         * 1 on, 0 off, -1 where it measured faster (forward 2^16, scheduled FP64 policy: +3 %) */
 };
@@ -592,7 +593,8 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       p->two_phase = value < 0 ? -1 : (value != 0);
       return NTT_OK;
     case NTT_OPT_FUSED_PRODUCT:
-      p->fused_product = value != 0;
+      if(value < 0 || value > 2) return fail(NTT_ERR_ARG, "fused product: 0, 1 or 2");
+      p->fused_product = (int)value;
       return NTT_OK;
     case NTT_OPT_XCD_LOCAL:
       p->xcd_local = value < 0 ? -1 : (value != 0);
@@ -972,17 +974,26 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
    * v = c - 2q, so the reduced forward transform is a valid producer too -- used where it is the faster launch (the
    * XCD-local kernel, N >= 2^15, large batches: +13..20 % over the per-pass lazy transform) */
   const bool canonical_a = team_applies(p, batch, false, false, false, ls.n);
-  int rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
-  if(rc) return rc;
-  USE_DEVICE(p->device);
-  /* N >= 2^15, large batches: the rest of the chain (column stages of b, block products, inverse column stages of c) as
-   * the three item kinds of ONE launch (ntt_kernels.h: team_product_kernel) */
+  /* N >= 2^15, large batches: the chain as the item kinds of ONE launch (ntt_kernels.h: team_product_kernel) -- column
+   * stages of b AND a, block products (both blocks through their twelve stages, product, inverse stages), inverse column
+   * stages of c: a^ never exists in memory (48N instead of 64N bytes across the fabric).  NTT_PRODUCT_FOUR=0 keeps a's
+   * forward transform as a launch of its own in front of the three-pass form (measurements, tests). */
+  void *ctl  = nullptr;
+  int   rc   = NTT_OK;
   if(canonical_a && !p->block_log) {
-    void *ctl = nullptr;
-    rc        = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch, &ctl);
+    rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch, &ctl);
     if(rc) return rc;
+  }
+  const bool four = ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  if(!four) {
+    rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
+    if(rc) return rc;
+  }
+  USE_DEVICE(p->device);
+  if(canonical_a && !p->block_log) {
     if(ctl) {
       ProdArgs pa{};
+      pa.four        = four;
       pa.b           = d_b;
       pa.ahat        = d_a;
       pa.out         = d_c;
@@ -996,8 +1007,9 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
       pa.num_cus     = p->num_cus;
       pa.team_ctl    = ctl;
       /* three passes, four workgroups per CU: the lag that keeps second- and third-pass items from waiting is larger than
-       * the transform's (measured, profiles/r03/sweep_product_lag.txt: flat optimum 12-14 at 2^17, 12-20 at 2^16, 20-24 at 2^15) */
-      pa.team_lag    = p->team_lag ? p->team_lag : (p->m == kTeamBlock + 3 ? 20 : (p->m == kTeamBlock + 4 ? 14 : 12));
+       * the transform's (measured, profiles/r03/sweep_product_lag.txt: flat optimum 12-14 at 2^17, 12-20 at 2^16, 20-24 at 2^15;
+       * with both operands' column tiles in the first pass: 8 at 2^17, 12-16 at 2^16, 20-24 at 2^15) */
+      pa.team_lag    = p->team_lag ? p->team_lag : (p->m == kTeamBlock + 3 ? 20 : (p->m == kTeamBlock + 4 ? 14 : (four ? 8 : 12)));
       pa.team_wpc    = p->team_wpc;
       pa.stream      = (hipStream_t)stream;
       hipError_t e = p->kcls == kWideClass ? launch_team_product<ArithF64W, 0>(pa)

@@ -1353,6 +1353,67 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
 /* ------------------------------------------------------------------ */
 /* products at N = 2^15 .. 2^17: three passes as items of one launch    */
 /* ------------------------------------------------------------------ */
+/* The same item with BOTH forward transforms inside (team_product_kernel<..., FOUR = true>): a's block comes in as the
+ * intermediate of a's column pass, is taken through the twelve block stages first and waits in 32 VGPRs -- the registers
+ * that hold the prefetched a^ words in the item above -- while b's block follows; a^ never exists in memory: 16N bytes
+ * fewer across the fabric per product (no write-through store of a^, no read of it) and one launch less. */
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_t *ablk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
+                                                   const Params<A> &pf, const Params<A> &pi, typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, 3>;
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>();
+  constexpr int      GL    = P::NG - 1;
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && !P::WAVE_LOCAL(0, 1), "twiddle placement / barrier this item assumes");
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  uint32_t tl = tid0;
+  asm volatile("" : "+v"(tl));
+  const uint32_t tid = tl;
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX>(raw, tid, ablk);
+  typename A::ctw pre[4][kE / 2];
+  preload_group_tw<A, LOGN, GL>(pre, tid, blk, pf);
+  fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid); /* (published by the first exchange's barriers) */
+  const auto forward = [&](typename A::val(&x)[kE]) {
+    run_group<A, LOGN, 0, false, MASKF>(x, tid, blk, pf);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+      if constexpr(GI + 1 == GL) {
+        run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
+      } else if constexpr(G::TBL(GI + 1) > 0) {
+        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tid, blk, pf, ltw + G::TBL_OFF(GI + 1));
+      } else {
+        run_group<A, LOGN, GI + 1, false, MASKF>(x, tid, blk, pf);
+      }
+    });
+  };
+  typename A::val xa[kE];
+  convert_inputs<A, false>(xa, raw, false, pf.c);
+  prefetch_first<LOGN, LDAUX>(raw, tid, bblk); /* b's words travel during a's twelve stages */
+  forward(xa);
+  typename A::val x[kE];
+  convert_inputs<A, false>(x, raw, false, pf.c);
+  forward(x);
+  uint32_t t2 = tid;
+  asm volatile("" : "+v"(t2));
+  preload_group_tw<A, LOGN, GL>(pre, t2, blk, pi); /* the inverse's first group: lands while the product is computed */
+  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
+  run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    if constexpr(G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0);
+    run_group<A, LOGN, GI - 1, true, MASKI>(x, tid, blk, pi);
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, cblk);
+}
+
 /*
  * c = a * b with a^ = fwd(a) already in HBM: the remaining chain -- column stages of b, per block forward x a^ -> inverse,
  * inverse column stages of c -- as the three item kinds of ONE launch in team_kernel's scheme (per-XCD in-order queues,
@@ -1429,7 +1490,7 @@ template <class A> struct KTeamProd {
   uint32_t     lag;
 };
 
-template <class A, int LEAD, int KSH>
+template <class A, int LEAD, int KSH, bool FOUR = false>
 __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A> kt)
 {
   constexpr int LOGN = kTeamBlock;
@@ -1456,7 +1517,9 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
   const uint32_t logn  = LOGN + LEAD;
   const uint32_t batch = (uint32_t)pf.nblocks;
   constexpr uint32_t NCOL = 1u << (LOGN - 8), NROW = 1u << LEAD;
-  constexpr uint32_t PER = NCOL + NROW + NCOL; /* items per step */
+  /* FOUR: the first pass takes the column tiles of BOTH operands (b's, then a's) and the product item transforms both blocks */
+  constexpr uint32_t NFIRST = FOUR ? 2u * NCOL : NCOL;
+  constexpr uint32_t PER    = NFIRST + NROW + NCOL; /* items per step */
   TeamProdCtl *const ctl = kt.ctl;
   const uint32_t lag = kt.lag;
   const uint32_t my  = xcc_id();
@@ -1485,13 +1548,13 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       const uint32_t k    = s_k2[it];
       const uint32_t step = k / PER, r = k % PER;
       if(step >= steps) break;
-      const uint32_t pass = r < NCOL ? 0u : (r < NCOL + NROW ? 1u : 2u);
-      const uint32_t item = pass == 0 ? r : (pass == 1 ? r - NCOL : r - NCOL - NROW);
+      const uint32_t pass = r < NFIRST ? 0u : (r < NFIRST + NROW ? 1u : 2u);
+      const uint32_t item = pass == 0 ? r : (pass == 1 ? r - NFIRST : r - NFIRST - NROW);
       const int64_t  j    = (int64_t)step - (int64_t)(pass * lag);
       if(j < 0 || j >= (int64_t)J) continue;
       const uint32_t pidx = q + 8u * (uint32_t)j;
       if(pass > 0) {
-        const uint32_t need = pass == 1 ? NCOL : NROW;
+        const uint32_t need = pass == 1 ? NFIRST : NROW;
         const uint32_t slot = pass == 1 ? pidx : batch + pidx;
         if(tid == 0) {
           while(__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
@@ -1502,10 +1565,16 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       const uint64_t *apoly = pp.ahat + ((uint64_t)pidx << logn);
       uint64_t *      cpoly = pp.out + ((uint64_t)pidx << logn);
       if(pass == 0) {
-        team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(bpoly, item * kTeamCols + tid, logn, pf, MID_LAZY);
+        uint64_t *const src = FOUR && item >= NCOL ? const_cast<uint64_t *>(apoly) : bpoly; /* (a is an operand buffer of the caller's: written here) */
+        team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(src, (item & (NCOL - 1u)) * kTeamCols + tid, logn, pf, MID_LAZY);
       } else if(pass == 1) {
-        team_product_item<A, KSH, kAuxNt, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
-                                                       cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
+        if constexpr(FOUR) {
+          team_product_item2<A, KSH, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
+                                                cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
+        } else {
+          team_product_item<A, KSH, kAuxNt, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
+                                                         cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
+        }
       } else {
         team_column_item<A, LEAD, true, CMASKI, kAuxNt, kAuxSc1>(cpoly, item * kTeamCols + tid, logn, pi, false);
       }
@@ -1642,6 +1711,7 @@ struct ProdArgs {
   int             max_grid, num_cus;
   void *          team_ctl; /* launch_team_product: device memory for the queues and 2 * batch counters */
   int             team_lag, team_wpc;
+  int             four; /* launch_team_product: ahat holds a's COEFFICIENTS; the launch transforms both operands */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
@@ -1938,7 +2008,7 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.nlimbs > 1 || !pa.team_ctl || !pa.a_lazy || pa.logn < kTeamBlock + 3 || pa.logn > kTeamBlock + 5) return hipErrorNotSupported;
+    if(pa.nlimbs > 1 || !pa.team_ctl || (!pa.a_lazy && !pa.four) || pa.logn < kTeamBlock + 3 || pa.logn > kTeamBlock + 5) return hipErrorNotSupported;
     KTeamProd<A> kt{};
     kt.k.f.a            = pa.b;
     const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
@@ -1959,6 +2029,15 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
     if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
     kt.k.f.wgs_per_limb = (uint32_t)wgs;
+    if(pa.four) {
+      /* ahat = a itself (coefficients): both forward transforms happen inside the launch */
+      switch(pa.logn - kTeamBlock) {
+        case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+        case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+        default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+      }
+      return hipGetLastError();
+    }
     switch(pa.logn - kTeamBlock) {
       case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
       case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;

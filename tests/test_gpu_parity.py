@@ -341,34 +341,43 @@ def test_xcd_local_two_pass_kernel(lib, oracle, m, bits):
 
 @pytest.mark.parametrize("m,bits", [(15, 50), (16, 52), (17, 50), (16, 31)])
 def test_xcd_local_product_kernel(lib, oracle, m, bits):
-    """products of 512+ polynomials at N = 2^15..2^17: after a^ = fwd(a), the rest of the chain (column stages of b, block
-    products, inverse column stages of c) runs as the three item kinds of ONE launch (team_product_kernel).  All aliasing
-    forms, ragged batches, sampled polynomials against the oracle and every polynomial against the four-transform chain."""
+    """products of 512+ polynomials at N = 2^15..2^17 as ONE launch (team_product_kernel): column stages of b and a, block
+    products (both blocks through their twelve stages, product, inverse stages), inverse column stages of c -- and its
+    three-pass form (NTT_OPT_FUSED_PRODUCT 2: a^ = fwd(a) by a launch of its own first).  All aliasing forms, ragged
+    batches, sampled polynomials against the oracle and every polynomial against the four-transform chain."""
     n = 1 << m
     q = lib.find_prime(bits, n, 2)
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
-    plan, chain = lib.Plan(n, q, w), lib.Plan(n, q, w)
+    plan, three, chain = lib.Plan(n, q, w), lib.Plan(n, q, w), lib.Plan(n, q, w)
+    three.set_option(lib.OPT_FUSED_PRODUCT, 2)
     chain.set_option(lib.OPT_FUSED_PRODUCT, 0)
     chain.set_option(lib.OPT_XCD_LOCAL, 0)
     for batch, alias, lag in ((512, "c", 0), (519, "a", 3), (777 if m < 17 else 521, "b", 1)):
-        plan.set_option(lib.OPT_XCD_LOCAL_LAG, lag)
         a = oracle.fill_uniform(batch * n, q, 1300 + batch)
         b = oracle.fill_uniform(batch * n, q, 1400 + batch)
         b[:8] = [0, 1, q - 1, q - 2, 2, 3, q // 2, q // 2 + 1]
+        a[:8] = [q - 1, 0, 1, q - 2, q // 2, 3, 2, q // 2 + 1]
         da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(a.size).upload(b), lib.DeviceBuffer(a.size)
-        out = {"a": da, "b": db, "c": dc}[alias]
-        plan.negacyclic_mul(out.ptr, da.ptr, db.ptr, batch)
-        got = out.download()
         sample = [0, 1, 7, 8, batch // 2, batch - 2, batch - 1]
         pick = np.concatenate([np.arange(p * n, (p + 1) * n) for p in sample])
-        assert np.array_equal(got[pick], cx.inv(oracle.pointwise(cx.fwd(a[pick]), cx.fwd(b[pick]), q))), (batch, alias)
+        want = cx.inv(oracle.pointwise(cx.fwd(a[pick]), cx.fwd(b[pick]), q))
+        got = None
+        for pl in (plan, three):
+            pl.set_option(lib.OPT_XCD_LOCAL_LAG, lag)
+            da.upload(a), db.upload(b)
+            out = {"a": da, "b": db, "c": dc}[alias]
+            pl.negacyclic_mul(out.ptr, da.ptr, db.ptr, batch)
+            res = out.download()
+            assert np.array_equal(res[pick], want), (batch, alias, pl is three)
+            assert got is None or np.array_equal(res, got), (batch, alias)
+            got = res
         da.upload(a), db.upload(b)
         chain.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
         assert np.array_equal(dc.download(), got), (batch, alias)
         for x in (da, db, dc):
             x.free()
-    plan.destroy(), chain.destroy()
+    plan.destroy(), three.destroy(), chain.destroy()
 
 
 def test_xcd_local_full_size_round_trip_and_cross_check(lib, oracle):

@@ -72,8 +72,8 @@ while time.time() < t_end:
         opts["block"] = int(rng.choice([12, 14]))
         plan.set_option(lib.OPT_BLOCK_LOG, opts["block"])
     if rng.random() < 0.3:
-        opts["fused_product"] = 0
-        plan.set_option(lib.OPT_FUSED_PRODUCT, 0)
+        opts["fused_product"] = int(rng.choice([0, 0, 2]))      # 2: a's forward transform as a launch of its own
+        plan.set_option(lib.OPT_FUSED_PRODUCT, opts["fused_product"])
     if m in (15, 16, 17) and rng.random() < 0.6:
         # both passes as items of one launch (needs batch >= 64; forced on for both directions, random lag / residency)
         opts["xcd_local"] = int(rng.choice([1, 1, 0]))
