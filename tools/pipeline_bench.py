@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--lag", type=int, default=0, help="XCD-local launches: polynomials between passes (0 = default)")
 ap.add_argument("--wpc", type=int, default=0, help="XCD-local launches: workgroups per CU (0 = default)")
 ap.add_argument("--xcd-local", type=int, default=-1)
+ap.add_argument("--alias", choices=["c", "a", "b"], default="c", help="where the product goes: its own buffer, over a, or over b")
 a = ap.parse_args()
 n = 1 << a.logn
 qs = [lib.find_prime(a.bits, n, k) for k in range(a.limbs)]
@@ -28,7 +29,7 @@ def fill():
         for l, q in enumerate(qs):
             lib.fill_uniform(b.ptr + 8 * l * per, per, q, 1000 + i, l * per)
 def step():
-    lib.rns_negacyclic_mul(plans, bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, a.batch)
+    lib.rns_negacyclic_mul(plans, bufs[{"c": 2, "a": 0, "b": 1}[a.alias]].ptr, bufs[0].ptr, bufs[1].ptr, a.batch)
 fill(); step(); lib.stream_sync()
 e0, e1 = lib.Event(), lib.Event()
 tot = 0.0
