@@ -79,7 +79,7 @@ typedef enum ntt_option {
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14; block by block between column passes, 88N
-                          * bytes, above -- and for 512 polynomials or more of N >= 2^15 the WHOLE chain, both forward
+                          * bytes, above -- and from 2^23 coefficients per operand of N >= 2^15 on the WHOLE chain, both forward
                           * transforms included, as one launch); 2 = as 1, but a's forward transform always as a launch of
                           * its own; 0 = fwd, fwd, pointwise, inv (72N / 120N bytes).  Results are identical. */
 } ntt_option;

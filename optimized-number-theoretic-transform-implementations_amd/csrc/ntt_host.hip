@@ -647,7 +647,7 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
  * the heavy one: the column items wait longer than the L2 can hold their polynomials) and keeps the per-pass launches.
  * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it; NTT_XCD_LOCAL in the
  * environment overrides the automatic choice the same way. */
-static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool wide, bool lazy, int nlimbs)
+static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool wide, bool lazy, int nlimbs, bool product = false)
 {
   if(p->arith != NTT_ARITH_F64 || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy || nlimbs != 1 ||
      batch < 64 || batch >= (1ull << 31)) {
@@ -656,6 +656,10 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
   int on = p->xcd_local;
   if(on < 0) on = env_int("NTT_XCD_LOCAL", -1);
   if(on >= 0) return on == 1;
+  /* the product launch (all transforms of a product as items of one launch) pays from 2^23 coefficients per operand on:
+   * 64 / 128 / 256 polynomials at 2^17 / 2^16 / 2^15 (measured against the per-chunk launches, single limb, batches
+   * 64..384: profiles/r03/ablations.txt (h)) */
+  if(product) return batch >= 64 && (batch << p->m) >= (1ull << 23);
   return !inverse && batch >= 512;
 }
 
@@ -973,7 +977,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   /* a^ = fwd(a).  The product kernels take a^ as lazy words v + 2q, v in (-2q, 2q); a canonical word c is the lazy word of
    * v = c - 2q, so the reduced forward transform is a valid producer too -- used where it is the faster launch (the
    * XCD-local kernel, N >= 2^15, large batches: +13..20 % over the per-pass lazy transform) */
-  const bool canonical_a = team_applies(p, batch, false, false, false, ls.n);
+  const bool canonical_a = team_applies(p, batch, false, false, false, ls.n, true);
   /* N >= 2^15, large batches: the chain as the item kinds of ONE launch (ntt_kernels.h: team_product_kernel) -- column
    * stages of b AND a, block products (both blocks through their twelve stages, product, inverse stages), inverse column
    * stages of c: a^ never exists in memory (48N instead of 64N bytes across the fabric).  NTT_PRODUCT_FOUR=0 keeps a's
