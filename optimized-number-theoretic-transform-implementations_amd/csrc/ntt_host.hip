@@ -969,7 +969,9 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
  *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14- or 2^12-point blocks (fwd block * a^ block
  *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
  *              inverse on c.                                                                   88N bytes, 5 launches
- *              (120N and 7 launches for fwd, fwd, pointwise, inv). */
+ *              (120N and 7 launches for fwd, fwd, pointwise, inv).
+ *   N > 2^14, 2^23 coefficients per operand or more: everything, both forward transforms included, as the items of
+ *              ONE launch (team_product_kernel<..., FOUR>): a^ never exists in memory.        48N bytes, 1 launch. */
 static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream,
                          const LimbSet *set = nullptr)
 {

@@ -16,8 +16,9 @@
  *                DESIGN.md section 3).
  * team_kernel  : both passes of a 2^15 .. 2^17 transform as ITEMS of one persistent launch: per-XCD in-order queues
  *                (the XCD is read from HW_REG_XCC_ID), per-polynomial hand-off counters, the intermediate kept in the
- *                XCD's L2 / the Infinity Cache; team_product_kernel: the same scheme with three item kinds for the
- *                b-chain of a product (column stages, block products with a^, inverse column stages).
+ *                XCD's L2 / the Infinity Cache; team_product_kernel: the same scheme with three item kinds for a whole
+ *                product (column stages of both operands, block products -- both blocks through their block stages,
+ *                product, inverse block stages --, inverse column stages; or, a^ given, the b-chain only).
  * MULTI        : kernel variants that serve several RNS limbs in one launch (a LimbRec per limb in the kernel arguments).
  * The same kernels serve four arithmetic policies (ntt_arith.h): FP64 with a reduction schedule, FP64 for moduli up
  * to 2^52, the reference's integer radix-2 arithmetic and its radix-4 formulation.
@@ -1351,69 +1352,8 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
 }
 
 /* ------------------------------------------------------------------ */
-/* products at N = 2^15 .. 2^17: three passes as items of one launch    */
+/* products at N = 2^15 .. 2^17: all passes as items of one launch      */
 /* ------------------------------------------------------------------ */
-/* The same item with BOTH forward transforms inside (team_product_kernel<..., FOUR = true>): a's block comes in as the
- * intermediate of a's column pass, is taken through the twelve block stages first and waits in 32 VGPRs -- the registers
- * that hold the prefetched a^ words in the item above -- while b's block follows; a^ never exists in memory: 16N bytes
- * fewer across the fabric per product (no write-through store of a^, no read of it) and one launch less. */
-template <class A, int KSH, int LDAUX, int STAUX>
-__device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_t *ablk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
-                                                   const Params<A> &pf, const Params<A> &pi, typename A::val *lds, typename A::ctw *tabl)
-{
-  constexpr int LOGN = kTeamBlock;
-  using P            = Plan<LOGN>;
-  using G            = Geom<LOGN, false, 3>;
-  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
-  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>();
-  constexpr int      GL    = P::NG - 1;
-  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && !P::WAVE_LOCAL(0, 1), "twiddle placement / barrier this item assumes");
-  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
-  uint32_t tl = tid0;
-  asm volatile("" : "+v"(tl));
-  const uint32_t tid = tl;
-  uint64_t raw[kE];
-  prefetch_first<LOGN, LDAUX>(raw, tid, ablk);
-  typename A::ctw pre[4][kE / 2];
-  preload_group_tw<A, LOGN, GL>(pre, tid, blk, pf);
-  fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid); /* (published by the first exchange's barriers) */
-  const auto forward = [&](typename A::val(&x)[kE]) {
-    run_group<A, LOGN, 0, false, MASKF>(x, tid, blk, pf);
-    static_for<0, P::NG - 1>([&](auto gg) {
-      constexpr int GI = decltype(gg)::value;
-      exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
-      if constexpr(GI + 1 == GL) {
-        run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
-      } else if constexpr(G::TBL(GI + 1) > 0) {
-        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tid, blk, pf, ltw + G::TBL_OFF(GI + 1));
-      } else {
-        run_group<A, LOGN, GI + 1, false, MASKF>(x, tid, blk, pf);
-      }
-    });
-  };
-  typename A::val xa[kE];
-  convert_inputs<A, false>(xa, raw, false, pf.c);
-  prefetch_first<LOGN, LDAUX>(raw, tid, bblk); /* b's words travel during a's twelve stages */
-  forward(xa);
-  typename A::val x[kE];
-  convert_inputs<A, false>(x, raw, false, pf.c);
-  forward(x);
-  uint32_t t2 = tid;
-  asm volatile("" : "+v"(t2));
-  preload_group_tw<A, LOGN, GL>(pre, t2, blk, pi); /* the inverse's first group: lands while the product is computed */
-  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
-  run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
-  static_for<0, P::NG - 1>([&](auto gg) {
-    constexpr int GI = P::NG - 1 - decltype(gg)::value;
-    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
-    if constexpr(G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0);
-    run_group<A, LOGN, GI - 1, true, MASKI>(x, tid, blk, pi);
-  });
-  uint64_t out[kE];
-  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
-  buffer_store_first_raw<LOGN, STAUX>(out, tid, cblk);
-}
-
 /*
  * c = a * b with a^ = fwd(a) already in HBM: the remaining chain -- column stages of b, per block forward x a^ -> inverse,
  * inverse column stages of c -- as the three item kinds of ONE launch in team_kernel's scheme (per-XCD in-order queues,
@@ -1471,6 +1411,67 @@ __device__ __forceinline__ void team_product_item(uint64_t *bblk, const uint64_t
     constexpr int GI = P::NG - 1 - decltype(gg)::value;
     exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
     if constexpr(G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0); /* (as in fused_product_kernel: keep the global twiddle requests behind the exchange) */
+    run_group<A, LOGN, GI - 1, true, MASKI>(x, tid, blk, pi);
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, cblk);
+}
+
+/* The same item with BOTH forward transforms inside (team_product_kernel<..., FOUR = true>): a's block comes in as the
+ * intermediate of a's column pass, is taken through the twelve block stages first and waits in 32 VGPRs -- the registers
+ * that hold the prefetched a^ words in the item above -- while b's block follows; a^ never exists in memory: 16N bytes
+ * fewer across the fabric per product (no write-through store of a^, no read of it) and one launch less. */
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_t *ablk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
+                                                   const Params<A> &pf, const Params<A> &pi, typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, 3>;
+  constexpr uint32_t MASKF = fused_mask<A, LOGN, false, KSH>();
+  constexpr uint32_t MASKI = fused_mask<A, LOGN, true, KSH>();
+  constexpr int      GL    = P::NG - 1;
+  static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && !P::WAVE_LOCAL(0, 1), "twiddle placement / barrier this item assumes");
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  uint32_t tl = tid0;
+  asm volatile("" : "+v"(tl));
+  const uint32_t tid = tl;
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX>(raw, tid, ablk);
+  typename A::ctw pre[4][kE / 2];
+  preload_group_tw<A, LOGN, GL>(pre, tid, blk, pf);
+  fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid); /* (published by the first exchange's barriers) */
+  const auto forward = [&](typename A::val(&x)[kE]) {
+    run_group<A, LOGN, 0, false, MASKF>(x, tid, blk, pf);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+      if constexpr(GI + 1 == GL) {
+        run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
+      } else if constexpr(G::TBL(GI + 1) > 0) {
+        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tid, blk, pf, ltw + G::TBL_OFF(GI + 1));
+      } else {
+        run_group<A, LOGN, GI + 1, false, MASKF>(x, tid, blk, pf);
+      }
+    });
+  };
+  typename A::val xa[kE];
+  convert_inputs<A, false>(xa, raw, false, pf.c);
+  prefetch_first<LOGN, LDAUX>(raw, tid, bblk); /* b's words travel during a's twelve stages */
+  forward(xa);
+  typename A::val x[kE];
+  convert_inputs<A, false>(x, raw, false, pf.c);
+  forward(x);
+  uint32_t t2 = tid;
+  asm volatile("" : "+v"(t2));
+  preload_group_tw<A, LOGN, GL>(pre, t2, blk, pi); /* the inverse's first group: lands while the product is computed */
+  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
+  run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    if constexpr(G::TBL(GI - 1) > 0) __builtin_amdgcn_sched_barrier(0);
     run_group<A, LOGN, GI - 1, true, MASKI>(x, tid, blk, pi);
   });
   uint64_t out[kE];
