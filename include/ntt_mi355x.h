@@ -77,11 +77,13 @@ typedef enum ntt_option {
                            * it measured faster: forward transforms of 512 polynomials or more.  Results are identical. */
   NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: 10, 8, 10 at 2^15, 2^16, 2^17) */
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
-  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch runs fwd(a) + one fused
-                          * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14; block by block between column passes, 88N
-                          * bytes, above -- and from 2^23 coefficients per operand of N >= 2^15 on the WHOLE chain, both forward
-                          * transforms included, as one launch); 2 = as 1, but a's forward transform always as a launch of
-                          * its own; 0 = fwd, fwd, pointwise, inv (72N / 120N bytes).  Results are identical. */
+  NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
+                          * operands through the forward stages, multiplies in registers and runs the inverse (24N bytes
+                          * up to 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise, 48N bytes across the
+                          * fabric; smaller batches of N >= 2^15: fwd(a), then block by block between column passes, 88N
+                          * bytes); 2 = a's forward transform always as a launch of its own in front of the fused
+                          * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14); 0 = fwd, fwd, pointwise, inv (72N / 120N
+                          * bytes).  Results are identical. */
 } ntt_option;
 
 typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
@@ -145,7 +147,8 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
  * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
- * transform -- or, large batches of N >= 2^15, holding only the column stages of it); d_b is overwritten likewise
+ * transform -- or, large batches of N >= 2^15, holding only the column stages of it -- or, the one-launch form up to
+ * 2^14, not written at all); d_b is overwritten likewise
  * (four-launch chain), overwritten by the column passes of its forward transform
  * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined.

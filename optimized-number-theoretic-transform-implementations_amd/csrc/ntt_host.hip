@@ -965,7 +965,8 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
 }
 
 /* c = a * b with the fused product kernels (FP64, N = 2^8 .. 2^17).
- *   N <= 2^14: a^ = fwd(a) (lazy words); ONE launch: b -> fwd -> * a^ -> inv -> c.            40N bytes, 2 launches.
+ *   N <= 2^14: ONE launch: a -> fwd, b -> fwd, product in registers, -> inv -> c.            24N bytes, 1 launch
+ *              (NTT_OPT_FUSED_PRODUCT 2: a^ = fwd(a) (lazy words) by a launch of its own first: 40N bytes, 2 launches).
  *   N > 2^14 : a^ = fwd(a); per chunk: column stages on b, ONE launch over its 2^14- or 2^12-point blocks (fwd block * a^ block
  *              -> inverse block: the product is element-wise, so it fuses block by block), column stages of the
  *              inverse on c.                                                                   88N bytes, 5 launches
@@ -991,7 +992,10 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     if(rc) return rc;
   }
   const bool four = ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
-  if(!four) {
+  /* N <= 2^14: a's coefficients go straight into the fused kernel, which takes both operands through the forward
+   * stages (24N instead of 40N bytes, one launch; a is left as it was) */
+  const bool both = p->m <= kFusedMax && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  if(!four && !both) {
     rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
     if(rc) return rc;
   }
@@ -1055,6 +1059,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.logn     = (uint32_t)p->m;
     pa.block_log = (uint32_t)pblk;
     pa.a_lazy   = 1;
+    pa.both     = both;
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;
     pa.stream   = (hipStream_t)stream;

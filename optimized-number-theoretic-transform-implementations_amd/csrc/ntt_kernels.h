@@ -1253,10 +1253,14 @@ template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_pro
  * 88N bytes instead of 120N.  A workgroup then always sees the same block position (its stride is a multiple of the
  * blocks per polynomial), whose forward table slice it keeps in LDS; the mirrored read would need the slice of the
  * complementary position, so the inverse half takes that one group's twiddles from global memory instead. */
-template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false>
+/* BOTH (whole polynomials): pp.ahat holds a's COEFFICIENTS and the kernel takes them through the forward stages too -- a^
+ * waits, as doubles, in the 32 VGPRs that hold the prefetched a^ words otherwise, so the register budget is the same; a^
+ * never exists in memory (24N instead of 40N bytes per product, one launch instead of two) and a is left untouched. */
+template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false, bool BOTH = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_kernel(const KProd<A> kp)
 {
+  static_assert(!BOTH || WHOLE, "both forward transforms in the kernel: whole polynomials only");
   uint32_t            bid, gdim;
   const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
   using P = Plan<LOGN>;
@@ -1291,7 +1295,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
   __syncthreads();
   uint64_t raw[kE];
-  prefetch_first<LOGN>(raw, tid, pf.a + (b << LOGN));
+  prefetch_first<LOGN>(raw, tid, (BOTH ? pp.ahat : pf.a) + (b << LOGN));
   pin_raw(raw);
   for(; b < pf.nblocks; b += stride) {
     /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
@@ -1304,33 +1308,51 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     asm volatile("" : "+v"(tl));
     typename A::ctw pre[4][kE / 2];
     preload_group_tw<A, LOGN, GL>(pre, tl, blk, pf);
+    const auto forward = [&](typename A::val(&v)[kE]) {
+      run_group<A, LOGN, 0, false, MASKF>(v, tl, blk, pf);
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = decltype(gg)::value;
+        exchange<A, LOGN, GI, GI + 1>(v, tl, lds_all);
+        if constexpr(GI + 1 == GL) {
+          run_group_preloaded<A, LOGN, GL, MASKF>(v, pre, pf);
+        } else if constexpr(G::TBL(GI + 1) > 0) {
+          run_group<A, LOGN, GI + 1, false, MASKF, true>(v, tl, blk, pf, ltw + G::TBL_OFF(GI + 1));
+        } else {
+          run_group<A, LOGN, GI + 1, false, MASKF>(v, tl, blk, pf);
+        }
+      });
+    };
     typename A::val x[kE];
-    convert_inputs<A, false>(x, raw, false, pf.c);
-    /* a^ in the last group's layout: requested now, used after the 14 forward stages */
-    prefetch_last<LOGN>(raw, tl, pp.ahat + (b << LOGN));
-    run_group<A, LOGN, 0, false, MASKF>(x, tl, blk, pf);
-    static_for<0, P::NG - 1>([&](auto gg) {
-      constexpr int GI = decltype(gg)::value;
-      exchange<A, LOGN, GI, GI + 1>(x, tl, lds_all);
-      if constexpr(GI + 1 == GL) {
-        run_group_preloaded<A, LOGN, GL, MASKF>(x, pre, pf);
-      } else if constexpr(G::TBL(GI + 1) > 0) {
-        run_group<A, LOGN, GI + 1, false, MASKF, true>(x, tl, blk, pf, ltw + G::TBL_OFF(GI + 1));
-      } else {
-        run_group<A, LOGN, GI + 1, false, MASKF>(x, tl, blk, pf);
-      }
-    });
+    typename A::val xa[BOTH ? kE : 1];
+    if constexpr(BOTH) {
+      convert_inputs<A, false>(xa, raw, false, pf.c);
+      prefetch_first<LOGN>(raw, tl, pf.a + (b << LOGN)); /* b's words travel during a's forward stages */
+      forward(xa);
+      /* (b's words are converted after a's last stage, not before: interleaved by the scheduler, x, xa and the raw words
+       * lived side by side and spilled) */
+      __builtin_amdgcn_sched_barrier(0);
+      convert_inputs<A, false>(x, raw, false, pf.c);
+    } else {
+      convert_inputs<A, false>(x, raw, false, pf.c);
+      /* a^ in the last group's layout: requested now, used after the 14 forward stages */
+      prefetch_last<LOGN>(raw, tl, pp.ahat + (b << LOGN));
+    }
+    forward(x);
     /* the inverse's first group: its twiddles land while the product is computed */
     asm volatile("" : "+v"(tl));
     preload_group_tw<A, LOGN, GL>(pre, tl, blk, pi);
-    static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<ALAZY>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    if constexpr(BOTH) {
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
+    } else {
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<ALAZY>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    }
     /* the next block's loads reuse a^'s registers: not before the last product has read them (interleaved by
      * the scheduler, the two lived side by side and spilled) */
     __builtin_amdgcn_sched_barrier(0);
     {
       const bool     more = b + stride < pf.nblocks;
       const uint64_t nb   = more ? b + stride : b;
-      prefetch_first<LOGN>(raw, tl, pf.a + (nb << LOGN), more);
+      prefetch_first<LOGN>(raw, tl, (BOTH ? pp.ahat : pf.a) + (nb << LOGN), more);
     }
     run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -1593,7 +1615,7 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
  * the product and the inverse half appended.  Every per-lane group has its forward table in LDS at these sizes, and the
  * inverse half reads all of them mirrored, so the kernel issues no per-lane global twiddle load at all; a^ arrives in
  * the last group's layout as 16-byte loads.  40N bytes per product instead of 72N. */
-template <class A, int LOGN, int KSH, bool MULTI = false>
+template <class A, int LOGN, int KSH, bool MULTI = false, bool BOTH = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_small_kernel(const KProd<A> kp)
 {
@@ -1626,17 +1648,31 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     uint64_t   b    = b0 + sub;
     const bool live = b < pf.nblocks;
     if(!live) b = pf.nblocks - 1; /* idle sub-blocks shadow a real polynomial (barriers are workgroup-wide), never store */
+    const auto forward = [&](typename A::val(&v)[kE]) {
+      run_group<A, LOGN, 0, false, MASKF, (G::TBL(0) > 0)>(v, t, 0u, pf, gtw);
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = decltype(gg)::value;
+        exchange<A, LOGN, GI, GI + 1>(v, t, lds);
+        run_group<A, LOGN, GI + 1, false, MASKF, (G::TBL(GI + 1) > 0)>(v, t, 0u, pf, gtw + G::TBL_OFF(GI + 1));
+      });
+    };
     typename A::val x[kE];
-    global_load_first<A, LOGN, false>(x, t, pf.a + (b << LOGN), false, pf.c);
-    uint64_t raw[kE];
-    prefetch_last<LOGN>(raw, t, pp.ahat + (b << LOGN));
-    run_group<A, LOGN, 0, false, MASKF, (G::TBL(0) > 0)>(x, t, 0u, pf, gtw);
-    static_for<0, P::NG - 1>([&](auto gg) {
-      constexpr int GI = decltype(gg)::value;
-      exchange<A, LOGN, GI, GI + 1>(x, t, lds);
-      run_group<A, LOGN, GI + 1, false, MASKF, (G::TBL(GI + 1) > 0)>(x, t, 0u, pf, gtw + G::TBL_OFF(GI + 1));
-    });
-    static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    uint64_t        raw[kE];
+    if constexpr(BOTH) {
+      /* a's coefficients through the same forward stages first; a^ waits in registers (the ones a^'s words occupy otherwise) */
+      typename A::val xa[kE];
+      global_load_first<A, LOGN, false>(xa, t, pp.ahat + (b << LOGN), false, pf.c);
+      prefetch_first<LOGN>(raw, t, pf.a + (b << LOGN));
+      forward(xa);
+      convert_inputs<A, false>(x, raw, false, pf.c);
+      forward(x);
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
+    } else {
+      global_load_first<A, LOGN, false>(x, t, pf.a + (b << LOGN), false, pf.c);
+      prefetch_last<LOGN>(raw, t, pp.ahat + (b << LOGN));
+      forward(x);
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
+    }
     constexpr int GL = P::NG - 1;
     run_group<A, LOGN, GL, true, MASKI, (G::TBL(GL) > 0), (G::TBL(GL) > 0)>(x, t, 0u, pi, gtw + G::TBL_OFF(GL));
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -1713,6 +1749,7 @@ struct ProdArgs {
   void *          team_ctl; /* launch_team_product: device memory for the queues and 2 * batch counters */
   int             team_lag, team_wpc;
   int             four; /* launch_team_product: ahat holds a's COEFFICIENTS; the launch transforms both operands */
+  int             both; /* launch_product, N <= 2^14: the same for the fused product kernels */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
@@ -1937,8 +1974,10 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     cap &= ~((1ull << s0) - 1);
     if(wgs > cap) wgs = cap;
     if(wgs == 0) return hipSuccess;
-    /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) */
-    if(!pa.a_lazy) return hipErrorNotSupported;
+    /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) -- or not
+     * at all: pa.both, whole polynomials, a's coefficients in pa.ahat */
+    if(!pa.a_lazy && !pa.both) return hipErrorNotSupported;
+    if(pa.both && s0 != 0) return hipErrorInvalidValue;
     if(blog < 12) {
       switch(pa.logn) {
 #define NTT_SMALL_PRODUCT(LN)                                                                                       \
@@ -1951,6 +1990,11 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     gcap = gcap / nl > 0 ? gcap / nl : 1;                                                                           \
     if(g > gcap) g = gcap;                                                                                          \
     pp.f.wgs_per_limb = (unsigned)g;                                                                                \
+    if(pa.both) {                                                                                                   \
+      if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true, true>), dim3((unsigned)(g * nl)), dim3(GS::WG), 0, pa.stream, pp); \
+      else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
+      return hipGetLastError();                                                                                     \
+    }                                                                                                               \
     if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true>), dim3((unsigned)(g * nl)), dim3(GS::WG), 0, pa.stream, pp); \
     else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
     return hipGetLastError();                                                                                       \
@@ -1973,6 +2017,11 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       cap12 &= ~((1ull << s0) - 1);
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
       pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(pa.both) {
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        return hipGetLastError();
+      }
       if(nl > 1) {
         if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
@@ -1987,11 +2036,21 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
       if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
       pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(pa.both) {
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G13::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
+        return hipGetLastError();
+      }
       if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G13::WG), 0, pa.stream, pp);
       else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
       return hipGetLastError();
     }
     pp.f.wgs_per_limb = (uint32_t)wgs;
+    if(pa.both) {
+      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      return hipGetLastError();
+    }
     if(nl > 1) {
       if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
       else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);

@@ -139,6 +139,16 @@ struct ArithF64Chk : ArithF64 {
     x = RED ? reduce(s, c) : s;
     y = mulmod_c(wneg, d, c);
   }
+  static val product_rr(val x, val y, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const double   r  = ArithF64::mulmod_c(reduce(y, c), reduce(x, c), c);
+    const __int128 ex = as_int(x) * as_int(y);
+    if((ex - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;      /* r == x * y (mod q), exactly */
+    if(__builtin_fabs(r) > 0.75 * c.q) g_chk_fail++;              /* the bound the inverse plan relies on */
+    return r;
+  }
   template <bool LAZY> static val product_in_domain(val x, uint64_t a, const consts &c)
   {
     see(x, c);
@@ -222,6 +232,10 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false>
 /* the fused product kernel (csrc/ntt_kernels.h fused_product_kernel) step by step: forward transform of b, product
  * with a^ in the last group's layout, inverse transform whose per-lane group reads the FORWARD twiddle table in the
  * LDS layout, mirrored (load_stage_tw MIRROR) */
+/* BOTH forward transforms inside the product kernels (their BOTH variants): `ahat` then holds a's coefficients and is taken
+ * through the same forward stages first (emu_set_product_both) */
+inline bool g_prod_both = false;
+
 template <class A, int LOGN, int KSH, bool ALAZY>
 void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, uint64_t batch, const Params<A> &pf,
                               const Params<A> &pi)
@@ -243,32 +257,40 @@ void emu_fused_product(uint64_t *out, const uint64_t *ahat, const uint64_t *b, u
     }
   }
   std::vector<typename A::val> lds(P::LDS_ELEMS);
-  std::vector<Regs<A>>         regs(P::T);
-  for(uint64_t pb = 0; pb < batch; pb++) {
-    const uint64_t *bb = b + (pb << LOGN);
+  std::vector<Regs<A>>         regs(P::T), regsa(P::T);
+  const bool both = g_prod_both;
+  const auto forward = [&](std::vector<Regs<A>> &rg, const uint64_t *src) {
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
-      global_load_first<A, LOGN, false>(regs[t].x, t, bb, false, pf.c);
-      run_group<A, LOGN, 0, false, MASKF>(regs[t].x, t, 0u, pf);
+      global_load_first<A, LOGN, false>(rg[t].x, t, src, false, pf.c);
+      run_group<A, LOGN, 0, false, MASKF>(rg[t].x, t, 0u, pf);
     }
     static_for<0, P::NG - 1>([&](auto gg) {
       constexpr int G = decltype(gg)::value;
-      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(rg[t].x, t, lds.data());
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
-        lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+        lds_gather<A, LOGN, G, G + 1>(rg[t].x, t, lds.data());
         if constexpr(G + 1 == GL) {
           typename A::ctw pre[4][kE / 2];
           preload_group_tw<A, LOGN, GL>(pre, t, 0u, pf);
-          run_group_preloaded<A, LOGN, GL, MASKF>(regs[t].x, pre, pf);
+          run_group_preloaded<A, LOGN, GL, MASKF>(rg[t].x, pre, pf);
         } else if constexpr(G + 1 == GT) {
-          run_group<A, LOGN, G + 1, false, MASKF, true>(regs[t].x, t, 0u, pf, table.data());
+          run_group<A, LOGN, G + 1, false, MASKF, true>(rg[t].x, t, 0u, pf, table.data());
         } else {
-          run_group<A, LOGN, G + 1, false, MASKF>(regs[t].x, t, 0u, pf);
+          run_group<A, LOGN, G + 1, false, MASKF>(rg[t].x, t, 0u, pf);
         }
       }
     });
+  };
+  for(uint64_t pb = 0; pb < batch; pb++) {
+    if(both) forward(regsa, ahat + (pb << LOGN));
+    forward(regs, b + (pb << LOGN));
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
       const uint32_t ib = P::IBASE(GL, t);
       for(int e = 0; e < kE; e++) {
+        if(both) {
+          regs[t].x[e] = A::product_rr(regs[t].x[e], regsa[t].x[e], pf.c);
+          continue;
+        }
         const uint64_t aw = ahat[(pb << LOGN) + ib + P::IOFF(GL, e)];
         regs[t].x[e]      = A::template product_in_domain<ALAZY>(regs[t].x[e], aw, pf.c);
       }
@@ -336,24 +358,32 @@ void emu_fused_product_small(uint64_t *out, const uint64_t *ahat, const uint64_t
     }
   });
   std::vector<typename A::val> lds(P::LDS_ELEMS);
-  std::vector<Regs<A>>         regs(P::T);
-  for(uint64_t pb = 0; pb < batch; pb++) {
-    const uint64_t *bb = b + (pb << LOGN);
+  std::vector<Regs<A>>         regs(P::T), regsa(P::T);
+  const bool both = g_prod_both;
+  const auto forward = [&](std::vector<Regs<A>> &rg, const uint64_t *src) {
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
-      global_load_first<A, LOGN, false>(regs[t].x, t, bb, false, pf.c);
-      run_group<A, LOGN, 0, false, MASKF, (emu_tbl<LOGN>(0) > 0)>(regs[t].x, t, 0u, pf, table.data());
+      global_load_first<A, LOGN, false>(rg[t].x, t, src, false, pf.c);
+      run_group<A, LOGN, 0, false, MASKF, (emu_tbl<LOGN>(0) > 0)>(rg[t].x, t, 0u, pf, table.data());
     }
     static_for<0, P::NG - 1>([&](auto gg) {
       constexpr int G = decltype(gg)::value;
-      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(rg[t].x, t, lds.data());
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
-        lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
-        run_group<A, LOGN, G + 1, false, MASKF, (emu_tbl<LOGN>(G + 1) > 0)>(regs[t].x, t, 0u, pf, table.data() + emu_tbl_off<LOGN>(G + 1));
+        lds_gather<A, LOGN, G, G + 1>(rg[t].x, t, lds.data());
+        run_group<A, LOGN, G + 1, false, MASKF, (emu_tbl<LOGN>(G + 1) > 0)>(rg[t].x, t, 0u, pf, table.data() + emu_tbl_off<LOGN>(G + 1));
       }
     });
+  };
+  for(uint64_t pb = 0; pb < batch; pb++) {
+    if(both) forward(regsa, ahat + (pb << LOGN));
+    forward(regs, b + (pb << LOGN));
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
       const uint32_t ib = P::IBASE(GL, t);
       for(int e = 0; e < kE; e++) {
+        if(both) {
+          regs[t].x[e] = A::product_rr(regs[t].x[e], regsa[t].x[e], pf.c);
+          continue;
+        }
         const uint64_t aw = ahat[(pb << LOGN) + ib + P::IOFF(GL, e)];
         regs[t].x[e]      = A::template product_in_domain<true>(regs[t].x[e], aw, pf.c);
       }
@@ -622,6 +652,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 }
 
 void emu_set_lazy(int on) { g_lazy = on != 0; }
+void emu_set_product_both(int on) { g_prod_both = on != 0; }
 
 #ifndef EMU_SAN_BUILD
 /* out = inv(fwd(b) * ahat) for polynomials of 2^14 points, as the fused product kernel computes it.  ahat: fwd(a),

@@ -23,6 +23,7 @@ class Emu:
         L.emu_chk_stats.argtypes = [U64P, C.c_int]
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
+        L.emu_set_product_both.argtypes = [C.c_int]
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
         L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
@@ -36,22 +37,27 @@ class Emu:
         self.lib.emu_set_lazy(0)
         return rc, a
 
-    def fused_product14(self, ahat, b, q, root, a_lazy=False, chk=False):
-        """inv(fwd(b) * ahat) as the fused product kernel computes it (N = 2^14)"""
+    def fused_product14(self, ahat, b, q, root, a_lazy=False, chk=False, both=False):
+        """inv(fwd(b) * ahat) as the fused product kernel computes it (N = 2^14); both: `ahat` holds a's COEFFICIENTS and
+        the kernel takes them through the forward stages too (its BOTH variant)"""
         ahat = np.ascontiguousarray(ahat, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
         out = np.zeros_like(b)
+        self.lib.emu_set_product_both(int(both))
         rc = self.lib.emu_fused_product14(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
                                           b.size >> 14, q, root, int(a_lazy), int(chk))
+        self.lib.emu_set_product_both(0)
         return rc, out
 
-    def fused_product_chk(self, ahat, b, m, q, root):
-        """inv(fwd(b) * ahat) as the product kernels for N = 2^8 .. 2^13 compute it, checked policy"""
+    def fused_product_chk(self, ahat, b, m, q, root, both=False):
+        """inv(fwd(b) * ahat) as the product kernels for N = 2^8 .. 2^13 compute it, checked policy (both: as above)"""
         ahat = np.ascontiguousarray(ahat, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
         out = np.zeros_like(b)
+        self.lib.emu_set_product_both(int(both))
         rc = self.lib.emu_fused_product_chk(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
                                             b.size >> m, m, q, root)
+        self.lib.emu_set_product_both(0)
         return rc, out
 
     def expand_radix4(self, w, q):

@@ -283,6 +283,10 @@ def test_fused_product_kernel_logic(oracle, emu, q):
         for chk in (True, False):
             rc, c = emu.fused_product14(ahat, b, q, w, a_lazy=lazy, chk=chk)
             assert rc == 0 and np.array_equal(c, expect), (lazy, chk)
+    # the BOTH variant: a's coefficients go through the forward stages inside the kernel, the factors meet in registers
+    for chk in (True, False):
+        rc, c = emu.fused_product14(a, b, q, w, a_lazy=True, chk=chk, both=True)
+        assert rc == 0 and np.array_equal(c, expect), ("both", chk)
     fails, maxb, maxr = emu.chk_stats()
     assert fails == 0
 
@@ -309,6 +313,8 @@ def test_fused_product_kernels_other_sizes_logic(oracle, emu, m):
         assert rc == 0
         rc, c = emu.fused_product_chk(ahat, b, m, q, w)
         assert rc == 0 and np.array_equal(c, expect), (m, hex(q))
+        rc, c = emu.fused_product_chk(a, b, m, q, w, both=True)     # both forward transforms inside the kernel
+        assert rc == 0 and np.array_equal(c, expect), ("both", m, hex(q))
         fails, maxb, maxr = emu.chk_stats()
         assert fails == 0, (m, hex(q))
 

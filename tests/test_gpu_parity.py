@@ -904,10 +904,11 @@ def test_full_batch_forward_cross_check(lib, oracle, kat, m, bits, batch):
 @pytest.mark.parametrize("m", [14, 13, 12, 11, 10, 9, 8])
 @pytest.mark.parametrize("q", [0x7fffffffe0001, 0x80000001c0001, 0x3ffffffdf0001, 0x7ffe0001, 0xffffffff00001])
 def test_fused_product_kernel(lib, oracle, q, m):
-    """N = 2^8 .. 2^14, FP64: negacyclic_mul = fwd(a) + ONE kernel (fwd(b) * a^ -> inverse, b never leaves the CU);
-    equals the oracle's inv(fwd(a) . fwd(b)), the four-launch chain (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial,
-    the schoolbook product; all aliasing forms; batches around the persistent grid.  (0xffffffff00001: a 52-bit prime,
-    served by the reduce-both-operands FP64 policy.)"""
+    """N = 2^8 .. 2^14, FP64: negacyclic_mul = ONE kernel (a and b through the forward stages, product in registers,
+    inverse; neither transform ever leaves the CU) -- or, NTT_OPT_FUSED_PRODUCT 2, fwd(a) by a launch of its own + ONE
+    kernel (fwd(b) * a^ -> inverse); both equal the oracle's inv(fwd(a) . fwd(b)), the four-launch chain
+    (NTT_OPT_FUSED_PRODUCT 0) and, for one polynomial, the schoolbook product; all aliasing forms; batches around the
+    persistent grid.  (0xffffffff00001: a 52-bit prime, served by the reduce-both-operands FP64 policy.)"""
     n = 1 << m
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
@@ -924,18 +925,22 @@ def test_fused_product_kernel(lib, oracle, q, m):
         expect = cx.inv(oracle.pointwise(cx.fwd(a[pick]), cx.fwd(b[pick]), q))
         da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
         outs = []
-        for fused in (1, 0):
+        for fused in (1, 2, 0):
             plan.set_option(lib.OPT_FUSED_PRODUCT, fused)
             da.upload(a), db.upload(b)
             plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
             outs.append(dc.download())
-        assert np.array_equal(outs[0], outs[1]), batch
+            if fused == 1:
+                assert np.array_equal(da.download(), a), batch      # the one-launch form only reads a
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), batch
         assert np.array_equal(outs[0][pick], expect), batch
+        for fused in (1, 2):
+            plan.set_option(lib.OPT_FUSED_PRODUCT, fused)
+            for alias in ("a", "b"):
+                da.upload(a), db.upload(b)
+                plan.negacyclic_mul((da if alias == "a" else db).ptr, da.ptr, db.ptr, batch)
+                assert np.array_equal((da if alias == "a" else db).download(), outs[0]), (batch, alias, fused)
         plan.set_option(lib.OPT_FUSED_PRODUCT, 1)
-        for alias in ("a", "b"):
-            da.upload(a), db.upload(b)
-            plan.negacyclic_mul((da if alias == "a" else db).ptr, da.ptr, db.ptr, batch)
-            assert np.array_equal((da if alias == "a" else db).download(), outs[0]), (batch, alias)
         da.upload(a)
         plan.negacyclic_mul(dc.ptr, da.ptr, da.ptr, batch)          # squaring takes the four-launch chain
         if batch == 1:

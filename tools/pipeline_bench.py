@@ -40,9 +40,10 @@ for _ in range(a.steps):
 ms = tot / a.steps
 prods = a.batch / (ms * 1e-3)
 # algorithmic bytes of a limb-product: SURVEY 8d's fused figure, 56N (fwd a 16N + fwd b 16N + product fused into the
-# inverse 24N); what the launches actually move is 40N for N <= 2^14 and 88N above
+# inverse 24N); what the launches actually move: see below
 byts = 56 * n * a.limbs * a.batch / (ms * 1e-3)
-moved = (40 if a.logn <= 14 else 88) * n * a.limbs * a.batch / (ms * 1e-3)
+# (one-launch products: 24N up to 2^14; 48N across the fabric from 2^23 coefficients per operand on, else 88N)
+moved = (24 if a.logn <= 14 else (48 if a.batch * n >= (1 << 23) and a.batch >= 64 else 88)) * n * a.limbs * a.batch / (ms * 1e-3)
 print("N=2^%d limbs=%d batch=%d %s: %.3f ms/step  %.0f RNS products/s  %.3f M limb-products/s  %.0f GB/s of 56N algorithmic bytes "
       "per limb-product = %.3f of 8 TB/s (bytes moved by the launches: %.0f GB/s)"
       % (a.logn, a.limbs, a.batch, "NTT_RNS_LOOP=" + os.environ.get("NTT_RNS_LOOP", "auto"), ms, prods, prods * a.limbs / 1e6,

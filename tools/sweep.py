@@ -57,7 +57,10 @@ for qs in a.qs:
                 lib.stream_sync(); e0.record()
                 for _ in range(a.steps): run()
                 e1.record(); ms = e1.elapsed_ms_since(e0) / a.steps
-                per = {"fwd": 16, "inv": 16, "fwdlazy": 16, "invlazy": 16, "mul": 56}[op] * n      # algorithmic bytes per polynomial (product: the fused figure 56N)
+                # algorithmic bytes per polynomial: a transform reads and writes every coefficient once; a product
+                # reads a and b and writes c -- 24N, what the one-launch product kernels actually move up to N = 2^14 (SURVEY's
+                # 56N counted three separate transforms; with it the small sizes would show fractions above 1)
+                per = {"fwd": 16, "inv": 16, "fwdlazy": 16, "invlazy": 16, "mul": 24}[op] * n
                 gbs = batch * per / ms / 1e6
                 print("%-6d %-18s %-5s %-7s %10d %12.3f %9.0f %6.3f" % (ln, qs, (["auto","u64","f64","r4"][plan.info()["arith"]] + ("w" if plan.info()["f64_class"] == 52 else "")), op, batch, batch / ms / 1e3, gbs, gbs / 8000))
             for b in bufs: b.free()
