@@ -80,8 +80,8 @@ typedef enum ntt_option {
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
                           * operands through the forward stages, multiplies in registers and runs the inverse (24N bytes
                           * up to 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise, 48N bytes across the
-                          * fabric; smaller batches of N >= 2^15: fwd(a), then block by block between column passes, 88N
-                          * bytes); 2 = a's forward transform always as a launch of its own in front of the fused
+                          * fabric; smaller batches of N >= 2^15: block by block between the column passes of both
+                          * operands, 72N bytes); 2 = a's forward transform always as a launch of its own in front of the fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14); 0 = fwd, fwd, pointwise, inv (72N / 120N
                           * bytes).  Results are identical. */
 } ntt_option;

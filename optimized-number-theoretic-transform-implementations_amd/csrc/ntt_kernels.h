@@ -1253,14 +1253,14 @@ template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_pro
  * 88N bytes instead of 120N.  A workgroup then always sees the same block position (its stride is a multiple of the
  * blocks per polynomial), whose forward table slice it keeps in LDS; the mirrored read would need the slice of the
  * complementary position, so the inverse half takes that one group's twiddles from global memory instead. */
-/* BOTH (whole polynomials): pp.ahat holds a's COEFFICIENTS and the kernel takes them through the forward stages too -- a^
+/* BOTH: pp.ahat holds a's COEFFICIENTS (blocks of a larger product: a after its column passes) and the kernel takes them through the forward stages too -- a^
  * waits, as doubles, in the 32 VGPRs that hold the prefetched a^ words otherwise, so the register budget is the same; a^
  * never exists in memory (24N instead of 40N bytes per product, one launch instead of two) and a is left untouched. */
 template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false, bool BOTH = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_kernel(const KProd<A> kp)
 {
-  static_assert(!BOTH || WHOLE, "both forward transforms in the kernel: whole polynomials only");
+  /* (!WHOLE && BOTH: the blocks of a larger product; pp.ahat then holds what a's column passes left, as pf.a does for b) */
   uint32_t            bid, gdim;
   const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
   using P = Plan<LOGN>;
@@ -1977,7 +1977,7 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     /* a^ always arrives as the lazy words ntt_fwd_batch_lazy leaves (the canonical-operand variant is not built) -- or not
      * at all: pa.both, whole polynomials, a's coefficients in pa.ahat */
     if(!pa.a_lazy && !pa.both) return hipErrorNotSupported;
-    if(pa.both && s0 != 0) return hipErrorInvalidValue;
+    if(pa.both && s0 != 0 && blog != 12 && blog != 14) return hipErrorInvalidValue;
     if(blog < 12) {
       switch(pa.logn) {
 #define NTT_SMALL_PRODUCT(LN)                                                                                       \
@@ -2018,8 +2018,13 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
       pp.f.wgs_per_limb = (uint32_t)wgs;
       if(pa.both) {
-        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
-        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        if(s0 == 0) {
+          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+          else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        } else {
+          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+          else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        }
         return hipGetLastError();
       }
       if(nl > 1) {
@@ -2047,8 +2052,13 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     }
     pp.f.wgs_per_limb = (uint32_t)wgs;
     if(pa.both) {
-      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
-      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      if(s0 == 0) {
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      } else {
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      }
       return hipGetLastError();
     }
     if(nl > 1) {
