@@ -157,6 +157,35 @@ NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const
 NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a,
                                      uint64_t *d_b, uint64_t batch, void *stream);
 
+/* ---- operands that already ARE in the NTT domain ("fusing the multiply into the inverse's first load
+ * saves 16N bytes").  Keys, plaintexts and ciphertexts of an FHE caller live in the NTT domain (bit-reversed order, as
+ * ntt_fwd_batch leaves them); what such a caller issues is the element-wise product of two transformed operands, or the
+ * inner product of a digit-decomposed ciphertext with a key, followed by ONE inverse transform.  The reference's
+ * primitive for it is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60) in a loop of its own in front of
+ * inv_ntt_*; here the products are formed inside the inverse transform's first pass, so neither the product nor the sum
+ * ever exists in memory.
+ *   flags: NTT_MUL_LAZY_IN      transformed operand words may be LAZY -- anywhere in [0,4q) (ntt_fwd_batch_lazy outputs, the
+ *                               reference's *_lazy range, include/ntt_reference.h:13-17) -- instead of canonical
+ *                               ([0,q)); ntt_mul_transformed_batch additionally needs them below 2^53
+ *          NTT_MUL_B_BROADCAST  every d_bhat[i] is ONE polynomial (N words; RNS: [limb][N]) shared by all polynomials of
+ *                               the batch: a key.  Traffic 8kN + 8N instead of 16kN + 8N bytes per output polynomial.
+ * Outputs are canonical coefficients in natural order, exactly inv_ntt_ref_harvey(pointwise products) of the reference. */
+enum { NTT_MUL_LAZY_IN = 1, NTT_MUL_B_BROADCAST = 2 };
+/* c = inv( a^ (.) b^ ): ONE launch up to N = 2^14 (24N bytes instead of 40N for pointwise + inverse); above, the product
+ * rides in the first pass of the inverse (40N instead of 56N).  d_c may alias d_ahat or d_bhat (not a broadcast b^). */
+NTT_API int ntt_inv_product_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_ahat, const uint64_t *d_bhat,
+                                  uint64_t batch, unsigned flags, void *stream);
+/* c = inv( sum_{i<k} a_i^ (.) b_i^ ), 1 <= k <= 32 (key switching: digits x key): d_ahat / d_bhat are HOST arrays of k
+ * device pointers, each operand laid out [batch][N].  Reads 16kN bytes (8kN with a broadcast key), writes 8N, one
+ * inverse transform.  For k > 1 d_c must not overlap any operand. */
+NTT_API int ntt_inv_dot_batch(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                              const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream);
+/* c = inv( fwd(a) (.) b^ ): a in coefficients, b^ transformed beforehand (a plaintext or key kept in the NTT domain).  One
+ * launch that takes a through the forward stages, multiplies by b^ in registers and runs the inverse (24N bytes up to
+ * 2^14).  d_a is left as it was up to N = 2^14 and OVERWRITTEN (scratch) above; d_c may alias d_a or d_bhat. */
+NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
+                                      unsigned flags, void *stream);
+
 /* ---- RNS limbs (BASELINE config 5: 4-prime RNS pipeline).  plans[l] is the plan of
  * prime q_l (same N, same device); data layout is [limb][batch][N], i.e. limb l of
  * every polynomial is the contiguous [batch][N] slab at d_x + l*batch*N.  Each limb is
@@ -170,6 +199,11 @@ NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a,
 NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
                                          uint64_t *d_b, uint64_t batch, void *stream);
+/* the NTT-domain products above over RNS limbs: every operand laid out [limb][batch][N] (a broadcast b^: [limb][N]) */
+NTT_API int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                                  const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream);
+NTT_API int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                          uint64_t batch, unsigned flags, void *stream);
 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);

@@ -141,6 +141,15 @@ struct ArithU64 {
   }
   /* lazy operands (any 64-bit values): the two Shoup folds accept them as they are */
   static NTT_HD uint64_t mulmod_full_lazy4(uint64_t a, uint64_t b, const consts &c) { return mulmod_full(a, b, c); }
+  /* Inner product in the NTT domain, c = inv(sum_i a_i^ (.) b_i^), in front of the inverse transform's first stage
+   * (dot_inv_kernel; generalises fast_mul_mod_q, include/internal/fast_mul_operators.h:56-60, to operand pairs).  One term
+   * from two stored words -- canonical or lazy alike for this policy -- is fully reduced; the running sum is kept in
+   * [0,q) by one conditional subtract per term: a valid input ([0,2q)) of the inverse butterflies. */
+  static constexpr int kDotEvery = 1 << 30; /* terms between two folds of the running sum: never needed */
+  static constexpr int kDotChunk = 2;       /* products the kernel lets the scheduler interleave (register budget) */
+  template <bool LAZY> static NTT_HD val dot_term(uint64_t a, uint64_t b, const consts &c) { return mulmod_full(a, b, c); }
+  static NTT_HD val dot_acc(val acc, val t, const consts &c) { return csub(acc + t, c.q); }
+  static NTT_HD val dot_fold(val acc, const consts &) { return acc; }
 };
 
 /* ------------------------------------------------------------------ */
@@ -456,6 +465,29 @@ struct ArithF64 {
     const double d     = fma_(-k, c.q, h);
     return to_canonical(d + l, c);
   }
+  /* Inner product in the NTT domain: c = inv(sum_i a_i^ (.) b_i^) with the products formed where the inverse transform
+   * would convert its input words (dot_inv_kernel).  One term from two STORED words -- canonical [0,q) or, LAZY, anywhere
+   * in [0,4q) (folded below 2q with integer operations first: 4q may exceed 2^53 just above 2^51) --: only b is reduced
+   * to |y| <= q/2 (three exact instructions); with |x| < q the quotient estimate from the rounded product is within
+   * 1/2 + 1.5 |x y / q| 2^-52 <= 1/2 + 1.5 theta2 of the truth (theta2 = q / 2^53 <= 0.2503), so |r| <= 0.8755 q, h - k q is
+   * an integer below 1.01 q < 2^53 and the result is exact (the argument of DESIGN.md 4.1 / 4.8).  A single term is a valid
+   * input of the inverse reduction plan (which assumes 1); a running sum is folded back to |.| <= q/2 every kDotEvery
+   * terms, 1/2 + 3 * 0.8755 = 3.13 staying below every class's exactness limit (3.87 q for q ~ 2^51), and once at the end. */
+  static constexpr int kDotEvery = 3;
+  static constexpr int kDotChunk = 4; /* products the kernel lets the scheduler interleave (register budget) */
+  template <bool LAZY> static NTT_HD val dot_term(uint64_t a, uint64_t b, const consts &c)
+  {
+    if(LAZY) {
+      a = a < 2 * c.qi ? a : a - 2 * c.qi;
+      b = b < 2 * c.qi ? b : b - 2 * c.qi;
+    }
+    const double x0 = u64_to_f64_lt52(a), y0 = u64_to_f64_lt52(b);
+    const double x  = LAZY ? x0 - c.q : x0;
+    const double y  = reduce(LAZY ? y0 - c.q : y0, c);
+    return mulmod_c(y, x, c);
+  }
+  static NTT_HD val dot_acc(val acc, val t, const consts &) { return acc + t; }
+  static NTT_HD val dot_fold(val acc, const consts &c) { return reduce(acc, c); }
 };
 
 /* ------------------------------------------------------------------ */
@@ -525,6 +557,23 @@ template <class Base> struct WideF64 : Base {
   }
   /* 4q exceeds 2^53: no lazy form; reduced outputs satisfy the lazy contract */
   static NTT_HD uint64_t store_fwd_lazy(val v, const consts &c) { return Base::store_fwd(v, c); }
+  /* inner-product terms (see ArithF64::dot_term): BOTH factors reduced to |.| <= q/2, so the quotient estimate is within
+   * 1/2 + 1.5 (q/4) 2^-52 = 1/2 + 0.75 theta2 <= 0.875 of the truth for theta2 = q / 2^53 up to 1/2: |r| <= 0.875 q, a valid
+   * operand of this policy's inverse butterflies (pairs of products: 1.75 q < 2^53); the running sum is folded after
+   * every term: 1/2 + 0.875 < 2 */
+  static constexpr int kDotEvery = 1;
+  static constexpr int kDotChunk = 2;
+  template <bool LAZY> static NTT_HD val dot_term(uint64_t a, uint64_t b, const consts &c)
+  {
+    if(LAZY) {
+      a = a < 2 * c.qi ? a : a - 2 * c.qi;
+      b = b < 2 * c.qi ? b : b - 2 * c.qi;
+    }
+    const double x0 = Base::u64_to_f64_lt52(a), y0 = Base::u64_to_f64_lt52(b);
+    const double x  = Base::reduce(LAZY ? x0 - c.q : x0, c);
+    const double y  = Base::reduce(LAZY ? y0 - c.q : y0, c);
+    return Base::mulmod_c(y, x, c);
+  }
 };
 using ArithF64W = WideF64<ArithF64>;
 

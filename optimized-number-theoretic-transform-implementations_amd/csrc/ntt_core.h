@@ -866,6 +866,64 @@ NTT_HD void convert_inputs(typename A::val (&x)[kE], const uint64_t (&raw)[kE], 
   }
 }
 
+/* Inner product in the NTT domain (dot_inv_kernel): the thread's 16 slots of one operand pair a_i^, b_i^ as raw words
+ * (last-kind layout: what the inverse transform's first group consumes) become the first term of the running sums
+ * (FIRST) or are added to them.  lazy: the words may be anywhere in [0,4q) -- ONE wave-uniform branch around the tile. */
+NTT_HD void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0); /* the scheduler moves nothing across this point */
+#endif
+}
+/* slots [E0, E1) of the tile */
+template <class A, int E0, int E1>
+NTT_HD void dot_slots(typename A::val (&x)[kE], const uint64_t (&ra)[kE], const uint64_t (&rb)[kE], bool lazy,
+                      const typename A::consts &c)
+{
+  if(lazy) {
+    static_for<E0, E1>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      x[E]            = A::dot_acc(x[E], A::template dot_term<true>(ra[E], rb[E], c), c);
+    });
+  } else {
+    static_for<E0, E1>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      x[E]            = A::dot_acc(x[E], A::template dot_term<false>(ra[E], rb[E], c), c);
+    });
+  }
+}
+/* slots [E0, E1) of the tile, CH at a time: on the device the scheduler is fenced between the chunks, so that at most CH
+ * products are in flight (each holds about ten temporaries next to the 64 registers of words and the 32 running sums) */
+template <class A, int E0 = 0, int E1 = kE, int CH = A::kDotChunk>
+NTT_HD void dot_tile(typename A::val (&x)[kE], const uint64_t (&ra)[kE], const uint64_t (&rb)[kE], bool lazy,
+                     const typename A::consts &c)
+{
+  static_for<0, (E1 - E0) / CH>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    sched_fence();
+    dot_slots<A, E0 + C * CH, E0 + C * CH + CH>(x, ra, rb, lazy, c);
+    sched_fence();
+  });
+}
+template <class A> NTT_HD void dot_fold_tile(typename A::val (&x)[kE], const typename A::consts &c)
+{
+  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::dot_fold(x[decltype(ee)::value], c); });
+}
+/* raw words of a block in the last-kind layout (runs of 2^RL consecutive indices per lane, 16-byte loads), slots [E0, E1) */
+template <int LOGN, int E0 = 0, int E1 = kE> NTT_HD void load_last_raw(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  static_assert(E0 % 2 == 0 && E1 % 2 == 0, "slots come in pairs");
+  static_for<E0 / 2, E1 / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    const u64x2   v = stream_load2(coef_at(blk + P::IOFF(G, E), ib));
+    raw[E]          = v.a;
+    raw[E + 1]      = v.b;
+  });
+}
+
 /* first-kind group: slot e <-> index (e << LT) + t : 8-byte coalesced */
 template <class A, int LOGN, bool INV>
 NTT_HD void global_load_first(typename A::val (&x)[kE], uint32_t t, const uint64_t *blk,

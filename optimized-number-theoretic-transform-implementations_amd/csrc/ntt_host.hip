@@ -45,6 +45,11 @@ template <> hipError_t launch_team_product<ArithF64, 0>(const ProdArgs &);
 template <> hipError_t launch_team_product<ArithF64, 1>(const ProdArgs &);
 template <> hipError_t launch_team_product<ArithF64, 18>(const ProdArgs &);
 template <> hipError_t launch_team_product<ArithF64W, 0>(const ProdArgs &);
+template <> hipError_t launch_dot<ArithU64, 0>(const DotArgs &);
+template <> hipError_t launch_dot<ArithF64, 0>(const DotArgs &);
+template <> hipError_t launch_dot<ArithF64, 1>(const DotArgs &);
+template <> hipError_t launch_dot<ArithF64, 18>(const DotArgs &);
+template <> hipError_t launch_dot<ArithF64W, 0>(const DotArgs &);
 } // namespace ntt
 
 /* ------------------------------------------------------------------ */
@@ -231,10 +236,14 @@ struct ntt_plan {
   int        team_lag = 0, team_wpc = 0; /* 0 = the kernel's defaults */
   struct TeamBuf {
     void * stream;
-    void * d;
+    void * d;       /* block of the direct launches on this stream */
     size_t bytes;
+    void * g;       /* block of the launches CAPTURED on this stream: its address is baked into graph nodes, so it is never
+                     * freed, regrown or shared with direct launches before the plan is destroyed */
+    size_t gbytes;
   };
   std::vector<TeamBuf> team_bufs;
+  std::vector<void *>  team_retired; /* outgrown direct blocks: launches still queued may use them, freed with the plan */
   std::mutex           team_mu;
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
@@ -530,7 +539,11 @@ extern "C" void ntt_plan_destroy(ntt_plan *p)
   if(p->d_inv) (void)hipFree(p->d_inv);
   if(p->d_fwd8) (void)hipFree(p->d_fwd8);
   if(p->d_inv8) (void)hipFree(p->d_inv8);
-  for(const ntt_plan::TeamBuf &tb : p->team_bufs) (void)hipFree(tb.d);
+  for(const ntt_plan::TeamBuf &tb : p->team_bufs) {
+    if(tb.d) (void)hipFree(tb.d);
+    if(tb.g) (void)hipFree(tb.g);
+  }
+  for(void *d : p->team_retired) (void)hipFree(d);
   if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
@@ -543,12 +556,15 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[2] = (uint64_t)p->m;
   info[3] = (uint64_t)p->arith;
   info[4] = p->kcls == kWideClass ? 52u : (uint64_t)p->kcls; /* 52: the reduce-both-operands policy for q up to 2^52 */
-  /* launches (= passes over the data) of one forward transform of a large batch: 1 where the two-phase kernel is the
-   * default (2^16 forward, scheduled FP64 policy) or forced, else the pass list's length */
+  /* launches (= passes over the data) of one forward transform of a large batch: 1 where one launch carries both passes --
+   * the XCD-local kernel (FP64 policies, N = 2^15..2^17, unless switched off: its automatic choice takes forward
+   * transforms of 512 polynomials or more) or the two-phase kernel where it is forced -- else the pass list's length */
   {
-    const bool tp = !p->generic && p->arith == NTT_ARITH_F64 && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3 &&
+    const bool f64big = !p->generic && p->arith == NTT_ARITH_F64;
+    const bool team   = f64big && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && p->xcd_local != 0;
+    const bool tp     = f64big && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3 &&
                     (p->two_phase == 1 || (p->two_phase < 0 && p->m == kFusedMax + 2 && p->kcls != kWideClass));
-    info[5] = tp ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
+    info[5] = (team || tp) ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
   }
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
@@ -663,7 +679,15 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
   return !inverse && batch >= 512;
 }
 
-/* the stream's control block, at least sizeof(TeamCtl) + batch counters */
+/* The stream's control block, at least sizeof(TeamCtl) + batch counters.
+ * A (plan, stream) pair owns TWO blocks, both allocated by the first direct (uncaptured) call: one for direct launches
+ * and one for launches captured into HIP graphs.  A captured launch bakes the block's address into its memset and kernel
+ * nodes, so the graph block is never freed or regrown while the plan lives, and direct launches never touch it: a graph
+ * replayed on another stream cannot collide with direct calls on the capture stream.  (Two graphs captured on the same
+ * plan and stream share the graph block: replay them one after the other, not concurrently -- INTEGRATION.md.)
+ * Nothing here synchronises the device: an outgrown direct block is retired, not freed (launches still queued may be
+ * using it), and released with the plan.  While capturing nothing is allocated (not capturable): without a graph block of
+ * sufficient size *out stays null and the caller takes the per-pass launches. */
 static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
 {
   const size_t need = sizeof(TeamCtl) + (size_t)batch * sizeof(unsigned);
@@ -671,24 +695,31 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   *out = nullptr;
-  for(ntt_plan::TeamBuf &tb : p->team_bufs) {
-    if(tb.stream != stream) continue;
-    if(tb.bytes < need) {
-      if(capturing) return NTT_OK; /* (no buffer: the caller takes the other path) */
-      HIP_TRY(hipFree(tb.d)); /* (waits for the launches that still use it) */
-      tb.d     = nullptr;
-      tb.bytes = 0;
-      HIP_TRY(hipMalloc(&tb.d, need * 2));
-      tb.bytes = need * 2;
-    }
-    *out = tb.d;
+  ntt_plan::TeamBuf *tb = nullptr;
+  for(ntt_plan::TeamBuf &t : p->team_bufs) {
+    if(t.stream == stream) tb = &t;
+  }
+  if(capturing) {
+    if(tb && tb->g && tb->gbytes >= need) *out = tb->g;
     return NTT_OK;
   }
-  if(capturing) return NTT_OK;
-  void *d = nullptr;
-  HIP_TRY(hipMalloc(&d, need * 2));
-  p->team_bufs.push_back(ntt_plan::TeamBuf{stream, d, need * 2});
-  *out = d;
+  if(!tb) {
+    p->team_bufs.push_back(ntt_plan::TeamBuf{stream, nullptr, 0, nullptr, 0});
+    tb = &p->team_bufs.back();
+  }
+  if(tb->bytes < need) {
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, need * 2));
+    if(tb->d) p->team_retired.push_back(tb->d);
+    tb->d     = d;
+    tb->bytes = need * 2;
+  }
+  if(!tb->g) {
+    /* the graph block is sized once, by the first direct call (run the largest batch once before capturing) */
+    HIP_TRY(hipMalloc(&tb->g, tb->bytes));
+    tb->gbytes = tb->bytes;
+  }
+  *out = tb->d;
   return NTT_OK;
 }
 
@@ -898,6 +929,24 @@ __global__ void __launch_bounds__(256) pointwise_kernel(uint64_t *c, const uint6
   }
 }
 
+/* c = (ACC ? c : 0) + a * b: the unfused form of the inner product in the NTT domain (plans the fused kernel is not built
+ * for: column-pass-only plans, the radix-4 formulation, N < 2^6).  bmask = N - 1 when b is ONE polynomial shared by the
+ * batch, else all ones. */
+template <class A, bool LAZYIN, bool ACC>
+__global__ void __launch_bounds__(256) pointwise_acc_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t bmask,
+                                                            uint64_t q, const typename A::consts k)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t t = LAZYIN ? A::mulmod_full_lazy4(a[i], b[i & bmask], k) : A::mulmod_full(a[i], b[i & bmask], k);
+    if constexpr(ACC) {
+      const uint64_t v = c[i] + t; /* both canonical: < 2q < 2^64 */
+      c[i]             = v < q ? v : v - q;
+    } else {
+      c[i] = t;
+    }
+  }
+}
+
 static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
 {
   uint64_t g = (n + 255) / 256;
@@ -973,8 +1022,10 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
  *              (120N and 7 launches for fwd, fwd, pointwise, inv).
  *   N > 2^14, 2^23 coefficients per operand or more: everything, both forward transforms included, as the items of
  *              ONE launch (team_product_kernel<..., FOUR>): a^ never exists in memory.        48N bytes, 1 launch. */
+/* ahat_given: d_a already holds a^ = fwd(a) (canonical or lazy words below 2^53): c = inv(fwd(b) (.) a^), the three-pass
+ * forms of the kernels (ntt_mul_transformed_batch) */
 static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream,
-                         const LimbSet *set = nullptr)
+                         const LimbSet *set = nullptr, bool ahat_given = false)
 {
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   /* a^ = fwd(a).  The product kernels take a^ as lazy words v + 2q, v in (-2q, 2q); a canonical word c is the lazy word of
@@ -991,14 +1042,14 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch, &ctl);
     if(rc) return rc;
   }
-  const bool four = ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  const bool four = !ahat_given && ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
   /* N <= 2^14: a's coefficients go straight into the fused kernel, which takes both operands through the forward
    * stages (24N instead of 40N bytes, one launch; a is left as it was) */
   /* N > 2^14 below the one-launch form's batch: the same inside the block launch of every chunk -- a gets b's column
    * passes and the blocks of both operands meet in registers (72N instead of 88N bytes, 6 launches per chunk, no
    * transform of a in front) */
-  const bool both = !four && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
-  if(!four && !both) {
+  const bool both = !ahat_given && !four && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  if(!four && !both && !ahat_given) {
     rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
     if(rc) return rc;
   }
@@ -1207,6 +1258,208 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
   for(int l = 0; !rc && l < nlimbs; l++) {
     const uint64_t off = (uint64_t)l * batch * plans[l]->N;
     rc                 = ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);
+  }
+  return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* products of operands that are in the NTT domain      */
+/* ------------------------------------------------------------------ */
+static hipError_t dispatch_dot(const ntt_plan *p, const DotArgs &da)
+{
+  if(p->arith == NTT_ARITH_U64) return launch_dot<ArithU64, 0>(da);
+  switch(p->kcls) {
+    case kWideClass: return launch_dot<ArithF64W, 0>(da);
+    case 18: return launch_dot<ArithF64, 18>(da);
+    case 1: return launch_dot<ArithF64, 1>(da);
+    default: return launch_dot<ArithF64, 0>(da);
+  }
+}
+
+/* plans the fused kernel serves: the radix-2 policies on blocks of 2^6 points and more */
+static bool dot_kernel_applies(const ntt_plan *p)
+{
+  return (p->arith == NTT_ARITH_F64 || p->arith == NTT_ARITH_U64) && !p->generic && p->m >= kFusedMin && env_int("NTT_DOT_UNFUSED", 0) == 0;
+}
+
+/* c = inv(sum_i a_i^ (.) b_i^).  One launch up to N = 2^14: the products are formed where the inverse transform would
+ * convert its input words (dot_inv_kernel).  Above: per 256 MiB chunk of c that kernel over the blocks (the product rides in
+ * the inverse's first pass), then the inverse's column passes on c -- 16kN + 24N bytes instead of 24kN + 32N.  Plans the
+ * kernel is not built for (column-pass-only, radix-4 formulation, N < 2^6) accumulate the products with pointwise
+ * launches and run their own inverse transform.  ls: the limbs one launch serves; b_limb_stride: words between the limbs
+ * of a b operand. */
+static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch,
+                   unsigned flags, void *stream, const LimbSet *set = nullptr, uint64_t b_limb_stride = 0)
+{
+  if(!p || !d_c || !a || !b) return fail(NTT_ERR_ARG, "null argument");
+  if(k < 1 || k > kMaxDot) return fail(NTT_ERR_ARG, "number of operand pairs must be 1 .. 32");
+  if(flags & ~(unsigned)(NTT_MUL_LAZY_IN | NTT_MUL_B_BROADCAST)) return fail(NTT_ERR_ARG, "unknown flag");
+  for(int i = 0; i < k; i++) {
+    if(!a[i] || !b[i]) return fail(NTT_ERR_ARG, "null operand");
+  }
+  if(batch == 0) return NTT_OK;
+  if(!p->has_inv) return fail(NTT_ERR_ARG, "plan lacks the inverse table");
+  const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0, bcast = (flags & NTT_MUL_B_BROADCAST) != 0;
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  USE_DEVICE(p->device);
+  if(!dot_kernel_applies(p) || (ls.n > 1 && p->arith != NTT_ARITH_F64)) {
+    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
+    const uint64_t n  = batch * p->N;
+    const dim3     g(grid_for(n)), t(256);
+    hipStream_t    st = (hipStream_t)stream;
+    const uint64_t bm = bcast ? p->N - 1 : ~0ull;
+    for(int i = 0; i < k; i++) {
+#define NTT_PW_ACC(A, CONSTS)                                                                                              \
+  do {                                                                                                                     \
+    if(lazy) {                                                                                                             \
+      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);   \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);   \
+    } else {                                                                                                               \
+      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);  \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);  \
+    }                                                                                                                      \
+  } while(0)
+      if(p->arith == NTT_ARITH_F64) NTT_PW_ACC(ArithF64, p->cf);
+      else NTT_PW_ACC(ArithU64, p->cu);
+#undef NTT_PW_ACC
+      HIP_TRY(hipGetLastError());
+    }
+    return run_transform(p, d_c, batch, true, false, stream);
+  }
+  const int      pblk  = p->m > kFusedMax ? (p->block_log ? p->block_log : multi_pass_block(p->m, true, p->arith == NTT_ARITH_F64)) : p->m;
+  const PassList L     = make_passes(p->m, false, pblk);
+  uint64_t       chunk = batch;
+  if(L.n > 1) {
+    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t) * (uint64_t)ls.n);
+    if(chunk < 1) chunk = 1;
+    if(chunk > batch) chunk = batch;
+  }
+  const uint64_t *ca[kMaxDot], *cb[kMaxDot];
+  for(uint64_t first = 0; first < batch; first += chunk) {
+    const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
+    const uint64_t off = first * p->N;
+    for(int i = 0; i < k; i++) {
+      ca[i] = a[i] + off;
+      cb[i] = bcast ? b[i] : b[i] + off;
+    }
+    DotArgs da{};
+    da.out           = d_c + off;
+    da.a             = ca;
+    da.b             = cb;
+    da.npairs        = k;
+    da.lazy_in       = lazy;
+    da.b_bcast       = bcast;
+    da.limbs         = ls.d;
+    da.nlimbs        = ls.n;
+    da.limb_stride   = ls.stride;
+    da.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
+    da.batch         = nb;
+    da.logn          = (uint32_t)p->m;
+    da.block_log     = (uint32_t)pblk;
+    da.max_grid      = p->max_grid;
+    da.num_cus       = p->num_cus;
+    da.stream        = (hipStream_t)stream;
+    hipError_t e = dispatch_dot(p, da);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    for(int j = L.n - 2; j >= 0; j--) { /* the inverse's column passes on c; the last one ends the transform (N^-1) */
+      int rc = launch_one_pass(p, L.p[j], d_c + off, nb, true, false, false, j == 0, stream, ls);
+      if(rc) return rc;
+    }
+  }
+  return NTT_OK;
+}
+
+extern "C" int ntt_inv_dot_batch(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                                 const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream)
+{
+  return inv_dot(p, d_c, k, d_ahat, d_bhat, batch, flags, stream);
+}
+
+extern "C" int ntt_inv_product_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_ahat, const uint64_t *d_bhat,
+                                     uint64_t batch, unsigned flags, void *stream)
+{
+  return inv_dot(p, d_c, 1, &d_ahat, &d_bhat, batch, flags, stream);
+}
+
+/* c = inv(fwd(a) (.) b^): the product kernels' form with one operand already transformed (fused_product_kernel /
+ * team_product_kernel without BOTH / FOUR); plans those kernels are not built for take fwd, pointwise, inv */
+static int mul_transformed(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
+                           void *stream, const LimbSet *set = nullptr)
+{
+  if(!p || !d_c || !d_a || !d_bhat) return fail(NTT_ERR_ARG, "null argument");
+  if(flags & ~(unsigned)NTT_MUL_LAZY_IN) return fail(NTT_ERR_ARG, "unknown flag");
+  if(batch == 0) return NTT_OK;
+  if(!p->has_fwd || !p->has_inv) return fail(NTT_ERR_ARG, "plan lacks a table");
+  if(d_a == d_bhat) return fail(NTT_ERR_ARG, "the coefficient operand and the transformed operand must be different buffers");
+  /* (the kernels take b^ as lazy words v + 2q: a canonical word c is the lazy word of v = c - 2q, so one form serves both) */
+  if(fused_product_applies(p, d_c, d_bhat, d_a, batch)) {
+    return fused_product(p, d_c, const_cast<uint64_t *>(d_bhat), d_a, batch, stream, set, true);
+  }
+  if(set && set->n > 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
+  const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0;
+  int rc = p->arith == NTT_ARITH_U64_R4 ? ntt_fwd_batch(p, d_a, batch, stream) : ntt_fwd_batch_lazy(p, d_a, batch, stream);
+  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_bhat, batch, stream, lazy || p->arith != NTT_ARITH_U64_R4);
+  if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
+  return rc;
+}
+
+extern "C" int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
+                                         unsigned flags, void *stream)
+{
+  return mul_transformed(p, d_c, d_a, d_bhat, batch, flags, stream);
+}
+
+extern "C" int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                                     const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  if(rc || batch == 0) return rc;
+  if(k < 1 || k > kMaxDot || !d_ahat || !d_bhat) return fail(NTT_ERR_ARG, "number of operand pairs must be 1 .. 32");
+  const uint64_t N = plans[0]->N, slab = batch * N;
+  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
+  const uint64_t *la[kMaxDot], *lb[kMaxDot];
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && dot_kernel_applies(plans[0])) {
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet ls{recs.data(), n, slab};
+      for(int i = 0; i < k; i++) {
+        la[i] = d_ahat[i] + (uint64_t)first * slab;
+        lb[i] = d_bhat[i] + (uint64_t)first * bslab;
+      }
+      rc = inv_dot(plans[first], d_c + (uint64_t)first * slab, k, la, lb, batch, flags, stream, &ls, bslab);
+    }
+    return rc;
+  }
+  for(int l = 0; !rc && l < nlimbs; l++) {
+    for(int i = 0; i < k; i++) {
+      la[i] = d_ahat[i] + (uint64_t)l * slab;
+      lb[i] = d_bhat[i] + (uint64_t)l * bslab;
+    }
+    rc = inv_dot(plans[l], d_c + (uint64_t)l * slab, k, la, lb, batch, flags, stream);
+  }
+  return rc;
+}
+
+extern "C" int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                             uint64_t batch, unsigned flags, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  if(rc || batch == 0) return rc;
+  const uint64_t slab = batch * plans[0]->N;
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && fused_product_applies(plans[0], d_c, d_bhat, d_a, batch)) {
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet  ls{recs.data(), n, slab};
+      const uint64_t off = (uint64_t)first * slab;
+      rc                 = mul_transformed(plans[first], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &ls);
+    }
+    return rc;
+  }
+  for(int l = 0; !rc && l < nlimbs; l++) {
+    const uint64_t off = (uint64_t)l * slab;
+    rc                 = mul_transformed(plans[l], d_c + off, d_a + off, d_bhat + off, batch, flags, stream);
   }
   return rc;
 }
@@ -1564,6 +1817,10 @@ int compat_arith(uint64_t q, uint64_t N, CompatKind kind, bool inverse)
 void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t q, const uint64_t *w,
                 const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv)
 {
+  if(!is_pow2(N) || N < 2 || !a1 || !w) { /* (the table's slot 1 is read below: checked before anything is touched) */
+    g_err = "N must be a power of two >= 2 and the pointers non-null";
+    die(fn);
+  }
   const int      device  = env_int("NTT_DEVICE", 0);
   const int      arith   = compat_arith(q, N, kind, inverse);
   const uint64_t entries = kind == kCompatR4 ? 2 * N : N;

@@ -942,8 +942,25 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
  *     adopts queues nobody has claimed), so exactly one L2 sees all items of a polynomial even on a device that exposes
  *     fewer XCDs than eight.
  * Correctness never rests on placement assumptions: the XCD is read, and a hand-off only happens inside one XCD.
+ * MEMORY-ORDER INVARIANT of the hand-off (team_kernel, team_product_kernel, team_dot kernels).  The signal is a relaxed
+ * agent-scope atomic behind s_waitcnt vmcnt(0) + a workgroup barrier, the poll a relaxed agent-scope load in front of a
+ * workgroup barrier; there is deliberately NO release/acquire fence (an agent-scope release is buffer_wbl2: it writes back
+ * every dirty L2 line of the XCD, the neighbours' results included -- 8 us per hand-off) and no buffer_inv on the consumer.
+ * That is sound because producer and consumer sit on ONE XCD, i.e. behind one L2, which is the point of coherence for
+ * them (stores are complete in that L2 once vmcnt reaches 0; the per-CU vector cache is write-through), PROVIDED that no
+ * CU's vector cache (TCP) can hold a stale copy of a line the consumer reads:
+ *   (1) a line that a later pass of the same launch overwrites from ANOTHER CU is only ever read with sc0 sc1 loads,
+ *       which do not allocate in the TCP (kAuxSc0Sc1: the inputs of the first pass);
+ *   (2) every other load (nt: may allocate) of a line that is overwritten later in the launch is issued by the very item
+ *       that overwrites it: items are block-aligned (a row item reads and writes exactly its own 2^12-point block, a
+ *       column item its own 2 KiB row segments), so the only CU that may cache the old contents is the one whose own
+ *       write-through stores replace them;
+ *   (3) TCPs start a launch invalid, and the launch never reads a final output again.
+ * Changing a cache policy or making items overlap in lines breaks this silently; tests/test_gpu_parity.py
+ * (test_xcd_local_*) and tools/soak.py compare every polynomial with the per-pass path for that reason.
  * Reference precedent for finishing a sub-transform while its data is close: third_party/hexl/fwd-ntt-avx512.c:311-329.
  */
+static_assert(kAuxSc0Sc1 == 17 && kAuxNt == 2 && kAuxSc1 == 16, "cache-policy encodings the hand-off invariant is written for");
 struct TeamCtl {
   unsigned next[8][32];  /* per queue: next item; one 128-byte line each */
   unsigned owner[8][32]; /* per queue: 0 = unclaimed, else 1 + the XCD that processes it */
@@ -1684,6 +1701,195 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* products of operands that ARE in the NTT domain                      */
+/* ------------------------------------------------------------------ */
+/*
+ * c = inv( sum_{i<k} a_i^ (.) b_i^ ): the other half of SURVEY 8(f) f1 ("fusing the multiply into the inverse's first load
+ * saves 16N bytes").  Keys, ciphertexts and plaintexts of an FHE caller live in the NTT domain; what it issues is the
+ * pointwise product of two transformed operands (k = 1) or the inner product of a digit-decomposed ciphertext with a
+ * key (key switching, k = 2 .. tens) followed by ONE inverse transform.  This kernel is the inverse block kernel with its
+ * input conversion replaced: where fused_kernel<.., INV> turns the 16 words of a thread into values, this one reads the 16
+ * words of every a_i^ and b_i^ in the same layout (the product is element-wise, so the inverse's first group's layout
+ * serves), forms the k products and their sum in registers (A::dot_term / dot_acc / dot_fold) and runs the inverse stages
+ * on the sum.  HBM traffic: 16kN bytes in, 8N out -- 24N for a plain product instead of 40N for pointwise + inverse, no
+ * intermediate ever written; with B_BCAST the b_i^ are ONE polynomial each, shared by the batch (a key: read from the
+ * L2), and the traffic is 8kN + 8N.  Blocks of a larger transform (LASTINV = false: N > 2^14, the column stages of the
+ * inverse follow as launches of their own) work the same way: the product rides in the first pass of the inverse.
+ * Reference primitive this generalises: fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
+ */
+constexpr int kMaxDot = 32; /* operand pairs of one launch (2 x 32 pointers in the kernel arguments) */
+
+template <class A> struct KDot {
+  KArgs<A>        k;             /* k.a = c (limb 0), nblocks / s0 / logn as for an inverse block pass */
+  uint32_t        npairs;        /* 1 .. kMaxDot */
+  uint32_t        lazy_in;       /* operand words may be lazy: anywhere in [0,4q) */
+  uint32_t        b_bcast;       /* every b_i^ is one polynomial per limb, shared by the whole batch */
+  uint64_t        b_limb_stride; /* words between consecutive limbs of a b operand */
+  const uint64_t *a[kMaxDot];
+  const uint64_t *b[kMaxDot];
+};
+
+template <class A, int LOGN, int KSH, bool LASTINV, bool MULTI = false>
+__global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<LOGN, true, flavor_of<A>()>::WPS)) dot_inv_kernel(const KDot<A> kd)
+{
+  uint32_t        bid, gdim, limb;
+  const Params<A> p = limb_params<A, true, MULTI>(kd.k, bid, gdim, limb);
+  using P = Plan<LOGN>;
+  using G = Geom<LOGN, true, flavor_of<A>()>;
+  constexpr uint32_t MASK   = fused_mask<A, LOGN, true, KSH>() | (LASTINV ? kLastInvFlag : 0u);
+  constexpr int      LDS_TW = G::LDS_TW;
+  __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
+  const uint32_t   tid   = threadIdx.x;
+  const uint32_t   sub   = tid >> P::LT;
+  const uint32_t   t     = tid & (P::T - 1);
+  typename A::val *lds   = lds_all + sub * P::LDS_ELEMS;
+  const uint32_t   bmask = (1u << p.s0) - 1u;
+  const uint32_t   np    = kd.npairs;
+  const bool       lazy  = kd.lazy_in != 0;
+  const bool       bc    = kd.b_bcast != 0;
+  const uint64_t   aoff  = (uint64_t)limb * kd.k.limb_stride; /* (MULTI off: limb == 0, both offsets fold away) */
+  const uint64_t   boff  = (uint64_t)limb * kd.b_limb_stride;
+
+  /* (MULTI -- several limbs in one launch -- exists for batches that cannot fill the chip: a workgroup sees one or two blocks,
+   * there is nothing to prefetch across, and the plain loop below needs fewer registers next to the run-time limb's constants) */
+  if constexpr(G::PERSISTENT && A::kCompact && !MULTI) {
+    static_assert(G::BPW == 1, "the persistent inverse loop owns one block per workgroup");
+    constexpr int  GL  = P::NG - 1;
+    constexpr bool LTW = LDS_TW > 0;
+    const uint64_t stride = gdim;
+    uint64_t       b      = bid;
+    if(b >= p.nblocks) return;
+    typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+    const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
+    if constexpr(LTW) {
+      fill_lds_tables<A, LOGN, true>(tabl, p, (uint32_t)b & bmask, tid);
+      __syncthreads();
+    }
+    /* Register budget (2^14: 128 VGPRs at four waves per SIMD).  The transform kernel keeps the first executed group's
+     * twelve per-lane twiddles resident (24 VGPRs) next to ONE prefetched block (32); here the next block's FIRST PAIR is
+     * two blocks of words (64), so the twiddles are requested per block instead (from the L2, in front of the products that
+     * hide their latency) and the prefetch is issued after the last exchange, when the LDS addresses and the per-lane
+     * twiddles of the middle groups are dead: the words then have the last group, the stores and the next block's
+     * twiddle request to arrive. */
+    constexpr bool IPRE = stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
+    uint64_t ra[kE], rb[kE];
+    prefetch_last<LOGN>(ra, tid, kd.a[0] + aoff + (b << LOGN));
+    prefetch_last<LOGN>(rb, tid, kd.b[0] + boff + ((bc ? (b & bmask) : b) << LOGN));
+    pin_raw(ra);
+    pin_raw(rb);
+    for(; b < p.nblocks; b += stride) {
+      const uint32_t blk  = (uint32_t)b & bmask;
+      const uint64_t bb   = bc ? (uint64_t)blk : b;
+      uint64_t *     base = p.a + (b << LOGN);
+      /* (an opaque copy of the thread id ties the per-block twiddle request and every lane-dependent address to the
+       * iteration: hoisted, they would stay in registers -- or scratch -- for the whole launch; see fused_product_kernel) */
+      uint32_t tl = tid;
+      asm volatile("" : "+v"(tl));
+      typename A::val x[kE];
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = typename A::val{}; });
+      /* every pair but the last: add its products, request the next pair */
+#pragma unroll 1
+      for(uint32_t i = 0; i + 1 < np; i++) {
+        if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
+        dot_tile<A, 0, kE, 2>(x, ra, rb, lazy, p.c);
+        prefetch_last<LOGN>(ra, tl, kd.a[i + 1] + aoff + (b << LOGN));
+        prefetch_last<LOGN>(rb, tl, kd.b[i + 1] + boff + (bb << LOGN));
+        sched_fence();
+      }
+      if(np > 1 && (np - 1) % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
+      /* the last pair.  The first executed group's twiddles are requested half way through its products -- which hide
+       * most of their L2 latency --, when half of the 64 registers of words are free again (any earlier and they would
+       * have to live next to all of them) */
+      dot_tile<A, 0, kE / 2>(x, ra, rb, lazy, p.c);
+      typename A::ctw pre[4][kE / 2];
+      if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tl, blk, p);
+      dot_tile<A, kE / 2, kE>(x, ra, rb, lazy, p.c);
+      if(np > 1) dot_fold_tile<A>(x, p.c);
+      if constexpr(IPRE) {
+        run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+      } else if constexpr(G::TBL(GL) > 0) {
+        run_group<A, LOGN, GL, true, MASK, true>(x, tl, blk, p, ltw + G::TBL_OFF(GL));
+      } else {
+        run_group<A, LOGN, GL, true, MASK>(x, tl, blk, p);
+      }
+      const bool     more = b + stride < p.nblocks;
+      const uint64_t nb   = more ? b + stride : b;
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = P::NG - 1 - decltype(gg)::value;
+        exchange<A, LOGN, GI, GI - 1>(x, tl, lds_all);
+        if constexpr(GI == 1) {
+          /* the next block's first pair, operand a: always issued (a dead descriptor moves no data past the end) */
+          uint32_t t2 = tid;
+          asm volatile("" : "+v"(t2));
+          sched_fence();
+          prefetch_last<LOGN>(ra, t2, kd.a[0] + aoff + (nb << LOGN), more);
+          sched_fence();
+        }
+        if constexpr(G::TBL(GI - 1) > 0) {
+          run_group<A, LOGN, GI - 1, true, MASK, true>(x, tl, blk, p, ltw + G::TBL_OFF(GI - 1));
+        } else {
+          run_group<A, LOGN, GI - 1, true, MASK>(x, tl, blk, p);
+        }
+      });
+      {
+        /* ... operand b: behind the last group's butterflies, whose temporaries do not fit next to 64 registers of words */
+        uint32_t t3 = tid;
+        asm volatile("" : "+v"(t3));
+        sched_fence();
+        prefetch_last<LOGN>(rb, t3, kd.b[0] + boff + ((bc ? (nb & bmask) : nb) << LOGN), more);
+        sched_fence();
+      }
+      uint64_t out[kE];
+      static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = out_word<A, true, false>(x[decltype(ee)::value], !LASTINV, p.c); });
+      buffer_store_first_raw<LOGN>(out, tl, base);
+    }
+    return;
+  } else {
+    /* small blocks (several per workgroup, sharing the LDS tables), the integer policies, several limbs: the plain loop */
+    const lds_ctw_ptr<A> gtw = (lds_ctw_ptr<A>)reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+    if constexpr(LDS_TW > 0) {
+      /* blocks below 2^12 are whole polynomials; larger ones may be blocks of a bigger transform: a workgroup then always
+       * sees the same block position (its stride is a multiple of the blocks per polynomial: launch_dot_blocks) */
+      fill_lds_tables<A, LOGN, true>(reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS), p,
+                                     G::BPW == 1 ? ((uint32_t)bid & bmask) : 0u, tid);
+      __syncthreads();
+    }
+    for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gdim * G::BPW) {
+      uint64_t   b    = b0 + sub;
+      const bool live = b < p.nblocks;
+      if(!live) b = p.nblocks - 1; /* idle sub-blocks shadow a real block (barriers are workgroup-wide), never store */
+      const uint32_t blk  = (uint32_t)b & bmask;
+      const uint64_t bb   = bc ? (uint64_t)blk : b;
+      uint64_t *     base = p.a + (b << LOGN);
+      typename A::val x[kE];
+      static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = typename A::val{}; });
+#pragma unroll 1
+      for(uint32_t i = 0; i < np; i++) {
+        if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
+        /* half a tile at a time: 32 registers of words next to the 32 running sums */
+        static_for<0, 2>([&](auto hh) {
+          constexpr int H = decltype(hh)::value;
+          uint64_t      ra[kE], rb[kE];
+          sched_fence();
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, t, kd.a[i] + aoff + (b << LOGN));
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, t, kd.b[i] + boff + (bb << LOGN));
+          dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
+        });
+      }
+      if(np > 1) dot_fold_tile<A>(x, p.c);
+      run_group<A, LOGN, P::NG - 1, true, MASK, (G::TBL(P::NG - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(P::NG - 1));
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = P::NG - 1 - decltype(gg)::value;
+        exchange<A, LOGN, GI, GI - 1>(x, t, lds);
+        run_group<A, LOGN, GI - 1, true, MASK, (G::TBL(GI - 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI - 1));
+      });
+      /* (a pass that does not end the transform keeps the integer policies' lazy range, as fused_kernel's does) */
+      if(live) global_store_first<A, LOGN, true>(x, t, base, p.c, !LASTINV);
+    }
+  }
+}
+
 template <class A, int R, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
 {
@@ -1754,6 +1960,24 @@ struct ProdArgs {
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
 template <class A, int KSH> hipError_t launch_team_product(const ProdArgs &pa);
+
+/* c = inverse block pass of sum_i a_i^ (.) b_i^ (dot_inv_kernel) */
+struct DotArgs {
+  uint64_t *             out;
+  const uint64_t *const *a; /* HOST arrays of npairs device pointers (limb 0's slabs) */
+  const uint64_t *const *b;
+  int                    npairs;
+  int                    lazy_in, b_bcast;
+  const void *           limbs; /* HOST array of LimbRec<A> */
+  int                    nlimbs;
+  uint64_t               limb_stride, b_limb_stride;
+  uint64_t               batch;     /* per limb */
+  uint32_t               logn;
+  uint32_t               block_log; /* N > 2^14: log2 of the blocks (12 or 14); the inverse column passes follow as launches of their own */
+  int                    max_grid, num_cus;
+  hipStream_t            stream;
+};
+template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
 
 /* What a pass stores: the last pass of a transform honours the caller's lazy flag; every earlier pass of an
  * integer policy keeps the reference's lazy ranges in HBM (no reduction between stages, as in
@@ -2116,6 +2340,84 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     return hipGetLastError();
   }
 }
+
+template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks(const DotArgs &da)
+{
+  using G = Geom<LOGN, true, flavor_of<A>()>;
+  KDot<A> kd{};
+  kd.k.a                 = da.out;
+  const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(da.limbs);
+  const uint64_t    nl   = (uint64_t)(da.nlimbs > 0 ? da.nlimbs : 1);
+  for(uint64_t l = 0; l < nl && l < (uint64_t)kMaxLimbs; l++) kd.k.limbs[l] = recs[l];
+  kd.k.limb_stride = da.limb_stride;
+  kd.k.logn        = da.logn;
+  kd.k.s0          = da.logn - (uint32_t)LOGN;
+  kd.k.lastinv     = LASTINV ? 1u : 0u;
+  kd.k.lazy        = LASTINV ? 0u : 1u;
+  kd.k.nblocks     = da.batch << kd.k.s0;
+  kd.npairs        = (uint32_t)da.npairs;
+  kd.lazy_in       = (uint32_t)da.lazy_in;
+  kd.b_bcast       = (uint32_t)da.b_bcast;
+  kd.b_limb_stride = da.b_limb_stride;
+  for(int i = 0; i < da.npairs && i < kMaxDot; i++) {
+    kd.a[i] = da.a[i];
+    kd.b[i] = da.b[i];
+  }
+  /* the grid of the inverse block kernel (launch_fused): resident workgroups striding over the blocks */
+  uint64_t wgs = (kd.k.nblocks + G::BPW - 1) / G::BPW;
+  uint64_t cap = 1ull << 20;
+  if(G::PERSISTENT) {
+    constexpr int by_lds   = G::WG_PER_CU0;
+    constexpr int by_waves = (G::WPS * 4 * 64) / G::WG;
+    constexpr int per_cu   = by_lds < by_waves ? by_lds : by_waves;
+    cap                    = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+  }
+  if(!G::PERSISTENT && G::LDS_TW > 0) {
+    if(kd.k.s0 != 0) return hipErrorInvalidValue;
+    constexpr int per_cu = G::WG_PER_CU0 < 8 ? G::WG_PER_CU0 : 8;
+    cap                  = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
+  }
+  if(da.max_grid > 0) cap = (uint64_t)da.max_grid;
+  cap = cap / nl > 0 ? cap / nl : 1;
+  if(G::BPW == 1 && kd.k.s0 > 0) { /* a workgroup keeps the tables of ONE block position */
+    if(cap < (1ull << kd.k.s0)) cap = 1ull << kd.k.s0;
+    cap &= ~((1ull << kd.k.s0) - 1);
+  }
+  if(wgs > cap) wgs = cap;
+  if(wgs == 0) return hipSuccess;
+  kd.k.wgs_per_limb = (uint32_t)wgs;
+  if(nl > 1) {
+    if constexpr(multi_limb_built<A>()) {
+      hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, LASTINV, true>), dim3((unsigned)(wgs * nl)), dim3(G::WG), 0, da.stream, kd);
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
+  hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, LASTINV, false>), dim3((unsigned)wgs), dim3(G::WG), 0, da.stream, kd);
+  return hipGetLastError();
+}
+
+template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
+{
+  if(da.npairs < 1 || da.npairs > kMaxDot || da.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(da.logn > (uint32_t)kFusedMax) {
+    if(da.block_log == (uint32_t)kFusedSmallBlock) return launch_dot_blocks<A, kFusedSmallBlock, KSH, false>(da);
+    if(da.block_log == (uint32_t)kFusedLarge) return launch_dot_blocks<A, kFusedLarge, KSH, false>(da);
+    return hipErrorInvalidValue;
+  }
+  switch(da.logn) {
+#define NTT_DOT_CASE(LN) \
+  case LN: return launch_dot_blocks<A, LN, KSH, true>(da);
+    NTT_DOT_CASE(6) NTT_DOT_CASE(7) NTT_DOT_CASE(8) NTT_DOT_CASE(9) NTT_DOT_CASE(10) NTT_DOT_CASE(11) NTT_DOT_CASE(12) NTT_DOT_CASE(13)
+    NTT_DOT_CASE(14)
+#undef NTT_DOT_CASE
+    default: return hipErrorNotSupported;
+  }
+}
+
+#define NTT_DEFINE_LAUNCH_DOT(A, KSH) \
+  template <> hipError_t launch_dot<A, KSH>(const DotArgs &da) { return launch_dot_impl<A, KSH>(da); }
 
 #define NTT_DEFINE_LAUNCH_PRODUCT(A, KSH) \
   template <> hipError_t launch_team_product<A, KSH>(const ProdArgs &pa) { return launch_team_product_impl<A, KSH>(pa); } \

@@ -158,6 +158,24 @@ struct ArithF64Chk : ArithF64 {
     if(__builtin_fabs(r) > 0.75 * c.q) g_chk_fail++;              /* the bound the inverse plan relies on */
     return r;
   }
+  /* inner-product terms (dot_inv_kernel): exact product of the two stored words, bound of ArithF64::dot_term */
+  template <bool LAZY> static val dot_term(uint64_t a, uint64_t b, const consts &c)
+  {
+    if(LAZY ? (a >= 4 * c.qi || b >= 4 * c.qi) : (a >= c.qi || b >= c.qi)) g_chk_fail++; /* operand range of the contract */
+    const double   r  = ArithF64::dot_term<LAZY>(a, b, c);
+    const __int128 ex = (__int128)(a % c.qi) * (__int128)(b % c.qi);
+    if((ex - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;       /* r == a * b (mod q), exactly */
+    if(__builtin_fabs(r) > 0.8756 * c.q) g_chk_fail++;            /* the bound the folding schedule relies on */
+    return r;
+  }
+  static val dot_acc(val acc, val t, const consts &c)
+  {
+    const double s = acc + t;
+    see(s, c);
+    if((as_int(acc) + as_int(t)) != as_int(s)) g_chk_fail++;      /* the running sum is exact */
+    return s;
+  }
+  static val dot_fold(val acc, const consts &c) { return reduce(acc, c); }
   static tw expand(ctw w, const consts &c)
   {
     const tw t = ArithF64::expand(w, c);
@@ -402,6 +420,102 @@ void emu_fused_product_small(uint64_t *out, const uint64_t *ahat, const uint64_t
   }
 }
 
+/* dot_inv_kernel (csrc/ntt_kernels.h) step by step: the inverse block pass whose inputs are the sums of the element-wise
+ * products of k operand pairs given in the NTT domain (last-kind layout), with the running sum folded as the kernel folds it */
+template <class A, int LOGN, int KSH, bool LASTINV>
+void emu_dot_blocks(const Params<A> &p, int k, const uint64_t *const *a, const uint64_t *const *b, bool lazy, bool bcast)
+{
+  using P                 = Plan<LOGN>;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (LASTINV ? kLastInvFlag : 0u);
+  constexpr int      GL   = P::NG - 1;
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         regs(P::T);
+  const uint64_t bmask = (1ull << p.s0) - 1;
+  for(uint64_t blkid = 0; blkid < p.nblocks; blkid++) {
+    const uint32_t blk  = (uint32_t)(blkid & bmask);
+    const uint64_t bb   = bcast ? (uint64_t)blk : blkid;
+    uint64_t *     base = p.a + (blkid << LOGN);
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      typename A::val(&x)[kE] = regs[t].x;
+      for(int e = 0; e < kE; e++) x[e] = typename A::val{};
+      for(int i = 0; i < k; i++) {
+        uint64_t ra[kE], rb[kE];
+        load_last_raw<LOGN>(ra, t, a[i] + (blkid << LOGN));
+        load_last_raw<LOGN>(rb, t, b[i] + (bb << LOGN));
+        if(i != 0 && i % A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
+        dot_tile<A>(x, ra, rb, lazy, p.c);
+      }
+      if(k > 1) dot_fold_tile<A>(x, p.c);
+    }
+    /* (all products are formed before anything is stored: c may alias an operand) */
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      if constexpr(A::kCompact && P::R(GL) < 4) {
+        typename A::ctw pre[4][kE / 2];
+        preload_group_tw<A, LOGN, GL>(pre, t, blk, p);
+        run_group_preloaded<A, LOGN, GL, MASK, true>(regs[t].x, pre, p);
+      } else {
+        run_group<A, LOGN, GL, true, MASK>(regs[t].x, t, blk, p);
+      }
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = P::NG - 1 - decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+        run_group<A, LOGN, G - 1, true, MASK>(regs[t].x, t, blk, p);
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_first<A, LOGN, true>(regs[t].x, t, base, p.c, !LASTINV);
+  }
+}
+
+template <class A, int R, bool INV, int KSH>
+static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, bool wide, bool lastinv,
+                       const typename A::tw *tab, const typename A::consts &c, bool lazy_out);
+
+/* the library's inv_dot (ntt_host.hip): one block launch up to 2^14; above, the dot kernel over the blocks and the
+ * inverse's column passes */
+template <class A, int KSH>
+int emu_dot_run(uint64_t *out, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch, int m, const typename A::tw *tab,
+                const typename A::ctw *tab8, const typename A::consts &c, bool lazy, bool bcast)
+{
+  if(m < kFusedMin) return -1;
+  const int      pblk = m > kFusedMax ? multi_pass_block(m, true, A::kTracksBounds) : m;
+  const PassList L    = make_passes(m, false, pblk);
+  Params<A>      p{};
+  p.a       = out;
+  p.tw      = tab;
+  p.tw8     = tab8;
+  p.c       = c;
+  p.logn    = (uint32_t)m;
+  p.s0      = (uint32_t)(m - pblk);
+  p.lastinv = m <= kFusedMax;
+  p.nblocks = batch << p.s0;
+  if(m > kFusedMax) {
+    if(pblk == kFusedSmallBlock) emu_dot_blocks<A, kFusedSmallBlock, KSH, false>(p, k, a, b, lazy, bcast);
+    else emu_dot_blocks<A, kFusedLarge, KSH, false>(p, k, a, b, lazy, bcast);
+    for(int j = L.n - 2; j >= 0; j--) {
+      const Pass &ps = L.p[j];
+      const bool  li = ps.s == 0;
+      switch(ps.r) {
+        case 1: emu_column<A, 1, true, KSH>(out, batch, m, ps.s, false, li, tab, c, j != 0); break;
+        case 2: emu_column<A, 2, true, KSH>(out, batch, m, ps.s, false, li, tab, c, j != 0); break;
+        case 3: emu_column<A, 3, true, KSH>(out, batch, m, ps.s, false, li, tab, c, j != 0); break;
+        case 4: emu_column<A, 4, true, KSH>(out, batch, m, ps.s, false, li, tab, c, j != 0); break;
+        default: return -1;
+      }
+    }
+    return 0;
+  }
+  switch(m) {
+#define CASE(LN) \
+  case LN: emu_dot_blocks<A, LN, KSH, true>(p, k, a, b, lazy, bcast); return 0;
+    CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+    default: return -1;
+  }
+}
+
 template <class A, int R, bool INV, int KSH>
 static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, bool wide, bool lastinv,
                        const typename A::tw *tab, const typename A::consts &c, bool lazy_out)
@@ -511,6 +625,8 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
   KW template void emu_fused_product_small<A, 10, K> EMU_PROD_ARGS(A);         \
   KW template void emu_fused_product_small<A, 9, K> EMU_PROD_ARGS(A);          \
   KW template void emu_fused_product_small<A, 8, K> EMU_PROD_ARGS(A);
+#define EMU_DOT_ARGS(A) (uint64_t *, int, const uint64_t *const *, const uint64_t *const *, uint64_t, int, const typename A::tw *, const typename A::ctw *, const typename A::consts &, bool, bool)
+#define EMU_DOT(KW, A, K) KW template int emu_dot_run<A, K> EMU_DOT_ARGS(A);
 using WideChk = WideF64<ArithF64Chk>;
 #if EMU_PART >= 0
 #  define P1(KW) EMU_RUN(KW, ArithU64, 0) EMU_RUN(KW, ArithU64R4, 0) EMU_RUN(KW, ArithF64W, 0)
@@ -521,8 +637,10 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P6(KW) EMU_PROD(KW, ArithF64, 0) EMU_PROD(KW, ArithF64, 1) EMU_PROD(KW, ArithF64, 18) \
                  EMU_PROD(KW, ArithF64Chk, 0) EMU_PROD(KW, ArithF64Chk, 1) EMU_PROD(KW, ArithF64Chk, 18)
 #  define P7(KW) EMU_PROD_OTHER(KW, ArithF64Chk, 0) EMU_PROD_OTHER(KW, ArithF64Chk, 1) EMU_PROD_OTHER(KW, WideChk, 0)
+#  define P8(KW) EMU_DOT(KW, ArithU64, 0) EMU_DOT(KW, ArithF64Chk, 0)
+#  define P9(KW) EMU_DOT(KW, ArithF64Chk, 1) EMU_DOT(KW, WideChk, 0)
 #  if EMU_PART == 0
-P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern)
+P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern)
 #  elif EMU_PART == 1
 P1()
 #  elif EMU_PART == 2
@@ -537,6 +655,10 @@ P5()
 P6()
 #  elif EMU_PART == 7
 P7()
+#  elif EMU_PART == 8
+P8()
+#  elif EMU_PART == 9
+P9()
 #  endif
 #endif
 
@@ -745,6 +867,41 @@ int emu_fused_product_chk(uint64_t *out, const uint64_t *ahat, const uint64_t *b
   RUNM(ArithF64Chk, 0)
 #undef RUNM
 #undef RUNQ
+}
+#endif
+
+#ifndef EMU_SAN_BUILD
+/* out = inv(sum_i a_i (.) b_i) for operands in the NTT domain, as dot_inv_kernel (+ the inverse's column passes above
+ * 2^14) computes it.  a: k x [batch][N], b: k x [batch][N] (bcast: k x [N]).  arith 0: integer radix-2; 1: the CHECKED
+ * FP64 policy of q's class (the reduce-both-operands policy above 2^51(1+2^-10)). */
+int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root, int arith,
+                int lazy, int bcast)
+{
+  const uint64_t N    = 1ull << m;
+  const uint64_t rinv = h_powmod(root, q - 2, q);
+  const auto     wi   = h_power_table(rinv, N, q);
+  const auto     wix  = h_with_folded_ninv(wi, h_powmod(N % q, q - 2, q), q);
+  std::vector<const uint64_t *> pa(k), pb(k);
+  for(int i = 0; i < k; i++) {
+    pa[i] = a + (uint64_t)i * batch * N;
+    pb[i] = b + (uint64_t)i * (bcast ? N : batch * N);
+  }
+  if(arith == 0) {
+    std::vector<TwU64> tab(wix.size());
+    for(size_t i = 0; i < wix.size(); i++) tab[i] = h_tw_u64(wix[i], q);
+    const auto c = h_consts_u64(q, N, wi);
+    return emu_dot_run<ArithU64, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
+  }
+  const bool wide = !h_f64_eligible(q);
+  if(wide && !h_f64w_eligible(q)) return -2;
+  std::vector<TwF64>  ti(wix.size());
+  std::vector<double> ti8(wi.size());
+  for(size_t i = 0; i < wix.size(); i++) ti[i] = h_tw_f64(wix[i], q);
+  for(size_t i = 0; i < wi.size(); i++) ti8[i] = h_tw_f64(wi[i], q).w;
+  const auto c = h_consts_f64(q, N, wi);
+  if(wide) return emu_dot_run<WideChk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
+  if(h_f64_ksh(q) >= 1) return emu_dot_run<ArithF64Chk, 1>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
+  return emu_dot_run<ArithF64Chk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
 }
 #endif
 

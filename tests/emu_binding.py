@@ -27,6 +27,7 @@ class Emu:
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
         L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
+        L.emu_inv_dot.argtypes = [U64P, C.c_int, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
         """arith: 0 = integer radix-2, 1 = FP64, 2 = checked FP64, 3 = integer radix-4 (expanded table)"""
@@ -58,6 +59,18 @@ class Emu:
         rc = self.lib.emu_fused_product_chk(out.ctypes.data_as(U64P), ahat.ctypes.data_as(U64P), b.ctypes.data_as(U64P),
                                             b.size >> m, m, q, root)
         self.lib.emu_set_product_both(0)
+        return rc, out
+
+    def inv_dot(self, a_list, b_list, m, q, root, arith=1, lazy=False, bcast=False):
+        """inv(sum_i a_i (.) b_i) for operands in the NTT domain as dot_inv_kernel (+ the inverse's column passes above 2^14)
+        computes it.  arith 0: integer radix-2, 1: the checked FP64 policy of q's class."""
+        k = len(a_list)
+        a = np.ascontiguousarray(np.concatenate(a_list), dtype=np.uint64)
+        b = np.ascontiguousarray(np.concatenate(b_list), dtype=np.uint64)
+        batch = a_list[0].size >> m
+        out = np.zeros(batch << m, dtype=np.uint64)
+        rc = self.lib.emu_inv_dot(out.ctypes.data_as(U64P), k, a.ctypes.data_as(U64P), b.ctypes.data_as(U64P), batch, m, q, root,
+                                  arith, int(lazy), int(bcast))
         return rc, out
 
     def expand_radix4(self, w, q):

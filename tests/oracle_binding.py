@@ -130,6 +130,20 @@ class Oracle:
         self.lib.orc_pointwise(ptr(c), ptr(a), ptr(b), a.size, q)
         return c
 
+    def dot(self, a_list, b_list, q, N=None, bcast=False):
+        """sum_i a_i (.) b_i mod q, element-wise (the reference's fast_mul_mod_q semantics per product, include/internal/
+        fast_mul_operators.h:56-60, here with 128-bit products); bcast: every b_i is one polynomial of N words shared by
+        the batch.  Operand words may be lazy (any 64-bit value): they are reduced first."""
+        acc = None
+        for a, b in zip(a_list, b_list):
+            a = np.ascontiguousarray(a, dtype=np.uint64) % np.uint64(q)
+            b = np.ascontiguousarray(b, dtype=np.uint64) % np.uint64(q)
+            if bcast:
+                b = np.tile(b, a.size // N)
+            t = self.pointwise(a, b, q)
+            acc = t if acc is None else (acc + t) % np.uint64(q)
+        return acc
+
     def schoolbook(self, a, b, N, q):
         c = np.zeros(N, dtype=np.uint64)
         self.lib.orc_negacyclic_schoolbook(ptr(c), ptr(a), ptr(b), N, q)

@@ -393,3 +393,93 @@ def test_fp64_class_boundary_moduli(oracle, emu, m):
         assert emu.chk_stats()[0] == 0, hex(q)
         if not wide:
             assert emu.transform(a, m, q, w, 4)[0] == 0          # the wide policy is valid for every q < 2^52 as well
+
+
+# ---- products of operands in the NTT domain: dot_inv_kernel's logic and arithmetic on the CPU -------------------------
+def _dot_operands(oracle, n, q, batch, k, seed, lazy, bcast):
+    """k operand pairs in the NTT domain: uniform words, with the extreme residues in the first slots; lazy: random
+    multiples of q added so that the words cover [0,4q)"""
+    rng = np.random.default_rng(seed)
+    a_list, b_list = [], []
+    for i in range(k):
+        a = oracle.fill_uniform(batch * n, q, seed + 2 * i)
+        b = oracle.fill_uniform((1 if bcast else batch) * n, q, seed + 2 * i + 1)
+        a[:3], b[:3] = q - 1, q - 1
+        a[3:6], b[3:5] = 0, q // 2
+        if lazy:
+            a = a + rng.integers(0, 4, a.size).astype(np.uint64) * np.uint64(q)
+            b = b + rng.integers(0, 4, b.size).astype(np.uint64) * np.uint64(q)
+            a[0], b[0] = 4 * q - 1, 4 * q - 1
+        a_list.append(a)
+        b_list.append(b)
+    return a_list, b_list
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 8])
+@pytest.mark.parametrize("m,q", [(12, 0x7fffffffe0001), (14, 0x7fffffffe0001), (14, 0x3ffffffdf0001), (8, 0x7ffe0001),
+                                 (13, 0xffffffff00001), (14, 0xffffffff00001), (11, 0x7fffffffe0001)])
+def test_dot_kernel_logic_checked_policy(oracle, emu, m, q, k):
+    """c = inv(sum_i a_i^ (.) b_i^) as dot_inv_kernel forms it -- products where the inverse transform would convert its
+    inputs, running sums folded every kDotEvery terms -- with the CHECKED FP64 policy (every value an integer below 2^53,
+    every product exact, every bound of ntt_arith.h held), canonical and lazy operand words, per-polynomial and
+    broadcast b; three modulus classes: scheduled class 0 (51 bits), class 1 (50 bits / small), reduce-both-operands (52 bits)"""
+    n = 1 << m
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    for lazy, bcast in ((False, False), (True, False), (False, True), (True, True)):
+        a_list, b_list = _dot_operands(oracle, n, q, 2, k, 4000 + 10 * m + k, lazy, bcast)
+        emu.chk_stats(reset=True)
+        rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=1, lazy=lazy, bcast=bcast)
+        assert rc == 0
+        exp = cx.inv(oracle.dot(a_list, b_list, q, n, bcast))
+        assert np.array_equal(got, exp), (m, hex(q), k, lazy, bcast)
+        fails, maxb, _ = emu.chk_stats()
+        assert fails == 0
+        assert maxb < 2.0 ** 53 / q * (1 - 1 / 64)
+
+
+def test_dot_kernel_logic_worst_case_sums(oracle, emu):
+    """all-(q-1) and alternating-sign operands drive every term to its largest magnitude and every running sum to the
+    edge of its folding schedule: still exact, k up to the launch limit"""
+    m, q = 12, 0x7fffffffe0001
+    n = 1 << m
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    for k in (4, 7, 32):
+        hi = np.full(n, q - 1, dtype=np.uint64)
+        mid = np.full(n, q // 2, dtype=np.uint64)
+        a_list = [hi if i % 2 == 0 else mid for i in range(k)]
+        b_list = [mid if i % 3 == 0 else hi for i in range(k)]
+        emu.chk_stats(reset=True)
+        rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=1)
+        assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q)))
+        assert emu.chk_stats()[0] == 0
+
+
+@pytest.mark.parametrize("m,q", [(15, 0x7fffffffe0001), (16, 0xffffffff00001), (17, 0x3ffffffdf0001)])
+def test_dot_kernel_logic_two_pass_sizes(oracle, emu, m, q):
+    """above 2^14 the product rides in the blocks of the inverse's first pass (2^12-point blocks at 2^15 / 2^16, 2^14 at 2^17),
+    the column passes follow: same result as inverse(sum of products)"""
+    n = 1 << m
+    if (q - 1) % (2 * n):
+        q = oracle.find_prime(50, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    a_list, b_list = _dot_operands(oracle, n, q, 1, 2, 4100 + m, False, False)
+    rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=1)
+    assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q)))
+
+
+@pytest.mark.parametrize("m,q", [(6, 0x1e01), (10, 0x10001), (14, 0x1000000000b00001), (12, 0xffffffffffc0001), (15, 0xffffffffffc0001)])
+def test_dot_kernel_logic_integer_policy(oracle, emu, m, q):
+    """the same kernel with the reference's integer arithmetic (fast_mul_mod_q per product, one conditional subtract per
+    term), moduli up to 60 bits, lazy words included"""
+    n = 1 << m
+    if (q - 1) % (2 * n) or not oracle.lib.orc_is_prime(q):
+        q = oracle.find_prime(60, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    for k, lazy, bcast in ((1, False, False), (3, True, False), (5, False, True)):
+        a_list, b_list = _dot_operands(oracle, n, q, 2, k, 4200 + m, lazy, bcast)
+        rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=0, lazy=lazy, bcast=bcast)
+        assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q, n, bcast))), (m, hex(q), k)

@@ -1376,3 +1376,216 @@ def test_block_sizes_below_the_column_pass_agree(lib, oracle, m, arith):
         with pytest.raises(lib.NttError):
             p17.set_option(lib.OPT_BLOCK_LOG, 12)
         p17.destroy()
+
+
+# ---- operands in the NTT domain (second half): ntt_inv_product_batch / ntt_inv_dot_batch / ntt_mul_transformed_batch
+def _ntt_domain_operands(oracle, n, q, batch, k, seed, lazy, bcast):
+    """k operand pairs of `batch` polynomials in the NTT domain: uniform words with the extreme residues in the first
+    slots; lazy: random multiples of q added so that the words cover [0,4q) (4q - 1 included)"""
+    rng = np.random.default_rng(seed)
+    a_list, b_list = [], []
+    for i in range(k):
+        a = oracle.fill_uniform(batch * n, q, seed + 2 * i)
+        b = oracle.fill_uniform((1 if bcast else batch) * n, q, seed + 2 * i + 1)
+        a[:3], b[:3] = q - 1, q - 1
+        a[3:6], b[3:5] = 0, q // 2
+        if lazy:
+            a = a + rng.integers(0, 4, a.size).astype(np.uint64) * np.uint64(q)
+            b = b + rng.integers(0, 4, b.size).astype(np.uint64) * np.uint64(q)
+            a[0], b[0] = 4 * q - 1, 4 * q - 1
+        a_list.append(a)
+        b_list.append(b)
+    return a_list, b_list
+
+
+_DOT_MODULI = {"f64_class0": (51, 0), "f64_class1": (50, 0), "f64_52bit": (52, 0), "f64_small": (31, 0), "u64_60bit": (60, 0)}
+
+
+@pytest.mark.parametrize("cls", sorted(_DOT_MODULI))
+@pytest.mark.parametrize("m", [8, 12, 13, 14, 16, 17])
+def test_inv_dot_in_the_ntt_domain(lib, oracle, m, cls):
+    """c = inv(sum_{i<k} a_i^ (.) b_i^), operands given in the NTT domain: ONE launch up to 2^14 (the products are formed where
+    the inverse transform would convert its input words), the product riding in the inverse's first pass above; against
+    the oracle's inverse of the 128-bit element-wise products' sum, for k = 1, 2, 3, 8, canonical and lazy ([0,4q)) operand
+    words, per-polynomial and broadcast b, c aliasing a^ or b^ (k = 1), ragged batches either side of the persistent grid,
+    chunk by chunk above 2^14; modulus classes: scheduled FP64 class 0 / 1, reduce-both-operands (52 bits), integer (60 bits)"""
+    n = 1 << m
+    bits, skip = _DOT_MODULI[cls]
+    q = lib.find_prime(bits, n, skip)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    want = {"f64_class0": (lib.ARITH_F64, 0), "f64_class1": (lib.ARITH_F64, 1), "f64_52bit": (lib.ARITH_F64, 52),
+            "f64_small": (lib.ARITH_F64, 18), "u64_60bit": (lib.ARITH_U64, 0)}[cls]
+    info = plan.info()
+    assert (info["arith"], info["f64_class"] if want[0] == lib.ARITH_F64 else 0) == want
+    big = 300 if m <= 14 else 6
+    for k, batch, lazy, bcast in ((1, 1, False, False), (1, big, False, False), (1, 3, True, False), (2, 3, False, False),
+                                  (3, big if m <= 12 else 5, True, False), (8, 2, False, True), (2, 5, True, True),
+                                  (1, 5, False, True)):
+        a_list, b_list = _ntt_domain_operands(oracle, n, q, batch, k, 5000 + 7 * m + k, lazy, bcast)
+        expect = cx.inv(oracle.dot(a_list, b_list, q, n, bcast))
+        flags = (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0)
+        da = [lib.DeviceBuffer(a.size).upload(a) for a in a_list]
+        db = [lib.DeviceBuffer(b.size).upload(b) for b in b_list]
+        dc = lib.DeviceBuffer(batch * n)
+        for chunk in ((256, 1) if m > 14 else (256,)):
+            plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+            if k == 1:
+                plan.inv_product(dc.ptr, da[0].ptr, db[0].ptr, batch, flags)
+            else:
+                plan.inv_dot(dc.ptr, [x.ptr for x in da], [x.ptr for x in db], batch, flags)
+            assert np.array_equal(dc.download(), expect), (k, batch, lazy, bcast, chunk)
+        if k == 1:
+            plan.inv_product(da[0].ptr, da[0].ptr, db[0].ptr, batch, flags)         # c aliases a^
+            assert np.array_equal(da[0].download(), expect), ("alias a", batch, lazy, bcast)
+            if not bcast:
+                da[0].upload(a_list[0])
+                plan.inv_product(db[0].ptr, da[0].ptr, db[0].ptr, batch, flags)     # c aliases b^
+                assert np.array_equal(db[0].download(), expect), ("alias b", batch, lazy)
+        for x in da + db + [dc]:
+            x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("m,arith", [(4, "auto"), (10, "generic"), (12, "r4"), (15, "generic"), (16, "u64")])
+def test_inv_dot_plans_without_the_fused_kernel(lib, oracle, m, arith):
+    """plans the fused kernel is not built for (N < 2^6, column-pass-only plans, the radix-4 formulation) accumulate the
+    products with pointwise launches and run their own inverse; the integer policy above 2^14 takes the kernel's
+    two-pass form: same results"""
+    n = 1 << m
+    q = lib.find_prime(50 if arith != "u64" else 59, n)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w, arith={"r4": lib.ARITH_U64_R4, "u64": lib.ARITH_U64}.get(arith, lib.ARITH_AUTO))
+    if arith == "generic":
+        plan.set_generic(True)
+    for k, batch, lazy, bcast in ((1, 3, False, False), (3, 2, True, False), (4, 3, False, True)):
+        a_list, b_list = _ntt_domain_operands(oracle, n, q, batch, k, 5100 + m, lazy, bcast)
+        expect = cx.inv(oracle.dot(a_list, b_list, q, n, bcast))
+        da = [lib.DeviceBuffer(a.size).upload(a) for a in a_list]
+        db = [lib.DeviceBuffer(b.size).upload(b) for b in b_list]
+        dc = lib.DeviceBuffer(batch * n)
+        plan.inv_dot(dc.ptr, [x.ptr for x in da], [x.ptr for x in db], batch,
+                     (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0))
+        assert np.array_equal(dc.download(), expect), (k, batch, lazy, bcast)
+        for x in da + db + [dc]:
+            x.free()
+    plan.destroy()
+
+
+def test_inv_dot_bad_arguments(lib, oracle):
+    n, q = 256, 0x1e01
+    plan = lib.Plan(n, q, lib.min_root(q, n))
+    d = lib.DeviceBuffer(n)
+    with pytest.raises(lib.NttError):
+        plan.inv_dot(d.ptr, [d.ptr] * 33, [d.ptr] * 33, 1)          # more pairs than one launch carries
+    with pytest.raises(lib.NttError):
+        plan.inv_product(d.ptr, d.ptr, d.ptr, 1, flags=64)          # unknown flag
+    with pytest.raises(lib.NttError):
+        plan.inv_product(0, d.ptr, d.ptr, 1)
+    plan.inv_product(d.ptr, d.ptr, d.ptr, 0)                        # empty batch: nothing to do
+    d.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("bits", [51, 50, 52])
+@pytest.mark.parametrize("m", [8, 11, 12, 13, 14, 15, 16, 17])
+def test_mul_by_a_transformed_operand(lib, oracle, m, bits):
+    """c = inv(fwd(a) (.) b^) with b^ transformed beforehand (a key / plaintext kept in the NTT domain): the product
+    kernels' form with one operand given in the NTT domain, canonical or lazy words, every aliasing form, small batches
+    (block launches) and -- N >= 2^15 -- the batch size from which the whole chain is one launch"""
+    n = 1 << m
+    q = lib.find_prime(bits, n)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    batches = (1, 5, 300) if m <= 14 else (3, (1 << 23) >> m)
+    for batch in batches:
+        a = oracle.fill_uniform(batch * n, q, 91)
+        bhat = oracle.fill_uniform(batch * n, q, 92)
+        bhat[:4] = [0, q - 1, 1, q // 2]
+        sample = list(range(batch)) if batch <= 8 else sorted({0, 1, batch // 2, batch - 2, batch - 1, min(batch - 1, 255), min(batch - 1, 256)})
+        pick = np.concatenate([np.arange(p * n, (p + 1) * n) for p in sample])
+        expect = cx.inv(oracle.pointwise(cx.fwd(a[pick]), bhat[pick], q))
+        lazy_b = bhat + np.uint64(q) * (np.arange(bhat.size, dtype=np.uint64) % np.uint64(3 if 4 * q <= 2 ** 53 else 1))
+        da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+        for words, flags in ((bhat, 0), (lazy_b, lib.MUL_LAZY_IN)):
+            da.upload(a), db.upload(words)
+            plan.mul_transformed(dc.ptr, da.ptr, db.ptr, batch, flags)
+            got = dc.download()
+            assert np.array_equal(got[pick], expect), (batch, flags)
+            assert np.array_equal(db.download(), words)                 # the transformed operand is only read
+            if m <= 14:
+                assert np.array_equal(da.download(), a)                  # ... and so is a up to 2^14
+            da.upload(a)
+            plan.mul_transformed(da.ptr, da.ptr, db.ptr, batch, flags)     # c aliases a
+            assert np.array_equal(da.download(), got), (batch, flags, "alias a")
+            da.upload(a)
+            plan.mul_transformed(db.ptr, da.ptr, db.ptr, batch, flags)     # c aliases b^
+            assert np.array_equal(db.download(), got), (batch, flags, "alias b^")
+        for x in (da, db, dc):
+            x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("logn,batch", [(12, 2), (14, 1), (14, 600), (16, 2), (16, 70)])
+def test_rns_products_in_the_ntt_domain(lib, oracle, logn, batch, monkeypatch):
+    """the NTT-domain products over RNS limbs ([limb][batch][N]; a broadcast key: [limb][N]): one launch over the limbs
+    when a limb's share cannot fill the chip, limb by limb otherwise -- both forms forced in turn, against the oracle"""
+    n = 1 << logn
+    nl, k = 4, 3
+    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    slab = batch * n
+    rng_ops = [[_ntt_domain_operands(oracle, n, q, batch, k, 5200 + 11 * l, False, True) for l, q in enumerate(qs)]]
+    ops = rng_ops[0]
+    a_all = [np.concatenate([ops[l][0][i] for l in range(nl)]) for i in range(k)]        # [limb][batch][N]
+    key_all = [np.concatenate([ops[l][1][i] for l in range(nl)]) for i in range(k)]      # [limb][N]
+    sample = sorted({0, batch // 2, batch - 1})
+    expect = []
+    for l, (q, w) in enumerate(zip(qs, ws)):
+        cx = oracle.ctx(n, q, w)
+        full = cx.inv(oracle.dot(ops[l][0], ops[l][1], q, n, True)) if batch <= 8 else None
+        for p_ in sample:
+            if full is not None:
+                expect.append(full[p_ * n:(p_ + 1) * n])
+            else:
+                sl = slice(p_ * n, (p_ + 1) * n)
+                expect.append(cx.inv(oracle.dot([x[sl] for x in ops[l][0]], ops[l][1], q, n, True)))
+    da = [lib.DeviceBuffer(x.size).upload(x) for x in a_all]
+    dk = [lib.DeviceBuffer(x.size).upload(x) for x in key_all]
+    dc = lib.DeviceBuffer(nl * slab)
+    outs = []
+    for loop in ("0", "1"):
+        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        lib.rns_inv_dot(plans, dc.ptr, [x.ptr for x in da], [x.ptr for x in dk], batch, lib.MUL_B_BROADCAST)
+        got = dc.download()
+        outs.append(got)
+        j = 0
+        for l in range(nl):
+            for p_ in sample:
+                assert np.array_equal(got[l * slab + p_ * n: l * slab + (p_ + 1) * n], expect[j]), (loop, l, p_)
+                j += 1
+    assert np.array_equal(outs[0], outs[1])
+    # c = inv(fwd(a) (.) b^) over the limbs, b^ per polynomial
+    a_co = np.concatenate([oracle.fill_uniform(slab, q, 5300 + l) for l, q in enumerate(qs)])
+    bh = np.concatenate([oracle.fill_uniform(slab, q, 5400 + l) for l, q in enumerate(qs)])
+    dco, dbh = lib.DeviceBuffer(a_co.size), lib.DeviceBuffer(bh.size).upload(bh)
+    outs = []
+    for loop in ("0", "1"):
+        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        dco.upload(a_co)
+        lib.rns_mul_transformed(plans, dc.ptr, dco.ptr, dbh.ptr, batch)
+        outs.append(dc.download())
+    assert np.array_equal(outs[0], outs[1])
+    for l, (q, w) in enumerate(zip(qs, ws)):
+        cx = oracle.ctx(n, q, w)
+        for p_ in sample:
+            sl = slice(l * slab + p_ * n, l * slab + (p_ + 1) * n)
+            assert np.array_equal(outs[0][sl], cx.inv(oracle.pointwise(cx.fwd(a_co[sl]), bh[sl], q))), (l, p_)
+    for x in da + dk + [dc, dco, dbh]:
+        x.free()
+    for p in plans:
+        p.destroy()
