@@ -245,6 +245,9 @@ def cpu_baseline(workload=None, lib=None, budget_s=10.0):
                      "%d-op slabs per thread; single core: %d warm-ups, 10 x %d calls, min of means = %.1f us per call"
                      % (int(ops), what, w.logn, hex(q), secs, nthr, allowed, online,
                         "none" if quota is None else "%.1f CPUs" % quota, slab_ops, 10, inner, ns / 1e3)}
+    res["sample"] += ("; the %s is compiled gcc -O3 -march=x86-64-v3 in the build container (oracle/Makefile) and travels as a "
+                      "binary -- built off-box, not -march=native on this host (scalar 64-bit code: the difference is small)"
+                      % ("reference" if kind == "reference" else "restatement"))
     if w.limbs > 1:
         res["sample"] += "; an RNS product = %d limb-products" % w.limbs
     if kind != "reference":
@@ -400,6 +403,22 @@ class GpuShard:
                 best = ms
         return words * 16 / (best * 1e-3) / 1e9
 
+    def shape_ceiling_gbs(self, reps=6):
+        """the same with the memory shape of the 2^14 block kernels themselves (ntt_shape_probe: persistent workgroups,
+        next block prefetched in registers, 16-byte accesses): the best memory-only skeleton, measured in this run"""
+        words = (self.limbs * self.slab) & ~((1 << 14) - 1)
+        if words == 0:
+            return None
+        best = None
+        for r in range(reps + 1):
+            self.ev0.record(self.stream)
+            self.lib.shape_probe(self.buf.ptr, words, 0, device=self.device, stream=self.stream)
+            self.ev1.record(self.stream)
+            ms = self.ev1.elapsed_ms_since(self.ev0)
+            if r and (best is None or ms < best):
+                best = ms
+        return words * 16 / (best * 1e-3) / 1e9
+
     def polys(self, which, base=None, limb=0):
         import numpy as np
         buf = base if base is not None else self.buf
@@ -490,7 +509,7 @@ def kernel_chain(w, arith, f64_class):
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,
-                step_ms=None, f64_class=0):
+                step_ms=None, f64_class=0, shape_gbs=None):
     n = n or N
     w = workload
     bytes_per_unit = w.bytes_per_unit if w else 16 * n
@@ -531,8 +550,12 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
             # point, not the ceiling: memory-only skeletons of the kernel's own shape reach 0.67-0.72 of the peak,
             # profiles/r02/skeleton.txt)
             "copy_probe": copy_gbs, "frac_of_copy_probe": (achieved / copy_gbs) if copy_gbs else None,
-            "best_memory_only_skeleton_frac": 0.717,
-            "frac_of_best_memory_only_skeleton": achieved / HBM_PEAK_GBS / 0.717}
+            # measured in this run as well (ntt_shape_probe): the memory shape of the 2^14 block kernels without their
+            # arithmetic -- persistent 1024-thread workgroups, register prefetch, 16-byte accesses; null when not measured
+            "shape_probe": shape_gbs,
+            "best_memory_only_skeleton_frac": (shape_gbs / HBM_PEAK_GBS) if shape_gbs else None,
+            "best_memory_only_skeleton_source": "ntt_shape_probe, measured in this run after the timed region" if shape_gbs else None,
+            "frac_of_best_memory_only_skeleton": (achieved / shape_gbs) if shape_gbs else None}
     if step_ms:
         roof["step_ms_min"] = min(step_ms)
         roof["step_ms_median"] = statistics.median(step_ms)
@@ -553,6 +576,91 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     }
 
 
+class Parity:
+    """Parity spot check on the benchmarked launches themselves: the first warm-up step runs on the whole shard; the first
+    and the last polynomial of the shard are compared with the oracle (no separate probe launch, so a profiler's per-kernel
+    statistics contain full-size launches only).  capture() before the steps, check() after the first warm-up."""
+
+    def __init__(self, w, shard, batch):
+        self.w, self.s, self.batch, self.n = w, shard, batch, w.n
+        self.before, self.mid = {}, {}
+
+    def capture(self):
+        s, w = self.s, self.w
+        s.fill()
+        s.sync()
+        which = [0, self.batch - 1]
+        if w.kind == "rns_product":
+            words = s.limbs * s.slab
+
+            class View:      # operand set 0 inside the big buffer
+                def __init__(self, off):
+                    self.off = off
+
+                def download(self, cnt, offset):
+                    return s.buf.download(cnt, self.off + offset)
+            for l in (0, w.limbs - 1):
+                self.before["a%d" % l] = s.polys(which, base=View(0), limb=l)
+                self.before["b%d" % l] = s.polys(which, base=View(words), limb=l)
+        else:
+            self.before["a"] = s.polys(which)
+
+    def check(self):
+        import numpy as np
+        from oracle_binding import Oracle
+        s, w, n = self.s, self.w, self.n
+        s.sync()
+        orc = Oracle()
+        which = [0, self.batch - 1]
+        if w.kind == "fwd":
+            cx = orc.ctx(n, w.qs[0], w.roots[0])
+            assert np.array_equal(s.polys(which), cx.fwd(self.before["a"])), "GPU forward NTT differs from the oracle"
+        elif w.kind == "roundtrip":
+            assert np.array_equal(s.polys(which), self.before["a"]), "forward+inverse round trip is not the identity"
+        else:
+            for l in (0, w.limbs - 1):
+                cx = orc.ctx(n, w.qs[l], w.roots[l])
+                exp = cx.inv(orc.pointwise(cx.fwd(self.before["a%d" % l]), cx.fwd(self.before["b%d" % l]), w.qs[l]))
+                assert np.array_equal(s.polys(which, base=s.out, limb=l), exp), "GPU RNS product differs from the oracle"
+
+    def check_roundtrip_forward(self):
+        """config 3: the forward half against the oracle, on a separate small launch after the timed region (the timed
+        steps are whole round trips)"""
+        import numpy as np
+        from oracle_binding import Oracle
+        cx = Oracle().ctx(self.n, self.w.qs[0], self.w.roots[0])
+        a = self.before["a"]
+        assert np.array_equal(self.s.plan.fwd_host(a), cx.fwd(a)), "GPU forward NTT differs from the oracle"
+        self.mid["fwd_checked"] = True
+
+
+def also_config(lib, config, steps=6, warmup=1, check=True):
+    """BASELINE configs 2, 3 and 5 beside the headline (only the default run is driver-timed): the
+    config's one-GPU share through the same GpuShard / run_steps / Parity code as `--config N`, after the headline's timed
+    region, a few steps each, parity spot-checked on the first warm-up step like the headline.  Compact block: value, unit,
+    frac of 8 TB/s at the config's algorithmic bytes per unit, mean / min step time."""
+    w = workload_for(config).resolve(lib)
+    batch = w.per_gpu_batch("weak", 1)
+    shard = GpuShard(lib, 0, 0, batch, n=w.n, kind=w.kind, qs=w.qs, roots=w.roots, steps_total=steps + max(warmup, 1))
+    par = Parity(w, shard, batch)
+    if check:
+        par.capture()
+    elapsed, kernel_ms = run_steps([shard], steps, max(warmup, 1 if check else 0), shard.sync, par.check if check else None)
+    if check and w.kind == "roundtrip":
+        par.check_roundtrip_forward()
+    step_ms = shard.step_ms()
+    gbs = batch * w.bytes_per_unit / (kernel_ms[0] * 1e-3) / 1e9
+    kname, launches = kernel_chain(w, shard.arith(), shard.f64_class())
+    out = {"value": batch / (elapsed / steps), "unit": w.unit, "frac": gbs / HBM_PEAK_GBS, "achieved_GBs": gbs,
+           "kernel_ms": kernel_ms[0], "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": max(warmup, 1 if check else 0),
+           "step_ms_min": min(step_ms), "frac_at_min": batch * w.bytes_per_unit / (min(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_unit": w.bytes_per_unit, "batch_per_gpu": batch, "N": w.n,
+           "q": [hex(q) for q in w.qs], "parity_checked": bool(check), "kernel": kname, "launches_per_step": launches,
+           "workload": w.metric}
+    shard.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -565,6 +673,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side measurements (copy probe, other primes): profiler runs then see the step's kernels only")
     ap.add_argument("--logn", type=int, default=0, help="(experiments, config 4 only) other transform sizes")
+    ap.add_argument("--no-also", action="store_true", help="default run: skip the also_config2/3/5 blocks")
+    ap.add_argument("--also-steps", type=int, default=6, help="timed steps of each also_configN block")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -618,65 +728,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # parity spot check on the benchmarked launches themselves: the first warm-up step runs on the whole shard; the first
-    # and the last polynomial of shard 0 are compared with the oracle (no separate probe launch, so the profiler's
-    # per-kernel statistics contain full-size launches only)
+    # parity spot check on the benchmarked launches themselves (class Parity): first and last polynomial of shard 0
+    # against the oracle after the first warm-up step
     check = rank == 0 and not os.environ.get("NTT_BENCH_NOCHECK")   # (ablation builds compute garbage on purpose)
-    before = {}
-
-    def parity():
-        s = shards[0]
-        s.sync()
-        from oracle_binding import Oracle
-        orc = Oracle()
-        which = [0, batch - 1]
-        if w.kind == "fwd":
-            cx = orc.ctx(n, w.qs[0], w.roots[0])
-            assert np.array_equal(s.polys(which), cx.fwd(before["a"])), "GPU forward NTT differs from the oracle"
-        elif w.kind == "roundtrip":
-            assert np.array_equal(s.polys(which), before["a"]), "forward+inverse round trip is not the identity"
-        else:
-            for l in (0, w.limbs - 1):
-                cx = orc.ctx(n, w.qs[l], w.roots[l])
-                exp = cx.inv(orc.pointwise(cx.fwd(before["a%d" % l]), cx.fwd(before["b%d" % l]), w.qs[l]))
-                assert np.array_equal(s.polys(which, base=s.out, limb=l), exp), "GPU RNS product differs from the oracle"
-
-    mid = {}
-
-    def capture():
-        s = shards[0]
-        s.fill()
-        s.sync()
-        which = [0, batch - 1]
-        if w.kind == "rns_product":
-            words = s.limbs * s.slab
-
-            class View:      # operand set 0 inside the big buffer
-                def __init__(self, off):
-                    self.off = off
-
-                def download(self, cnt, offset):
-                    return s.buf.download(cnt, self.off + offset)
-            for l in (0, w.limbs - 1):
-                before["a%d" % l] = s.polys(which, base=View(0), limb=l)
-                before["b%d" % l] = s.polys(which, base=View(words), limb=l)
-        else:
-            before["a"] = s.polys(which)
-
-    def parity_roundtrip_forward():
-        """config 3: the forward half against the oracle, on a separate small launch after the timed region (the timed
-        steps are whole round trips)"""
-        s = shards[0]
-        from oracle_binding import Oracle
-        cx = Oracle().ctx(n, w.qs[0], w.roots[0])
-        a = before["a"]
-        assert np.array_equal(s.plan.fwd_host(a), cx.fwd(a)), "GPU forward NTT differs from the oracle"
-        mid["fwd_checked"] = True
+    par = Parity(w, shards[0], batch)
 
     if check:
-        capture()
+        par.capture()
     elapsed, kernel_ms = run_steps(shards, args.steps, max(args.warmup, 1 if check else 0), barrier,
-                                   parity if check else None)
+                                   par.check if check else None)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     elapsed = allreduce_max(dist, elapsed, device="cuda" if on_gpu else None)
     if dist is not None:
@@ -690,18 +750,24 @@ def main():
     if rank == 0:
         s0 = shards[0]
         if check and w.kind == "roundtrip":
-            parity_roundtrip_forward()
+            par.check_roundtrip_forward()
         # after the timed region, on shard 0's resident buffer
         copy_gbs = None if args.headline_only else s0.copy_ceiling_gbs()
+        shape_gbs = None if args.headline_only else s0.shape_ceiling_gbs()
         slow = max(range(len(shards)), key=lambda i: kernel_ms[i] if i < len(kernel_ms) else 0) if world == 1 else 0
         out = make_report(args, n_gpus, batch, elapsed, kernel_ms, s0.arith(), s0.hbm_passes(), n=n, copy_gbs=copy_gbs,
-                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class())
+                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class(), shape_gbs=shape_gbs)
         if n_gpus == 1 and not args.headline_only:
             if w.config == 4 and n == N:
                 out["also_literal_50_bit_q"] = literal_50_bit(lib, s0, args.steps)
             if w.config == 3:
                 out["also_reference_case_17"] = side_forward(lib, s0, Q, max(args.steps // 2, 2),
                                                              "forward only, 51-bit q of reference test case 17")
+            if w.config == 4 and n == N and not args.no_also:
+                # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
+                # above): the driver only runs this default command, so their numbers ride on its line
+                for cfg in (2, 3, 5):
+                    out["also_config%d" % cfg] = also_config(lib, cfg, steps=args.also_steps, check=check)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, lib)
         print(json.dumps(out), flush=True)

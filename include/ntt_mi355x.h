@@ -232,6 +232,11 @@ NTT_API int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, 
  * -- no arithmetic, no LDS, the same 8 B in + 8 B out per coefficient as an in-place NTT.  mask = 0 leaves the
  * data unchanged.  n must be even. */
 NTT_API int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream);
+/* the same measurement in the memory shape of the 2^14 block kernels themselves: one persistent 1024-thread workgroup per CU,
+ * 2^14-word blocks as 16-byte loads with the next block prefetched in registers, XOR, 16-byte stores (whole KiB per wave and
+ * instruction) -- the best memory-only skeleton of the transform kernels (profiles/r02/skeleton.txt), measured in the run
+ * that quotes it.  n must be a multiple of 2^14. */
+NTT_API int ntt_shape_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream);
 
 /* ---- multi-GPU: one call drives every listed device (per-device streams, no
  * collective -- polynomials are independent).  plans[g], d_a[g] and

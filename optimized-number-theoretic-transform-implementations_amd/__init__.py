@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
-    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
+    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
     "ntt_compat_release", "ntt_compat_cached_plans",
     # reference signatures (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h)
     "fwd_ntt_ref_harvey_lazy", "inv_ntt_ref_harvey", "fwd_ntt_ref_harvey_lazy_dbl",
@@ -124,6 +124,7 @@ _sig("ntt_event_elapsed_ms", C.c_int, C.c_int, VOIDP, VOIDP, C.POINTER(C.c_float
 _sig("ntt_fill_uniform", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_poly_checksum", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_rmw_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_shape_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_batch_multi", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), U64P, C.c_int)
 _sig("ntt_compat_release", None)
 _sig("ntt_compat_cached_plans", C.c_int)
@@ -226,6 +227,11 @@ def poly_checksum(dout, dptr, N, batch, device=0, stream=None):
 def rmw_probe(dptr, n, mask=0, device=0, stream=None):
     """in-place read-XOR-write of n words: the measured ceiling of the transform's memory shape"""
     _check(_lib.ntt_rmw_probe(device, dptr, n, mask, stream))
+
+
+def shape_probe(dptr, n, mask=0, device=0, stream=None):
+    """the same in the memory shape of the 2^14 block kernels (persistent workgroups, register prefetch, 16-byte accesses)"""
+    _check(_lib.ntt_shape_probe(device, dptr, n, mask, stream))
 
 
 def stream_sync(device=0, stream=None):

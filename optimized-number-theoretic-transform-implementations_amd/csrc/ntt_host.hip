@@ -1517,6 +1517,66 @@ extern "C" int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mas
   return NTT_OK;
 }
 
+/* The memory shape of the 2^14 block kernels without their arithmetic (tools/skel.hip "T1024 C16 ld16 st1 mode1": the best
+ * memory-only skeleton measured, profiles/r02/skeleton.txt): one persistent 1024-thread workgroup per CU, a block of 2^14
+ * words per iteration as eight 16-byte loads per thread with the NEXT block's loads in flight (register prefetch), XOR,
+ * eight 16-byte stores -- every load and store instruction of a wave covers one contiguous KiB. */
+__global__ void __launch_bounds__(1024, 4) shape_probe_kernel(uint64_t *a, uint64_t nblocks, uint64_t mask)
+{
+  constexpr int  LOGN = 14;
+  const uint32_t t    = threadIdx.x;
+  uint64_t       b    = blockIdx.x;
+  if(b >= nblocks) return;
+  u64x2 raw[8];
+  {
+    const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(a + (b << LOGN));
+#pragma unroll
+    for(int h = 0; h < 8; h++) raw[h] = buffer_load_u64x2(r, t * 16u, (uint32_t)h * 16384u);
+  }
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  for(; b < nblocks; b += gridDim.x) {
+    u64x2 x[8];
+#pragma unroll
+    for(int h = 0; h < 8; h++) x[h] = u64x2{raw[h].a ^ mask, raw[h].b ^ mask};
+    const bool     more = b + gridDim.x < nblocks;
+    const uint64_t nb   = more ? b + gridDim.x : b;
+    {
+      const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(a + (nb << LOGN), more);
+#pragma unroll
+      for(int h = 0; h < 8; h++) raw[h] = buffer_load_u64x2(r, t * 16u, (uint32_t)h * 16384u);
+    }
+    const __amdgpu_buffer_rsrc_t w = block_rsrc<LOGN>(a + (b << LOGN));
+#pragma unroll
+    for(int h = 0; h < 8; h++) {
+      v4u32 v;
+      v.x = (unsigned)x[h].a;
+      v.y = (unsigned)(x[h].a >> 32);
+      v.z = (unsigned)x[h].b;
+      v.w = (unsigned)(x[h].b >> 32);
+      __builtin_amdgcn_raw_buffer_store_b128(v, w, (int)(t * 16u), (int)((uint32_t)h * 16384u), 0);
+    }
+  }
+}
+
+extern "C" int ntt_shape_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream)
+{
+  int rc = check_device(device);
+  if(rc) return rc;
+  if(!d_a || (n & ((1ull << 14) - 1)) || ((uintptr_t)d_a & 15)) return fail(NTT_ERR_ARG, "shape probe: null, unaligned or not a multiple of 2^14 words");
+  if(n == 0) return NTT_OK;
+  USE_DEVICE(device);
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  const uint64_t nblocks = n >> 14;
+  const unsigned grid    = (unsigned)(nblocks < (uint64_t)cus ? nblocks : (uint64_t)cus);
+  hipLaunchKernelGGL(shape_probe_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, d_a, nblocks, mask);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* thin HIP wrappers                                                   */
 /* ------------------------------------------------------------------ */

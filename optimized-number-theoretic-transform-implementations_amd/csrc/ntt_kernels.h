@@ -1730,6 +1730,26 @@ template <class A> struct KDot {
   const uint64_t *b[kMaxDot];
 };
 
+/* The b operand of a pair goes through the caches (no nt hint): when ONE polynomial serves the whole batch (a key) every
+ * block re-reads it and it must stay in the L2 -- with nt loads the broadcast form measured no faster than the
+ * per-polynomial one (profiles/r04/domain_bench_first.txt).  The hint is an instruction bit, and a run-time branch between
+ * two sets of loads makes the register allocator keep both sets apart (77 spilled VGPRs): one policy for both forms. */
+constexpr int kDotAuxB = 0;
+/* tuning knobs of the persistent loop (A/B builds: tools/build_dot_variant.sh) */
+#ifndef NTT_DOT_AUX_A
+#  define NTT_DOT_AUX_A 0 /* cache policy of the a operand's loads: plain, like b's (measured +3 % over nt at k = 1, +10 % with a broadcast key at k = 8: profiles/r04/ab_dot.txt) */
+#endif
+#ifndef NTT_DOT_A_AT
+#  define NTT_DOT_A_AT 1 /* the next block's a words are requested behind the exchange into this group (1 = the last one) */
+#endif
+#ifndef NTT_DOT_LOOP_CHUNK
+#  define NTT_DOT_LOOP_CHUNK 2 /* products in flight inside the pair loop */
+#endif
+template <int LOGN> __device__ __forceinline__ void prefetch_last_b(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
+{
+  prefetch_last<LOGN, kDotAuxB>(raw, t, blk, live);
+}
+
 template <class A, int LOGN, int KSH, bool LASTINV, bool MULTI = false>
 __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<LOGN, true, flavor_of<A>()>::WPS)) dot_inv_kernel(const KDot<A> kd)
 {
@@ -1774,8 +1794,8 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
      * twiddle request to arrive. */
     constexpr bool IPRE = stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
     uint64_t ra[kE], rb[kE];
-    prefetch_last<LOGN>(ra, tid, kd.a[0] + aoff + (b << LOGN));
-    prefetch_last<LOGN>(rb, tid, kd.b[0] + boff + ((bc ? (b & bmask) : b) << LOGN));
+    prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tid, kd.a[0] + aoff + (b << LOGN));
+    prefetch_last_b<LOGN>(rb, tid, kd.b[0] + boff + ((bc ? (b & bmask) : b) << LOGN));
     pin_raw(ra);
     pin_raw(rb);
     for(; b < p.nblocks; b += stride) {
@@ -1792,9 +1812,9 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
 #pragma unroll 1
       for(uint32_t i = 0; i + 1 < np; i++) {
         if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
-        dot_tile<A, 0, kE, 2>(x, ra, rb, lazy, p.c);
-        prefetch_last<LOGN>(ra, tl, kd.a[i + 1] + aoff + (b << LOGN));
-        prefetch_last<LOGN>(rb, tl, kd.b[i + 1] + boff + (bb << LOGN));
+        dot_tile<A, 0, kE, NTT_DOT_LOOP_CHUNK>(x, ra, rb, lazy, p.c);
+        prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tl, kd.a[i + 1] + aoff + (b << LOGN));
+        prefetch_last_b<LOGN>(rb, tl, kd.b[i + 1] + boff + (bb << LOGN));
         sched_fence();
       }
       if(np > 1 && (np - 1) % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
@@ -1818,12 +1838,12 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = P::NG - 1 - decltype(gg)::value;
         exchange<A, LOGN, GI, GI - 1>(x, tl, lds_all);
-        if constexpr(GI == 1) {
+        if constexpr(GI == NTT_DOT_A_AT) {
           /* the next block's first pair, operand a: always issued (a dead descriptor moves no data past the end) */
           uint32_t t2 = tid;
           asm volatile("" : "+v"(t2));
           sched_fence();
-          prefetch_last<LOGN>(ra, t2, kd.a[0] + aoff + (nb << LOGN), more);
+          prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, t2, kd.a[0] + aoff + (nb << LOGN), more);
           sched_fence();
         }
         if constexpr(G::TBL(GI - 1) > 0) {
@@ -1837,7 +1857,7 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
         uint32_t t3 = tid;
         asm volatile("" : "+v"(t3));
         sched_fence();
-        prefetch_last<LOGN>(rb, t3, kd.b[0] + boff + ((bc ? (nb & bmask) : nb) << LOGN), more);
+        prefetch_last_b<LOGN>(rb, t3, kd.b[0] + boff + ((bc ? (nb & bmask) : nb) << LOGN), more);
         sched_fence();
       }
       uint64_t out[kE];
