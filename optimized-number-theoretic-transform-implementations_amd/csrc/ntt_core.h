@@ -1146,6 +1146,48 @@ NTT_HD void column_pass_thread_r4(uint64_t *poly, uint32_t col, uint32_t logn, u
   });
 }
 
+/* ------------------------------------------------------------------ */
+/* in-launch work queues of the XCD-local kernels (team_kernel, team_product_kernel) */
+/* ------------------------------------------------------------------ */
+/*
+ * A launch has eight in-order queues (one per XCD).  The polynomials of the launch -- `total` of them: with several RNS
+ * limbs in one launch, limb l's polynomial p is number l * batch + p -- are dealt to the queues statically: queue q owns
+ * q, q + 8, q + 16, ...  Entry k of a queue (k = 0, 1, 2, ... as handed out by an atomic counter) decodes to one ITEM:
+ *   step = k / PER, r = k % PER, PER = n0 + n1 + n2 items of the (up to three) passes of one polynomial;
+ *   pass 0 items of the queue's polynomial number j = step, pass 1 items of j = step - lag, pass 2 items of
+ *   j = step - 2 lag: a later pass runs `lag` polynomials behind the one before it.
+ * An item whose j falls outside [0, J) is a hole (the queue's head and tail): nothing to do.  Items of pass P > 0 wait until
+ * all items of pass P - 1 of their polynomial have signalled completion; those were handed out EARLIER in the same queue
+ * (step - lag < step, and inside a step the passes are in order), so whoever waits, waits for an item that is already in
+ * the hands of a running workgroup: no deadlock whatever the number of resident workgroups.  Pass-0 items never wait.
+ * tests/test_team_protocol.py simulates the protocol on this very function.
+ */
+struct TeamItem {
+  uint32_t stop;  /* the queue is exhausted: leave it */
+  uint32_t valid; /* 0: a hole, fetch the next entry */
+  uint32_t pass, item;
+  uint32_t v;     /* the polynomial, 0 .. total-1 (limb * batch + polynomial) */
+};
+
+NTT_HD uint32_t team_queue_polys(uint32_t total, uint32_t q) { return total > q ? (total - q + 7u) / 8u : 0u; }
+
+NTT_HD TeamItem team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag, uint32_t n0, uint32_t n1, uint32_t n2)
+{
+  const uint32_t J      = team_queue_polys(total, q);
+  const uint32_t npass  = n2 ? 3u : 2u;
+  const uint32_t steps  = J + (npass - 1u) * lag;
+  const uint32_t per    = n0 + n1 + n2;
+  const uint32_t step   = k / per, r = k % per;
+  TeamItem       it;
+  it.stop  = step >= steps ? 1u : 0u;
+  it.pass  = r < n0 ? 0u : (r < n0 + n1 ? 1u : 2u);
+  it.item  = it.pass == 0 ? r : (it.pass == 1 ? r - n0 : r - n0 - n1);
+  const int64_t j = (int64_t)step - (int64_t)it.pass * (int64_t)lag;
+  it.valid = (!it.stop && j >= 0 && j < (int64_t)J) ? 1u : 0u;
+  it.v     = q + 8u * (uint32_t)(j < 0 ? 0 : j);
+  return it;
+}
+
 template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
 {
   if constexpr(!A::kTracksBounds) {

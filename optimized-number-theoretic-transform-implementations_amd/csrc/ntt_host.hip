@@ -663,10 +663,13 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
  * the heavy one: the column items wait longer than the L2 can hold their polynomials) and keeps the per-pass launches.
  * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it; NTT_XCD_LOCAL in the
  * environment overrides the automatic choice the same way. */
+/* nlimbs > 1: the limbs of an RNS set in ONE launch (the queues run over all limbs' polynomials): `batch` is per limb */
 static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool wide, bool lazy, int nlimbs, bool product = false)
 {
-  if(p->arith != NTT_ARITH_F64 || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy || nlimbs != 1 ||
-     batch < 64 || batch >= (1ull << 31)) {
+  if(nlimbs < 1 || nlimbs > kMaxLimbs) return false;
+  batch *= (uint64_t)nlimbs; /* polynomials of the launch */
+  if(p->arith != NTT_ARITH_F64 || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy || batch < 64 ||
+     batch >= (1ull << 29)) {
     return false;
   }
   int on = p->xcd_local;
@@ -748,15 +751,15 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     /* the queue heads and counters live in a buffer the plan keeps per stream; it is allocated on first use -- except
      * while the stream is being captured into a HIP graph (allocation is not capturable): the call then takes the
      * per-pass launches, which need no memory of their own */
-    int rc = team_buffer(const_cast<ntt_plan *>(p), stream, batch, &ctl);
+    int rc = team_buffer(const_cast<ntt_plan *>(p), stream, batch * (uint64_t)ls.n, &ctl);
     if(rc) return rc;
   }
   if(ctl) {
     PassArgs pa{};
     pa.a           = d_a;
     pa.limbs       = ls.d;
-    pa.nlimbs      = 1;
-    pa.limb_stride = 0;
+    pa.nlimbs      = ls.n;
+    pa.limb_stride = ls.stride;
     pa.batch       = batch;
     pa.logn        = (uint32_t)p->m;
     pa.fused       = 3;
@@ -1039,7 +1042,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   void *ctl  = nullptr;
   int   rc   = NTT_OK;
   if(canonical_a && !p->block_log) {
-    rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch, &ctl);
+    rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch * (uint64_t)ls.n, &ctl);
     if(rc) return rc;
   }
   const bool four = !ahat_given && ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
@@ -1062,8 +1065,8 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
       pa.ahat        = d_a;
       pa.out         = d_c;
       pa.limbs       = ls.d;
-      pa.nlimbs      = 1;
-      pa.limb_stride = 0;
+      pa.nlimbs      = ls.n;
+      pa.limb_stride = ls.stride;
       pa.batch       = batch;
       pa.logn        = (uint32_t)p->m;
       pa.a_lazy      = 1;
@@ -1202,6 +1205,17 @@ static bool rns_one_launch_pays(const ntt_plan *p, uint64_t batch)
   return wg_equivalents < 8ull * (uint64_t)p->num_cus;
 }
 
+/* Large per-limb batches at N = 2^15..2^17: the XCD-local launches (team_kernel, team_product_kernel) take the limb as part
+ * of the queue entry, so a whole RNS set is ONE launch there too -- no launch tails between the limbs (measured 3.5 % of a
+ * config-5 step, profiles/r03/ablations.txt (f)).  NTT_RNS_LOOP=1 keeps the per-limb launches. */
+static bool rns_team_launch(const ntt_plan *p, int nlimbs, uint64_t batch, bool inverse, bool product)
+{
+  const char *env = getenv("NTT_RNS_LOOP");
+  if(env && atoi(env) != 0) return false;
+  return team_applies(p, batch, inverse, false, false, nlimbs < kMaxLimbs ? nlimbs : kMaxLimbs, product) &&
+         team_applies(p, batch, inverse, false, false, 1, product); /* (a limb's own share qualifies: same lag tuning) */
+}
+
 /* the records of limbs [first, first + n) as one host array */
 static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first, int n)
 {
@@ -1214,7 +1228,7 @@ static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch)) {
+  if(rns_uniform(nlimbs, plans) && (rns_one_launch_pays(plans[0], batch) || rns_team_launch(plans[0], nlimbs, batch, inverse, false))) {
     for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
       const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
       const std::vector<unsigned char> recs = rns_records(plans, first, n);
@@ -1245,7 +1259,8 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && fused_product_applies(plans[0], d_c, d_a, d_b, batch)) {
+  if(rns_uniform(nlimbs, plans) && fused_product_applies(plans[0], d_c, d_a, d_b, batch) &&
+     (rns_one_launch_pays(plans[0], batch) || (rns_team_launch(plans[0], nlimbs, batch, false, true) && !plans[0]->block_log))) {
     for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
       const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
       const std::vector<unsigned char> recs = rns_records(plans, first, n);

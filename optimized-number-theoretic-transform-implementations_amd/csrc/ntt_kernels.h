@@ -968,10 +968,22 @@ struct TeamCtl {
 };
 
 template <class A> struct KTeam {
-  KArgs<A> k;   /* a, limbs[0], logn; nblocks = polynomials */
-  TeamCtl *ctl; /* zeroed before the launch */
-  uint32_t lag; /* polynomials between a first-pass item and the second-pass items of the same queue */
+  KArgs<A> k;      /* a, limbs[], limb_stride, logn; nblocks = polynomials PER LIMB */
+  TeamCtl *ctl;    /* zeroed before the launch */
+  uint32_t lag;    /* polynomials between a first-pass item and the second-pass items of the same queue */
+  uint32_t nlimbs; /* MULTI kernels: limbs of the launch (polynomial v of the queues = limb * batch + polynomial) */
 };
+
+/* MULTI (several RNS limbs in one launch): the item's limb picks the tables, the constants and the slab.  The items of these
+ * kernels fetch their tables per item anyway, so a limb that changes from item to item costs scalar loads only. */
+template <class A, bool INV> __device__ __forceinline__ void team_limb(Params<A> &p, const KArgs<A> &k, uint32_t limb)
+{
+  const LimbRec<A> &r = k.limbs[limb];
+  p.a   = k.a + (uint64_t)limb * k.limb_stride;
+  p.tw  = INV ? r.tw_i : r.tw_f;
+  p.tw8 = INV ? r.tw8_i : r.tw8_f;
+  p.c   = r.c;
+}
 
 __device__ __forceinline__ uint32_t xcc_id()
 {
@@ -1111,7 +1123,7 @@ __device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, 
   buffer_store_first_raw<LOGN, STAUX>(out, tid, base);
 }
 
-template <class A, int LEAD, bool INV, int KSH>
+template <class A, int LEAD, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
 {
   constexpr int LOGN = kTeamBlock;
@@ -1128,7 +1140,8 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
   constexpr uint32_t CMASK = column_mask<A, LEAD, INV, KSH>();
   constexpr bool     MID_LAZY = !A::kTracksBounds; /* words between the passes: canonical for the FP64 policies */
   const uint32_t logn  = LOGN + LEAD;
-  const uint32_t batch = (uint32_t)p.nblocks;
+  const uint32_t batch = (uint32_t)p.nblocks;      /* polynomials per limb */
+  const uint32_t total = MULTI ? batch * kt.nlimbs : batch;
   constexpr uint32_t NCOL = 1u << (LOGN - 8);      /* column items per polynomial: 2^(m - LEAD) columns / 256 */
   constexpr uint32_t NROW = 1u << LEAD;            /* row items per polynomial */
   constexpr uint32_t NA   = INV ? NROW : NCOL;     /* first-pass items */
@@ -1146,8 +1159,6 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
     const bool mine = s_k != 0;
     __syncthreads();
     if(!mine) continue;
-    const uint32_t J = batch > q ? (batch - q + 7u) / 8u : 0u; /* polynomials of this queue: q, q + 8, ... */
-    const uint32_t steps = J + lag;
     /* Every lane-0 block of this loop is followed at once by a workgroup barrier.  A lane-0 block at the END of the body
      * (the completion signal used to sit there) ends up next to the loop's back edge, and the compiler then lets lane 0
      * leave the loop "early" while lanes 1-63 of its wave wait at the next iteration's barrier for the item only lane 0
@@ -1164,15 +1175,20 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
       }
       sig = kNoSignal;
       __syncthreads();
-      const uint32_t k = s_k2[it];
-      const uint32_t step = k / (NA + NB), r = k % (NA + NB);
-      if(step >= steps) break;
-      const bool     second = r >= NA;
-      const uint32_t item   = second ? r - NA : r;
-      const int64_t  j      = second ? (int64_t)step - (int64_t)lag : (int64_t)step;
-      if(j < 0 || j >= (int64_t)J) continue;
-      const uint32_t pidx = q + 8u * (uint32_t)j;
-      uint64_t *     poly = p.a + ((uint64_t)pidx << logn);
+      /* queue entry -> (pass, item, polynomial): ntt_core.h team_decode, the function tests/test_team_protocol.py simulates */
+      const TeamItem ti = team_decode(uniform_u32(s_k2[it]), q, total, lag, NA, NB, 0u);
+      if(ti.stop) break;
+      if(!ti.valid) continue;
+      const bool     second = ti.pass != 0;
+      const uint32_t item   = ti.item;
+      const uint32_t pidx   = ti.v;
+      uint32_t       pl     = pidx; /* the polynomial inside its limb */
+      if constexpr(MULTI) {
+        const uint32_t limb = pidx / batch;
+        pl                  = pidx - limb * batch;
+        team_limb<A, INV>(p, kt.k, limb);
+      }
+      uint64_t *poly = p.a + ((uint64_t)pl << logn);
       if(second) {
         if(tid == 0) {
 #ifdef NTT_TEAM_WATCHDOG
@@ -1184,7 +1200,7 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
             if(++spins > (1u << 15)) {
               ctl->owner[q][1] = pidx + 1u;
               ctl->owner[q][2] = __hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ctl->owner[q][3] = k;
+              ctl->owner[q][3] = s_k2[it];
               break;
             }
           }
@@ -1525,12 +1541,13 @@ struct TeamProdCtl {
 };
 
 template <class A> struct KTeamProd {
-  KProd<A>     k;   /* f.a = b, ahat, out = c; f.nblocks = polynomials */
-  TeamProdCtl *ctl; /* zeroed before the launch */
+  KProd<A>     k;      /* f.a = b, ahat, out = c (limb 0's slabs; f.limb_stride apart); f.nblocks = polynomials PER LIMB */
+  TeamProdCtl *ctl;    /* zeroed before the launch */
   uint32_t     lag;
+  uint32_t     nlimbs; /* MULTI kernels: limbs of the launch */
 };
 
-template <class A, int LEAD, int KSH, bool FOUR = false>
+template <class A, int LEAD, int KSH, bool FOUR = false, bool MULTI = false>
 __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A> kt)
 {
   constexpr int LOGN = kTeamBlock;
@@ -1555,14 +1572,15 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
   constexpr uint32_t CMASKI = column_mask<A, LEAD, true, KSH>();
   constexpr bool     MID_LAZY = !A::kTracksBounds;
   const uint32_t logn  = LOGN + LEAD;
-  const uint32_t batch = (uint32_t)pf.nblocks;
+  const uint32_t batch = (uint32_t)pf.nblocks; /* polynomials per limb */
+  const uint32_t total = MULTI ? batch * kt.nlimbs : batch;
   constexpr uint32_t NCOL = 1u << (LOGN - 8), NROW = 1u << LEAD;
   /* FOUR: the first pass takes the column tiles of BOTH operands (b's, then a's) and the product item transforms both blocks */
   constexpr uint32_t NFIRST = FOUR ? 2u * NCOL : NCOL;
-  constexpr uint32_t PER    = NFIRST + NROW + NCOL; /* items per step */
   TeamProdCtl *const ctl = kt.ctl;
   const uint32_t lag = kt.lag;
   const uint32_t my  = xcc_id();
+  uint64_t       loff = 0; /* the item's limb: word offset of its slabs (MULTI) */
   for(uint32_t qq = 0; qq < 8; qq++) {
     const uint32_t q = (my + qq) & 7u;
     if(tid == 0) {
@@ -1573,10 +1591,8 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
     const bool mine = s_k != 0;
     __syncthreads();
     if(!mine) continue;
-    const uint32_t J     = batch > q ? (batch - q + 7u) / 8u : 0u;
-    const uint32_t steps = J + 2u * lag;
     constexpr uint32_t kNoSignal = 0xffffffffu;
-    uint32_t           sig       = kNoSignal; /* index into done[]: polynomial, or batch + polynomial for the second pass */
+    uint32_t           sig       = kNoSignal; /* index into done[]: polynomial, or total + polynomial for the second pass */
     for(uint32_t it = 0;; it ^= 1u) {
       /* (lane-0 blocks are followed at once by a workgroup barrier: see team_kernel) */
       if(tid == 0) {
@@ -1585,25 +1601,34 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       }
       sig = kNoSignal;
       __syncthreads();
-      const uint32_t k    = s_k2[it];
-      const uint32_t step = k / PER, r = k % PER;
-      if(step >= steps) break;
-      const uint32_t pass = r < NFIRST ? 0u : (r < NFIRST + NROW ? 1u : 2u);
-      const uint32_t item = pass == 0 ? r : (pass == 1 ? r - NFIRST : r - NFIRST - NROW);
-      const int64_t  j    = (int64_t)step - (int64_t)(pass * lag);
-      if(j < 0 || j >= (int64_t)J) continue;
-      const uint32_t pidx = q + 8u * (uint32_t)j;
+      const TeamItem ti = team_decode(uniform_u32(s_k2[it]), q, total, lag, NFIRST, NROW, NCOL);
+      if(ti.stop) break;
+      if(!ti.valid) continue;
+      const uint32_t pass = ti.pass, item = ti.item, pidx = ti.v;
+      uint32_t       pl   = pidx; /* the polynomial inside its limb */
+      if constexpr(MULTI) {
+        const uint32_t limb = pidx / batch;
+        pl                  = pidx - limb * batch;
+        loff                = (uint64_t)limb * kt.k.f.limb_stride;
+        const LimbRec<A> &r = kt.k.f.limbs[limb];
+        pf.tw  = r.tw_f;
+        pf.tw8 = r.tw8_f;
+        pf.c   = r.c;
+        pi.tw  = r.tw_i;
+        pi.tw8 = r.tw8_i;
+        pi.c   = r.c;
+      }
       if(pass > 0) {
         const uint32_t need = pass == 1 ? NFIRST : NROW;
-        const uint32_t slot = pass == 1 ? pidx : batch + pidx;
+        const uint32_t slot = pass == 1 ? pidx : total + pidx;
         if(tid == 0) {
           while(__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
       }
-      uint64_t *      bpoly = pf.a + ((uint64_t)pidx << logn);
-      const uint64_t *apoly = pp.ahat + ((uint64_t)pidx << logn);
-      uint64_t *      cpoly = pp.out + ((uint64_t)pidx << logn);
+      uint64_t *      bpoly = pf.a + loff + ((uint64_t)pl << logn);
+      const uint64_t *apoly = pp.ahat + loff + ((uint64_t)pl << logn);
+      uint64_t *      cpoly = pp.out + loff + ((uint64_t)pl << logn);
       if(pass == 0) {
         uint64_t *const src = FOUR && item >= NCOL ? const_cast<uint64_t *>(apoly) : bpoly; /* (a is an operand buffer of the caller's: written here) */
         team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(src, (item & (NCOL - 1u)) * kTeamCols + tid, logn, pf, MID_LAZY);
@@ -1621,7 +1646,7 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       if(pass < 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        sig = pass == 0 ? pidx : batch + pidx;
+        sig = pass == 0 ? pidx : total + pidx;
       }
     }
   }
@@ -2136,27 +2161,31 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
   }
 }
 
-/* pa.r = LEAD (3..5), pa.batch polynomials of 2^(12 + LEAD) points; pa.team_ctl: TeamCtl with batch counters, zeroed here */
+/* pa.r = LEAD (3..5), pa.batch polynomials of 2^(12 + LEAD) points per limb; pa.team_ctl: TeamCtl with nlimbs * batch counters,
+ * zeroed here.  Several limbs (an RNS set, [limb][batch][N]): the MULTI variant, the queues run over all limbs' polynomials. */
 template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const PassArgs &pa)
 {
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.nlimbs > 1 || !pa.team_ctl || pa.wide || pa.lazy) return hipErrorNotSupported;
+    const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
+    if(nl > (uint64_t)kMaxLimbs || !pa.team_ctl || pa.wide || pa.lazy || nl * pa.batch >= (1ull << 31)) return hipErrorNotSupported;
     KTeam<A> kt{};
     kt.k         = make_kargs<A>(pa);
     kt.k.lastinv = (uint32_t)pa.inverse;
     kt.k.nblocks = pa.batch;
     kt.ctl       = static_cast<TeamCtl *>(pa.team_ctl);
     kt.lag       = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 6);
-    const size_t bytes = sizeof(TeamCtl) + (size_t)pa.batch * sizeof(unsigned);
+    kt.nlimbs    = (uint32_t)nl;
+    const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * pa.batch) * sizeof(unsigned);
     hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
     if(e != hipSuccess) return e;
     /* four workgroups per CU: 40,580 bytes of LDS each (32.9 KB exchange buffer + 7.5 KB table), at most 128 VGPRs */
     uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
     if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
     kt.k.wgs_per_limb = (uint32_t)wgs;
-    hipLaunchKernelGGL((team_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt);
+    if(nl > 1) hipLaunchKernelGGL((team_kernel<A, LEAD, INV, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt);
+    else hipLaunchKernelGGL((team_kernel<A, LEAD, INV, KSH, false>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt);
     return hipGetLastError();
   }
 }
@@ -2316,18 +2345,23 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
   }
 }
 
-/* the b-chain of a product at N = 2^15..2^17 as one launch (team_product_kernel); pa.team_ctl: TeamProdCtl + 2 * batch counters */
+/* a product at N = 2^15..2^17 as one launch (team_product_kernel); pa.team_ctl: TeamProdCtl + 2 * nlimbs * batch counters.
+ * Several limbs ([limb][batch][N] slabs, limb_stride apart): the MULTI variants -- ONE launch for a whole RNS product. */
 template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &pa)
 {
   if constexpr(!A::kCompact) {
     return hipErrorNotSupported;
   } else {
-    if(pa.nlimbs > 1 || !pa.team_ctl || (!pa.a_lazy && !pa.four) || pa.logn < kTeamBlock + 3 || pa.logn > kTeamBlock + 5) return hipErrorNotSupported;
+    const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
+    if(nl > (uint64_t)kMaxLimbs || !pa.team_ctl || (!pa.a_lazy && !pa.four) || pa.logn < kTeamBlock + 3 || pa.logn > kTeamBlock + 5 ||
+       nl * pa.batch >= (1ull << 30)) {
+      return hipErrorNotSupported;
+    }
     KTeamProd<A> kt{};
     kt.k.f.a            = pa.b;
     const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
-    kt.k.f.limbs[0]     = recs[0];
-    kt.k.f.limb_stride  = 0;
+    for(uint64_t l = 0; l < nl; l++) kt.k.f.limbs[l] = recs[l];
+    kt.k.f.limb_stride  = nl > 1 ? pa.limb_stride : 0;
     kt.k.f.logn         = pa.logn;
     kt.k.f.s0           = pa.logn - kTeamBlock;
     kt.k.f.nblocks      = pa.batch;
@@ -2336,27 +2370,35 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     kt.k.a_lazy         = 1;
     kt.ctl              = static_cast<TeamProdCtl *>(pa.team_ctl);
     kt.lag              = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 8);
-    const size_t bytes = sizeof(TeamProdCtl) + 2 * (size_t)pa.batch * sizeof(unsigned);
+    kt.nlimbs           = (uint32_t)nl;
+    const size_t bytes = sizeof(TeamProdCtl) + 2 * (size_t)(nl * pa.batch) * sizeof(unsigned);
     hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
     if(e != hipSuccess) return e;
     /* four workgroups per CU (121 VGPRs, 40.6 KB of LDS each) */
     uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
     if(pa.max_grid > 0) wgs = (uint64_t)pa.max_grid;
     kt.k.f.wgs_per_limb = (uint32_t)wgs;
+    const dim3 g((unsigned)wgs), t(256);
+#define NTT_TEAM_PROD(LEADV, FOURV)                                                                                \
+  do {                                                                                                             \
+    if(nl > 1) hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, FOURV, true>), g, t, 0, pa.stream, kt);      \
+    else hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, FOURV, false>), g, t, 0, pa.stream, kt);           \
+  } while(0)
     if(pa.four) {
       /* ahat = a itself (coefficients): both forward transforms happen inside the launch */
       switch(pa.logn - kTeamBlock) {
-        case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
-        case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
-        default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH, true>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+        case 3: NTT_TEAM_PROD(3, true); break;
+        case 4: NTT_TEAM_PROD(4, true); break;
+        default: NTT_TEAM_PROD(5, true); break;
       }
       return hipGetLastError();
     }
     switch(pa.logn - kTeamBlock) {
-      case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
-      case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
-      default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH>), dim3((unsigned)wgs), dim3(256), 0, pa.stream, kt); break;
+      case 3: NTT_TEAM_PROD(3, false); break;
+      case 4: NTT_TEAM_PROD(4, false); break;
+      default: NTT_TEAM_PROD(5, false); break;
     }
+#undef NTT_TEAM_PROD
     return hipGetLastError();
   }
 }
@@ -2440,8 +2482,10 @@ template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
   template <> hipError_t launch_dot<A, KSH>(const DotArgs &da) { return launch_dot_impl<A, KSH>(da); }
 
 #define NTT_DEFINE_LAUNCH_PRODUCT(A, KSH) \
-  template <> hipError_t launch_team_product<A, KSH>(const ProdArgs &pa) { return launch_team_product_impl<A, KSH>(pa); } \
   template <> hipError_t launch_product<A, KSH>(const ProdArgs &pa) { return launch_product_impl<A, KSH>(pa); }
+/* (a translation unit of its own per policy: inst_team_*.hip) */
+#define NTT_DEFINE_LAUNCH_TEAM_PRODUCT(A, KSH) \
+  template <> hipError_t launch_team_product<A, KSH>(const ProdArgs &pa) { return launch_team_product_impl<A, KSH>(pa); }
 
 /* body of launch_pass<A,KSH>; each instantiating .hip file expands this once */
 #define NTT_DEFINE_LAUNCH_PASS(A, KSH)                                                   \

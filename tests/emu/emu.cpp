@@ -905,6 +905,17 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
 }
 #endif
 
+/* the queue-entry decode of the XCD-local kernels (ntt_core.h team_decode): out = {stop, valid, pass, item, v} */
+void emu_team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t *out)
+{
+  const TeamItem it = team_decode(k, q, total, lag, n0, n1, n2);
+  out[0] = it.stop;
+  out[1] = it.valid;
+  out[2] = it.pass;
+  out[3] = it.item;
+  out[4] = it.v;
+}
+
 /* the product's host-side builder of the 2N-entry radix-4 table (ntt_tables.h), for the table tests */
 void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q)
 {

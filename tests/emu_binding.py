@@ -27,6 +27,7 @@ class Emu:
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
         L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
+        L.emu_team_decode.argtypes = [C.c_uint32] * 7 + [C.POINTER(C.c_uint32)]
         L.emu_inv_dot.argtypes = [U64P, C.c_int, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
@@ -72,6 +73,13 @@ class Emu:
         rc = self.lib.emu_inv_dot(out.ctypes.data_as(U64P), k, a.ctypes.data_as(U64P), b.ctypes.data_as(U64P), batch, m, q, root,
                                   arith, int(lazy), int(bcast))
         return rc, out
+
+    def team_decode(self, k, q, total, lag, n0, n1, n2):
+        """queue entry k of queue q -> (stop, valid, pass, item, polynomial): csrc/ntt_core.h team_decode, the function the
+        XCD-local kernels call"""
+        out = (C.c_uint32 * 5)()
+        self.lib.emu_team_decode(k, q, total, lag, n0, n1, n2, out)
+        return tuple(int(x) for x in out)
 
     def expand_radix4(self, w, q):
         w = np.ascontiguousarray(w, dtype=np.uint64)

@@ -1589,3 +1589,47 @@ def test_rns_products_in_the_ntt_domain(lib, oracle, logn, batch, monkeypatch):
         x.free()
     for p in plans:
         p.destroy()
+
+
+@pytest.mark.parametrize("m,nl,batch", [(15, 4, 70), (16, 3, 64), (17, 4, 33), (16, 16, 9)])
+def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, monkeypatch):
+    """N = 2^15..2^17: the XCD-local launches take the limb as part of the queue entry, so a whole RNS set -- forward
+    transforms, the product (both forms: both operands in coefficients; one operand transformed beforehand) -- is ONE launch
+    over all limbs' polynomials.  Word for word the per-limb launches (NTT_RNS_LOOP=1), samples against the oracle; ragged
+    per-limb batches (the queues run over limb * batch + polynomial)."""
+    n = 1 << m
+    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    for p in plans:
+        p.set_option(lib.OPT_XCD_LOCAL, 1)          # (the automatic choice needs 512 polynomials for a plain transform)
+    slab = batch * n
+    a = np.concatenate([oracle.fill_uniform(slab, q, 6100 + l) for l, q in enumerate(qs)])
+    b = np.concatenate([oracle.fill_uniform(slab, q, 6200 + l) for l, q in enumerate(qs)])
+    da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+    res = {}
+    for loop in ("1", "0"):
+        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        da.upload(a)
+        lib.rns_fwd(plans, da.ptr, batch)
+        res["fwd", loop] = da.download()
+        da.upload(a), db.upload(b)
+        lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+        res["mul", loop] = dc.download()
+        da.upload(a), db.upload(res["fwd", loop])
+        lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, batch)        # c = inv(fwd(a) (.) b^), b^ = fwd(a): the square
+        res["mult", loop] = dc.download()
+    for kind in ("fwd", "mul", "mult"):
+        assert np.array_equal(res[kind, "0"], res[kind, "1"]), kind
+    for l in (0, nl - 1):
+        cx = oracle.ctx(n, qs[l], ws[l])
+        for p_ in (0, batch - 1):
+            sl = slice(l * slab + p_ * n, l * slab + (p_ + 1) * n)
+            fa = cx.fwd(a[sl])
+            assert np.array_equal(res["fwd", "0"][sl], fa), (l, p_)
+            assert np.array_equal(res["mul", "0"][sl], cx.inv(oracle.pointwise(fa, cx.fwd(b[sl]), qs[l]))), (l, p_)
+            assert np.array_equal(res["mult", "0"][sl], cx.inv(oracle.pointwise(fa, fa, qs[l]))), (l, p_)
+    for x in (da, db, dc):
+        x.free()
+    for p in plans:
+        p.destroy()
