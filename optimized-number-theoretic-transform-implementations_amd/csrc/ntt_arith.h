@@ -78,6 +78,7 @@ struct ArithU64 {
   /* no 8-byte twiddle form: the Shoup quotient cannot be rebuilt without a division */
   static constexpr bool kCompact = false;
   static constexpr bool kRadix4  = false;
+  static constexpr bool kWide52  = false;
   using ctw                      = uint64_t;
   static NTT_HD tw expand(ctw w, const consts &) { return tw{w, 0}; }
 
@@ -272,6 +273,7 @@ struct ArithF64 {
    * quotient of a full record, so the same bounds apply. */
   static constexpr bool kCompact = true;
   static constexpr bool kRadix4  = false;
+  static constexpr bool kWide52  = false; /* WideF64: the kernels' MASK means "reduce the multiplied operand" */
   using ctw                      = double;
   static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, fma_(w, c.qinv, w * c.qinv_lo)}; }
 
@@ -495,35 +497,43 @@ struct ArithF64 {
 /* ------------------------------------------------------------------ */
 /*
  * Above 2^51(1+2^-10) the balanced-double policy has less than two bits of headroom below 2^53: no value may
- * exceed 2q.  Instead of a reduction schedule this policy reduces BOTH operands of every butterfly to |.| <= q/2
- * (three exact instructions each), which keeps every intermediate below 2q without any bookkeeping:
- *   forward  x~ = red(x), y~ = red(y), m = y~ * w mod q with |m| <= (1/2 + 1.5 * 0.5 * theta2) q <= 0.88 q,
- *            outputs |x~ +- m| <= 1.38 q;  h - k*q is an integer with |.| <= (0.88 + 0.13) q < 2q <= 2^53: exact
+ * reach 2q.  The pass-through operand x of every butterfly is reduced to |.| <= q/2 (three exact instructions); the
+ * MULTIPLIED operand y is reduced where a compile-time schedule says so (forward; round 4) or always (inverse):
+ *   forward  x~ = red(x), m = y * w mod q with y reduced or not.  With |y| <= B q and theta2 = q / 2^53 < 1/2:
+ *            full record (stored w/q):   |m| <= (1/2 +     B theta2) q,  |h - k q| <= (1/2 + 1.5 B theta2) q
+ *            compact twiddle (mulmod_c): |m| <= (1/2 + 1.5 B theta2) q,  |h - k q| <= (1/2 + 2   B theta2) q
+ *            (|l| = |h - y w| <= ulp(h)/2 <= B theta2 q / 2), outputs |x~ +- m| <= (1/2 + eps) q + |m|.  Everything must stay
+ *            below 2^53 = q / theta2, i.e. below 2 q in the worst case: f64w_fwd_schedule (below) follows B stage by stage
+ *            and reduces y only where one of the three bounds would pass 2 (1 - 2^-6): with full records one stage in
+ *            five (B: 1 -> 1.5 -> 1.75 -> 1.875 -> 1.94 -> reduce), with compact twiddles every stage.  At N = 2^14 that is
+ *            7 of 14 stages: 12.5 instead of 14 instructions per butterfly on average.
  *   inverse  s = x + y, d = x - y of values bounded by 1.38 q each (canonical inputs: < 2q): exact below 2^53 because
  *            the pairs a stage combines are either both reduced sums (<= q/2) or both products (<= 0.88 q) or both
- *            canonical inputs; s~ = red(s), y' = red(d) * w mod q
- * 14 instead of 8 instructions per butterfly -- measured against the integer policy it replaces for 52-bit moduli
- * in profiles/r02/ablations.txt.  The MASK / reduction-plan machinery of the kernels is simply ignored (RED is
- * not looked at); lazy outputs do not exist below 2^53 (4q > 2^53) and fall back to canonical ones.
- * Written as a mixin so that the emulator's checked policy can be run through the very same butterflies.
+ *            canonical inputs; s~ = red(s), y' = red(d) * w mod q.  (An unreduced d would leave products up to 1.25 q, and the
+ *            next stage's difference of two of them is not below 2q: no schedule exists here.)
+ * The emulator's checked policy runs the same butterflies (tests/test_emu.py: every value an integer below 2^53, every
+ * product exact, for the largest 52-bit primes and adversarial inputs).  Lazy outputs do not exist below 2^53 (4q > 2^53)
+ * and fall back to canonical ones.  Written as a mixin so that the checked policy goes through the very same code.
  */
 template <class Base> struct WideF64 : Base {
   using val    = typename Base::val;
   using tw     = typename Base::tw;
   using ctw    = typename Base::ctw;
   using consts = typename Base::consts;
+  static constexpr bool kWide52 = true;
 
+  /* RED: reduce the multiplied operand too (f64w_fwd_schedule) */
   template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
   {
     const double xr = Base::reduce(x, c);
-    const double m  = Base::mulmod(t, Base::reduce(y, c), c);
+    const double m  = Base::mulmod(t, RED ? Base::reduce(y, c) : y, c);
     x               = xr + m;
     y               = xr - m;
   }
   template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, ctw w, const consts &c)
   {
     const double xr = Base::reduce(x, c);
-    const double m  = Base::mulmod_c(w, Base::reduce(y, c), c);
+    const double m  = Base::mulmod_c(w, RED ? Base::reduce(y, c) : y, c);
     x               = xr + m;
     y               = xr - m;
   }
@@ -652,6 +662,37 @@ constexpr F64Sched f64_schedule_forced(bool inverse, int nstages, int ksh, doubl
       } else {
         b = nr;
       }
+    }
+  }
+  return F64Sched{mask, b};
+}
+
+/* ------------------------------------------------------------------ */
+/* compile-time schedule for WideF64's forward butterflies              */
+/* ------------------------------------------------------------------ */
+/*
+ * Bit s set => the butterflies of the stage at processing position s reduce their MULTIPLIED operand (the pass-through
+ * operand is always reduced).  Model in units of q at the class's worst case theta2 = q / 2^53 = 1/2 (q -> 2^52), with the
+ * slack conventions of f64_schedule; c = 1 for a full twiddle record, 1.5 for a compact one (cmask bit):
+ *   keep y (|y| <= B):  product  rho = 1/2 + c B theta2;  exactness  E = rho + B theta2 / 2;  outputs  B' = 1/2 + rho
+ *   all of them must stay below LIM = 2 (1 - 2^-6); otherwise y is reduced first (B -> 1/2).
+ */
+constexpr F64Sched f64w_fwd_schedule(int nstages, double b_in, uint32_t cmask)
+{
+  const double theta2 = 0.5;
+  const double lim    = 2.0 * (1.0 - 1.0 / 64.0);
+  double       b      = b_in;
+  uint32_t     mask   = 0;
+  for(int s = 0; s < nstages; s++) {
+    const double cc   = ((cmask >> s) & 1u) ? 1.5 : 1.0;
+    const double rho  = 0.5 + cc * b * theta2 * 1.001 + 0.001;
+    const double ex   = rho + 0.5 * b * theta2 * 1.001;
+    const double outb = 0.501 + rho;
+    if(ex > lim || outb > lim || b > lim) {
+      mask |= 1u << s;
+      b = 0.501 + (0.5 + cc * 0.501 * theta2 * 1.001 + 0.001);
+    } else {
+      b = outb;
     }
   }
   return F64Sched{mask, b};

@@ -1027,6 +1027,12 @@ template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uin
      * N^-1 butterfly its (unused) bit does not disturb the earlier ones */
     /* stages whose twiddles are compact estimate the quotient from the rounded
      * product (ArithF64::mulmod_c): 1.5x the error term at those positions */
+    if constexpr(A::kWide52) {
+      /* moduli up to 2^52: forward = which stages also reduce the multiplied operand (ntt_arith.h f64w_fwd_schedule); the
+       * inverse butterflies of that policy reduce everything and ignore the mask */
+      if constexpr(INV) return 0;
+      else return f64w_fwd_schedule(LOGN, 1.0, fused_cmask<A, LOGN>()).mask;
+    }
     if constexpr(INV) return kRedPlanFlag | (uint32_t)KSH; /* per-butterfly plan (bfly_reduces) */
     constexpr F64Sched sc = f64_schedule(false, LOGN, KSH, 1.0, fused_cmask<A, LOGN>(), LAZY ? kLazyBound : 1e30);
     /* store_fwd_lazy builds the bit pattern of v + 2q with one fma: only correct while |v| <= kLazyBound * q.  The
@@ -1192,6 +1198,8 @@ template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
 {
   if constexpr(!A::kTracksBounds) {
     return 0;
+  } else if constexpr(A::kWide52) {
+    return INV ? 0u : f64w_fwd_schedule(R, 1.0, 0u).mask; /* (column passes read full records) */
   } else {
     return f64_schedule(INV, R, KSH, 1.0).mask;
   }

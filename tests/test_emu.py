@@ -321,9 +321,10 @@ def test_fused_product_kernels_other_sizes_logic(oracle, emu, m):
 
 @pytest.mark.parametrize("m", [6, 9, 12, 13, 14, 15])
 def test_wide_fp64_policy_52_bit_moduli(oracle, emu, m):
-    """ArithF64W: moduli between 2^51(1+2^-10) and 2^52 (less than one bit below 2^53/2): both operands of every
-    butterfly are reduced; bit-exact against the oracle, every value an integer below 2^53 and every product exact
-    (checked policy), for the largest 52-bit primes and for a 51-bit one"""
+    """ArithF64W: moduli between 2^51(1+2^-10) and 2^52 (less than one bit below 2^53/2): the pass-through operand of
+    every butterfly is reduced, the multiplied one where the compile-time schedule says so (forward: f64w_fwd_schedule;
+    inverse: always); bit-exact against the oracle, every value an integer below 2^53 and every product exact (checked
+    policy), for the largest 52-bit primes and for a 51-bit one, on random and adversarial inputs"""
     n = 1 << m
     for q in (oracle.find_prime(52, n, 0), oracle.find_prime(52, n, 3), 0x7fffffffe0001):
         if (q - 1) % (2 * n):
@@ -347,8 +348,17 @@ def test_wide_fp64_policy_52_bit_moduli(oracle, emu, m):
         if m <= 12:
             rc, got = emu.transform(a, m, q, w, 5, generic=True)
             assert rc == 0 and np.array_equal(got, expect)
+        # inputs that drive the unreduced multiplied operands to the edge of the schedule's bounds: all-(q-1), +-1 pattern,
+        # the largest balanced magnitude
+        for adv in (np.full(n, q - 1, dtype=np.uint64), np.where(np.arange(n) % 2 == 0, q - 1, 1).astype(np.uint64),
+                    np.full(n, q // 2, dtype=np.uint64), np.where(np.arange(n) % 3 == 0, q // 2 + 1, q - 1).astype(np.uint64)):
+            rc, got = emu.transform(adv, m, q, w, 5)
+            assert rc == 0 and np.array_equal(got, cx.fwd(adv)), hex(q)
+            rc, got = emu.transform(adv, m, q, w, 5, inverse=True)
+            assert rc == 0 and np.array_equal(got, cx.inv(adv)), hex(q)
         fails, maxb, maxr = emu.chk_stats()
-        assert fails == 0 and maxb < 2.0 and maxr < 0.9, (hex(q), fails, maxb, maxr)
+        # (products of unreduced operands: |m| <= (1/2 + 1.5 B theta2) q with B < 2, theta2 < 1/2)
+        assert fails == 0 and maxb < 2.0 and maxr < 1.99, (hex(q), fails, maxb, maxr)
     assert emu.transform(a, m, (1 << 52) + 1, 3, 4)[0] == -2
 
 
