@@ -244,6 +244,11 @@ NTT_API int ntt_shape_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask
  * when all shards are done.  inverse != 0 selects the inverse transform. */
 NTT_API int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const *d_a,
                             const uint64_t *batch, int inverse);
+/* the same for RNS products c = a * b (BASELINE config 5 on several GPUs): plans[g * nlimbs + l] is limb l's plan on
+ * shard g's device; d_c[g], d_a[g], d_b[g] are that shard's [limb][batch[g]][N] slabs (aliasing rules of
+ * ntt_rns_negacyclic_mul_batch) */
+NTT_API int ntt_rns_mul_multi(int ndev, int nlimbs, ntt_plan *const *plans, uint64_t *const *d_c, uint64_t *const *d_a,
+                              uint64_t *const *d_b, const uint64_t *batch);
 
 /* ---- reference-signature entry points: housekeeping ----
  * The single-polynomial functions of ntt_reference.h / ntt_radix4.h / ntt_radix4x4.h / ntt_seal.h keep

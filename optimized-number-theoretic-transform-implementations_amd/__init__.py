@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
-    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_batch_multi", "ntt_min_root", "ntt_find_prime",
+    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
     "ntt_compat_release", "ntt_compat_cached_plans",
     # reference signatures (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h)
     "fwd_ntt_ref_harvey_lazy", "inv_ntt_ref_harvey", "fwd_ntt_ref_harvey_lazy_dbl",
@@ -126,6 +126,7 @@ _sig("ntt_poly_checksum", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64
 _sig("ntt_rmw_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_shape_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_batch_multi", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), U64P, C.c_int)
+_sig("ntt_rns_mul_multi", C.c_int, C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.POINTER(VOIDP), C.POINTER(VOIDP), U64P)
 _sig("ntt_compat_release", None)
 _sig("ntt_compat_cached_plans", C.c_int)
 _sig("ntt_min_root", C.c_uint64, C.c_uint64, C.c_uint64)
@@ -383,6 +384,14 @@ def batch_multi(plans, dptrs, batches, inverse=False):
     dp = (VOIDP * n)(*dptrs)
     bt = (C.c_uint64 * n)(*batches)
     _check(_lib.ntt_batch_multi(n, ph, dp, bt, int(inverse)))
+
+
+def rns_mul_multi(plan_sets, dcs, das, dbs, batches):
+    """RNS products across devices: plan_sets[g] = the limbs' plans on shard g's device"""
+    ndev, nl = len(plan_sets), len(plan_sets[0])
+    ph = (VOIDP * (ndev * nl))(*[p.h for ps in plan_sets for p in ps])
+    _check(_lib.ntt_rns_mul_multi(ndev, nl, ph, (VOIDP * ndev)(*dcs), (VOIDP * ndev)(*das), (VOIDP * ndev)(*dbs),
+                                  (C.c_uint64 * ndev)(*batches)))
 
 
 # --------------------------------------------------------------------------

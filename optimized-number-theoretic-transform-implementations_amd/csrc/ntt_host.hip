@@ -1732,6 +1732,47 @@ extern "C" int ntt_batch_multi(int ndev, ntt_plan *const *plans, uint64_t *const
   return NTT_OK;
 }
 
+/* RNS products across devices (BASELINE config 5 "on 8 GPUs" from one C call): shard g -- nlimbs plans on ONE device,
+ * slabs [limb][batch[g]][N] resident there -- is enqueued on that device's own stream; the call returns when every shard is
+ * done.  Like ntt_batch_multi: no collective, polynomials are independent. */
+extern "C" int ntt_rns_mul_multi(int ndev, int nlimbs, ntt_plan *const *plans, uint64_t *const *d_c, uint64_t *const *d_a,
+                                 uint64_t *const *d_b, const uint64_t *batch)
+{
+  if(ndev <= 0 || nlimbs <= 0 || !plans || !d_c || !d_a || !d_b || !batch) return fail(NTT_ERR_ARG, "bad argument");
+  int launched = 0, rc = NTT_OK;
+  for(int g = 0; g < ndev && !rc; g++) {
+    ntt_plan *const *pg = plans + (size_t)g * nlimbs; /* plans[g * nlimbs + l]: limb l on device g */
+    rc                  = rns_check(nlimbs, pg);
+    if(rc) break;
+    ntt_plan *p = pg[0];
+    {
+      std::lock_guard<std::mutex> lock(g_own_stream_mu);
+      if(!p->own_stream) {
+        DeviceGuard guard(p->device);
+        if(!guard.ok || hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) {
+          rc = fail(NTT_ERR_HIP, "ntt_rns_mul_multi: stream creation failed");
+          break;
+        }
+      }
+    }
+    rc = ntt_rns_negacyclic_mul_batch(nlimbs, pg, d_c[g], d_a[g], d_b[g], batch[g], (void *)p->own_stream);
+    if(!rc) launched = g + 1;
+  }
+  std::string first_error = rc ? g_err : std::string();
+  for(int g = 0; g < launched; g++) { /* join every stream that received work, also when a later device failed */
+    ntt_plan *p = plans[(size_t)g * nlimbs];
+    DeviceGuard guard(p->device);
+    if(!guard.ok || hipStreamSynchronize(p->own_stream) != hipSuccess) {
+      if(!rc) {
+        rc          = NTT_ERR_HIP;
+        first_error = "ntt_rns_mul_multi: hipStreamSynchronize failed";
+      }
+    }
+  }
+  if(rc) return fail(rc, first_error);
+  return NTT_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* parameter helpers (reference: tests/test_cases.h:113-142)           */
 /* ------------------------------------------------------------------ */

@@ -1633,3 +1633,37 @@ def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, monk
         x.free()
     for p in plans:
         p.destroy()
+
+
+def test_rns_products_across_devices_from_one_call(lib, oracle):
+    """ntt_rns_mul_multi: BASELINE config 5's shape -- RNS products sharded over the visible devices (1 on the test box, so
+    two shards are folded onto it: each shard has its own plans and therefore its own stream) from ONE C call"""
+    n, nl = 1 << 15, 3
+    ndev = lib.device_count()
+    shards = max(2, ndev)
+    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plan_sets = [[lib.Plan(n, q, w, device=g % ndev) for q, w in zip(qs, ws)] for g in range(shards)]
+    batches = [5 + 60 * g for g in range(shards)]          # a small shard (block launches) and one of one-launch size
+    hosts_a, hosts_b, da, db, dc = [], [], [], [], []
+    for g, bt in enumerate(batches):
+        a = np.concatenate([oracle.fill_uniform(bt * n, q, 6300 + 10 * g + l) for l, q in enumerate(qs)])
+        b = np.concatenate([oracle.fill_uniform(bt * n, q, 6400 + 10 * g + l) for l, q in enumerate(qs)])
+        hosts_a.append(a), hosts_b.append(b)
+        da.append(lib.DeviceBuffer(a.size, device=g % ndev).upload(a))
+        db.append(lib.DeviceBuffer(b.size, device=g % ndev).upload(b))
+        dc.append(lib.DeviceBuffer(a.size, device=g % ndev))
+    lib.rns_mul_multi(plan_sets, [x.ptr for x in dc], [x.ptr for x in da], [x.ptr for x in db], batches)
+    for g, bt in enumerate(batches):
+        got = dc[g].download()
+        for l in (0, nl - 1):
+            cx = oracle.ctx(n, qs[l], ws[l])
+            for p_ in (0, bt - 1):
+                sl = slice(l * bt * n + p_ * n, l * bt * n + (p_ + 1) * n)
+                exp = cx.inv(oracle.pointwise(cx.fwd(hosts_a[g][sl]), cx.fwd(hosts_b[g][sl]), qs[l]))
+                assert np.array_equal(got[sl], exp), (g, l, p_)
+    for x in da + db + dc:
+        x.free()
+    for ps in plan_sets:
+        for p in ps:
+            p.destroy()

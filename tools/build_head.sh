@@ -8,7 +8,7 @@ rm -rf build/prev; mkdir -p build/prev
 git archive $rev optimized-number-theoretic-transform-implementations_amd/csrc include | tar -x -C $tmp
 src=$tmp/optimized-number-theoretic-transform-implementations_amd/csrc
 pids=()
-for f in ntt_host inst_u64 inst_u64r4 inst_f64k0 inst_f64k1 inst_f64k18 inst_f64w; do
+for f in $(cd $src && ls ntt_host.hip inst_*.hip | sed 's/\.hip$//'); do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
      -I$tmp/include -I$tmp/include/internal -I$src -c -o build/prev/$f.o $src/$f.hip &
   pids+=($!)

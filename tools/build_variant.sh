@@ -4,7 +4,7 @@ set -e
 name=$1; flags=$2
 mkdir -p build/$name
 pids=()
-for f in ntt_host inst_u64 inst_u64r4 inst_f64k0 inst_f64k1 inst_f64k18 inst_f64w; do
+for f in $(cd optimized-number-theoretic-transform-implementations_amd/csrc && ls ntt_host.hip inst_*.hip | sed 's/\.hip$//'); do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden $flags \
      -Iinclude -Iinclude/internal -Ioptimized-number-theoretic-transform-implementations_amd/csrc \
      -c -o build/$name/$f.o optimized-number-theoretic-transform-implementations_amd/csrc/$f.hip &

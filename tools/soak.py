@@ -5,7 +5,8 @@ Every round draws a transform size 2^1..2^18, a prime of 20..60 bits with 2N | q
 library offers for it, a ragged batch (with a bias to the persistent grids' edges: 255, 256, 257, 511, ...), plan
 options (chunk size, grid cap, two-phase, XCD-local launch with random lag and residency, column-only engine, fused
 product on/off), now and then an RNS set (one launch over all limbs or the per-prime loop) and checks, bit for bit against
-the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms.
+the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms, the products of
+operands given in the NTT domain (inner products of k pairs, canonical / lazy / broadcast; one operand transformed beforehand).
 usage: python3 tools/soak.py [--seconds 300] [--seed 1] [--max-coeffs 2^22]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -140,6 +141,47 @@ while time.time() < t_end:
         for d in (da, db, dc):
             d.free()
         checks += 1
+    # operands in the NTT domain: c = inv(sum_i a_i^ (.) b_i^) with k pairs, canonical or lazy words, per-polynomial or
+    # broadcast b, c aliasing an operand (k = 1); c = inv(fwd(a) (.) b^) in a random aliasing form
+    if rng.random() < 0.6:
+        kk = int(rng.choice([1, 1, 2, 3, 5, 8]))
+        if kk * batch * n > 4 * args.max_coeffs:
+            kk = 1
+        lz_in, bc = bool(rng.random() < 0.4), bool(rng.random() < 0.35)
+        mult = 4 if lz_in else 1
+        ah = [orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40))) for _ in range(kk)]
+        bh = [orc.fill_uniform((1 if bc else batch) * n, q, int(rng.integers(1, 1 << 40))) for _ in range(kk)]
+        if lz_in:
+            ah = [x + np.uint64(q) * rng.integers(0, mult, size=x.shape, dtype=np.uint64) for x in ah]
+            bh = [x + np.uint64(q) * rng.integers(0, mult, size=x.shape, dtype=np.uint64) for x in bh]
+        expd = cx.inv(orc.dot(ah, bh, q, n, bc))
+        dah = [lib.DeviceBuffer(x.size).upload(x) for x in ah]
+        dbh = [lib.DeviceBuffer(x.size).upload(x) for x in bh]
+        flags = (lib.MUL_LAZY_IN if lz_in else 0) | (lib.MUL_B_BROADCAST if bc else 0)
+        alias = int(rng.integers(0, 3)) if kk == 1 else 0
+        if alias == 2 and bc:
+            alias = 0
+        dst = lib.DeviceBuffer(batch * n) if alias == 0 else (dah[0] if alias == 1 else dbh[0])
+        plan.inv_dot(dst.ptr, [x.ptr for x in dah], [x.ptr for x in dbh], batch, flags)
+        if not np.array_equal(dst.download(), expd):
+            fail("inv_dot", k=kk, lazy=lz_in, bcast=bc, alias=alias, **ctxt)
+        for d in dah + dbh + ([dst] if alias == 0 else []):
+            d.free()
+        checks += 1
+        # (lazy words for the product kernels must stay below 2^53; the radix-4 policy takes canonical words)
+        bw = want if (4 * q > (1 << 53) or info["arith"] == lib.ARITH_U64_R4 or rng.random() < 0.5) else \
+            want + np.uint64(q) * rng.integers(0, 3, size=want.shape, dtype=np.uint64)
+        b2 = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
+        expm = cx.inv(orc.pointwise(cx.fwd(b2), want, q))
+        dco, dbw = lib.DeviceBuffer(b2.size).upload(b2), lib.DeviceBuffer(bw.size).upload(bw)
+        alias = int(rng.integers(0, 3))
+        dst = lib.DeviceBuffer(batch * n) if alias == 0 else (dco if alias == 1 else dbw)
+        plan.mul_transformed(dst.ptr, dco.ptr, dbw.ptr, batch, lib.MUL_LAZY_IN if bw is not want else 0)
+        if not np.array_equal(dst.download(), expm):
+            fail("mul_transformed", alias=alias, lazy=bw is not want, **ctxt)
+        for d in [dco, dbw] + ([dst] if alias == 0 else []):
+            d.free()
+        checks += 1
     plan.destroy()
     # reference-signature entry points on the caller's own tables (one polynomial, host pointers): bit-exact lazy values
     if rng.random() < 0.15 and m >= 2 and q < (1 << 60):
@@ -159,10 +201,12 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             lib.compat_release()
     # RNS sets: one launch over all limbs against the per-prime loop's semantics (every limb against the oracle)
-    if rng.random() < 0.12 and 8 <= m <= 16:
+    if rng.random() < 0.15 and 8 <= m <= 17:
         nl = int(rng.choice([2, 3, 4, 7, 16, 17]))
         rb = int(rng.choice([1, 2, 3, 8]))
-        if nl * rb * n <= args.max_coeffs:
+        if m >= 15 and rng.random() < 0.5:
+            nl, rb = int(rng.choice([2, 3, 4])), int(rng.choice([22, 33, 64, 70]))   # one XCD-local launch over the limbs
+        if nl * rb * n <= max(args.max_coeffs, (1 << 25) if m >= 15 else 0):
             rbits = int(rng.choice([45, 49, 50]))
             qs = [lib.find_prime(rbits, n, i) for i in range(nl)]
             if all(qs) and len(set(qs)) == nl:
@@ -178,18 +222,27 @@ while time.time() < t_end:
                 back = da.download()
                 lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, rb)
                 pr = dc.download()
+                da.upload(ra), db.upload(f)
+                lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, rb)        # inv(fwd(a) (.) fwd(a)): the square
+                sq = dc.download()
+                da.upload(f), db.upload(f)
+                lib.rns_inv_dot(plans, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], rb)   # inv(2 a^ (.) a^)
+                dt = dc.download()
                 for l, (x, y) in enumerate(zip(qs, ws)):
                     c2 = orc.ctx(n, x, y)
                     sl = slice(l * rb * n, (l + 1) * rb * n)
-                    if not np.array_equal(f[sl], c2.fwd(ra[sl])) or not np.array_equal(back[sl], ra[sl]) or \
-                       not np.array_equal(pr[sl], c2.inv(orc.pointwise(c2.fwd(ra[sl]), c2.fwd(rbv[sl]), x))):
+                    fa = c2.fwd(ra[sl])
+                    if not np.array_equal(f[sl], fa) or not np.array_equal(back[sl], ra[sl]) or \
+                       not np.array_equal(pr[sl], c2.inv(orc.pointwise(fa, c2.fwd(rbv[sl]), x))) or \
+                       not np.array_equal(sq[sl], c2.inv(orc.pointwise(fa, fa, x))) or \
+                       not np.array_equal(dt[sl], c2.inv(orc.dot([fa, fa], [fa, fa], x))):
                         fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=os.environ["NTT_RNS_LOOP"], q=hex(x))
                 del os.environ["NTT_RNS_LOOP"]
                 for d in (da, db, dc):
                     d.free()
                 for pl in plans:
                     pl.destroy()
-                checks += 3 * nl
+                checks += 5 * nl
                 stats_rns = stats.setdefault(("rns", 0, 0), 0)
                 stats[("rns", 0, 0)] = stats_rns + 1
     rounds += 1
