@@ -52,7 +52,7 @@ SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NTT = 16 * N       # one 8-byte read + one 8-byte write per coefficient
 METRIC = "batched forward NTTs/sec at N=2^14, 50-bit q; achieved HBM GB/s vs peak"
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -541,7 +541,7 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r03/pmc_traffic.json), "
+            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r04/pmc_traffic.json), "
                               "not collected in this run" if traffic is not None else None,
             "kernel": kname, "launches_per_step": launches, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
             "algorithmic_bytes_per_step": batch * bytes_per_unit,
@@ -634,7 +634,7 @@ class Parity:
         self.mid["fwd_checked"] = True
 
 
-def also_config(lib, config, steps=6, warmup=1, check=True):
+def also_config(lib, config, steps=8, warmup=3, check=True):
     """BASELINE configs 2, 3 and 5 beside the headline (only the default run is driver-timed): the
     config's one-GPU share through the same GpuShard / run_steps / Parity code as `--config N`, after the headline's timed
     region, a few steps each, parity spot-checked on the first warm-up step like the headline.  Compact block: value, unit,
@@ -674,7 +674,7 @@ def main():
                     help="skip the side measurements (copy probe, other primes): profiler runs then see the step's kernels only")
     ap.add_argument("--logn", type=int, default=0, help="(experiments, config 4 only) other transform sizes")
     ap.add_argument("--no-also", action="store_true", help="default run: skip the also_config2/3/5 blocks")
-    ap.add_argument("--also-steps", type=int, default=6, help="timed steps of each also_configN block")
+    ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each also_configN block (3 warm-ups in front)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

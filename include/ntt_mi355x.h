@@ -72,16 +72,21 @@ typedef enum ntt_option {
                           * (3 or 4 column stages), 14 (1 or 2), 0 (default) = the faster one as measured.  Results
                           * are identical. */
   NTT_OPT_XCD_LOCAL = 7,  /* N = 2^15..2^17 (FP64): 1 = both passes of a transform as items of ONE launch, every polynomial
-                           * handled by the workgroups of one XCD so that the intermediate stays in that XCD's L2 (fabric
-                           * traffic 24N instead of 32N bytes per transform); 0 = one launch per pass; -1 (default) = where
-                           * it measured faster: forward transforms of 512 polynomials or more.  Results are identical. */
+                           * handled by the workgroups of one XCD, the intermediate handed over inside that XCD (MEASURED
+                           * fabric traffic per transform, FETCH x2 + WRITE counters: 24N bytes at 2^15, where the L2 retains
+                           * the intermediate at the shipped lag; 32N at 2^16 and 2^17, where it does not and the second pass is
+                           * served by the Infinity Cache -- the gain there is one launch instead of two per chunk);
+                           * 0 = one launch per pass; -1 (default) = where it measured faster: forward transforms of 512
+                           * polynomials or more.  Results are identical. */
   NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: 10, 8, 10 at 2^15, 2^16, 2^17) */
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
-                          * operands through the forward stages, multiplies in registers and runs the inverse (24N bytes
-                          * up to 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise, 48N bytes across the
-                          * fabric; smaller batches of N >= 2^15: block by block between the column passes of both
-                          * operands, 72N bytes); 2 = a's forward transform always as a launch of its own in front of the fused
+                          * operands through the forward stages, multiplies in registers and runs the inverse: 24N bytes up to
+                          * 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise one launch (all limbs of an RNS set
+                          * included), whose MEASURED fabric traffic is about 85N bytes per product at 2^17 (a, b, two of the
+                          * three intermediates and the twiddles: the L2 retains nothing at that size) against 56N algorithmic;
+                          * smaller batches of N >= 2^15: block by block between the column passes of both operands, 72N
+                          * bytes); 2 = a's forward transform always as a launch of its own in front of the fused
                           * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14); 0 = fwd, fwd, pointwise, inv (72N / 120N
                           * bytes).  Results are identical. */
 } ntt_option;
@@ -193,8 +198,10 @@ NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t
  * primitive is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
  * When one limb's share alone cannot fill the GPU (a ciphertext: a few polynomials x tens of primes) and the limbs'
  * plans agree in policy and options (primes of one bit size always do), ONE launch per pass serves up to 16 limbs: a
- * workgroup picks its limb's tables and constants from an array in the kernel arguments.  Large per-limb batches and
- * mixed sets are served limb by limb.  Results are identical either way (environment NTT_RNS_LOOP=1 / 0 forces a form). ---- */
+ * workgroup picks its limb's tables and constants from an array in the kernel arguments.  At N = 2^15..2^17 large per-limb
+ * batches are ONE launch over the limbs too (the XCD-local kernels take the limb as part of their queue entries); other large
+ * batches and mixed sets are served limb by limb.  Results are identical either way (environment NTT_RNS_LOOP=1 forces the
+ * per-limb form, =0 the one-launch form wherever it is built). ---- */
 NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,

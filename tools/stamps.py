@@ -15,7 +15,9 @@ plan.fwd(buf.ptr, batch); lib.stream_sync()
 f = lib._lib.ntt_debug_stamps
 f.argtypes = [C.c_void_p, C.c_int]
 assert f(None, 1) == 0
-plan.fwd(buf.ptr, batch); lib.stream_sync()
+e0, e1 = lib.Event(), lib.Event()
+e0.record(); plan.fwd(buf.ptr, batch); e1.record()
+launch_ms = e1.elapsed_ms_since(e0)
 out = np.zeros((256, 16, 12), dtype=np.uint64)
 assert f(out.ctypes.data, 0) == 0
 iters = batch / 256
@@ -29,3 +31,6 @@ for n, v in zip(names, per):
     if v > 0: print("  %-28s %8.0f  %5.1f%%" % (n, v, 100 * v / tot))
 spread = out.astype(np.float64).sum(axis=2).mean(axis=0) / iters
 print("per-wave totals min/max: %.0f / %.0f" % (spread.min(), spread.max()))
+# in-kernel shader clock under this load: cycles a wave counts per block iteration / wall time of an iteration (one launch =
+# batch / 256 iterations per workgroup; the stamp build itself is a few per cent slower than the shipped kernel)
+print("launch %.3f ms (stamp build) = %.2f us per block iteration -> in-kernel shader clock %.2f GHz" % (launch_ms, launch_ms * 1e3 / iters, tot / (launch_ms * 1e3 / iters) / 1e3))
