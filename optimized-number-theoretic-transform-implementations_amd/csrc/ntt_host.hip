@@ -1345,7 +1345,12 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
   const PassList L     = make_passes(p->m, false, pblk);
   uint64_t       chunk = batch;
   if(L.n > 1) {
-    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t) * (uint64_t)ls.n);
+    /* the chunk is what must still be in the Infinity Cache when the column pass reads c back; here the operands stream
+     * through that cache as well (two to 2k times the chunk), so a smaller chunk than the transforms' 256 MiB pays at
+     * N = 2^15 and 2^16 (measured: 128 MiB +4..7 %, 64 MiB the same for k = 3 and slower for k = 1, none at 2^17;
+     * profiles/r04/dot_chunk.txt).  An explicit NTT_OPT_CHUNK_MIB is honoured as given. */
+    const uint64_t mib = p->chunk_mib == 256 && p->m <= kFusedMax + 2 ? 128 : (uint64_t)p->chunk_mib;
+    chunk              = (mib << 20) / (p->N * sizeof(uint64_t) * (uint64_t)ls.n);
     if(chunk < 1) chunk = 1;
     if(chunk > batch) chunk = batch;
   }

@@ -1667,3 +1667,79 @@ def test_rns_products_across_devices_from_one_call(lib, oracle):
     for ps in plan_sets:
         for p in ps:
             p.destroy()
+
+
+def test_captured_xcd_local_launch_survives_regrowth_and_concurrent_direct_calls():
+    """a captured XCD-local launch bakes its queue/counter block into the graph.  The plan now keeps a
+    block of its own for captured launches: (i) a later direct call with a LARGER batch on the capture stream regrows the
+    direct block only -- the graph, replayed afterwards, still runs on live memory and equals the oracle; (ii) the graph
+    replayed on ANOTHER stream while direct calls of the same plan run on the capture stream: both results right (separate
+    counters).  The NTT-domain products (no workspace at all) are captured beside the transform."""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, batch, big, q = 1 << 15, 512, 1536, 0x7fffffffe0001
+w = lib.min_root(q, n)
+cx = orc.ctx(n, q, w)
+plan = lib.Plan(n, q, w, device=0)
+ta = torch.zeros(batch * n, dtype=torch.int64, device="cuda:0")
+sa, tk, tc = torch.zeros_like(ta), torch.zeros(n, dtype=torch.int64, device="cuda:0"), torch.zeros_like(ta)
+tbig = torch.zeros(big * n, dtype=torch.int64, device="cuda:0")
+g, s, s2 = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    plan.fwd(ta.data_ptr(), batch, stream=s.cuda_stream)          # warm: the (plan, stream) pair gets its two blocks
+s.synchronize()
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    ta.copy_(sa)
+    plan.fwd(ta.data_ptr(), batch, stream=st)                     # one XCD-local launch, on the graph block
+    plan.inv_product(tc.data_ptr(), ta.data_ptr(), tk.data_ptr(), batch, lib.MUL_B_BROADCAST, stream=st)   # c = inv(a^ . key^)
+key = orc.fill_uniform(n, q, 77)
+tk.copy_(torch.from_numpy(cx.fwd(key).view(np.int64)))
+def check(seed):
+    a = orc.fill_uniform(batch * n, q, seed)
+    sa.copy_(torch.from_numpy(a.view(np.int64)))
+    torch.cuda.synchronize()
+    return a
+def verify(a, tag):
+    f, c = ta.cpu().numpy().view(np.uint64), tc.cpu().numpy().view(np.uint64)
+    for j in (0, 255, 256, 511):
+        sl = slice(j * n, (j + 1) * n)
+        fa = cx.fwd(a[sl])
+        assert np.array_equal(f[sl], fa), (tag, "fwd", j)
+        assert np.array_equal(c[sl], cx.inv(orc.pointwise(fa, cx.fwd(key), q))), (tag, "product", j)
+a = check(1); g.replay(); torch.cuda.synchronize(); verify(a, "first replay")
+# (i) a direct call with a larger batch on the capture stream: the direct block is outgrown and replaced
+bigv = orc.fill_uniform(big * n, q, 5)
+tbig.copy_(torch.from_numpy(bigv.view(np.int64))); torch.cuda.synchronize()
+with torch.cuda.stream(s):
+    plan.fwd(tbig.data_ptr(), big, stream=s.cuda_stream)
+s.synchronize()
+got = tbig.cpu().numpy().view(np.uint64)
+for j in (0, 1535):
+    assert np.array_equal(got[j * n:(j + 1) * n], cx.fwd(bigv[j * n:(j + 1) * n])), ("direct big", j)
+a = check(2); g.replay(); torch.cuda.synchronize(); verify(a, "replay after regrowth")
+# (ii) the graph on another stream while direct calls of the same plan run on the capture stream
+a = check(3)
+tbig.copy_(torch.from_numpy(bigv.view(np.int64))); torch.cuda.synchronize()
+with torch.cuda.stream(s2):
+    g.replay()
+with torch.cuda.stream(s):
+    plan.fwd(tbig.data_ptr(), big, stream=s.cuda_stream)
+torch.cuda.synchronize()
+verify(a, "concurrent replay")
+got = tbig.cpu().numpy().view(np.uint64)
+for j in (0, 700, 1535):
+    assert np.array_equal(got[j * n:(j + 1) * n], cx.fwd(bigv[j * n:(j + 1) * n])), ("concurrent direct", j)
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
