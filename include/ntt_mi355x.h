@@ -175,7 +175,8 @@ NTT_API int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t 
  *          NTT_MUL_B_BROADCAST  every d_bhat[i] is ONE polynomial (N words; RNS: [limb][N]) shared by all polynomials of
  *                               the batch: a key.  Traffic 8kN + 8N instead of 16kN + 8N bytes per output polynomial.
  * Outputs are canonical coefficients in natural order, exactly inv_ntt_ref_harvey(pointwise products) of the reference. */
-enum { NTT_MUL_LAZY_IN = 1, NTT_MUL_B_BROADCAST = 2 };
+enum { NTT_MUL_LAZY_IN = 1, NTT_MUL_B_BROADCAST = 2,
+       NTT_MUL_ACCUMULATE = 4 /* ntt_fwd_mul_batch: c^ += ... instead of c^ = ... (c^ canonical on entry) */ };
 /* c = inv( a^ (.) b^ ): ONE launch up to N = 2^14 (24N bytes instead of 40N for pointwise + inverse); above, the product
  * rides in the first pass of the inverse (40N instead of 56N).  d_c may alias d_ahat or d_bhat (not a broadcast b^). */
 NTT_API int ntt_inv_product_batch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_ahat, const uint64_t *d_bhat,
@@ -190,6 +191,14 @@ NTT_API int ntt_inv_dot_batch(const ntt_plan *p, uint64_t *d_c, int k, const uin
  * 2^14).  d_a is left as it was up to N = 2^14 and OVERWRITTEN (scratch) above; d_c may alias d_a or d_bhat. */
 NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
                                       unsigned flags, void *stream);
+/* c^ = fwd(a) (.) b^, or with NTT_MUL_ACCUMULATE c^ += fwd(a) (.) b^: a in coefficients, the result STAYS in the NTT domain
+ * (canonical words, bit-reversed order as ntt_fwd_batch leaves them): a plaintext or key-switching key kept transformed is
+ * multiplied in where the forward transform would reduce and store its outputs -- the multiply-accumulate of a key-switching
+ * inner product, digit by digit.  ONE launch up to N = 2^14: 24N bytes (16N with NTT_MUL_B_BROADCAST) instead of 40N for
+ * ntt_fwd_batch + ntt_pointwise_mul_batch; accumulating 32N (24N) instead of 48N.  d_a is left as it was up to 2^14 and
+ * OVERWRITTEN (scratch) above; d_c may alias d_a (not when accumulating) or d_bhat. */
+NTT_API int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
+                              void *stream);
 
 /* ---- RNS limbs (BASELINE config 5: 4-prime RNS pipeline).  plans[l] is the plan of
  * prime q_l (same N, same device); data layout is [limb][batch][N], i.e. limb l of
@@ -211,6 +220,8 @@ NTT_API int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *
                                   const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream);
 NTT_API int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
                                           uint64_t batch, unsigned flags, void *stream);
+NTT_API int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                  uint64_t batch, unsigned flags, void *stream);
 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);

@@ -39,7 +39,7 @@ VOIDP = C.c_void_p
 NTT_OK = 0
 ARITH_AUTO, ARITH_U64, ARITH_F64, ARITH_U64_R4 = 0, 1, 2, 3
 FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
-MUL_LAZY_IN, MUL_B_BROADCAST = 1, 2
+MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
 OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU = 7, 8, 9
 
@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
     "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
-    "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
@@ -110,6 +110,8 @@ _sig("ntt_mul_transformed_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint6
 _sig("ntt_rns_inv_dot_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64,
      C.c_uint, VOIDP)
 _sig("ntt_rns_mul_transformed_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_fwd_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_fwd_mul_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
 _sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
@@ -319,6 +321,10 @@ class Plan:
     def mul_transformed(self, dc, da, dbhat, batch, flags=0, stream=None):
         _check(_lib.ntt_mul_transformed_batch(self.h, dc, da, dbhat, batch, flags, stream))
 
+    def fwd_mul(self, dc, da, dbhat, batch, flags=0, stream=None):
+        """c^ = fwd(a) (.) b^ (MUL_ACCUMULATE: c^ += ...): the result stays in the NTT domain"""
+        _check(_lib.ntt_fwd_mul_batch(self.h, dc, da, dbhat, batch, flags, stream))
+
     # host-array conveniences used by the parity tests
     def fwd_host(self, a, wide=False, lazy=False):
         a = np.ascontiguousarray(a, dtype=np.uint64)
@@ -372,6 +378,10 @@ def rns_inv_dot(plans, dc, dahats, dbhats, batch, flags=0, stream=None):
     k = len(dahats)
     _check(_lib.ntt_rns_inv_dot_batch(len(plans), _plan_array(plans), dc, k, (VOIDP * k)(*dahats), (VOIDP * k)(*dbhats), batch,
                                       flags, stream))
+
+
+def rns_fwd_mul(plans, dc, da, dbhat, batch, flags=0, stream=None):
+    _check(_lib.ntt_rns_fwd_mul_batch(len(plans), _plan_array(plans), dc, da, dbhat, batch, flags, stream))
 
 
 def rns_mul_transformed(plans, dc, da, dbhat, batch, flags=0, stream=None):

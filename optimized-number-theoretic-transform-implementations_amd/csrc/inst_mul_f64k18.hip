@@ -1,0 +1,6 @@
+/* inst_mul_f64k18.hip -- instantiates the forward-transform-times-b^ kernels (fwd_mul_kernel) for (ArithF64, headroom class 18). */
+#include "ntt_kernels.h"
+
+namespace ntt {
+NTT_DEFINE_LAUNCH_FWD_MUL(ArithF64, 18)
+} /* namespace ntt */

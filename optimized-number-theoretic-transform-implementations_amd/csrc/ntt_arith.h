@@ -151,6 +151,12 @@ struct ArithU64 {
   template <bool LAZY> static NTT_HD val dot_term(uint64_t a, uint64_t b, const consts &c) { return mulmod_full(a, b, c); }
   static NTT_HD val dot_acc(val acc, val t, const consts &c) { return csub(acc + t, c.q); }
   static NTT_HD val dot_fold(val acc, const consts &) { return acc; }
+  /* Product at the OUTPUT of a forward transform: c^ = fwd(a) (.) b^ (+ c^), the result staying in the NTT domain
+   * (fwd_mul_kernel).  x: the forward transform's working value ([0,4q)), b: a stored word (canonical, or lazy); the
+   * product is fully reduced (fast_mul_mod_q semantics, fast_mul_operators.h:56-60); acc: a canonical word. */
+  template <bool LAZY> static NTT_HD val mul_out(val x, uint64_t b, const consts &c) { return mulmod_full(x, b, c); }
+  static NTT_HD uint64_t mul_store(val r, const consts &) { return r; }
+  static NTT_HD uint64_t mul_store_acc(val r, uint64_t acc, const consts &c) { return csub(r + acc, c.q); }
 };
 
 /* ------------------------------------------------------------------ */
@@ -490,6 +496,20 @@ struct ArithF64 {
   }
   static NTT_HD val dot_acc(val acc, val t, const consts &) { return acc + t; }
   static NTT_HD val dot_fold(val acc, const consts &c) { return reduce(acc, c); }
+  /* Product at the OUTPUT of a forward transform: c^ = fwd(a) (.) b^ (+ c^), the result staying in the NTT domain
+   * (fwd_mul_kernel).  x: the last stage's value (|x| <= B q, B q < 2^53), b: a stored word -- canonical or, LAZY, anywhere in
+   * [0,4q) (folded below 2q with integer operations, re-centred by q).  Both factors are reduced to |.| <= q/2, so the
+   * bounds of product_in_domain hold (|r| <= 0.7 q; 0.875 q for moduli up to 2^52: theta2 < 1/2).  With an accumulator word
+   * (canonical, < q) the sum is below 1.875 q < 2^53: exact, and to_canonical reduces it. */
+  template <bool LAZY> static NTT_HD val mul_out(val x, uint64_t b, const consts &c)
+  {
+    if(LAZY) b = b < 2 * c.qi ? b : b - 2 * c.qi;
+    const double y0 = u64_to_f64_lt52(b);
+    const double y  = reduce(LAZY ? y0 - c.q : y0, c);
+    return mulmod_c(y, reduce(x, c), c);
+  }
+  static NTT_HD uint64_t mul_store(val r, const consts &c) { return to_canonical(r, c); }
+  static NTT_HD uint64_t mul_store_acc(val r, uint64_t acc, const consts &c) { return to_canonical(r + u64_to_f64_lt52(acc), c); }
 };
 
 /* ------------------------------------------------------------------ */

@@ -905,6 +905,49 @@ NTT_HD void dot_tile(typename A::val (&x)[kE], const uint64_t (&ra)[kE], const u
     sched_fence();
   });
 }
+/* Product at the output of a forward transform (fwd_mul_kernel), slots [E0, E1) of the last group's layout:
+ * u = canonical(x * b + rc); rc holds the accumulator words, or zeros when the call does not accumulate.  lazy: a
+ * wave-uniform branch around the chunk. */
+template <class A, int E0, int E1>
+NTT_HD void mul_out_slots(uint64_t (&u)[kE], const typename A::val (&x)[kE], const uint64_t (&rb)[kE], const uint64_t (&rc)[kE],
+                          bool lazy, const typename A::consts &c)
+{
+  if(lazy) {
+    static_for<E0, E1>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      u[E]            = A::mul_store_acc(A::template mul_out<true>(x[E], rb[E], c), rc[E], c);
+    });
+  } else {
+    static_for<E0, E1>([&](auto ee) {
+      constexpr int E = decltype(ee)::value;
+      u[E]            = A::mul_store_acc(A::template mul_out<false>(x[E], rb[E], c), rc[E], c);
+    });
+  }
+}
+/* CH slots at a time with the scheduler fenced in between (register budget, as dot_tile) */
+template <class A, int E0, int E1, int CH = 2>
+NTT_HD void mul_out_tile(uint64_t (&u)[kE], const typename A::val (&x)[kE], const uint64_t (&rb)[kE], const uint64_t (&rc)[kE],
+                         bool lazy, const typename A::consts &c)
+{
+  static_for<0, (E1 - E0) / CH>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    sched_fence();
+    mul_out_slots<A, E0 + C * CH, E0 + C * CH + CH>(u, x, rb, rc, lazy, c);
+    sched_fence();
+  });
+}
+/* store slots [E0, E1) of the last-kind layout as 16-byte words */
+template <int LOGN, int E0 = 0, int E1 = kE> NTT_HD void store_last_raw(const uint64_t (&u)[kE], uint32_t t, uint64_t *blk)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  static_for<E0 / 2, E1 / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    stream_store2(coef_at(blk + P::IOFF(G, E), ib), u64x2{u[E], u[E + 1]});
+  });
+}
+
 template <class A> NTT_HD void dot_fold_tile(typename A::val (&x)[kE], const typename A::consts &c)
 {
   static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::dot_fold(x[decltype(ee)::value], c); });

@@ -50,6 +50,11 @@ template <> hipError_t launch_dot<ArithF64, 0>(const DotArgs &);
 template <> hipError_t launch_dot<ArithF64, 1>(const DotArgs &);
 template <> hipError_t launch_dot<ArithF64, 18>(const DotArgs &);
 template <> hipError_t launch_dot<ArithF64W, 0>(const DotArgs &);
+template <> hipError_t launch_fwd_mul<ArithU64, 0>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithF64, 0>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithF64, 1>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithF64, 18>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithF64W, 0>(const MulArgs &);
 } // namespace ntt
 
 /* ------------------------------------------------------------------ */
@@ -1427,6 +1432,116 @@ extern "C" int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint6
                                          unsigned flags, void *stream)
 {
   return mul_transformed(p, d_c, d_a, d_bhat, batch, flags, stream);
+}
+
+/* c^ = fwd(a) (.) b^ (+ c^), the result staying in the NTT domain: the forward transform with the product where it would
+ * reduce and store its outputs (fwd_mul_kernel).  One launch up to N = 2^14; above, the forward column passes run on a in
+ * place (a is scratch there) and the product rides in the block pass, the forward transform's last one.  Plans without the
+ * kernel: forward transform of a in place, then a pointwise (accumulate) launch. */
+static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
+                   void *stream, const LimbSet *set = nullptr, uint64_t b_limb_stride = 0)
+{
+  if(!p || !d_c || !d_a || !d_bhat) return fail(NTT_ERR_ARG, "null argument");
+  if(flags & ~(unsigned)(NTT_MUL_LAZY_IN | NTT_MUL_B_BROADCAST | NTT_MUL_ACCUMULATE)) return fail(NTT_ERR_ARG, "unknown flag");
+  if(batch == 0) return NTT_OK;
+  if(!p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the forward table");
+  const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0, bcast = (flags & NTT_MUL_B_BROADCAST) != 0, acc = (flags & NTT_MUL_ACCUMULATE) != 0;
+  if(acc && d_c == d_a) return fail(NTT_ERR_ARG, "an accumulator cannot alias the coefficient operand");
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  USE_DEVICE(p->device);
+  if(!dot_kernel_applies(p) || (ls.n > 1 && p->arith != NTT_ARITH_F64)) {
+    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
+    int rc = run_transform(p, d_a, batch, false, false, stream);
+    if(rc) return rc;
+    const uint64_t n  = batch * p->N;
+    const dim3     g(grid_for(n)), t(256);
+    hipStream_t    st = (hipStream_t)stream;
+    const uint64_t bm = bcast ? p->N - 1 : ~0ull;
+#define NTT_PW_MUL(A, CONSTS)                                                                                              \
+  do {                                                                                                                     \
+    if(lazy) {                                                                                                             \
+      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);  \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);   \
+    } else {                                                                                                               \
+      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS); \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);  \
+    }                                                                                                                      \
+  } while(0)
+    if(p->arith == NTT_ARITH_F64) NTT_PW_MUL(ArithF64, p->cf);
+    else NTT_PW_MUL(ArithU64, p->cu);
+#undef NTT_PW_MUL
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+  }
+  const int      pblk  = p->m > kFusedMax ? (p->block_log ? p->block_log : multi_pass_block(p->m, false, p->arith == NTT_ARITH_F64)) : p->m;
+  const PassList L     = make_passes(p->m, false, pblk);
+  uint64_t       chunk = batch;
+  if(L.n > 1) {
+    chunk = ((uint64_t)p->chunk_mib << 20) / (p->N * sizeof(uint64_t) * (uint64_t)ls.n);
+    if(chunk < 1) chunk = 1;
+    if(chunk > batch) chunk = batch;
+  }
+  for(uint64_t first = 0; first < batch; first += chunk) {
+    const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
+    const uint64_t off = first * p->N;
+    for(int j = 0; j + 1 < L.n; j++) { /* forward column passes of a (every pass but the last, which is the block pass) */
+      int rc = launch_one_pass(p, L.p[j], d_a + off, nb, false, false, false, false, stream, ls);
+      if(rc) return rc;
+    }
+    MulArgs ma{};
+    ma.a             = d_a + off;
+    ma.b             = bcast ? d_bhat : d_bhat + off;
+    ma.out           = d_c + off;
+    ma.lazy_in       = lazy;
+    ma.b_bcast       = bcast;
+    ma.accumulate    = acc;
+    ma.limbs         = ls.d;
+    ma.nlimbs        = ls.n;
+    ma.limb_stride   = ls.stride;
+    ma.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
+    ma.batch         = nb;
+    ma.logn          = (uint32_t)p->m;
+    ma.block_log     = (uint32_t)pblk;
+    ma.max_grid      = p->max_grid;
+    ma.num_cus       = p->num_cus;
+    ma.stream        = (hipStream_t)stream;
+    hipError_t e = p->arith == NTT_ARITH_U64 ? launch_fwd_mul<ArithU64, 0>(ma)
+                   : p->kcls == kWideClass   ? launch_fwd_mul<ArithF64W, 0>(ma)
+                   : p->kcls == 18           ? launch_fwd_mul<ArithF64, 18>(ma)
+                   : p->kcls == 1            ? launch_fwd_mul<ArithF64, 1>(ma)
+                                             : launch_fwd_mul<ArithF64, 0>(ma);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  }
+  return NTT_OK;
+}
+
+extern "C" int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
+                                 unsigned flags, void *stream)
+{
+  return fwd_mul(p, d_c, d_a, d_bhat, batch, flags, stream);
+}
+
+extern "C" int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                     uint64_t batch, unsigned flags, void *stream)
+{
+  int rc = rns_check(nlimbs, plans);
+  if(rc || batch == 0) return rc;
+  const uint64_t N = plans[0]->N, slab = batch * N;
+  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && dot_kernel_applies(plans[0])) {
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet ls{recs.data(), n, slab};
+      rc = fwd_mul(plans[first], d_c + (uint64_t)first * slab, d_a + (uint64_t)first * slab, d_bhat + (uint64_t)first * bslab, batch, flags,
+                   stream, &ls, bslab);
+    }
+    return rc;
+  }
+  for(int l = 0; !rc && l < nlimbs; l++) {
+    rc = fwd_mul(plans[l], d_c + (uint64_t)l * slab, d_a + (uint64_t)l * slab, d_bhat + (uint64_t)l * bslab, batch, flags, stream);
+  }
+  return rc;
 }
 
 extern "C" int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,

@@ -1935,6 +1935,211 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* forward transform with the product at its output: c^ = fwd(a) (.) b^ (+ c^) */
+/* ------------------------------------------------------------------ */
+/*
+ * The counterpart of dot_inv_kernel on the other side of the path: the operand comes in as coefficients, the result STAYS in
+ * the NTT domain -- a plaintext or key factor b^ kept transformed is multiplied in where the forward block kernel would
+ * reduce and store its outputs, optionally added to what c^ already holds (the multiply-accumulate of a key-switching inner
+ * product, digit by digit).  24N bytes (16N with a broadcast b^) instead of 40N for forward transform + pointwise product;
+ * with the accumulator 32N (24N) instead of 48N.  The forward transform ends in the layout the element-wise product needs
+ * (runs of four consecutive coefficients per lane), so b^ and c^ are read and c^ written as 16-byte words by the lane that
+ * owns them: c may alias a or b^.  Blocks of a larger transform (N > 2^14: the block pass is the forward transform's LAST
+ * pass) work the same way.  Reference primitive: fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
+ * Registers (2^14: 128 VGPRs): the next block's words are in flight during the whole iteration (32), so the last group's
+ * twiddles are requested per block instead of staying resident (24), b^ is fetched in two halves -- the first one in front of
+ * the last group, the second one while the first half's products run -- and the accumulator words right where each half is
+ * finished.
+ */
+template <class A> struct KMul {
+  KArgs<A>        k;             /* k.a = a (coefficients, limb 0); nblocks / s0 / logn as for a forward block pass */
+  const uint64_t *b;             /* b^ (limb 0) */
+  uint64_t *      out;           /* c^ (limb 0) */
+  uint64_t        b_limb_stride; /* words between consecutive limbs of b^ */
+  uint32_t        lazy_in;       /* words of b^ may be lazy: anywhere in [0,4q) */
+  uint32_t        b_bcast;       /* b^ is one polynomial per limb, shared by the whole batch */
+  uint32_t        accumulate;    /* c^ += ... (c^ canonical on entry) */
+};
+
+/* live = false: a descriptor of zero records -- the loads return 0 and move no data (the accumulator words of a call that
+ * does not accumulate: a run-time branch around the loads would make the register allocator keep two sets apart) */
+template <int LOGN, int E0, int E1, int AUX = 0>
+__device__ __forceinline__ void prefetch_last_range(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk, bool live = true)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk, live);
+  static_for<E0 / 2, E1 / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    const u64x2   v = buffer_load_u64x2<AUX>(r, ib * 8u, P::IOFF(G, E) * 8u);
+    raw[E]          = v.a;
+    raw[E + 1]      = v.b;
+  });
+}
+template <int LOGN, int E0, int E1>
+__device__ __forceinline__ void buffer_store_last_range(const uint64_t (&u)[kE], uint32_t t, uint64_t *blk)
+{
+  using P           = Plan<LOGN>;
+  constexpr int G   = P::NG - 1;
+  const uint32_t ib = P::IBASE(G, t);
+  const __amdgpu_buffer_rsrc_t r = block_rsrc<LOGN>(blk);
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  static_for<E0 / 2, E1 / 2>([&](auto hh) {
+    constexpr int E = 2 * decltype(hh)::value;
+    v4u32         v;
+    v.x = (unsigned)u[E];
+    v.y = (unsigned)(u[E] >> 32);
+    v.z = (unsigned)u[E + 1];
+    v.w = (unsigned)(u[E + 1] >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(ib * 8u), (int)(P::IOFF(G, E) * 8u), 0);
+  });
+}
+
+template <class A, int LOGN, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS)) fwd_mul_kernel(const KMul<A> km)
+{
+  uint32_t        bid, gdim, limb;
+  const Params<A> p = limb_params<A, false, MULTI>(km.k, bid, gdim, limb);
+  using P = Plan<LOGN>;
+  using G = Geom<LOGN, false, flavor_of<A>()>;
+  constexpr uint32_t MASK   = fused_mask<A, LOGN, false, KSH>();
+  constexpr int      LDS_TW = G::LDS_TW;
+  __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
+  const uint32_t   tid   = threadIdx.x;
+  const uint32_t   sub   = tid >> P::LT;
+  const uint32_t   t     = tid & (P::T - 1);
+  typename A::val *lds   = lds_all + sub * P::LDS_ELEMS;
+  const uint32_t   bmask = (1u << p.s0) - 1u;
+  const bool       lazy  = km.lazy_in != 0;
+  const bool       bc    = km.b_bcast != 0;
+  const bool       acc   = km.accumulate != 0;
+  const uint64_t * bptr  = km.b + (uint64_t)limb * km.b_limb_stride; /* (MULTI off: limb == 0) */
+  uint64_t *       cptr  = km.out + (uint64_t)limb * km.k.limb_stride;
+
+  if constexpr(G::PERSISTENT && A::kCompact && !MULTI) {
+    constexpr int  GL  = P::NG - 1;
+    constexpr bool PRE = stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0;
+    constexpr bool LTW = LDS_TW > 0;
+    static_assert(P::NG >= 3, "the persistent blocks have at least three stage groups");
+    const uint32_t         tt     = G::BPW == 1 ? tid : t;
+    typename A::val *const ll     = G::BPW == 1 ? lds_all : lds;
+    const uint64_t         stride = (uint64_t)gdim * G::BPW;
+    uint64_t               b0     = (uint64_t)bid * G::BPW;
+    if(b0 >= p.nblocks) return;
+    const uint64_t lastb = p.nblocks - 1;
+    uint64_t       b     = G::BPW == 1 ? b0 : (b0 + sub < p.nblocks ? b0 + sub : lastb);
+    typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+    const lds_ctw_ptr<A>   ltw  = (lds_ctw_ptr<A>)tabl;
+    if constexpr(LTW) {
+      fill_lds_tables<A, LOGN, false>(tabl, p, (uint32_t)b & bmask, tid);
+      __syncthreads();
+    }
+    uint64_t raw[kE];
+    prefetch_first<LOGN>(raw, tt, p.a + (b << LOGN));
+    pin_raw(raw);
+    for(; b0 < p.nblocks; b0 += stride) {
+      const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
+      b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
+      const uint32_t  blk   = (uint32_t)b & bmask;
+      const uint64_t *bblk  = bptr + ((bc ? (uint64_t)blk : b) << LOGN);
+      uint64_t *      cblk  = cptr + (b << LOGN);
+      uint32_t        tl    = tt;
+      asm volatile("" : "+v"(tl)); /* ties the per-block requests to the iteration (see dot_inv_kernel) */
+      typename A::val x[kE];
+      convert_inputs<A, false>(x, raw, false, p.c);
+      {
+        const bool     more = b0 + stride < p.nblocks;
+        const uint64_t nb0  = more ? b0 + stride : b0;
+        const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
+        prefetch_first<LOGN>(raw, tl, p.a + (nb << LOGN), more);
+      }
+      run_group<A, LOGN, 0, false, MASK>(x, tl, blk, p);
+      typename A::ctw pre[4][kE / 2];
+      uint64_t        rb[kE], rc[kE];
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = decltype(gg)::value;
+        if constexpr(PRE && GI + 1 == GL) {
+          /* the last group's twiddles: requested in front of the exchange into it (its LDS round trip hides part of the L2
+           * latency; a whole group ahead they would live through the table group next to the prefetched block: spills) */
+          sched_fence();
+          preload_group_tw<A, LOGN, GL>(pre, tl, blk, p);
+          sched_fence();
+        }
+        exchange<A, LOGN, GI, GI + 1>(x, tl, ll);
+        if constexpr(PRE && GI + 1 == GL) {
+          run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+        } else if constexpr(G::TBL(GI + 1) > 0) {
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tl, blk, p, ltw + G::TBL_OFF(GI + 1));
+        } else {
+          run_group<A, LOGN, GI + 1, false, MASK>(x, tl, blk, p);
+        }
+      });
+      /* the products, a quarter of the tile at a time, the next quarter's words in flight meanwhile: at most eight 16-byte
+       * words of b^ and c^ per thread live next to the 32 values and the 32 prefetched words of the next block */
+      uint64_t u[kE];
+      uint32_t t2 = tt; /* (a fresh opaque copy: the lane offsets of this phase are computed here, not carried through the groups) */
+      asm volatile("" : "+v"(t2));
+      sched_fence();
+      prefetch_last_range<LOGN, 0, 4>(rb, t2, bblk);
+      static_for<0, 4>([&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        sched_fence();
+        /* this quarter's accumulator words (zeros, and no traffic, when the call does not accumulate) and the next
+         * quarter's b^ words */
+        prefetch_last_range<LOGN, 4 * Q, 4 * Q + 4>(rc, t2, cblk, acc);
+        if constexpr(Q < 3) prefetch_last_range<LOGN, 4 * Q + 4, 4 * Q + 8>(rb, t2, bblk);
+        sched_fence();
+        mul_out_tile<A, 4 * Q, 4 * Q + 4, 1>(u, x, rb, rc, lazy, p.c); /* (one product at a time: two need 14 registers more than there are) */
+        if(live) buffer_store_last_range<LOGN, 4 * Q, 4 * Q + 4>(u, t2, cblk);
+        sched_fence();
+      });
+    }
+    return;
+  } else {
+    /* small blocks (several per workgroup), the integer policies, several limbs: the plain loop */
+    const lds_ctw_ptr<A> gtw = (lds_ctw_ptr<A>)reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS);
+    if constexpr(LDS_TW > 0) {
+      fill_lds_tables<A, LOGN, false>(reinterpret_cast<typename A::ctw *>(lds_all + G::BPW * P::LDS_ELEMS), p,
+                                      G::BPW == 1 ? ((uint32_t)bid & bmask) : 0u, tid);
+      __syncthreads();
+    }
+    for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gdim * G::BPW) {
+      uint64_t   b    = b0 + sub;
+      const bool live = b < p.nblocks;
+      if(!live) b = p.nblocks - 1;
+      const uint32_t  blk  = (uint32_t)b & bmask;
+      const uint64_t *bblk = bptr + ((bc ? (uint64_t)blk : b) << LOGN);
+      uint64_t *      cblk = cptr + (b << LOGN);
+      /* (an opaque copy of the thread id per block: the integer policy's per-lane twiddle addresses would otherwise be
+       * computed once for the launch and sit in registers -- or scratch -- throughout) */
+      uint32_t tg = t;
+      asm volatile("" : "+v"(tg));
+      typename A::val x[kE];
+      global_load_first<A, LOGN, false>(x, tg, p.a + (b << LOGN), false, p.c);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tg, blk, p, gtw);
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int GI = decltype(gg)::value;
+        exchange<A, LOGN, GI, GI + 1>(x, tg, lds);
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, tg, blk, p, gtw + G::TBL_OFF(GI + 1));
+      });
+      static_for<0, 4>([&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        uint64_t      rb[kE], rc[kE], u[kE];
+        sched_fence();
+        load_last_raw<LOGN, 4 * Q, 4 * Q + 4>(rb, tg, bblk);
+        /* (the accumulator words: c^ itself, or zeros when the call does not accumulate) */
+        if(acc) load_last_raw<LOGN, 4 * Q, 4 * Q + 4>(rc, tg, cblk);
+        else static_for<4 * Q, 4 * Q + 4>([&](auto ee) { rc[decltype(ee)::value] = 0; });
+        mul_out_tile<A, 4 * Q, 4 * Q + 4, 1>(u, x, rb, rc, lazy, p.c);
+        if(live) store_last_raw<LOGN, 4 * Q, 4 * Q + 4>(u, tg, cblk);
+        sched_fence();
+      });
+    }
+  }
+}
+
 template <class A, int R, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
 {
@@ -2023,6 +2228,23 @@ struct DotArgs {
   hipStream_t            stream;
 };
 template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
+
+/* c^ = forward block pass of a, times b^ (+ c^) (fwd_mul_kernel) */
+struct MulArgs {
+  uint64_t *      a;   /* coefficients (N > 2^14: after the forward column passes) */
+  const uint64_t *b;   /* b^ */
+  uint64_t *      out; /* c^ */
+  int             lazy_in, b_bcast, accumulate;
+  const void *    limbs; /* HOST array of LimbRec<A> */
+  int             nlimbs;
+  uint64_t        limb_stride, b_limb_stride;
+  uint64_t        batch;
+  uint32_t        logn;
+  uint32_t        block_log; /* N > 2^14: log2 of the blocks (12 or 14) */
+  int             max_grid, num_cus;
+  hipStream_t     stream;
+};
+template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
 
 /* What a pass stores: the last pass of a transform honours the caller's lazy flag; every earlier pass of an
  * integer policy keeps the reference's lazy ranges in HBM (no reduction between stages, as in
@@ -2477,6 +2699,81 @@ template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
     default: return hipErrorNotSupported;
   }
 }
+
+template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const MulArgs &ma)
+{
+  using G = Geom<LOGN, false, flavor_of<A>()>;
+  KMul<A> km{};
+  km.k.a                 = ma.a;
+  const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(ma.limbs);
+  const uint64_t    nl   = (uint64_t)(ma.nlimbs > 0 ? ma.nlimbs : 1);
+  for(uint64_t l = 0; l < nl && l < (uint64_t)kMaxLimbs; l++) km.k.limbs[l] = recs[l];
+  km.k.limb_stride = ma.limb_stride;
+  km.k.logn        = ma.logn;
+  km.k.s0          = ma.logn - (uint32_t)LOGN;
+  km.k.nblocks     = ma.batch << km.k.s0;
+  km.b             = ma.b;
+  km.out           = ma.out;
+  km.b_limb_stride = ma.b_limb_stride;
+  km.lazy_in       = (uint32_t)ma.lazy_in;
+  km.b_bcast       = (uint32_t)ma.b_bcast;
+  km.accumulate    = (uint32_t)ma.accumulate;
+  /* the grid of the forward block kernel (launch_fused) */
+  uint64_t wgs = (km.k.nblocks + G::BPW - 1) / G::BPW;
+  uint64_t cap = 1ull << 20;
+  if(G::PERSISTENT) {
+    constexpr int by_lds   = G::WG_PER_CU0;
+    constexpr int by_waves = (G::WPS * 4 * 64) / G::WG;
+    constexpr int per_cu   = by_lds < by_waves ? by_lds : by_waves;
+    cap                    = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+  }
+  if(!G::PERSISTENT && G::LDS_TW > 0) {
+    if(km.k.s0 != 0) return hipErrorInvalidValue;
+    constexpr int per_cu = G::WG_PER_CU0 < 8 ? G::WG_PER_CU0 : 8;
+    cap                  = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
+  }
+  if(ma.max_grid > 0) cap = (uint64_t)ma.max_grid;
+  cap = cap / nl > 0 ? cap / nl : 1;
+  if(G::BPW == 1 && km.k.s0 > 0) { /* a workgroup keeps the tables of ONE block position */
+    if(cap < (1ull << km.k.s0)) cap = 1ull << km.k.s0;
+    cap &= ~((1ull << km.k.s0) - 1);
+  }
+  if(G::BPW > 1 && km.k.s0 > 0) return hipErrorInvalidValue; /* (two blocks per workgroup: whole polynomials only) */
+  if(wgs > cap) wgs = cap;
+  if(wgs == 0) return hipSuccess;
+  km.k.wgs_per_limb = (uint32_t)wgs;
+  if(nl > 1) {
+    if constexpr(multi_limb_built<A>()) {
+      hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, true>), dim3((unsigned)(wgs * nl)), dim3(G::WG), 0, ma.stream, km);
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
+  hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, false>), dim3((unsigned)wgs), dim3(G::WG), 0, ma.stream, km);
+  return hipGetLastError();
+}
+
+template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
+{
+  if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(ma.logn > (uint32_t)kFusedMax) {
+    if(ma.block_log == (uint32_t)kFusedSmallBlock) return launch_fwd_mul_blocks<A, kFusedSmallBlock, KSH>(ma);
+    if(ma.block_log == (uint32_t)kFusedLarge) return launch_fwd_mul_blocks<A, kFusedLarge, KSH>(ma);
+    return hipErrorInvalidValue;
+  }
+  switch(ma.logn) {
+#define NTT_MUL_CASE(LN) \
+  case LN: return launch_fwd_mul_blocks<A, LN, KSH>(ma);
+    NTT_MUL_CASE(6) NTT_MUL_CASE(7) NTT_MUL_CASE(8) NTT_MUL_CASE(9) NTT_MUL_CASE(10) NTT_MUL_CASE(11) NTT_MUL_CASE(12) NTT_MUL_CASE(13)
+    NTT_MUL_CASE(14)
+#undef NTT_MUL_CASE
+    default: return hipErrorNotSupported;
+  }
+}
+
+#define NTT_DEFINE_LAUNCH_FWD_MUL(A, KSH) \
+  template <> hipError_t launch_fwd_mul<A, KSH>(const MulArgs &ma) { return launch_fwd_mul_impl<A, KSH>(ma); }
 
 #define NTT_DEFINE_LAUNCH_DOT(A, KSH) \
   template <> hipError_t launch_dot<A, KSH>(const DotArgs &da) { return launch_dot_impl<A, KSH>(da); }

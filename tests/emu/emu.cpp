@@ -176,6 +176,27 @@ struct ArithF64Chk : ArithF64 {
     return s;
   }
   static val dot_fold(val acc, const consts &c) { return reduce(acc, c); }
+  /* product at the output of a forward transform (fwd_mul_kernel): exact, bounded, and the sum with an accumulator word
+   * stays an integer below 2^53 */
+  template <bool LAZY> static val mul_out(val x, uint64_t b, const consts &c)
+  {
+    see(x, c);
+    if(LAZY ? b >= 4 * c.qi : b >= c.qi) g_chk_fail++;
+    const double   r  = ArithF64::mul_out<LAZY>(x, b, c);
+    const __int128 ex = as_int(x) * (__int128)(b % c.qi);
+    if((ex - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;
+    if(__builtin_fabs(r) > 0.88 * c.q) g_chk_fail++;
+    return r;
+  }
+  static uint64_t mul_store(val r, const consts &c) { return store_fwd(r, c); }
+  static uint64_t mul_store_acc(val r, uint64_t acc, const consts &c)
+  {
+    if(acc >= c.qi) g_chk_fail++;
+    const double s = r + u64_to_f64_lt52(acc);
+    see(s, c);
+    if(as_int(r) + (__int128)acc != as_int(s)) g_chk_fail++;
+    return store_fwd(s, c);
+  }
   static tw expand(ctw w, const consts &c)
   {
     const tw t = ArithF64::expand(w, c);
@@ -473,6 +494,85 @@ template <class A, int R, bool INV, int KSH>
 static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, bool wide, bool lastinv,
                        const typename A::tw *tab, const typename A::consts &c, bool lazy_out);
 
+/* fwd_mul_kernel step by step: the forward block pass with the product by b^ (and the accumulator) where the outputs would
+ * be reduced and stored */
+template <class A, int LOGN, int KSH>
+void emu_fwd_mul_blocks(const Params<A> &p, const uint64_t *bhat, uint64_t *out, bool lazy, bool bcast, bool acc)
+{
+  using P                 = Plan<LOGN>;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, false, KSH>();
+  constexpr int      GL   = P::NG - 1;
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         regs(P::T);
+  const uint64_t bmask = (1ull << p.s0) - 1;
+  for(uint64_t blkid = 0; blkid < p.nblocks; blkid++) {
+    const uint32_t  blk  = (uint32_t)(blkid & bmask);
+    const uint64_t *bblk = bhat + ((bcast ? (uint64_t)blk : blkid) << LOGN);
+    uint64_t *      cblk = out + (blkid << LOGN);
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      global_load_first<A, LOGN, false>(regs[t].x, t, p.a + (blkid << LOGN), false, p.c);
+      run_group<A, LOGN, 0, false, MASK>(regs[t].x, t, blk, p);
+    }
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int G = decltype(gg)::value;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+        if constexpr(A::kCompact && G + 1 == GL) {
+          typename A::ctw pre[4][kE / 2];
+          preload_group_tw<A, LOGN, GL>(pre, t, blk, p);
+          run_group_preloaded<A, LOGN, GL, MASK>(regs[t].x, pre, p);
+        } else {
+          run_group<A, LOGN, G + 1, false, MASK>(regs[t].x, t, blk, p);
+        }
+      }
+    });
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      uint64_t rb[kE], rc[kE], u[kE];
+      load_last_raw<LOGN>(rb, t, bblk);
+      if(acc) load_last_raw<LOGN>(rc, t, cblk);
+      else for(int e = 0; e < kE; e++) rc[e] = 0;
+      mul_out_tile<A, 0, kE, 1>(u, regs[t].x, rb, rc, lazy, p.c);
+      store_last_raw<LOGN>(u, t, cblk);
+    }
+  }
+}
+
+/* the library's fwd_mul (ntt_host.hip): one block launch up to 2^14; above, the forward column passes on a, then the blocks */
+template <class A, int KSH>
+int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t batch, int m, const typename A::tw *tab,
+                    const typename A::ctw *tab8, const typename A::consts &c, bool lazy, bool bcast, bool acc)
+{
+  if(m < kFusedMin) return -1;
+  const int      pblk = m > kFusedMax ? multi_pass_block(m, false, A::kTracksBounds) : m;
+  const PassList L    = make_passes(m, false, pblk);
+  for(int j = 0; j + 1 < L.n; j++) {
+    const Pass &ps = L.p[j];
+    switch(ps.r) {
+      case 1: emu_column<A, 1, false, KSH>(a, batch, m, ps.s, false, false, tab, c, true); break;
+      case 2: emu_column<A, 2, false, KSH>(a, batch, m, ps.s, false, false, tab, c, true); break;
+      case 3: emu_column<A, 3, false, KSH>(a, batch, m, ps.s, false, false, tab, c, true); break;
+      case 4: emu_column<A, 4, false, KSH>(a, batch, m, ps.s, false, false, tab, c, true); break;
+      default: return -1;
+    }
+  }
+  Params<A> p{};
+  p.a       = a;
+  p.tw      = tab;
+  p.tw8     = tab8;
+  p.c       = c;
+  p.logn    = (uint32_t)m;
+  p.s0      = (uint32_t)(m - pblk);
+  p.nblocks = batch << p.s0;
+  switch(pblk) {
+#define CASE(LN) \
+  case LN: emu_fwd_mul_blocks<A, LN, KSH>(p, bhat, out, lazy, bcast, acc); return 0;
+    CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+    default: return -1;
+  }
+}
+
 /* the library's inv_dot (ntt_host.hip): one block launch up to 2^14; above, the dot kernel over the blocks and the
  * inverse's column passes */
 template <class A, int KSH>
@@ -627,6 +727,8 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
   KW template void emu_fused_product_small<A, 8, K> EMU_PROD_ARGS(A);
 #define EMU_DOT_ARGS(A) (uint64_t *, int, const uint64_t *const *, const uint64_t *const *, uint64_t, int, const typename A::tw *, const typename A::ctw *, const typename A::consts &, bool, bool)
 #define EMU_DOT(KW, A, K) KW template int emu_dot_run<A, K> EMU_DOT_ARGS(A);
+#define EMU_MUL_ARGS(A) (uint64_t *, uint64_t *, const uint64_t *, uint64_t, int, const typename A::tw *, const typename A::ctw *, const typename A::consts &, bool, bool, bool)
+#define EMU_MUL(KW, A, K) KW template int emu_fwd_mul_run<A, K> EMU_MUL_ARGS(A);
 using WideChk = WideF64<ArithF64Chk>;
 #if EMU_PART >= 0
 #  define P1(KW) EMU_RUN(KW, ArithU64, 0) EMU_RUN(KW, ArithU64R4, 0) EMU_RUN(KW, ArithF64W, 0)
@@ -639,8 +741,10 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P7(KW) EMU_PROD_OTHER(KW, ArithF64Chk, 0) EMU_PROD_OTHER(KW, ArithF64Chk, 1) EMU_PROD_OTHER(KW, WideChk, 0)
 #  define P8(KW) EMU_DOT(KW, ArithU64, 0) EMU_DOT(KW, ArithF64Chk, 0)
 #  define P9(KW) EMU_DOT(KW, ArithF64Chk, 1) EMU_DOT(KW, WideChk, 0)
+#  define P10(KW) EMU_MUL(KW, ArithU64, 0) EMU_MUL(KW, ArithF64Chk, 0)
+#  define P11(KW) EMU_MUL(KW, ArithF64Chk, 1) EMU_MUL(KW, WideChk, 0)
 #  if EMU_PART == 0
-P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern)
+P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern) P10(extern) P11(extern)
 #  elif EMU_PART == 1
 P1()
 #  elif EMU_PART == 2
@@ -659,6 +763,10 @@ P7()
 P8()
 #  elif EMU_PART == 9
 P9()
+#  elif EMU_PART == 10
+P10()
+#  elif EMU_PART == 11
+P11()
 #  endif
 #endif
 
@@ -902,6 +1010,36 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
   if(wide) return emu_dot_run<WideChk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
   if(h_f64_ksh(q) >= 1) return emu_dot_run<ArithF64Chk, 1>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
   return emu_dot_run<ArithF64Chk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
+}
+#endif
+
+#ifndef EMU_SAN_BUILD
+/* out = fwd(a) (.) b^ (+ out), the result in the NTT domain, as fwd_mul_kernel (+ the forward column passes above 2^14) computes
+ * it.  a: [batch][N] coefficients (overwritten above 2^14), b: [batch][N] or (bcast) [N]; arith as emu_inv_dot. */
+int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root, int arith, int lazy,
+                int bcast, int acc)
+{
+  const uint64_t N = 1ull << m;
+  const auto     w = h_power_table(root, N, q);
+  std::vector<uint64_t> dummy(2, 1);
+  if(arith == 0) {
+    std::vector<TwU64> tab(w.size());
+    for(size_t i = 0; i < w.size(); i++) tab[i] = h_tw_u64(w[i], q);
+    const auto c = h_consts_u64(q, N, dummy);
+    return emu_fwd_mul_run<ArithU64, 0>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
+  }
+  const bool wide = !h_f64_eligible(q);
+  if(wide && !h_f64w_eligible(q)) return -2;
+  std::vector<TwF64>  tf(w.size());
+  std::vector<double> tf8(w.size());
+  for(size_t i = 0; i < w.size(); i++) {
+    tf[i]  = h_tw_f64(w[i], q);
+    tf8[i] = tf[i].w;
+  }
+  const auto c = h_consts_f64(q, N, dummy);
+  if(wide) return emu_fwd_mul_run<WideChk, 0>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
+  if(h_f64_ksh(q) >= 1) return emu_fwd_mul_run<ArithF64Chk, 1>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
+  return emu_fwd_mul_run<ArithF64Chk, 0>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
 }
 #endif
 

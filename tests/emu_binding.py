@@ -27,6 +27,7 @@ class Emu:
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
         L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
+        L.emu_fwd_mul.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_team_decode.argtypes = [C.c_uint32] * 7 + [C.POINTER(C.c_uint32)]
         L.emu_inv_dot.argtypes = [U64P, C.c_int, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
 
@@ -72,6 +73,15 @@ class Emu:
         out = np.zeros(batch << m, dtype=np.uint64)
         rc = self.lib.emu_inv_dot(out.ctypes.data_as(U64P), k, a.ctypes.data_as(U64P), b.ctypes.data_as(U64P), batch, m, q, root,
                                   arith, int(lazy), int(bcast))
+        return rc, out
+
+    def fwd_mul(self, a, bhat, m, q, root, arith=1, lazy=False, bcast=False, acc=None):
+        """c^ = fwd(a) (.) b^ (+ acc) as fwd_mul_kernel computes it (checked FP64 policy, or arith 0: integer)"""
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        bhat = np.ascontiguousarray(bhat, dtype=np.uint64)
+        out = np.zeros_like(a) if acc is None else np.ascontiguousarray(acc, dtype=np.uint64).copy()
+        rc = self.lib.emu_fwd_mul(out.ctypes.data_as(U64P), a.ctypes.data_as(U64P), bhat.ctypes.data_as(U64P), a.size >> m, m, q, root,
+                                  arith, int(lazy), int(bcast), int(acc is not None))
         return rc, out
 
     def team_decode(self, k, q, total, lag, n0, n1, n2):

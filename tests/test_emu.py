@@ -493,3 +493,36 @@ def test_dot_kernel_logic_integer_policy(oracle, emu, m, q):
         a_list, b_list = _dot_operands(oracle, n, q, 2, k, 4200 + m, lazy, bcast)
         rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=0, lazy=lazy, bcast=bcast)
         assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q, n, bcast))), (m, hex(q), k)
+
+
+# ---- forward transform with the product at its output: fwd_mul_kernel's logic and arithmetic on the CPU ------------------
+@pytest.mark.parametrize("m,q,arith", [(12, 0x7fffffffe0001, 1), (14, 0x7fffffffe0001, 1), (14, 0x3ffffffdf0001, 1), (8, 0x7ffe0001, 1),
+                                       (13, 0xffffffff00001, 1), (14, 0xffffffff00001, 1), (15, 0x7fffffffe0001, 1), (16, 0xffffffff00001, 1),
+                                       (10, 0x10001, 0), (14, 0xffffffffffc0001, 0), (15, 0xffffffffffc0001, 0)])
+def test_fwd_mul_kernel_logic(oracle, emu, m, q, arith):
+    """c^ = fwd(a) (.) b^ and c^ += fwd(a) (.) b^ as fwd_mul_kernel forms them -- the product where the forward transform would
+    reduce and store its outputs -- with the CHECKED FP64 policy (every value an integer below 2^53, every product exact, the sum
+    with the accumulator exact) or the integer policy; canonical and lazy b^, per-polynomial and broadcast; above 2^14 the
+    product rides in the block pass behind the column passes"""
+    n = 1 << m
+    if (q - 1) % (2 * n) or not oracle.lib.orc_is_prime(q):
+        q = oracle.find_prime(60 if arith == 0 else 50, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    batch = 2 if m <= 14 else 1
+    a = _inputs(oracle, n, q, batch, 4300 + m)
+    fa = cx.fwd(a)
+    rng = np.random.default_rng(m)
+    for lazy, bcast, acc in ((False, False, False), (True, False, True), (False, True, True), (True, True, False)):
+        b = oracle.fill_uniform((1 if bcast else batch) * n, q, 4400 + m)
+        b[:4] = [q - 1, 0, q // 2, 1]
+        bw = b + (rng.integers(0, 4, b.size).astype(np.uint64) * np.uint64(q) if lazy else np.uint64(0))
+        c0 = oracle.fill_uniform(batch * n, q, 4500 + m)
+        c0[:2] = [q - 1, 0]
+        exp = oracle.pointwise(fa, np.tile(b, batch) if bcast else b, q)
+        if acc:
+            exp = (exp + c0) % np.uint64(q)
+        emu.chk_stats(reset=True)
+        rc, got = emu.fwd_mul(a, bw, m, q, w, arith=arith, lazy=lazy, bcast=bcast, acc=c0 if acc else None)
+        assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc)
+        assert emu.chk_stats()[0] == 0

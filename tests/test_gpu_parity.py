@@ -1743,3 +1743,99 @@ print("graph ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("cls", sorted(_DOT_MODULI))
+@pytest.mark.parametrize("m", [8, 11, 12, 13, 14, 15, 17])
+def test_forward_transform_times_a_transformed_operand(lib, oracle, m, cls):
+    """c^ = fwd(a) (.) b^ and c^ += fwd(a) (.) b^ (the result stays in the NTT domain): ONE launch up to 2^14 (the product where the
+    forward transform would reduce and store its outputs), riding in the block pass above; against the oracle's forward
+    transform and 128-bit products; canonical and lazy b^, per-polynomial and broadcast b^, accumulating or not, c aliasing a or
+    b^, ragged batches either side of the persistent grid, chunk by chunk above 2^14; every modulus class"""
+    n = 1 << m
+    bits, skip = _DOT_MODULI[cls]
+    q = lib.find_prime(bits, n, skip)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    rng = np.random.default_rng(m)
+    for batch in ((1, 5, 300) if m <= 14 else (1, 6)):
+        a = oracle.fill_uniform(batch * n, q, 7000 + m)
+        a[:3] = [q - 1, 0, q // 2]
+        sample = list(range(batch)) if batch <= 8 else [0, 1, 127, 255, 256, 257, 298, 299]
+        pick = np.concatenate([np.arange(p_ * n, (p_ + 1) * n) for p_ in sample])
+        fa = cx.fwd(a[pick])
+        da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+        for lazy, bcast, acc in ((False, False, False), (True, False, True), (False, True, True), (True, True, False), (False, False, True)):
+            b = oracle.fill_uniform((1 if bcast else batch) * n, q, 7100 + m)
+            b[:4] = [q - 1, 0, q // 2, 1]
+            bw = b + (rng.integers(0, 4, b.size).astype(np.uint64) * np.uint64(q) if lazy else np.uint64(0))
+            c0 = oracle.fill_uniform(batch * n, q, 7200 + m)
+            exp = oracle.pointwise(fa, np.tile(b, len(sample)) if bcast else b[pick], q)
+            if acc:
+                exp = (exp + c0[pick]) % np.uint64(q)
+            flags = (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0) | (lib.MUL_ACCUMULATE if acc else 0)
+            for chunk in ((256, 1) if m > 14 else (256,)):
+                plan.set_option(lib.OPT_CHUNK_MIB, chunk)
+                da.upload(a), db.upload(bw), dc.upload(c0)
+                plan.fwd_mul(dc.ptr, da.ptr, db.ptr, batch, flags)
+                assert np.array_equal(dc.download()[pick], exp), (batch, lazy, bcast, acc, chunk)
+                if m <= 14:
+                    assert np.array_equal(da.download(), a)                         # a is only read up to 2^14
+            assert np.array_equal(db.download(bw.size), bw)                          # b^ is only read
+            if not acc:
+                da.upload(a)
+                plan.fwd_mul(da.ptr, da.ptr, db.ptr, batch, flags)                  # c aliases a
+                assert np.array_equal(da.download()[pick], exp), (batch, lazy, bcast, "alias a")
+            if not bcast:
+                da.upload(a), db.upload(bw)
+                plan.fwd_mul(db.ptr, da.ptr, db.ptr, batch, flags & ~lib.MUL_ACCUMULATE)   # c aliases b^
+                want = oracle.pointwise(fa, b[pick], q)
+                assert np.array_equal(db.download()[pick], want), (batch, lazy, "alias b^")
+        for x in (da, db, dc):
+            x.free()
+    plan.destroy()
+
+
+def test_key_switching_inner_product_digit_by_digit(lib, oracle):
+    """the shape an FHE caller issues: acc^ = sum_i fwd(digit_i) (.) key_i^ over the limbs of an RNS set with a broadcast key
+    ([limb][N]), digit by digit with NTT_MUL_ACCUMULATE, then ONE inverse -- against the oracle; also on plans without the fused
+    kernels (column-only engine, radix-4 formulation)"""
+    n, nl, batch, k = 1 << 13, 3, 5, 3
+    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    slab = batch * n
+    digits = [np.concatenate([oracle.fill_uniform(slab, q, 7300 + 10 * i + l) for l, q in enumerate(qs)]) for i in range(k)]
+    keys = [np.concatenate([oracle.fill_uniform(n, q, 7400 + 10 * i + l) for l, q in enumerate(qs)]) for i in range(k)]   # [limb][N], NTT domain
+    dacc = lib.DeviceBuffer(nl * slab)
+    dd, dk = lib.DeviceBuffer(nl * slab), lib.DeviceBuffer(nl * n)
+    for i in range(k):
+        dd.upload(digits[i]), dk.upload(keys[i])
+        lib.rns_fwd_mul(plans, dacc.ptr, dd.ptr, dk.ptr, batch, lib.MUL_B_BROADCAST | (lib.MUL_ACCUMULATE if i else 0))
+    got_hat = dacc.download()
+    lib.rns_inv(plans, dacc.ptr, batch)
+    got = dacc.download()
+    for l, (q, w) in enumerate(zip(qs, ws)):
+        cx = oracle.ctx(n, q, w)
+        sl, kl = slice(l * slab, (l + 1) * slab), slice(l * n, (l + 1) * n)
+        exp_hat = oracle.dot([cx.fwd(d[sl]) for d in digits], [kk[kl] for kk in keys], q, n, True)
+        assert np.array_equal(got_hat[sl], exp_hat), l
+        assert np.array_equal(got[sl], cx.inv(exp_hat)), l
+    for p in plans:
+        p.destroy()
+    # plans the kernel is not built for
+    q, w = qs[0], ws[0]
+    cx = oracle.ctx(n, q, w)
+    a, b, c0 = digits[0][:slab], keys[0][:n], oracle.fill_uniform(slab, q, 7500)
+    exp = (oracle.pointwise(cx.fwd(a), np.tile(b, batch), q) + c0) % np.uint64(q)
+    for kind in ("generic", "r4"):
+        plan = lib.Plan(n, q, w, arith=lib.ARITH_U64_R4 if kind == "r4" else lib.ARITH_AUTO)
+        if kind == "generic":
+            plan.set_generic(True)
+        dd.upload(a), dk.upload(b), dacc.upload(c0)
+        plan.fwd_mul(dacc.ptr, dd.ptr, dk.ptr, batch, lib.MUL_B_BROADCAST | lib.MUL_ACCUMULATE)
+        assert np.array_equal(dacc.download(slab), exp), kind
+        plan.destroy()
+    for x in (dacc, dd, dk):
+        x.free()

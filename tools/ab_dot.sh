@@ -6,6 +6,6 @@ cd $GRAFT_REPO_ROOT
 for r in 1 2 3; do
   for l in "$@"; do
     if [ $l = tree ]; then unset NTT_LIB; else export NTT_LIB=build/libntt_$l.so; fi
-    echo "== $l round $r"; python3 tools/domain_bench.py $args | grep -v "^logn\|fwd(a)"
+    echo "== $l round $r"; python3 tools/domain_bench.py $args | grep -v "^logn\|fwd(a),"
   done
 done

@@ -70,6 +70,19 @@ for bits in a.bits:
         ms0 = timed(unfused, max(2, a.steps // 2))
         print("%-5d %-5d %-3s %-9s %8d %10.3f %10.3f %8.2f %14.3f %7.3f"
               % (ln, bits, "-", "fwd(a),b^", batch, ms, ms0, ms0 / ms, batch / ms / 1e3, 24 * n * batch / ms / 1e6 / 8000))
+        # c^ = fwd(a) (.) b^ and c^ += fwd(a) (.) b^ (result in the NTT domain): one launch against forward + pointwise
+        for bcast, acc in ((False, False), (True, False), (False, True), (True, True)):
+            flags = (lib.MUL_B_BROADCAST if bcast else 0) | (lib.MUL_ACCUMULATE if acc else 0)
+            run = lambda: plan.fwd_mul(c.ptr, abufs[0].ptr, bbufs[0].ptr, batch, flags)
+            os.environ.pop("NTT_DOT_UNFUSED", None)
+            ms = timed(run, a.steps)
+            os.environ["NTT_DOT_UNFUSED"] = "1"              # forward transform, then a pointwise (accumulate) launch
+            ms0 = timed(run, max(2, a.steps // 2))
+            os.environ.pop("NTT_DOT_UNFUSED", None)
+            byts = (16 + (0 if bcast else 8) + (8 if acc else 0)) * n * batch
+            print("%-5d %-5d %-3s %-9s %8d %10.3f %10.3f %8.2f %14.3f %7.3f"
+                  % (ln, bits, "mac" if acc else "mul", "fwd(a)" + (".key" if bcast else ".b^"), batch, ms, ms0, ms0 / ms, batch / ms / 1e3,
+                     byts / ms / 1e6 / 8000))
         for x in abufs + bbufs + [c]:
             x.free()
         plan.destroy()
