@@ -182,6 +182,26 @@ while time.time() < t_end:
         for d in [dco, dbw] + ([dst] if alias == 0 else []):
             d.free()
         checks += 1
+        # c^ = fwd(a) (.) b^ (+ c^): the result stays in the NTT domain; lazy / broadcast b^, accumulator, aliasing
+        lz_in, bc, ac = bool(rng.random() < 0.4), bool(rng.random() < 0.4), bool(rng.random() < 0.5)
+        bh = orc.fill_uniform((1 if bc else batch) * n, q, int(rng.integers(1, 1 << 40)))
+        bwv = bh + (np.uint64(q) * rng.integers(0, 4, size=bh.shape, dtype=np.uint64) if lz_in else np.uint64(0))
+        c0 = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
+        expf = orc.pointwise(want, np.tile(bh, batch) if bc else bh, q)
+        if ac:
+            expf = (expf + c0) % np.uint64(q)
+        dco, dbw, dcc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(bwv.size).upload(bwv), lib.DeviceBuffer(a.size).upload(c0)
+        alias = 0 if ac else int(rng.integers(0, 3))
+        if alias == 2 and bc:
+            alias = 0
+        dst = dcc if alias == 0 else (dco if alias == 1 else dbw)
+        plan.fwd_mul(dst.ptr, dco.ptr, dbw.ptr, batch, (lib.MUL_LAZY_IN if lz_in else 0) | (lib.MUL_B_BROADCAST if bc else 0) |
+                     (lib.MUL_ACCUMULATE if ac else 0))
+        if not np.array_equal(dst.download(batch * n), expf):
+            fail("fwd_mul", lazy=lz_in, bcast=bc, acc=ac, alias=alias, **ctxt)
+        for d in (dco, dbw, dcc):
+            d.free()
+        checks += 1
     plan.destroy()
     # reference-signature entry points on the caller's own tables (one polynomial, host pointers): bit-exact lazy values
     if rng.random() < 0.15 and m >= 2 and q < (1 << 60):
