@@ -1760,7 +1760,7 @@ template <class A> struct KDot {
  * per-polynomial one (profiles/r04/domain_bench_first.txt).  The hint is an instruction bit, and a run-time branch between
  * two sets of loads makes the register allocator keep both sets apart (77 spilled VGPRs): one policy for both forms. */
 constexpr int kDotAuxB = 0;
-/* tuning knobs of the persistent loop (A/B builds: tools/build_dot_variant.sh) */
+/* tuning knobs of the persistent loop (A/B builds: tools/build_tu_variant.sh) */
 #ifndef NTT_DOT_AUX_A
 #  define NTT_DOT_AUX_A 0 /* cache policy of the a operand's loads: plain, like b's (measured +3 % over nt at k = 1, +10 % with a broadcast key at k = 8: profiles/r04/ab_dot.txt) */
 #endif
@@ -1952,6 +1952,9 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
  * the last group, the second one while the first half's products run -- and the accumulator words right where each half is
  * finished.
  */
+#ifndef NTT_MUL_B0_EARLY
+#  define NTT_MUL_B0_EARLY 0 /* tuning (A/B builds): 1 = the first quarter of b^ is requested in front of the last group */
+#endif
 template <class A> struct KMul {
   KArgs<A>        k;             /* k.a = a (coefficients, limb 0); nblocks / s0 / logn as for a forward block pass */
   const uint64_t *b;             /* b^ (limb 0) */
@@ -2068,6 +2071,13 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
           sched_fence();
         }
         exchange<A, LOGN, GI, GI + 1>(x, tl, ll);
+#if NTT_MUL_B0_EARLY
+        if constexpr(GI + 1 == GL) {
+          sched_fence();
+          prefetch_last_range<LOGN, 0, 4>(rb, tl, bblk); /* the first quarter of b^ lands during the last group */
+          sched_fence();
+        }
+#endif
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
@@ -2082,7 +2092,9 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       uint32_t t2 = tt; /* (a fresh opaque copy: the lane offsets of this phase are computed here, not carried through the groups) */
       asm volatile("" : "+v"(t2));
       sched_fence();
+#if !NTT_MUL_B0_EARLY
       prefetch_last_range<LOGN, 0, 4>(rb, t2, bblk);
+#endif
       static_for<0, 4>([&](auto qq) {
         constexpr int Q = decltype(qq)::value;
         sched_fence();

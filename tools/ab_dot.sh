@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_dot.sh "<domain_bench.py args>" lib1 lib2 ... : same-box A/B of dot_inv_kernel builds (tools/build_dot_variant.sh),
+# tools/ab_dot.sh "<domain_bench.py args>" lib1 lib2 ... : same-box A/B of dot_inv_kernel builds (tools/build_tu_variant.sh),
 # three alternating rounds; "tree" = the working tree's library
 args=$1; shift
 cd $GRAFT_REPO_ROOT
