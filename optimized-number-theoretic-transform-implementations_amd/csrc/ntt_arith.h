@@ -328,6 +328,18 @@ struct ArithF64 {
     const double d = fma_(-k, c.q, h);
     return d + l;
   }
+  /* the same with the quotient estimated through the two-word reciprocal: k = rint(fma(h, qinv, h * qinv_lo)).  One
+   * instruction more than mulmod_c; the estimate then carries only the rounding of h and one final rounding -- within
+   * 2^-52 relative of y*w/q, as good as a stored quotient (mulmod), so the bounds of a FULL record apply.  Used where the
+   * 1.5x looser estimate of mulmod_c would force an extra reduction (WideF64's forward butterflies). */
+  static NTT_HD double mulmod_c2(ctw w, double y, const consts &c)
+  {
+    const double h = y * w;
+    const double k = rint_(fma_(h, c.qinv, h * c.qinv_lo));
+    const double l = fma_(y, w, -h);
+    const double d = fma_(-k, c.q, h);
+    return d + l;
+  }
   /* strict API: raw in [0,q).  WIDE (reference-signature shims): raw may be
    * anywhere in [0,8q) -- folded with integer conditional subtracts first. */
   template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
@@ -520,13 +532,15 @@ struct ArithF64 {
  * reach 2q.  The pass-through operand x of every butterfly is reduced to |.| <= q/2 (three exact instructions); the
  * MULTIPLIED operand y is reduced where a compile-time schedule says so (forward; round 4) or always (inverse):
  *   forward  x~ = red(x), m = y * w mod q with y reduced or not.  With |y| <= B q and theta2 = q / 2^53 < 1/2:
- *            full record (stored w/q):   |m| <= (1/2 +     B theta2) q,  |h - k q| <= (1/2 + 1.5 B theta2) q
- *            compact twiddle (mulmod_c): |m| <= (1/2 + 1.5 B theta2) q,  |h - k q| <= (1/2 + 2   B theta2) q
+ *            full record (stored w/q), or a compact twiddle with the two-word reciprocal (mulmod_c2):
+ *                                        |m| <= (1/2 +     B theta2) q,  |h - k q| <= (1/2 + 1.5 B theta2) q
+ *            (a compact twiddle with mulmod_c's one-word estimate: 1/2 + 1.5 B theta2 and 1/2 + 2 B theta2 -- it would have to
+ *            reduce y in EVERY stage, which is why this policy pays one instruction more per compact product instead)
  *            (|l| = |h - y w| <= ulp(h)/2 <= B theta2 q / 2), outputs |x~ +- m| <= (1/2 + eps) q + |m|.  Everything must stay
  *            below 2^53 = q / theta2, i.e. below 2 q in the worst case: f64w_fwd_schedule (below) follows B stage by stage
- *            and reduces y only where one of the three bounds would pass 2 (1 - 2^-6): with full records one stage in
- *            five (B: 1 -> 1.5 -> 1.75 -> 1.875 -> 1.94 -> reduce), with compact twiddles every stage.  At N = 2^14 that is
- *            7 of 14 stages: 12.5 instead of 14 instructions per butterfly on average.
+ *            and reduces y only where one of the three bounds would pass 2 (1 - 2^-6): one stage in five
+ *            (B: 1 -> 1.5 -> 1.75 -> 1.875 -> 1.94 -> reduce).  At N = 2^14: stages 4 and 9 of 14 -- 11.9 instead of 14 instructions
+ *            per butterfly on average (11 with a full record, 12 with a compact twiddle, +3 where y is reduced).
  *   inverse  s = x + y, d = x - y of values bounded by 1.38 q each (canonical inputs: < 2q): exact below 2^53 because
  *            the pairs a stage combines are either both reduced sums (<= q/2) or both products (<= 0.88 q) or both
  *            canonical inputs; s~ = red(s), y' = red(d) * w mod q.  (An unreduced d would leave products up to 1.25 q, and the
@@ -550,10 +564,12 @@ template <class Base> struct WideF64 : Base {
     x               = xr + m;
     y               = xr - m;
   }
+  /* compact twiddle: the quotient through the two-word reciprocal (mulmod_c2: +1 instruction), so that the stage obeys a full
+   * record's bounds and the schedule need not reduce y in every compact stage (-3 instructions in four stages of five) */
   template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, ctw w, const consts &c)
   {
     const double xr = Base::reduce(x, c);
-    const double m  = Base::mulmod_c(w, RED ? Base::reduce(y, c) : y, c);
+    const double m  = Base::mulmod_c2(w, RED ? Base::reduce(y, c) : y, c);
     x               = xr + m;
     y               = xr - m;
   }

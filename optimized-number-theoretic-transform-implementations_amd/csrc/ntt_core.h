@@ -1074,7 +1074,7 @@ template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uin
       /* moduli up to 2^52: forward = which stages also reduce the multiplied operand (ntt_arith.h f64w_fwd_schedule); the
        * inverse butterflies of that policy reduce everything and ignore the mask */
       if constexpr(INV) return 0;
-      else return f64w_fwd_schedule(LOGN, 1.0, fused_cmask<A, LOGN>()).mask;
+      else return f64w_fwd_schedule(LOGN, 1.0, 0u).mask; /* (compact stages use mulmod_c2: a full record's bounds) */
     }
     if constexpr(INV) return kRedPlanFlag | (uint32_t)KSH; /* per-butterfly plan (bfly_reduces) */
     constexpr F64Sched sc = f64_schedule(false, LOGN, KSH, 1.0, fused_cmask<A, LOGN>(), LAZY ? kLazyBound : 1e30);

@@ -68,6 +68,18 @@ struct ArithF64Chk : ArithF64 {
     if(rb > g_chk_maxr) g_chk_maxr = rb;
     return r;
   }
+  static double mulmod_c2(ctw w, double y, const consts &c)
+  {
+    const double   r  = ArithF64::mulmod_c2(w, y, c);
+    const __int128 ex = as_int(y) * as_int(w);
+    if((ex - as_int(r)) % (__int128)c.qi != 0) g_chk_fail++;       /* r == y*w (mod q), exactly */
+    /* the estimate is as good as a stored quotient: |r| <= (1/2 + |y|/q * theta2 (1 + slack)) q */
+    const double by = __builtin_fabs(y) / c.q, th2 = c.q / 9007199254740992.0;
+    if(__builtin_fabs(r) > (0.5 + by * th2 * 1.01 + 0.001) * c.q) g_chk_fail++;
+    const double rb = __builtin_fabs(r) / c.q;
+    if(rb > g_chk_maxr) g_chk_maxr = rb;
+    return r;
+  }
   static double reduce(double v, const consts &c)
   {
     const double   r = ArithF64::reduce(v, c);
