@@ -767,7 +767,10 @@ def main():
                 # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
                 # above): the driver only runs this default command, so their numbers ride on its line
                 for cfg in (2, 3, 5):
-                    out["also_config%d" % cfg] = also_config(lib, cfg, steps=args.also_steps, check=check)
+                    try:
+                        out["also_config%d" % cfg] = also_config(lib, cfg, steps=args.also_steps, check=check)
+                    except Exception as e:      # a side block must never cost the headline line; a parity failure says so
+                        out["also_config%d" % cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, lib)
         print(json.dumps(out), flush=True)
