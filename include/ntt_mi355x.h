@@ -188,7 +188,9 @@ NTT_API int ntt_inv_dot_batch(const ntt_plan *p, uint64_t *d_c, int k, const uin
                               const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream);
 /* c = inv( fwd(a) (.) b^ ): a in coefficients, b^ transformed beforehand (a plaintext or key kept in the NTT domain).  One
  * launch that takes a through the forward stages, multiplies by b^ in registers and runs the inverse (24N bytes up to
- * 2^14).  d_a is left as it was up to N = 2^14 and OVERWRITTEN (scratch) above; d_c may alias d_a or d_bhat. */
+ * 2^14).  d_a is left as it was up to N = 2^14 and OVERWRITTEN (scratch) above -- and at every size by plans the fused kernels
+ * are not built for (integer and radix-4 policies, column-only plans: forward transform in place, pointwise, inverse): treat
+ * it as scratch unless you know the plan.  d_c may alias d_a or d_bhat. */
 NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
                                       unsigned flags, void *stream);
 /* c^ = fwd(a) (.) b^, or with NTT_MUL_ACCUMULATE c^ += fwd(a) (.) b^: a in coefficients, the result STAYS in the NTT domain
@@ -196,7 +198,8 @@ NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t
  * multiplied in where the forward transform would reduce and store its outputs -- the multiply-accumulate of a key-switching
  * inner product, digit by digit.  ONE launch up to N = 2^14: 24N bytes (16N with NTT_MUL_B_BROADCAST) instead of 40N for
  * ntt_fwd_batch + ntt_pointwise_mul_batch; accumulating 32N (24N) instead of 48N.  d_a is left as it was up to 2^14 and
- * OVERWRITTEN (scratch) above; d_c may alias d_a (not when accumulating) or d_bhat. */
+ * OVERWRITTEN (scratch) above -- and at every size by plans without the fused kernel (radix-4 policy, column-only plans, N <
+ * 2^6: forward transform in place, then a pointwise launch); d_c may alias d_a (not when accumulating) or d_bhat. */
 NTT_API int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
                               void *stream);
 
