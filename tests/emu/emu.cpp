@@ -556,6 +556,9 @@ int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t b
                     const typename A::ctw *tab8, const typename A::consts &c, bool lazy, bool bcast, bool acc)
 {
   if(m < kFusedMin) return -1;
+#ifdef EMU_SAN_BUILD
+  if(m > kFusedMax) return -1;
+#endif
   const int      pblk = m > kFusedMax ? multi_pass_block(m, false, A::kTracksBounds) : m;
   const PassList L    = make_passes(m, false, pblk);
   for(int j = 0; j + 1 < L.n; j++) {
@@ -579,7 +582,11 @@ int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t b
   switch(pblk) {
 #define CASE(LN) \
   case LN: emu_fwd_mul_blocks<A, LN, KSH>(p, bhat, out, lazy, bcast, acc); return 0;
+#ifdef EMU_SAN_BUILD
+    CASE(6) CASE(8) CASE(12)
+#else
     CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#endif
 #undef CASE
     default: return -1;
   }
@@ -603,6 +610,9 @@ int emu_dot_run(uint64_t *out, int k, const uint64_t *const *a, const uint64_t *
   p.s0      = (uint32_t)(m - pblk);
   p.lastinv = m <= kFusedMax;
   p.nblocks = batch << p.s0;
+#ifdef EMU_SAN_BUILD
+  if(m > kFusedMax) return -1;
+#endif
   if(m > kFusedMax) {
     if(pblk == kFusedSmallBlock) emu_dot_blocks<A, kFusedSmallBlock, KSH, false>(p, k, a, b, lazy, bcast);
     else emu_dot_blocks<A, kFusedLarge, KSH, false>(p, k, a, b, lazy, bcast);
@@ -622,7 +632,11 @@ int emu_dot_run(uint64_t *out, int k, const uint64_t *const *a, const uint64_t *
   switch(m) {
 #define CASE(LN) \
   case LN: emu_dot_blocks<A, LN, KSH, true>(p, k, a, b, lazy, bcast); return 0;
+#ifdef EMU_SAN_BUILD /* sanitizer build: three block sizes keep the instrumented compile short */
+    CASE(6) CASE(8) CASE(12)
+#else
     CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#endif
 #undef CASE
     default: return -1;
   }
@@ -990,7 +1004,7 @@ int emu_fused_product_chk(uint64_t *out, const uint64_t *ahat, const uint64_t *b
 }
 #endif
 
-#ifndef EMU_SAN_BUILD
+/* (sanitizer build: the integer policy and the checked class-0 policy at 2^6, 2^8, 2^12) */
 /* out = inv(sum_i a_i (.) b_i) for operands in the NTT domain, as dot_inv_kernel (+ the inverse's column passes above
  * 2^14) computes it.  a: k x [batch][N], b: k x [batch][N] (bcast: k x [N]).  arith 0: integer radix-2; 1: the CHECKED
  * FP64 policy of q's class (the reduce-both-operands policy above 2^51(1+2^-10)). */
@@ -1019,13 +1033,15 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
   for(size_t i = 0; i < wix.size(); i++) ti[i] = h_tw_f64(wix[i], q);
   for(size_t i = 0; i < wi.size(); i++) ti8[i] = h_tw_f64(wi[i], q).w;
   const auto c = h_consts_f64(q, N, wi);
+#ifndef EMU_SAN_BUILD
   if(wide) return emu_dot_run<WideChk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
   if(h_f64_ksh(q) >= 1) return emu_dot_run<ArithF64Chk, 1>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
+#else
+  if(wide) return -2;
+#endif
   return emu_dot_run<ArithF64Chk, 0>(out, k, pa.data(), pb.data(), batch, m, ti.data(), ti8.data(), c, lazy != 0, bcast != 0);
 }
-#endif
 
-#ifndef EMU_SAN_BUILD
 /* out = fwd(a) (.) b^ (+ out), the result in the NTT domain, as fwd_mul_kernel (+ the forward column passes above 2^14) computes
  * it.  a: [batch][N] coefficients (overwritten above 2^14), b: [batch][N] or (bcast) [N]; arith as emu_inv_dot. */
 int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root, int arith, int lazy,
@@ -1049,11 +1065,14 @@ int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, i
     tf8[i] = tf[i].w;
   }
   const auto c = h_consts_f64(q, N, dummy);
+#ifndef EMU_SAN_BUILD
   if(wide) return emu_fwd_mul_run<WideChk, 0>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
   if(h_f64_ksh(q) >= 1) return emu_fwd_mul_run<ArithF64Chk, 1>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
+#else
+  if(wide) return -2;
+#endif
   return emu_fwd_mul_run<ArithF64Chk, 0>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
 }
-#endif
 
 /* the queue-entry decode of the XCD-local kernels (ntt_core.h team_decode): out = {stop, valid, pass, item, v} */
 void emu_team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t *out)

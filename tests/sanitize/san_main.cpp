@@ -24,6 +24,10 @@ int  emu_pointwise(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n
 int  emu_pointwise_lazy(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t q, int arith);
 void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q);
 int  emu_plan_info(int logn, uint64_t *info);
+int  emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root, int arith,
+                 int lazy, int bcast);
+int  emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, int m, uint64_t q, uint64_t root, int arith, int lazy,
+                 int bcast, int acc);
 }
 
 static int g_fail = 0;
@@ -101,6 +105,42 @@ int main()
       }
       CHECK(emu_pointwise_lazy(c2.data(), al.data(), bl.data(), n, q, arith) == 0);
       CHECK(c2 == c);
+    }
+    /* products of operands in the NTT domain (dot_inv_kernel, fwd_mul_kernel as the emulator runs them): the operand
+     * layouts, the broadcast index and the lazy folds under the sanitizers, against the oracle (block sizes 2^6, 2^8, 2^12) */
+    if(cs.m == 6 || cs.m == 8 || cs.m == 12) {
+      for(int arith : {0, 1}) {
+        if(arith == 1 && q > ((1ull << 51) + (1ull << 41))) continue;
+        for(int bcast = 0; bcast < 2; bcast++) {
+          const int             k = 3;
+          std::vector<uint64_t> da((size_t)k * batch * n), db((size_t)k * (bcast ? n : batch * n)), sum(batch * n, 0), t(batch * n);
+          orc_fill_uniform(da.data(), da.size(), q, 0xd07, cs.m);
+          orc_fill_uniform(db.data(), db.size(), q, 0xd08, cs.m);
+          for(int i = 0; i < k; i++) {
+            for(uint64_t pb = 0; pb < batch; pb++) {
+              orc_pointwise(t.data() + pb * n, da.data() + (size_t)i * batch * n + pb * n,
+                            db.data() + (size_t)i * (bcast ? n : batch * n) + (bcast ? 0 : pb * n), n, q);
+            }
+            for(uint64_t j = 0; j < batch * n; j++) sum[j] = (sum[j] + t[j]) % q;
+          }
+          std::vector<uint64_t> want(sum), lz_a(da), lz_b(db);
+          orc_inv_r2_batch(want.data(), batch, cx);
+          for(size_t j = 0; j < lz_a.size(); j++) lz_a[j] += (j % 4) * q;   /* lazy words: anywhere in [0,4q) */
+          for(size_t j = 0; j < lz_b.size(); j++) lz_b[j] += ((j / 3) % 4) * q;
+          CHECK(emu_inv_dot(got.data(), k, da.data(), db.data(), batch, cs.m, q, w, arith, 0, bcast) == 0);
+          CHECK(got == want);
+          CHECK(emu_inv_dot(got.data(), k, lz_a.data(), lz_b.data(), batch, cs.m, q, w, arith, 1, bcast) == 0);
+          CHECK(got == want);
+          /* c^ = fwd(a) (.) b^ + c^ */
+          std::vector<uint64_t> ac(a), acc0(batch * n), exp(batch * n);
+          orc_fill_uniform(acc0.data(), acc0.size(), q, 0xacc, cs.m);
+          for(uint64_t pb = 0; pb < batch; pb++) orc_pointwise(exp.data() + pb * n, ref.data() + pb * n, db.data() + (bcast ? 0 : pb * n), n, q);
+          for(uint64_t j = 0; j < batch * n; j++) exp[j] = (exp[j] + acc0[j]) % q;
+          got = acc0;
+          CHECK(emu_fwd_mul(got.data(), ac.data(), lz_b.data(), batch, cs.m, q, w, arith, 1, bcast, 1) == 0);
+          CHECK(got == exp);
+        }
+      }
     }
     /* the CPU timing harness of bench.py's cpu_baseline leg (oracle/cpu_bench.inc): a few milliseconds of each unit of
      * work on two threads, and the single-thread method, under the sanitizers */
