@@ -5,11 +5,14 @@
  * src/ntt_radix4x4.c:41-114 (same expanded tables as ntt_radix4.h).  On the GPU
  * the "two radix-4 levels per block" idea is the native shape of every kernel:
  * each thread keeps a 16-coefficient tile in registers for four stages
- * (csrc/ntt_core.h), so this symbol shares the radix-4 engine of ntt_radix4.h:
- * its lazy output is the one of fwd_ntt_radix4_lazy -- in [0,8q) and congruent to
- * the reference's radix-4x4 output (which pairs the stages differently when
- * log2 N is not a multiple of 4, src/ntt_radix4x4.c:81-113, and may then return
- * other representatives); identical after the header-inline reduction below.
+ * (csrc/ntt_core.h), so this symbol shares the radix-4 engine of ntt_radix4.h
+ * wherever the reference's radix-16 blocking is only another ORDER of the same
+ * butterflies (log2 N = 4k, 4k+1, 4k+2: identical lazy words).  When log2 N =
+ * 4k+3 the reference pairs the stages differently (src/ntt_radix4x4.c:91-111:
+ * radix-2 stage BEFORE the last radix-4 layer, including its reduction of
+ * a[group counter]); those sizes run layer by layer (csrc/ntt_core.h
+ * r4x4_layer_*), so the lazy output equals the reference's bit for bit at every
+ * size from 2^6 (tests/golden/lazy_words.json holds the reference's digests).
  */
 #ifndef NTT_MI355X_NTT_RADIX4X4_H
 #define NTT_MI355X_NTT_RADIX4X4_H

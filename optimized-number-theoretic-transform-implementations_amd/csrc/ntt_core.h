@@ -1248,4 +1248,47 @@ template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* fwd_ntt_radix4x4_lazy when log2 N = 4k+3, one layer at a time          */
+/* ------------------------------------------------------------------ */
+/*
+ * The reference's radix-16 formulation (src/ntt_radix4x4.c:41-114) runs the butterflies of fwd_ntt_radix4_lazy in
+ * another order -- no value changes -- EXCEPT for its remainder when log2 N = 4k+3 (:91-111): 2k radix-4 layers,
+ * then a radix-2 stage on distance-4 pairs, then the last radix-4 layer, where ntt_radix4.c runs 2k+1 radix-4 layers
+ * and ends on the radix-2 stage.  Same residues, other lazy words.  The reference-signature entry point serves those
+ * sizes (2^7, 2^11, 2^15: one polynomial per call, a drop-in path whose job is identical words, not throughput) with one
+ * launch per layer over global memory; `id` is the butterfly's index within the layer.  Host/device so that the CPU
+ * emulator (tests/emu) runs the very same functions.
+ */
+/* layer of `blocks` groups of 4*span coefficients, pack blocks + b (collect_roots, src/ntt_radix4x4.c:7-25; e = records
+ * {e[k], e_con[k]} of the caller's expanded table) */
+NTT_HD void r4x4_layer_r4(uint64_t *a, const TwU64 *e, uint64_t blocks, uint64_t span, uint64_t id, const ArithU64::consts &c)
+{
+  const uint64_t   b = id / span, i = id - b * span, k = blocks + b;
+  ArithU64R4::pack w;
+  w.w1        = e[2 * k];
+  w.w2        = e[4 * k];
+  w.w12       = e[4 * k + 1];
+  w.w3        = e[4 * k + 2];
+  w.nw13      = e[4 * k + 3];
+  uint64_t *x = a + 4 * span * b + i;
+  ArithU64R4::r4_fwd(x[0], x[span], x[2 * span], x[3 * span], w, c);
+}
+/* the radix-2 stage in front of the last radix-4 layer (:93-104): N/8 groups of 8, pairs (j, j+4), twiddle e[2(N/8+g)].
+ * The reference's loop applies reduce_8q_to_4q to a[i] for its GROUP counter i: coefficient 0 before its butterfly,
+ * coefficients 1 .. N/8-1 after theirs (each belongs to an earlier group i/8 < i) -- reproduced, or the words entering
+ * the last layer's Shoup products would differ */
+NTT_HD void r4x4_layer_r2(uint64_t *a, const TwU64 *e, uint64_t N, uint64_t id, const ArithU64::consts &c)
+{
+  const uint64_t groups = N >> 3, g = id >> 2, j = 8 * g + (id & 3);
+  const uint64_t q4     = 2 * c.q2;
+  uint64_t       x = a[j], y = a[j + 4];
+  if(j == 0) x = ArithU64::csub(x, q4);
+  ArithU64::fwd_bfly<false>(x, y, e[2 * (groups + g)], c); /* harvey_fwd_butterfly, fast_mul_operators.h:72-81 */
+  if(j >= 1 && j < groups) x = ArithU64::csub(x, q4);
+  if(j + 4 < groups) y = ArithU64::csub(y, q4);
+  a[j]     = x;
+  a[j + 4] = y;
+}
+
 } /* namespace ntt */

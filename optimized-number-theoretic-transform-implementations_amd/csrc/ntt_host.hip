@@ -2048,10 +2048,36 @@ int compat_arith(uint64_t q, uint64_t N, CompatKind kind, bool inverse)
   return NTT_ARITH_U64;
 }
 
+/* fwd_ntt_radix4x4_lazy at log2 N = 4k+3 (ntt_core.h, r4x4_layer_*; src/ntt_radix4x4.c:53-111): 2k radix-4 layers, the
+ * radix-2 stage on distance-4 pairs, the last radix-4 layer -- one launch each on the entry's stream */
+__global__ void __launch_bounds__(256) r4x4_r4_layer_kernel(uint64_t *a, const TwU64 *e, uint64_t blocks, uint64_t span, ArithU64::consts c)
+{
+  const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if(id < blocks * span) r4x4_layer_r4(a, e, blocks, span, id, c);
+}
+__global__ void __launch_bounds__(256) r4x4_r2_layer_kernel(uint64_t *a, const TwU64 *e, uint64_t N, ArithU64::consts c)
+{
+  const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if(id < N / 2) r4x4_layer_r2(a, e, N, id, c);
+}
+int run_r4x4_layers(const ntt_plan *p, uint64_t *d_a, hipStream_t st)
+{
+  const uint64_t N = p->N;
+  const TwU64 *  e = (const TwU64 *)p->d_fwd;
+  uint64_t       blocks = 1, span = N / 4;
+  for(; blocks < (N >> 3); blocks *= 4, span /= 4) {
+    hipLaunchKernelGGL(r4x4_r4_layer_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, st, d_a, e, blocks, span, p->cu);
+  }
+  hipLaunchKernelGGL(r4x4_r2_layer_kernel, dim3((unsigned)((N / 2 + 255) / 256)), dim3(256), 0, st, d_a, e, N, p->cu);
+  hipLaunchKernelGGL(r4x4_r4_layer_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, st, d_a, e, N / 4, (uint64_t)1, p->cu);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
 /* w, w_con: caller tables.  kind R2: N-entry radix-2 tables.  kind R4: 2N-entry expanded tables
  * (pre_compute.h:85-105), whose even slots are the radix-2 entries. */
 void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t q, const uint64_t *w,
-                const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv)
+                const uint64_t *w_con, CompatKind kind, bool inverse, uint64_t ninv, bool r4x4 = false)
 {
   if(!is_pow2(N) || N < 2 || !a1 || !w) { /* (the table's slot 1 is read below: checked before anything is touched) */
     g_err = "N must be a power of two >= 2 and the pointers non-null";
@@ -2155,7 +2181,9 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     die(fn);
   }
   /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
-  if(run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
+  /* (the radix-4x4 formulation has lazy words of its own only when log2 N = 4k+3: see run_r4x4_layers) */
+  const bool layered = r4x4 && !inverse && arith == NTT_ARITH_U64_R4 && (h_log2(N) & 3) == 3;
+  if(layered ? run_r4x4_layers(ent->plan, stage, st) : run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
   ok = hipMemcpyAsync(a1, stage, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
   if(ok && a2) ok = hipMemcpyAsync(a2, stage + N, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
   if(ok) ok = hipStreamSynchronize(st) == hipSuccess;
@@ -2215,13 +2243,13 @@ void inv_ntt_radix4(uint64_t a[], uint64_t N, uint64_t q, mul_op_t n_inv, const 
   compat_run("inv_ntt_radix4", a, nullptr, N, q, w, w_con, kCompatR4, true, (uint64_t)n_inv.op);
 }
 
-/* the radix-16 blocking of the reference (src/ntt_radix4x4.c:41-114) is a cache-friendlier order of radix-4
- * butterflies (with its own remainder handling when log2 N is not a multiple of 4); on the device the
- * register-resident stage groups play that role: this symbol returns fwd_ntt_radix4_lazy's values -- same range,
- * same residues */
+/* the radix-16 blocking of the reference (src/ntt_radix4x4.c:41-114) is a cache-friendlier order of fwd_ntt_radix4_lazy's
+ * butterflies -- on the device the register-resident stage groups play that role, and the values are the same -- except
+ * for its remainder handling when log2 N = 4k+3, which leaves other lazy words: those sizes run layer by layer
+ * (run_r4x4_layers), so that this symbol too returns the reference's words bit for bit at every size from 2^6 */
 void fwd_ntt_radix4x4_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])
 {
-  compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, w_con, kCompatR4, false, 0);
+  compat_run("fwd_ntt_radix4x4_lazy", a, nullptr, N, q, w, w_con, kCompatR4, false, 0, true);
 }
 
 void fwd_ntt_seal_lazy(uint64_t a[], uint64_t N, uint64_t q, const uint64_t w[], const uint64_t w_con[])

@@ -10,8 +10,10 @@ reference's own C sources compiled in place).  It
   2. checks that every reference variant agrees (radix-4, radix-4x4, seal, dbl, inverses);
   3. checks the oracle restatement bit-for-bit against the reference on those inputs,
      on full-range splitmix inputs, on edge inputs and on every table;
-  4. writes tests/golden/kat.json (parameters, digests, heads) and
-     tests/golden/case0_vectors.json (complete N=256 input/output vectors).
+  4. writes tests/golden/kat.json (parameters, digests, heads),
+     tests/golden/case0_vectors.json (complete N=256 input/output vectors) and
+     tests/golden/lazy_words.json (digests of the three *_lazy formulations' UNREDUCED outputs on
+     the uniform input of every case: what the reference returns before its header-inline reduction).
 
 The fixtures are data (inputs / expected outputs); no reference text is stored.
 """
@@ -54,7 +56,7 @@ def load():
     orc.orc_ctx_new.restype = C.c_void_p
     orc.orc_ctx_new.argtypes = [C.c_uint64] * 3
     orc.orc_ctx_free.argtypes = [C.c_void_p]
-    for f in ("orc_fwd_r2", "orc_fwd_r4", "orc_fwd_r2_lazy", "orc_fwd_r4_lazy"):
+    for f in ("orc_fwd_r2", "orc_fwd_r4", "orc_fwd_r2_lazy", "orc_fwd_r4_lazy", "orc_fwd_r4x4_lazy"):
         getattr(orc, f).argtypes = [U64P, C.c_uint64, C.c_uint64, U64P, U64P]
     orc.orc_inv_r2.argtypes = [U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                C.c_uint, U64P, U64P]
@@ -84,6 +86,9 @@ def main():
                         "fnv = FNV-1a-64 over little-endian bytes",
            "uniform_seed": UNI_SEED, "cases": []}
     vectors = {}
+    lazy = {"procedure": "uniform input of kat.json (orc_fill_uniform, uniform_seed, stream case << 32); digest = FNV-1a-64 of the "
+                         "words fwd_ntt_ref_harvey_lazy / fwd_ntt_radix4_lazy / fwd_ntt_radix4x4_lazy of the compiled reference "
+                         "leave in the buffer (expanded tables for the radix-4 forms)", "cases": []}
     for i in range(ncases):
         p = (C.c_uint64 * 5)()
         ref.ref_case_params(i, C.cast(p, U64P))
@@ -135,14 +140,21 @@ def main():
             orc.orc_inv_r4(ptr(t), n, q, cx.ninv, cx.ninv_con, cx.einv, cx.einv_con)
             assert np.array_equal(t, inp % np.uint64(q)), (i, "orc inv r4")
             # lazy outputs: reference and oracle must agree exactly too (same algorithm)
+            digests = {}
             for variant, fn, tb, tc in ((0, orc.orc_fwd_r2_lazy, cx.w, cx.wcon),
-                                        (1, orc.orc_fwd_r4_lazy, cx.e, cx.econ)):
+                                        (1, orc.orc_fwd_r4_lazy, cx.e, cx.econ),
+                                        (2, orc.orc_fwd_r4x4_lazy, cx.e, cx.econ)):
                 r, o = inp.copy(), inp.copy()
                 ref.ref_fwd_lazy(i, variant, ptr(r))
                 fn(ptr(o), n, q, tb, tc)
                 assert np.array_equal(r, o), (i, "lazy", variant)
-                bound = 4 * q if (variant == 0 or m % 2 == 1) else 8 * q
-                assert int(r.max()) < bound
+                # radix-4 butterflies leave [0,8q); a trailing radix-2 stage (log2 N odd, but not the 4k+3 order of
+                # the radix-4x4 formulation, which ends on a radix-4 layer) leaves [0,4q)
+                ends_r2 = variant == 0 or (m % 2 == 1 and not (variant == 2 and m % 4 == 3))
+                assert int(r.max()) < (4 * q if ends_r2 else 8 * q)
+                assert np.array_equal(r % np.uint64(q), expect)
+                digests[("ref_harvey", "radix4", "radix4x4")[variant]] = fnv(orc, r)
+            return digests
 
         check_oracle(a, ref_out)
         # --- full-range uniform inputs (the reference never exercises these) ---
@@ -150,7 +162,9 @@ def main():
         orc.orc_fill_uniform(ptr(u), n, q, UNI_SEED, i << 32)
         u_out = u.copy()
         ref.ref_fwd(i, 0, ptr(u_out))
-        check_oracle(u, u_out)
+        lazy_fnv = check_oracle(u, u_out)
+        lazy["cases"].append({"case": i, "m": m, "q": q, "uni_in_fnv": fnv(orc, u), "lazy_out_fnv": lazy_fnv,
+                              "radix4x4_differs_from_radix4": lazy_fnv["radix4"] != lazy_fnv["radix4x4"]})
         t = u_out.copy()
         ref.ref_inv(i, 1, ptr(t))
         assert np.array_equal(t, u)
@@ -192,6 +206,8 @@ def main():
         json.dump(out, f, indent=1)
     with open(os.path.join(gd, "case0_vectors.json"), "w") as f:
         json.dump(vectors, f)
+    with open(os.path.join(gd, "lazy_words.json"), "w") as f:
+        json.dump(lazy, f, indent=1)
     print("wrote", gd)
 
 

@@ -238,6 +238,30 @@ static void r4_inv_bfly(uint64_t *x, uint64_t *y, uint64_t *z, uint64_t *t,
 
 static int log2_is_even(uint64_t N) { return (log2_exact(N) & 1) == 0; }
 
+/* one layer of radix-4 butterflies: `blocks` groups of 4*span coefficients, group b with pack blocks+b
+ * (src/ntt_radix4.c:36-47; the butterflies of a layer are independent of each other) */
+static void r4_fwd_layer(uint64_t *a, uint64_t q, const uint64_t *e, const uint64_t *econ, uint64_t blocks, uint64_t span)
+{
+  for(uint64_t b = 0; b < blocks; b++) {
+    const r4pack p    = r4_pack(e, econ, blocks + b);
+    uint64_t *   base = a + 4 * span * b;
+    for(uint64_t i = 0; i < span; i++) {
+      r4_fwd_bfly(base + i, base + i + span, base + i + 2 * span, base + i + 3 * span, &p, q);
+    }
+  }
+}
+
+/* trailing radix-2 stage on neighbours, twiddle e[N+i] (src/ntt_radix4.c:56-61, src/ntt_radix4x4.c:83-90) */
+static void r2_fwd_tail_layer(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e, const uint64_t *econ)
+{
+  for(uint64_t i = 0; i < N; i += 2) {
+    const uint64_t x = orc_csub(orc_csub(a[i], 4 * q), 2 * q);
+    const uint64_t t = orc_shoup_lazy(e[N + i], econ[N + i], a[i + 1], q);
+    a[i]             = x + t;
+    a[i + 1]         = x - t + 2 * q;
+  }
+}
+
 /* src/ntt_radix4.c:27-62 */
 void orc_fwd_r4_lazy(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e,
                      const uint64_t *econ)
@@ -245,24 +269,42 @@ void orc_fwd_r4_lazy(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e,
   const int      even  = log2_is_even(N);
   const uint64_t bound = even ? N : N / 2;
   uint64_t       span  = N / 4;
-  for(uint64_t blocks = 1; blocks < bound; blocks *= 4, span /= 4) {
-    for(uint64_t b = 0; b < blocks; b++) {
-      const r4pack p    = r4_pack(e, econ, blocks + b);
-      uint64_t *   base = a + 4 * span * b;
-      for(uint64_t i = 0; i < span; i++) {
-        r4_fwd_bfly(base + i, base + i + span, base + i + 2 * span,
-                    base + i + 3 * span, &p, q);
+  for(uint64_t blocks = 1; blocks < bound; blocks *= 4, span /= 4) r4_fwd_layer(a, q, e, econ, blocks, span);
+  if(!even) r2_fwd_tail_layer(a, N, q, e, econ);
+}
+
+/* src/ntt_radix4x4.c:41-114.  The radix-16 steps (:53-78) are pairs of radix-4 layers whose butterflies run in a
+ * cache-friendlier ORDER; values only depend on the layers, so they are restated layer by layer here.  What differs
+ * from fwd_ntt_radix4_lazy is the remainder when log2 N = 4k+3 (:91-111): 4k stages as radix-16 steps, THEN one
+ * radix-2 stage on distance-4 pairs, THEN the last radix-4 layer (ntt_radix4.c ends on the radix-2 stage), so the
+ * lazy words differ although the residues agree.  That radix-2 loop (:95-104) reduces a[i] for its GROUP counter i
+ * (not for the coefficients of group i): by the time group i runs, coefficient i >= 1 has already been through its
+ * butterfly (it belongs to group i/8 < i), coefficient 0 has not.  Restated as: coefficient 0 is brought below 4q
+ * before its butterfly, coefficients 1 .. N/8-1 after theirs -- the same words the sequential loop leaves. */
+void orc_fwd_r4x4_lazy(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e, const uint64_t *econ)
+{
+  const int      rem    = log2_exact(N) & 3; /* :27-39 */
+  uint64_t       blocks = 1, span = N / 4;
+  for(; blocks < (N >> rem); blocks *= 16, span /= 16) { /* :53 */
+    r4_fwd_layer(a, q, e, econ, blocks, span);           /* :66-69, roots m + j      */
+    r4_fwd_layer(a, q, e, econ, 4 * blocks, span / 4);   /* :71-74, roots 4m + 4j + x */
+  }
+  if(rem == 1) r2_fwd_tail_layer(a, N, q, e, econ); /* :83-90 */
+  if(rem == 3) {                                    /* :91-104 */
+    const uint64_t groups = N / 8;
+    a[0]                  = orc_csub(a[0], 4 * q);
+    for(uint64_t g = 0; g < groups; g++) {
+      const uint64_t w = e[2 * (groups + g)], wc = econ[2 * (groups + g)];
+      for(uint64_t j = 8 * g; j < 8 * g + 4; j++) {
+        const uint64_t x = orc_csub(a[j], 2 * q); /* harvey_fwd_butterfly, fast_mul_operators.h:72-81 */
+        const uint64_t t = orc_shoup_lazy(w, wc, a[j + 4], q);
+        a[j]             = x + t;
+        a[j + 4]         = x - t + 2 * q;
       }
     }
+    for(uint64_t i = 1; i < groups; i++) a[i] = orc_csub(a[i], 4 * q);
   }
-  if(even) return;
-  /* trailing radix-2 stage, twiddle e[N+i] (:56-61) */
-  for(uint64_t i = 0; i < N; i += 2) {
-    const uint64_t x = orc_csub(orc_csub(a[i], 4 * q), 2 * q);
-    const uint64_t t = orc_shoup_lazy(e[N + i], econ[N + i], a[i + 1], q);
-    a[i]             = x + t;
-    a[i + 1]         = x - t + 2 * q;
-  }
+  if(rem >= 2) r4_fwd_layer(a, q, e, econ, N / 4, 1); /* :105-111 */
 }
 
 /* include/ntt_radix4.h:16-28 */

@@ -59,6 +59,8 @@ void orc_inv_r2(uint64_t *a, uint64_t N, uint64_t q, uint64_t ninv,
 /* ---- radix-4 path (src/ntt_radix4.c:7-114, include/ntt_radix4.h) ---- */
 void orc_fwd_r4_lazy(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e,
                      const uint64_t *econ);                       /* out < 8q */
+/* fwd_ntt_radix4x4_lazy (src/ntt_radix4x4.c:41-114): same residues, its own lazy words when log2 N = 4k+3 */
+void orc_fwd_r4x4_lazy(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e, const uint64_t *econ);
 void orc_fwd_r4(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e,
                 const uint64_t *econ);
 void orc_inv_r4(uint64_t *a, uint64_t N, uint64_t q, uint64_t ninv,

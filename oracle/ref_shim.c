@@ -86,15 +86,17 @@ EXPORT void ref_fwd(int i, int variant, uint64_t *a)
   }
 }
 
-/* variant: 0 radix-2 ref lazy (<4q), 1 radix-4 lazy (<8q) */
+/* variant: 0 radix-2 ref lazy (<4q), 1 radix-4 lazy (<8q), 2 radix-4x4 lazy (<8q) */
 EXPORT void ref_fwd_lazy(int i, int variant, uint64_t *a)
 {
   ref_init();
   const test_case_t *t = &tests[i];
   if(variant == 0) {
     fwd_ntt_ref_harvey_lazy(a, t->n, t->q, t->w_powers.ptr, t->w_powers_con.ptr);
-  } else {
+  } else if(variant == 1) {
     fwd_ntt_radix4_lazy(a, t->n, t->q, t->w_powers_r4.ptr, t->w_powers_con_r4.ptr);
+  } else {
+    fwd_ntt_radix4x4_lazy(a, t->n, t->q, t->w_powers_r4.ptr, t->w_powers_con_r4.ptr);
   }
 }
 
@@ -148,6 +150,13 @@ EXPORT void ref_fwd_r4_generic(uint64_t *a, uint64_t N, uint64_t q, const uint64
                                const uint64_t *econ)
 {
   fwd_ntt_radix4(a, N, q, e, econ);
+}
+
+/* the unreduced words of fwd_ntt_radix4_lazy (variant 1) / fwd_ntt_radix4x4_lazy (variant 2) at any size */
+EXPORT void ref_fwd_r4_lazy_generic(int variant, uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e, const uint64_t *econ)
+{
+  if(variant == 2) fwd_ntt_radix4x4_lazy(a, N, q, e, econ);
+  else fwd_ntt_radix4_lazy(a, N, q, e, econ);
 }
 
 EXPORT void ref_fwd_r4_batch(uint64_t *a, uint64_t batch, uint64_t N, uint64_t q,

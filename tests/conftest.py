@@ -29,6 +29,12 @@ def kat():
 
 
 @pytest.fixture(scope="session")
+def lazy_words():
+    with open(os.path.join(ROOT, "tests", "golden", "lazy_words.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def case0_vectors():
     with open(os.path.join(ROOT, "tests", "golden", "case0_vectors.json")) as f:
         return json.load(f)

@@ -1085,6 +1085,23 @@ void emu_team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag, uint3
   out[4] = it.v;
 }
 
+/* fwd_ntt_radix4x4_lazy at log2 N = 4k+3 through the product's layer functions (ntt_core.h r4x4_layer_*), every butterfly
+ * index of a layer in REVERSE order (the layers' butterflies are independent: any order gives the device's result) */
+void emu_fwd_r4x4_layers(uint64_t *a, uint64_t N, uint64_t q, const uint64_t *e, const uint64_t *econ)
+{
+  std::vector<TwU64> rec(2 * N);
+  for(uint64_t k = 0; k < 2 * N; k++) rec[k] = TwU64{e[k], econ[k]};
+  ArithU64::consts c{};
+  c.q  = q;
+  c.q2 = 2 * q;
+  uint64_t blocks = 1, span = N / 4;
+  for(; blocks < (N >> 3); blocks *= 4, span /= 4) {
+    for(uint64_t id = N / 4; id-- > 0;) r4x4_layer_r4(a, rec.data(), blocks, span, id, c);
+  }
+  for(uint64_t id = N / 2; id-- > 0;) r4x4_layer_r2(a, rec.data(), N, id, c);
+  for(uint64_t id = N / 4; id-- > 0;) r4x4_layer_r4(a, rec.data(), N / 4, 1, id, c);
+}
+
 /* the product's host-side builder of the 2N-entry radix-4 table (ntt_tables.h), for the table tests */
 void emu_expand_radix4(uint64_t *e, const uint64_t *w, uint64_t N, uint64_t q)
 {

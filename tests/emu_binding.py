@@ -29,6 +29,7 @@ class Emu:
         L.emu_fused_product_chk.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
         L.emu_fwd_mul.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_team_decode.argtypes = [C.c_uint32] * 7 + [C.POINTER(C.c_uint32)]
+        L.emu_fwd_r4x4_layers.argtypes = [U64P, C.c_uint64, C.c_uint64, U64P, U64P]
         L.emu_inv_dot.argtypes = [U64P, C.c_int, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
@@ -90,6 +91,15 @@ class Emu:
         out = (C.c_uint32 * 5)()
         self.lib.emu_team_decode(k, q, total, lag, n0, n1, n2, out)
         return tuple(int(x) for x in out)
+
+    def fwd_r4x4_layers(self, a, q, e, econ):
+        """fwd_ntt_radix4x4_lazy at log2 N = 4k+3 through csrc/ntt_core.h r4x4_layer_r4 / r4x4_layer_r2 (the functions the
+        layer kernels of ntt_host.hip call), on the caller's expanded table"""
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        e, econ = np.ascontiguousarray(e, dtype=np.uint64), np.ascontiguousarray(econ, dtype=np.uint64)
+        assert e.size == 2 * a.size == econ.size
+        self.lib.emu_fwd_r4x4_layers(a.ctypes.data_as(U64P), a.size, q, e.ctypes.data_as(U64P), econ.ctypes.data_as(U64P))
+        return a
 
     def expand_radix4(self, w, q):
         w = np.ascontiguousarray(w, dtype=np.uint64)

@@ -65,6 +65,10 @@ class Ctx:
         """fwd_ntt_radix4_lazy: outputs in [0,8q) (src/ntt_radix4.c:27-62)"""
         return self._lazy(self.orc.lib.orc_fwd_r4_lazy, "e", "econ", a)
 
+    def fwd_r4x4_lazy(self, a):
+        """fwd_ntt_radix4x4_lazy (src/ntt_radix4x4.c:41-114): fwd_r4_lazy's words unless log2 N = 4k+3"""
+        return self._lazy(self.orc.lib.orc_fwd_r4x4_lazy, "e", "econ", a)
+
     def inv(self, a):
         return self._batch(self.orc.lib.orc_inv_r2_batch, a)
 
@@ -89,7 +93,7 @@ class Oracle:
         L.orc_ctx_free.argtypes = [C.c_void_p]
         for f in ("orc_fwd_r2_batch", "orc_fwd_r4_batch", "orc_inv_r2_batch", "orc_inv_r4_batch"):
             getattr(L, f).argtypes = [U64P, C.c_uint64, C.c_void_p]
-        for f in ("orc_fwd_r2_lazy", "orc_fwd_r4_lazy"):
+        for f in ("orc_fwd_r2_lazy", "orc_fwd_r4_lazy", "orc_fwd_r4x4_lazy"):
             getattr(L, f).argtypes = [U64P, C.c_uint64, C.c_uint64, U64P, U64P]
         L.orc_fill_uniform.argtypes = [U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_fnv1a64.restype = C.c_uint64

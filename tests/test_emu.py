@@ -526,3 +526,20 @@ def test_fwd_mul_kernel_logic(oracle, emu, m, q, arith):
         rc, got = emu.fwd_mul(a, bw, m, q, w, arith=arith, lazy=lazy, bcast=bcast, acc=c0 if acc else None)
         assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc)
         assert emu.chk_stats()[0] == 0
+
+
+@pytest.mark.parametrize("m", [3, 7, 11, 15])
+def test_radix4x4_remainder_layers_logic(oracle, emu, m):
+    """log2 N = 4k+3: the layer functions behind fwd_ntt_radix4x4_lazy (2k radix-4 layers, the radix-2 stage with the
+    reference's reduction of a[group counter], the last radix-4 layer; src/ntt_radix4x4.c:53-111) leave the words of the
+    oracle's restatement, which oracle/gen_golden.py pins against the compiled reference"""
+    n = 1 << m
+    for q in (oracle.find_prime(59, n), oracle.find_prime(31, n), 0x10001 if m <= 15 else None):
+        if q is None:
+            continue
+        cx = oracle.ctx(n, q, oracle.min_root(q, n))
+        a = oracle.fill_uniform(n, q, 7100 + m)
+        a[: min(n, 16)] = q - 1
+        got = emu.fwd_r4x4_layers(a, q, cx.table("e"), cx.table("econ"))
+        assert np.array_equal(got, cx.fwd_r4x4_lazy(a))
+        assert not np.array_equal(got, cx.fwd_r4_lazy(a)) or m == 3

@@ -786,7 +786,7 @@ def test_lazy_outputs(lib, oracle, kat, i):
 
 
 @pytest.mark.parametrize("i", range(19))
-def test_reference_lazy_signatures_are_bit_exact(lib, oracle, kat, i):
+def test_reference_lazy_signatures_are_bit_exact(lib, oracle, kat, lazy_words, i):
     """the *_lazy entry points return exactly what the reference returns BEFORE its header-inline final
     reduction: the integer policies run the reference's own butterflies on the caller's w AND w_con"""
     c = kat["cases"][i]
@@ -802,13 +802,41 @@ def test_reference_lazy_signatures_are_bit_exact(lib, oracle, kat, i):
     x = a.copy()
     lib._lib.fwd_ntt_seal_lazy(x.ctypes.data_as(U64P), n, q, tw.ctypes.data_as(U64P), twc.ctypes.data_as(U64P))
     assert int(x.max()) < 4 * q and np.array_equal(x % np.uint64(q), cx.fwd(a))
-    for fn in (lib._lib.fwd_ntt_radix4_lazy, lib._lib.fwd_ntt_radix4x4_lazy):
+    # radix-4 and radix-4x4: each formulation's OWN words (they differ when log2 N = 4k+3: cases 3, 14, 15), on this input
+    # and on the uniform input whose digests tests/golden/lazy_words.json holds straight from the compiled reference
+    u = oracle.fill_uniform(n, q, 0x5EED5EED, i << 32)
+    lz = lazy_words["cases"][i]
+    assert oracle.fnv(u) == lz["uni_in_fnv"]
+    for fn, want, name in ((lib._lib.fwd_ntt_radix4_lazy, cx.fwd_r4_lazy, "radix4"),
+                           (lib._lib.fwd_ntt_radix4x4_lazy, cx.fwd_r4x4_lazy, "radix4x4")):
         x = a.copy()
         fn(x.ctypes.data_as(U64P), n, q, e.ctypes.data_as(U64P), ec.ctypes.data_as(U64P))
-        if m >= 6:
-            assert np.array_equal(x, cx.fwd_r4_lazy(a))       # every reference case incl. 14-18 (N = 2^15..2^17, two passes)
-        else:
-            assert int(x.max()) < 8 * q and np.array_equal(x % np.uint64(q), cx.fwd(a))
+        assert np.array_equal(x, want(a)), name             # every reference case incl. 14-18 (N = 2^15..2^17, two passes)
+        x = u.copy()
+        fn(x.ctypes.data_as(U64P), n, q, e.ctypes.data_as(U64P), ec.ctypes.data_as(U64P))
+        assert oracle.fnv(x) == lz["lazy_out_fnv"][name], name
+    x = u.copy()
+    lib._lib.fwd_ntt_ref_harvey_lazy(x.ctypes.data_as(U64P), n, q, tw.ctypes.data_as(U64P), twc.ctypes.data_as(U64P))
+    assert oracle.fnv(x) == lz["lazy_out_fnv"]["ref_harvey"]
+    lib.compat_release()
+
+
+@pytest.mark.parametrize("m", [6, 7, 11])
+def test_radix4x4_lazy_words_at_other_sizes(lib, oracle, m):
+    """2^7 and 2^11 with a 59-bit and a 31-bit modulus (the reference's only 4k+3 cases below 2^15 use q = 65537), and 2^6
+    (shared engine): the radix-4x4 symbol returns the oracle's words, large leading coefficients included"""
+    n = 1 << m
+    U64P = lib.U64P
+    for bits in (59, 31):
+        q = oracle.find_prime(bits, n)
+        cx = oracle.ctx(n, q, oracle.min_root(q, n))
+        a = oracle.fill_uniform(n, q, 1900 + m)
+        a[:16] = q - 1
+        e, ec = cx.table("e"), cx.table("econ")
+        x = a.copy()
+        lib._lib.fwd_ntt_radix4x4_lazy(x.ctypes.data_as(U64P), n, q, e.ctypes.data_as(U64P), ec.ctypes.data_as(U64P))
+        assert np.array_equal(x, cx.fwd_r4x4_lazy(a))
+        assert np.array_equal(x, cx.fwd_r4_lazy(a)) == (m % 4 != 3)
     lib.compat_release()
 
 

@@ -42,6 +42,52 @@ def test_uniform_kat(kat, oracle, i):
 
 
 @pytest.mark.parametrize("i", range(19))
+def test_lazy_words_of_the_three_formulations(kat, lazy_words, oracle, i):
+    """the UNREDUCED words the reference's *_lazy functions return (digests captured from the compiled reference,
+    oracle/gen_golden.py): radix-2, radix-4, and the radix-4x4 formulation, whose words differ from radix-4's exactly
+    when log2 N = 4k+3 (src/ntt_radix4x4.c:91-111: radix-2 stage BEFORE the last radix-4 layer)"""
+    c, lz = kat["cases"][i], lazy_words["cases"][i]
+    n, q = 1 << c["m"], c["q"]
+    assert (lz["case"], lz["m"], lz["q"]) == (i, c["m"], q) and lz["uni_in_fnv"] == c["uni_in_fnv"]
+    cx = _ctx(oracle, c)
+    u = oracle.fill_uniform(n, q, UNI_SEED, i << 32)
+    words = {"ref_harvey": cx.fwd_lazy(u), "radix4": cx.fwd_r4_lazy(u), "radix4x4": cx.fwd_r4x4_lazy(u)}
+    for name, x in words.items():
+        assert oracle.fnv(x) == lz["lazy_out_fnv"][name], name
+        assert np.array_equal(x % np.uint64(q), cx.fwd(u)), name
+    assert lz["radix4x4_differs_from_radix4"] == (c["m"] % 4 == 3)
+    assert np.array_equal(words["radix4"], words["radix4x4"]) == (c["m"] % 4 != 3)
+
+
+@pytest.mark.parametrize("m", range(1, 14))
+def test_radix4x4_lazy_words_at_sizes_without_a_reference_case(oracle, m):
+    """sizes 2 .. 2^13 (the reference's cases start at 2^8 and hold one 4k+3 size below 2^15): the restatement against
+    the compiled reference where this container has it (oracle/_ref); residues against the radix-2 path everywhere"""
+    import ctypes as C
+    import os
+    n = 1 << m
+    q = oracle.find_prime(30 + m, n)
+    cx = oracle.ctx(n, q, oracle.min_root(q, n))
+    a = oracle.fill_uniform(n, q, 900 + m)
+    a[: min(n, 8)] = q - 1                                   # large leading coefficients: the 8q -> 4q steps fire
+    x = cx.fwd_r4x4_lazy(a)
+    assert int(x.max()) < 8 * q and np.array_equal(x % np.uint64(q), cx.fwd(a))
+    if m % 4 != 3:
+        assert np.array_equal(x, cx.fwd_r4_lazy(a))
+    ref_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libntt_ref.so")
+    if os.path.exists(ref_path):
+        ref = C.CDLL(ref_path)
+        if hasattr(ref, "ref_fwd_r4_lazy_generic"):
+            U64P = C.POINTER(C.c_uint64)
+            e, ec = cx.table("e"), cx.table("econ")
+            for variant, want in ((1, cx.fwd_r4_lazy(a)), (2, x)):
+                r = a.copy()
+                ref.ref_fwd_r4_lazy_generic(variant, r.ctypes.data_as(U64P), C.c_uint64(n), C.c_uint64(q), e.ctypes.data_as(U64P),
+                                            ec.ctypes.data_as(U64P))
+                assert np.array_equal(r, want), variant
+
+
+@pytest.mark.parametrize("i", range(19))
 def test_edge_kats(kat, oracle, i):
     c = kat["cases"][i]
     n, q = 1 << c["m"], c["q"]
