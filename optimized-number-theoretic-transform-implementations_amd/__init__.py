@@ -41,7 +41,7 @@ ARITH_AUTO, ARITH_U64, ARITH_F64, ARITH_U64_R4 = 0, 1, 2, 3
 FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
 MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
-OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU = 7, 8, 9
+OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE = 7, 8, 9, 10
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [

@@ -79,6 +79,7 @@ struct ArithU64 {
   static constexpr bool kCompact = false;
   static constexpr bool kRadix4  = false;
   static constexpr bool kWide52  = false;
+  static constexpr bool kIntWide = false; /* ArithU64X: MASK = stages that fold the growing operand (u64x_schedule) */
   using ctw                      = uint64_t;
   static NTT_HD tw expand(ctw w, const consts &) { return tw{w, 0}; }
 
@@ -249,6 +250,123 @@ struct ArithU64R4 : ArithU64 {
 };
 
 /* ------------------------------------------------------------------ */
+/* ArithU64X<K>: integer arithmetic that spends the headroom above q     */
+/* ------------------------------------------------------------------ */
+/*
+ * The throughput form of the integer policy for the moduli the FP64 policies cannot serve (2^52 <= q < 2^61; round 4).
+ * Same tables, same canonical results as ArithU64 -- other lazy words, so the reference-signature entry points and plans
+ * created with NTT_ARITH_U64 keep the reference's butterflies (ArithU64) and only NTT_ARITH_AUTO plans run this one.
+ * Two changes to fast_mul_operators.h:49-92, both paid for with the bits between q and 2^64 (B = 8 * 2^K values of q fit:
+ * K = 0 for q < 2^61, 1 for q < 2^60, 3 for q < 2^58):
+ *   1. ESTIMATED Shoup quotient: with con = c1 2^32 + c0, y = t1 2^32 + t0,
+ *        Q' = c1 t1 + hi32(c1 t0) + hi32(c0 t1)          (3 multiplies instead of the 4 + carries of hi64(con * y))
+ *      drops floor(c0 t0 / 2^32) and two carries: Q - 2 <= Q' <= Q, so w y - Q' q lies in [0,4q) instead of [0,2q).
+ *   2. NO conditional subtraction per butterfly.  Forward: x' = x + m, y' = x + 4q - m with m in [0,4q): a value grows
+ *      by 4q per stage and is folded (x >= (B/2) q ? x - (B/2) q : x) only at the stages u64x_schedule names -- never
+ *      in a 14-stage block for K = 3 (4 + 4 * 14 = 60 < 64), every other stage for K = 1, every stage but the first
+ *      for K = 0.  The Shoup product takes ANY 64-bit y.  Inverse: s = x + y doubles, d = x - y + (B/2) q stays below
+ *      B q, the product comes back below 4q; the sum is brought below 4q by reduce_any (one 32-bit multiply estimates
+ *      s / q) where the schedule says so: every third stage for K = 3, every second for K = 1, and the LAST stage of
+ *      every pass, so that a pass hands on words below 4q whatever it computed.
+ * Per butterfly: 19 VALU instructions (9 multiplies) against ArithU64's 28 (10); measured +16..17 % at 2^12 / 2^14 on the
+ * forward transform (profiles/r04/ab_int_wide.txt), where the multiplies are 56 % of the issue time.
+ * Outputs: forward values below (4 + 4 stages) q are reduced by reduce_any + two conditional subtractions (lazy: reduce_any
+ * alone, < 4q: the lazy contract of include/ntt_reference.h:13-17); inverse values leave the last stage below 4q.
+ * reduce_any needs floor(2^64 / q) < 2^32 and its error term 2^32 / q small: q >= 2^40 (ntt_host.hip: int_wide_class).
+ */
+constexpr uint32_t u64x_schedule(bool inverse, int nstages, int K)
+{
+  const int B    = 8 << K; /* values stay below B q < 2^64 */
+  uint32_t  mask = 0;
+  int       b    = 4;      /* every pass starts from words below 4q (canonical, lazy, or the previous pass's) */
+  for(int s = 0; s < nstages; s++) {
+    if(!inverse) {
+      if(b + 4 > B) {
+        mask |= 1u << s;
+        b = b - B / 2 > B / 2 ? b - B / 2 : B / 2;
+      }
+      b += 4;
+    } else {
+      /* entry invariant 2b <= B: the sum fits, the difference's offset (B/2) q covers y */
+      if(s == nstages - 1 || 4 * b > B) {
+        mask |= 1u << s;
+        b = 4;
+      } else {
+        b = 2 * b;
+      }
+    }
+  }
+  return mask;
+}
+
+template <int K> struct ArithU64X : ArithU64 {
+  static_assert(K == 0 || K == 1 || K == 3, "headroom classes: B = 8, 16, 64 multiples of q below 2^64");
+  static constexpr bool kIntWide = true;
+  static constexpr int  kHead    = K;
+
+  static NTT_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+  static NTT_HD uint64_t half_range(const consts &c) { return c.q << (K + 2); } /* (B/2) q */
+
+  /* w y - Q' q in [0,4q) for ANY 64-bit y (see above) */
+  static NTT_HD uint64_t shoup_est(const tw &t, uint64_t y, const consts &c)
+  {
+    const uint32_t c1 = (uint32_t)(t.con >> 32), c0 = (uint32_t)t.con, t1 = (uint32_t)(y >> 32), t0 = (uint32_t)y;
+    const uint64_t Q  = (uint64_t)c1 * t1 + mulhi32(c1, t0) + mulhi32(c0, t1);
+    return t.w * y - Q * c.q;
+  }
+  /* any 64-bit v -> [0, 2.01 q), congruent: Q' = hi32(hi32(v) * floor(2^64/q)) satisfies v/q - 2 - 2^32/q < Q' <= v/q
+   * (hi32(v) > v/2^32 - 1 and floor(2^64/q) > 2^64/q - 1 give hi32(v) floor(2^64/q) / 2^32 > v/q - v/2^64 - 2^32/q, v/2^64 < 1,
+   * and the outer floor loses less than 1); the policy is used for q >= 2^40: 2^32/q <= 2^-8 */
+  static NTT_HD uint64_t reduce_any(uint64_t v, const consts &c)
+  {
+    const uint32_t Q = mulhi32((uint32_t)(v >> 32), (uint32_t)c.one.con);
+    return v - (uint64_t)Q * c.q;
+  }
+  /* the operand the schedule folds: forward x below B q -> below max(b, B) - B/2 ... (u64x_schedule); K = 0 is ArithU64's
+   * conditional subtraction at doubled ranges */
+  static NTT_HD uint64_t fold_fwd(uint64_t x, const consts &c) { return csub(x, half_range(c)); }
+  static NTT_HD uint64_t fold_inv(uint64_t s, const consts &c) { return K == 0 ? csub(s, 2 * c.q2) : reduce_any(s, c); }
+
+  template <bool INV, bool WIDE> static NTT_HD val load(uint64_t raw, const consts &c)
+  {
+    if(!WIDE) return raw;         /* [0,q), or a lazy word below 4q */
+    return csub(raw, 2 * c.q2);   /* [0,8q) -> [0,4q) */
+  }
+  template <bool RED> static NTT_HD void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const uint64_t x1 = RED ? fold_fwd(x, c) : x;
+    const uint64_t m  = shoup_est(t, y, c);
+    x                 = x1 + m;
+    y                 = x1 + 2 * c.q2 - m;
+  }
+  template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    const uint64_t s = x + y;
+    const uint64_t d = x + half_range(c) - y;
+    x                = RED ? fold_inv(s, c) : s;
+    y                = shoup_est(t, d, c);
+  }
+  /* last inverse stage with N^-1 folded in (fast_mul_operators.h:94-106): both outputs are products, below 4q */
+  static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const uint64_t s = x + y;
+    const uint64_t d = x + half_range(c) - y;
+    x                = shoup_est(c.ninv, s, c);
+    y                = shoup_est(c.wninv, d, c);
+  }
+  static NTT_HD uint64_t store_fwd(val v, const consts &c) { return csub(csub(reduce_any(v, c), c.q2), c.q); }
+  static NTT_HD uint64_t store_fwd_lazy(val v, const consts &c) { return reduce_any(v, c); } /* < 4q */
+  static NTT_HD uint64_t store_inv(val v, const consts &c) { return csub(csub(v, c.q2), c.q); } /* the last stage left < 4q */
+  static NTT_HD uint64_t store_inv_lazy(val v, const consts &c) { return csub(v, c.q2); } /* < 2q: the lazy inverse range */
+  static NTT_HD uint64_t store_fwd_sel(val v, const consts &c, uint64_t keep)
+  {
+    return csub(csub(reduce_any(v, c), c.q2 & keep), c.q & keep);
+  }
+  static NTT_HD uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return csub(csub(v, c.q2), c.q & keep); }
+  static NTT_HD val      scale_ninv(val v, const consts &c) { return shoup_est(c.ninv, v, c); }
+};
+
+/* ------------------------------------------------------------------ */
 /* ArithF64                                                            */
 /* ------------------------------------------------------------------ */
 /*
@@ -280,6 +398,7 @@ struct ArithF64 {
   static constexpr bool kCompact = true;
   static constexpr bool kRadix4  = false;
   static constexpr bool kWide52  = false; /* WideF64: the kernels' MASK means "reduce the multiplied operand" */
+  static constexpr bool kIntWide = false;
   using ctw                      = double;
   static NTT_HD tw expand(ctw w, const consts &c) { return tw{w, fma_(w, c.qinv, w * c.qinv_lo)}; }
 

@@ -1063,7 +1063,9 @@ template <class A, int LOGN> constexpr uint32_t fused_cmask()
 
 template <class A, int LOGN, bool INV, int KSH, bool LAZY = false> constexpr uint32_t fused_mask()
 {
-  if constexpr(!A::kTracksBounds) {
+  if constexpr(A::kIntWide) {
+    return u64x_schedule(INV, LOGN, A::kHead); /* ArithU64X: the stages that fold the growing operand */
+  } else if constexpr(!A::kTracksBounds) {
     return 0;
   } else {
     /* the schedule is causal, so when the last inverse stage is the folded
@@ -1239,7 +1241,9 @@ NTT_HD TeamItem team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag
 
 template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
 {
-  if constexpr(!A::kTracksBounds) {
+  if constexpr(A::kIntWide) {
+    return u64x_schedule(INV, R, A::kHead);
+  } else if constexpr(!A::kTracksBounds) {
     return 0;
   } else if constexpr(A::kWide52) {
     return INV ? 0u : f64w_fwd_schedule(R, 1.0, 0u).mask; /* (column passes read full records) */

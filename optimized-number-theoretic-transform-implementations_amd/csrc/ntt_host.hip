@@ -33,6 +33,9 @@ namespace ntt {
 /* defined in inst_*.hip */
 template <> hipError_t launch_pass<ArithU64, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithU64R4, 0>(const PassArgs &);
+template <> hipError_t launch_pass<ArithU64X<0>, 0>(const PassArgs &);
+template <> hipError_t launch_pass<ArithU64X<1>, 1>(const PassArgs &);
+template <> hipError_t launch_pass<ArithU64X<3>, 3>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 0>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 1>(const PassArgs &);
 template <> hipError_t launch_pass<ArithF64, 18>(const PassArgs &);
@@ -223,6 +226,8 @@ struct ntt_plan {
   int      m       = 0;
   int      arith   = NTT_ARITH_U64; /* resolved: U64, F64 or U64_R4 */
   int      kcls    = 0;             /* instantiated FP64 headroom class */
+  int      int_cls = -1;            /* integer policy: -1 = the reference's butterflies (ArithU64), else the headroom class K of
+                                     * ArithU64X<K> the transforms run with (same tables, same canonical results) */
   bool     generic = false;
   bool     has_fwd = false, has_inv = false;
   void *   d_fwd   = nullptr; /* U64/F64: N records (+16 folded N^-1 records, inverse); U64_R4: 2N expanded records */
@@ -263,6 +268,14 @@ struct ntt_plan {
 
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 static bool h_is_prime(uint64_t n); /* deterministic Miller-Rabin (below) */
+
+/* headroom class of ArithU64X for q (ntt_arith.h): B = 8 * 2^K multiples of q below 2^64; -1 = not served (reduce_any
+ * wants q >= 2^40 -- smaller moduli belong to the FP64 policies anyway -- and 8q < 2^64) */
+static int int_wide_class(uint64_t q)
+{
+  if(q < (1ull << 40) || q >= (1ull << 61)) return -1;
+  return q < (1ull << 58) ? 3 : (q < (1ull << 60) ? 1 : 0);
+}
 
 static int resolve_arith(int requested, uint64_t q, int m, int *out)
 {
@@ -417,6 +430,9 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->root     = root;
   p->m        = (int)h_log2(N);
   p->arith    = ar;
+  /* NTT_ARITH_AUTO on a modulus the FP64 policies cannot serve: the throughput form of the integer arithmetic; an
+   * explicit NTT_ARITH_U64 keeps the reference's butterflies and lazy words (NTT_OPT_INT_WIDE switches either way) */
+  p->int_cls  = (arith == NTT_ARITH_AUTO && ar == NTT_ARITH_U64 && env_int("NTT_INT_WIDE", 1) != 0) ? int_wide_class(q) : -1;
   {
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -561,6 +577,7 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
   info[2] = (uint64_t)p->m;
   info[3] = (uint64_t)p->arith;
   info[4] = p->kcls == kWideClass ? 52u : (uint64_t)p->kcls; /* 52: the reduce-both-operands policy for q up to 2^52 */
+  if(p->arith == NTT_ARITH_U64) info[4] = p->int_cls < 0 ? 0u : 100u + (uint64_t)p->int_cls; /* 100 + K: ArithU64X<K> */
   /* launches (= passes over the data) of one forward transform of a large batch: 1 where one launch carries both passes --
    * the XCD-local kernel (FP64 policies, N = 2^15..2^17, unless switched off: its automatic choice takes forward
    * transforms of 512 polynomials or more) or the two-phase kernel where it is forced -- else the pass list's length */
@@ -643,6 +660,26 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       }
       return fail(NTT_ERR_ARG, "headroom class not instantiated or not valid for this modulus");
     }
+    case NTT_OPT_INT_WIDE: {
+      /* 0: the reference's butterflies; 1: the widest headroom class q permits; 10 + K: class K (tests: a narrower class
+       * than q permits is always valid, it only folds more often) */
+      if(p->arith != NTT_ARITH_U64) return fail(NTT_ERR_ARG, "not a plan of the integer policy");
+      const int best = int_wide_class(p->q);
+      if(value == 0) {
+        p->int_cls = -1;
+        return NTT_OK;
+      }
+      if(best < 0) return fail(NTT_ERR_UNSUPPORTED, "the wide integer policy serves 2^40 <= q < 2^61");
+      if(value == 1) {
+        p->int_cls = best;
+        return NTT_OK;
+      }
+      if((value == 10 || value == 11 || value == 13) && value - 10 <= best) {
+        p->int_cls = (int)value - 10;
+        return NTT_OK;
+      }
+      return fail(NTT_ERR_ARG, "integer headroom class not instantiated or not valid for this modulus");
+    }
     default: return fail(NTT_ERR_ARG, "unknown option");
   }
 }
@@ -652,7 +689,14 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
 /* ------------------------------------------------------------------ */
 static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
 {
-  if(p->arith == NTT_ARITH_U64) return launch_pass<ArithU64, 0>(pa);
+  if(p->arith == NTT_ARITH_U64) {
+    switch(p->generic ? -1 : p->int_cls) { /* (generic = the column-pass cross-check path: the reference's butterflies) */
+      case 3: return launch_pass<ArithU64X<3>, 3>(pa);
+      case 1: return launch_pass<ArithU64X<1>, 1>(pa);
+      case 0: return launch_pass<ArithU64X<0>, 0>(pa);
+      default: return launch_pass<ArithU64, 0>(pa);
+    }
+  }
   if(p->arith == NTT_ARITH_U64_R4) return launch_pass<ArithU64R4, 0>(pa);
   switch(p->kcls) {
     case kWideClass: return launch_pass<ArithF64W, 0>(pa);

@@ -228,6 +228,107 @@ struct ArithF64Chk : ArithF64 {
   static uint64_t store_inv(val v, const consts &c) { return store_fwd(v, c); }
 };
 
+/* ------------------------------------------------------------------ */
+/* ArithU64XChk<K>: the wide integer policy with its range claims        */
+/* (ntt_arith.h, ArithU64X) asserted against 128-bit arithmetic.          */
+/* ------------------------------------------------------------------ */
+/* g_u64x_worst: every estimated product / reduce_any returns the LARGEST representative its claim allows (below 4q /
+ * below 2.01 q) instead of the one the arithmetic happened to produce: still congruent, so results stay right, but
+ * every value now grows as fast as u64x_schedule assumes -- a run without a flagged wrap-around then covers the
+ * worst case of the schedule, not just the data at hand. */
+inline int g_u64x_worst = 0;
+
+template <int K> struct ArithU64XChk : ArithU64X<K> {
+  using Base   = ArithU64X<K>;
+  using val    = typename Base::val;
+  using tw     = typename Base::tw;
+  using consts = typename Base::consts;
+  using u128   = unsigned __int128;
+  static constexpr uint64_t kB = 8u << K;
+
+  static void see(uint64_t v, const consts &c)
+  {
+    const double b = (double)v / (double)c.q;
+    if(b > g_chk_maxb) g_chk_maxb = b;
+  }
+  static uint64_t shoup_est(const tw &t, uint64_t y, const consts &c)
+  {
+    uint64_t r = Base::shoup_est(t, y, c);
+    if(r >= 4 * c.q || (uint64_t)(((u128)t.w * y) % c.q) != r % c.q) g_chk_fail++;
+    if(g_u64x_worst) r += (4 * c.q - 1 - r) / c.q * c.q;
+    return r;
+  }
+  static uint64_t reduce_any(uint64_t v, const consts &c)
+  {
+    uint64_t r = Base::reduce_any(v, c);
+    if((u128)r * 100 >= (u128)c.q * 201 || r % c.q != v % c.q) g_chk_fail++;
+    if(g_u64x_worst)
+      while((u128)(r + c.q) * 100 < (u128)c.q * 201) r += c.q;
+    return r;
+  }
+  static uint64_t fold_inv(uint64_t s, const consts &c)
+  {
+    if(K == 0 && s >= 8 * c.q) g_chk_fail++; /* one conditional subtraction of 4q must do */
+    return K == 0 ? Base::csub(s, 4 * c.q) : reduce_any(s, c);
+  }
+  template <bool INV, bool WIDE> static val load(uint64_t raw, const consts &c)
+  {
+    if(raw >= (WIDE ? 8 : 4) * c.q) g_chk_fail++; /* the caller's contract */
+    return Base::template load<INV, WIDE>(raw, c);
+  }
+  template <bool RED> static void fwd_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    see(x, c);
+    if((u128)x >= (u128)kB * c.q) g_chk_fail++;
+    const uint64_t x1 = RED ? Base::fold_fwd(x, c) : x;
+    const uint64_t m  = shoup_est(t, y, c);
+    if((u128)x1 + 4 * (u128)c.q >= ((u128)1 << 64) || (u128)x1 + m >= (u128)kB * c.q) g_chk_fail++; /* no wrap-around, below B q */
+    x = x1 + m;
+    y = x1 + 4 * c.q - m;
+  }
+  template <bool RED> static void inv_bfly(val &x, val &y, const tw &t, const consts &c)
+  {
+    see(x, c);
+    see(y, c);
+    const uint64_t half = Base::half_range(c);
+    if(x >= half || y >= half) g_chk_fail++; /* entry invariant 2b <= B: the sum fits, the offset covers y */
+    const uint64_t s = x + y;
+    const uint64_t d = x + half - y;
+    x                = RED ? fold_inv(s, c) : s;
+    y                = shoup_est(t, d, c);
+  }
+  static void inv_bfly_last(val &x, val &y, const consts &c)
+  {
+    const uint64_t half = Base::half_range(c);
+    if(x >= half || y >= half) g_chk_fail++;
+    const uint64_t s = x + y;
+    const uint64_t d = x + half - y;
+    x                = shoup_est(c.ninv, s, c);
+    y                = shoup_est(c.wninv, d, c);
+  }
+  static uint64_t canon(uint64_t v, const consts &c) { return Base::csub(Base::csub(v, c.q2), c.q); }
+  static uint64_t store_fwd(val v, const consts &c)
+  {
+    const uint64_t u = canon(reduce_any(v, c), c);
+    if(u != v % c.q) g_chk_fail++;
+    return u;
+  }
+  static uint64_t store_fwd_lazy(val v, const consts &c) { return reduce_any(v, c); }
+  static uint64_t store_inv(val v, const consts &c)
+  {
+    if(v >= 4 * c.q) g_chk_fail++; /* the last stage of every pass is a folding one */
+    return canon(v, c);
+  }
+  static uint64_t store_inv_lazy(val v, const consts &c)
+  {
+    if(v >= 4 * c.q) g_chk_fail++;
+    return Base::csub(v, c.q2);
+  }
+  static uint64_t store_fwd_sel(val v, const consts &c, uint64_t keep) { return keep ? store_fwd(v, c) : store_fwd_lazy(v, c); }
+  static uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return keep ? store_inv(v, c) : store_inv_lazy(v, c); }
+  static val      scale_ninv(val v, const consts &c) { return shoup_est(c.ninv, v, c); }
+};
+
 template <class A> struct Regs {
   typename A::val x[kE];
 };
@@ -769,8 +870,11 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P9(KW) EMU_DOT(KW, ArithF64Chk, 1) EMU_DOT(KW, WideChk, 0)
 #  define P10(KW) EMU_MUL(KW, ArithU64, 0) EMU_MUL(KW, ArithF64Chk, 0)
 #  define P11(KW) EMU_MUL(KW, ArithF64Chk, 1) EMU_MUL(KW, WideChk, 0)
+#  define P12(KW) EMU_RUN(KW, ArithU64XChk<0>, 0) EMU_RUN(KW, ArithU64XChk<1>, 1)
+#  define P13(KW) EMU_RUN(KW, ArithU64XChk<3>, 3)
 #  if EMU_PART == 0
 P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern) P10(extern) P11(extern)
+P12(extern) P13(extern)
 #  elif EMU_PART == 1
 P1()
 #  elif EMU_PART == 2
@@ -793,6 +897,10 @@ P9()
 P10()
 #  elif EMU_PART == 11
 P11()
+#  elif EMU_PART == 12
+P12()
+#  elif EMU_PART == 13
+P13()
 #  endif
 #endif
 
@@ -835,6 +943,20 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
     const auto c = h_consts_u64(q, N, wi);
     return inverse ? emu_run<ArithU64, true, 0>(a, batch, m, tab.data(), c, generic, wide)
                    : emu_run<ArithU64, false, 0>(a, batch, m, tab.data(), c, generic, wide);
+  }
+  if(arith == 6) { /* the wide integer policy (ArithU64X<K>, K = ksh_force), checked: same tables as arith 0 */
+    std::vector<TwU64> tab(src.size());
+    for(uint64_t i = 0; i < src.size(); i++) tab[i] = h_tw_u64(src[i], q);
+    const auto c = h_consts_u64(q, N, wi);
+    if(q < (1ull << 40) || q >= (1ull << (ksh_force == 3 ? 58 : (ksh_force == 1 ? 60 : 61)))) return -2;
+#define EMU_U64X(KK)                                                                                            \
+  return inverse ? emu_run<ArithU64XChk<KK>, true, KK>(a, batch, m, tab.data(), c, generic, wide)                \
+                 : emu_run<ArithU64XChk<KK>, false, KK>(a, batch, m, tab.data(), c, generic, wide);
+    if(ksh_force == 3) { EMU_U64X(3) }
+    if(ksh_force == 1) { EMU_U64X(1) }
+    if(ksh_force == 0) { EMU_U64X(0) }
+#undef EMU_U64X
+    return -3;
   }
   if(arith == 3) { /* the reference's radix-4 formulation on the expanded table */
     if(m < kFusedMin || m > kRadix4Max || generic) return -4;
@@ -908,6 +1030,7 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 }
 
 void emu_set_lazy(int on) { g_lazy = on != 0; }
+void emu_set_u64x_worst(int on) { g_u64x_worst = on != 0; }
 void emu_set_product_both(int on) { g_prod_both = on != 0; }
 
 #ifndef EMU_SAN_BUILD

@@ -23,6 +23,7 @@ class Emu:
         L.emu_chk_stats.argtypes = [U64P, C.c_int]
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
+        L.emu_set_u64x_worst.argtypes = [C.c_int]
         L.emu_set_product_both.argtypes = [C.c_int]
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
@@ -33,7 +34,8 @@ class Emu:
         L.emu_inv_dot.argtypes = [U64P, C.c_int, U64P, U64P, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
 
     def transform(self, a, m, q, root, arith, inverse=False, generic=False, wide=False, ksh=-1, lazy=False):
-        """arith: 0 = integer radix-2, 1 = FP64, 2 = checked FP64, 3 = integer radix-4 (expanded table)"""
+        """arith: 0 = integer radix-2, 1 = FP64, 2 = checked FP64, 3 = integer radix-4 (expanded table), 4 / 5 = FP64 up to 2^52
+        (5: checked), 6 = the wide integer policy ArithU64X<ksh>, checked"""
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
         self.lib.emu_set_lazy(int(lazy))
         rc = self.lib.emu_transform(a.ctypes.data_as(U64P), a.size >> m, m, q, root, arith, int(inverse),
@@ -112,6 +114,11 @@ class Emu:
         assert self.lib.emu_plan_info(logn, v.ctypes.data_as(U64P)) == 0
         keys = ("NG", "R0", "RL", "T", "ROW", "LDS_ELEMS", "wave_local", "fmask", "imask", "conflict_free")
         return dict(zip(keys, [int(x) for x in v]))
+
+    def set_u64x_worst(self, on):
+        """arith=6 (checked ArithU64X): products and reduce_any return the largest representative their claims allow, so
+        that every value grows as fast as the compile-time schedule assumes"""
+        self.lib.emu_set_u64x_worst(int(on))
 
     def chk_stats(self, reset=True):
         """(violations, max |v|/q, max |product|/q) recorded by the checked FP64 policy (arith=2)"""

@@ -543,3 +543,49 @@ def test_radix4x4_remainder_layers_logic(oracle, emu, m):
         got = emu.fwd_r4x4_layers(a, q, cx.table("e"), cx.table("econ"))
         assert np.array_equal(got, cx.fwd_r4x4_lazy(a))
         assert not np.array_equal(got, cx.fwd_r4_lazy(a)) or m == 3
+
+
+@pytest.mark.parametrize("k,top", [(3, 58), (1, 60), (0, 61)])
+@pytest.mark.parametrize("m", [6, 9, 12, 13, 14, 16])
+def test_wide_integer_policy(oracle, emu, m, k, top):
+    """ArithU64X<K> (ntt_arith.h): estimated Shoup quotient, no conditional subtraction per butterfly, folds where
+    u64x_schedule says.  Bit-exact against the oracle for the largest prime of each headroom class and a 53-bit one,
+    forward / inverse / lazy / wide inputs / column-pass form; the checked policy asserts every range claim against 128-bit
+    arithmetic (no wrap-around, products below 4q, reduce_any below 2.01 q, sums below (B/2) q at every inverse stage) --
+    once with the words the arithmetic produces and once with every product and fold replaced by the LARGEST representative
+    its claim allows, which makes the values grow as fast as the schedule assumes"""
+    n = 1 << m
+    B = 8 << k
+    for q in (_prime_near(oracle, (1 << top) - 1, n), _prime_near(oracle, 1 << 52, n, below=False)):
+        assert (1 << 40) <= q < (1 << top)
+        w = oracle.min_root(q, n)
+        cx = oracle.ctx(n, q, w)
+        a = oracle.fill_uniform(2 * n, q, 64 + m + k)
+        a[:6] = [0, 1, q - 1, q - 2, q // 2, q // 2 + 1]
+        expect = cx.fwd(a)
+        emu.chk_stats()
+        for worst in (0, 1):
+            emu.set_u64x_worst(worst)
+            rc, got = emu.transform(a, m, q, w, 6, ksh=k)
+            assert rc == 0 and np.array_equal(got, expect), (hex(q), worst)
+            rc, back = emu.transform(got, m, q, w, 6, ksh=k, inverse=True)
+            assert rc == 0 and np.array_equal(back, a), (hex(q), worst)
+            rc, lz = emu.transform(a + np.uint64(3 * q), m, q, w, 6, ksh=k, lazy=True)     # lazy words in, lazy words out
+            assert rc == 0 and int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), expect)
+            rc, lb = emu.transform(expect + np.uint64(3 * q), m, q, w, 6, ksh=k, inverse=True, lazy=True)
+            assert rc == 0 and int(lb.max()) < 2 * q and np.array_equal(lb % np.uint64(q), a)
+            rc, back = emu.transform(expect + np.uint64(7 * q), m, q, w, 6, ksh=k, inverse=True, wide=True)
+            assert rc == 0 and np.array_equal(back, a)
+            rc, got = emu.transform(a + np.uint64(7 * q), m, q, w, 6, ksh=k, wide=True)
+            assert rc == 0 and np.array_equal(got, expect)
+            if m <= 12:
+                rc, got = emu.transform(a, m, q, w, 6, ksh=k, generic=True)
+                assert rc == 0 and np.array_equal(got, expect)
+                rc, back = emu.transform(expect, m, q, w, 6, ksh=k, generic=True, inverse=True)
+                assert rc == 0 and np.array_equal(back, a)
+            fails, maxb, _ = emu.chk_stats()
+            assert fails == 0 and maxb < B, (hex(q), worst, fails, maxb)
+            if worst and m >= 12 and k == 3:
+                assert maxb > 40, maxb        # the injection works: values do climb towards 4 + 4 * stages
+        emu.set_u64x_worst(0)
+    assert emu.transform(a, m, (1 << top) + 1, 3, 6, ksh=k)[0] == -2

@@ -1102,6 +1102,83 @@ def test_wide_fp64_policy_52_bit_moduli(lib, oracle, m):
     plan.destroy(), pu.destroy()
 
 
+def _ntt_prime_near(oracle, bound, n, below=True):
+    step = 2 * n
+    q = (bound // step) * step + 1
+    if below and q > bound:
+        q -= step
+    if not below and q <= bound:
+        q += step
+    while not oracle.lib.orc_is_prime(q):
+        q += -step if below else step
+    return q
+
+
+@pytest.mark.parametrize("m", [6, 8, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("k,top", [(3, 58), (1, 60), (0, 61)])
+def test_wide_integer_policy(lib, oracle, m, k, top):
+    """moduli the FP64 policies cannot serve (q >= 2^52): NTT_ARITH_AUTO plans run the transforms with ArithU64X<K>
+    (estimated Shoup quotient, no conditional subtraction per butterfly; csrc/ntt_arith.h) -- the largest prime of each
+    headroom class and a 53-bit one against the oracle: forward, inverse, lazy and wide words, products and the
+    NTT-domain entry points (which keep the reference's butterflies on the same tables), every narrower class forced,
+    and the reference's butterflies (NTT_OPT_INT_WIDE 0 / a plan created with NTT_ARITH_U64) giving the same results"""
+    n = 1 << m
+    for q in (_ntt_prime_near(oracle, (1 << top) - 1, n), _ntt_prime_near(oracle, 1 << 52, n, below=False)):
+        w = oracle.min_root(q, n)
+        cx = oracle.ctx(n, q, w)
+        plan = lib.Plan(n, q, w)
+        best = 3 if q < (1 << 58) else (1 if q < (1 << 60) else 0)
+        info = plan.info()
+        assert info["arith"] == lib.ARITH_U64 and info["f64_class"] == 100 + best and (best == k or q < (1 << 53))
+        batch = 3
+        a = oracle.fill_uniform(batch * n, q, 6100 + m + k)
+        a[:6] = [0, 1, q - 1, q - 2, q // 2, q // 2 + 1]
+        expect = cx.fwd(a)
+        b = oracle.fill_uniform(batch * n, q, 6200 + m)
+        bhat = cx.fwd(b)
+        prod = cx.inv(oracle.pointwise(expect, bhat, q))
+        for opt in [1] + [10 + c for c in (0, 1, 3) if c <= best] + [0]:
+            plan.set_option(lib.OPT_INT_WIDE, opt)
+            assert plan.info()["f64_class"] == (0 if opt == 0 else 100 + (best if opt == 1 else opt - 10))
+            assert np.array_equal(plan.fwd_host(a), expect), (hex(q), opt)
+            assert np.array_equal(plan.inv_host(expect), a), (hex(q), opt)
+            lz = plan.fwd_host(a + np.uint64(3 * q), lazy=True)                    # lazy words in, lazy words out
+            assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), expect)
+            lb = plan.inv_host(expect + np.uint64(q if opt == 0 else 3 * q), lazy=True)   # (the reference's inverse takes [0,2q))
+            assert int(lb.max()) < 2 * q and np.array_equal(lb % np.uint64(q), a), (hex(q), opt)
+            assert np.array_equal(plan.fwd_host(a + np.uint64(7 * q), wide=True), expect)
+            assert np.array_equal(plan.inv_host(expect + np.uint64(7 * q), wide=True), a)
+            da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+            plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
+            assert np.array_equal(dc.download(), prod), (hex(q), opt)
+            da.upload(expect), db.upload(bhat)
+            plan.inv_product(dc.ptr, da.ptr, db.ptr, batch)
+            assert np.array_equal(dc.download(), prod), (hex(q), opt)
+            da.upload(a), db.upload(bhat)
+            plan.fwd_mul(dc.ptr, da.ptr, db.ptr, batch)
+            assert np.array_equal(dc.download(), oracle.pointwise(expect, bhat, q)), (hex(q), opt)
+            da.free(), db.free(), dc.free()
+        if m in (12, 16):
+            plan.set_option(lib.OPT_INT_WIDE, 1)
+            plan.set_generic(1)                                                      # column passes only: the reference's butterflies
+            assert np.array_equal(plan.fwd_host(a), expect) and np.array_equal(plan.inv_host(expect), a)
+        with pytest.raises(lib.NttError):
+            plan.set_option(lib.OPT_INT_WIDE, 12)
+        if best < 3:
+            with pytest.raises(lib.NttError):
+                plan.set_option(lib.OPT_INT_WIDE, 13)
+        pu = lib.Plan(n, q, w, arith=lib.ARITH_U64)                                  # explicit: the reference's butterflies and lazy words
+        assert pu.info()["f64_class"] == 0
+        assert np.array_equal(pu.fwd_host(a, lazy=True), cx.fwd_lazy(a))
+        plan.destroy(), pu.destroy()
+    small = lib.Plan(1 << 8, 0x1e01, oracle.min_root(0x1e01, 1 << 8), arith=lib.ARITH_U64)
+    with pytest.raises(lib.NttError):
+        small.set_option(lib.OPT_INT_WIDE, 1)                                        # below 2^40: not served
+    with pytest.raises(lib.NttError):
+        lib.Plan(n, oracle.find_prime(50, n), oracle.min_root(oracle.find_prime(50, n), n)).set_option(lib.OPT_INT_WIDE, 1)   # an FP64 plan
+    small.destroy()
+
+
 def test_compat_device_selection_env():
     """NTT_DEVICE (with NTT_COMPAT_ARITH the only environment the library reads): the reference-signature entry points
     run on that device, and a device that does not exist makes them fail loudly (stderr + abort), never silently"""

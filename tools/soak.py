@@ -35,7 +35,7 @@ def fail(what, **kw):
 while time.time() < t_end:
     m = int(rng.integers(1, 19))
     n = 1 << m
-    bits = int(rng.choice([int(rng.integers(max(m + 2, 20), 61)), 50, 51, 52, 60]))
+    bits = int(rng.choice([int(rng.integers(max(m + 2, 20), 61)), 50, 51, 52, 60, 58, 57]))
     q = lib.find_prime(bits, n, int(rng.integers(0, 4)))
     if q == 0:
         continue
@@ -66,6 +66,12 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         opts["two_phase"] = 1
         plan.set_option(lib.OPT_TWO_PHASE, 1)
+    if info["arith"] == lib.ARITH_U64 and (1 << 40) <= q and rng.random() < 0.5:
+        # the wide integer policy: on for plans that did not choose it, off for those that did, or a narrower class
+        best = 3 if q < (1 << 58) else (1 if q < (1 << 60) else 0)
+        opts["int_wide"] = int(rng.choice([0, 1] + [10 + c for c in (0, 1, 3) if c <= best]))
+        plan.set_option(lib.OPT_INT_WIDE, opts["int_wide"])
+        info = plan.info()
     if rng.random() < 0.2 and arith != lib.ARITH_U64_R4:
         opts["generic"] = 1
         plan.set_generic(1)
