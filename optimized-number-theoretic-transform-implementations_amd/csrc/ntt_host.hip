@@ -54,6 +54,12 @@ template <> hipError_t launch_dot<ArithF64, 1>(const DotArgs &);
 template <> hipError_t launch_dot<ArithF64, 18>(const DotArgs &);
 template <> hipError_t launch_dot<ArithF64W, 0>(const DotArgs &);
 template <> hipError_t launch_fwd_mul<ArithU64, 0>(const MulArgs &);
+template <> hipError_t launch_dot<ArithU64X<0>, 0>(const DotArgs &);
+template <> hipError_t launch_dot<ArithU64X<1>, 1>(const DotArgs &);
+template <> hipError_t launch_dot<ArithU64X<3>, 3>(const DotArgs &);
+template <> hipError_t launch_fwd_mul<ArithU64X<0>, 0>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithU64X<1>, 1>(const MulArgs &);
+template <> hipError_t launch_fwd_mul<ArithU64X<3>, 3>(const MulArgs &);
 template <> hipError_t launch_fwd_mul<ArithF64, 0>(const MulArgs &);
 template <> hipError_t launch_fwd_mul<ArithF64, 1>(const MulArgs &);
 template <> hipError_t launch_fwd_mul<ArithF64, 18>(const MulArgs &);
@@ -1331,7 +1337,14 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
 /* ------------------------------------------------------------------ */
 static hipError_t dispatch_dot(const ntt_plan *p, const DotArgs &da)
 {
-  if(p->arith == NTT_ARITH_U64) return launch_dot<ArithU64, 0>(da);
+  if(p->arith == NTT_ARITH_U64) {
+    switch(p->int_cls) { /* (same tables; the wide policy's stages around fast_mul_mod_q's products) */
+      case 3: return launch_dot<ArithU64X<3>, 3>(da);
+      case 1: return launch_dot<ArithU64X<1>, 1>(da);
+      case 0: return launch_dot<ArithU64X<0>, 0>(da);
+      default: return launch_dot<ArithU64, 0>(da);
+    }
+  }
   switch(p->kcls) {
     case kWideClass: return launch_dot<ArithF64W, 0>(da);
     case 18: return launch_dot<ArithF64, 18>(da);
@@ -1549,7 +1562,10 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     ma.max_grid      = p->max_grid;
     ma.num_cus       = p->num_cus;
     ma.stream        = (hipStream_t)stream;
-    hipError_t e = p->arith == NTT_ARITH_U64 ? launch_fwd_mul<ArithU64, 0>(ma)
+    hipError_t e = p->arith == NTT_ARITH_U64 ? (p->int_cls == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
+                                                : p->int_cls == 1 ? launch_fwd_mul<ArithU64X<1>, 1>(ma)
+                                                : p->int_cls == 0 ? launch_fwd_mul<ArithU64X<0>, 0>(ma)
+                                                                  : launch_fwd_mul<ArithU64, 0>(ma))
                    : p->kcls == kWideClass   ? launch_fwd_mul<ArithF64W, 0>(ma)
                    : p->kcls == 18           ? launch_fwd_mul<ArithF64, 18>(ma)
                    : p->kcls == 1            ? launch_fwd_mul<ArithF64, 1>(ma)

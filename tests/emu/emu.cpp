@@ -872,9 +872,10 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P11(KW) EMU_MUL(KW, ArithF64Chk, 1) EMU_MUL(KW, WideChk, 0)
 #  define P12(KW) EMU_RUN(KW, ArithU64XChk<0>, 0) EMU_RUN(KW, ArithU64XChk<1>, 1)
 #  define P13(KW) EMU_RUN(KW, ArithU64XChk<3>, 3)
+#  define P14(KW) EMU_DOT(KW, ArithU64XChk<3>, 3) EMU_DOT(KW, ArithU64XChk<0>, 0) EMU_MUL(KW, ArithU64XChk<3>, 3) EMU_MUL(KW, ArithU64XChk<0>, 0)
 #  if EMU_PART == 0
 P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern) P10(extern) P11(extern)
-P12(extern) P13(extern)
+P12(extern) P13(extern) P14(extern)
 #  elif EMU_PART == 1
 P1()
 #  elif EMU_PART == 2
@@ -901,6 +902,8 @@ P11()
 P12()
 #  elif EMU_PART == 13
 P13()
+#  elif EMU_PART == 14
+P14()
 #  endif
 #endif
 
@@ -953,8 +956,10 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
   return inverse ? emu_run<ArithU64XChk<KK>, true, KK>(a, batch, m, tab.data(), c, generic, wide)                \
                  : emu_run<ArithU64XChk<KK>, false, KK>(a, batch, m, tab.data(), c, generic, wide);
     if(ksh_force == 3) { EMU_U64X(3) }
+#ifndef EMU_SAN_BUILD /* (sanitizer build: one class keeps the instrumented compile short) */
     if(ksh_force == 1) { EMU_U64X(1) }
     if(ksh_force == 0) { EMU_U64X(0) }
+#endif
 #undef EMU_U64X
     return -3;
   }
@@ -1149,6 +1154,16 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
     const auto c = h_consts_u64(q, N, wi);
     return emu_dot_run<ArithU64, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
   }
+#ifndef EMU_SAN_BUILD
+  if(arith == 6) { /* the wide integer policy, checked: class 3 below 2^58, else class 0 */
+    if(q < (1ull << 40) || q >= (1ull << 61)) return -2;
+    std::vector<TwU64> tab(wix.size());
+    for(size_t i = 0; i < wix.size(); i++) tab[i] = h_tw_u64(wix[i], q);
+    const auto c = h_consts_u64(q, N, wi);
+    return q < (1ull << 58) ? emu_dot_run<ArithU64XChk<3>, 3>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0)
+                            : emu_dot_run<ArithU64XChk<0>, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
+  }
+#endif
   const bool wide = !h_f64_eligible(q);
   if(wide && !h_f64w_eligible(q)) return -2;
   std::vector<TwF64>  ti(wix.size());
@@ -1179,6 +1194,16 @@ int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, i
     const auto c = h_consts_u64(q, N, dummy);
     return emu_fwd_mul_run<ArithU64, 0>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
   }
+#ifndef EMU_SAN_BUILD
+  if(arith == 6) {
+    if(q < (1ull << 40) || q >= (1ull << 61)) return -2;
+    std::vector<TwU64> tab(w.size());
+    for(size_t i = 0; i < w.size(); i++) tab[i] = h_tw_u64(w[i], q);
+    const auto c = h_consts_u64(q, N, dummy);
+    return q < (1ull << 58) ? emu_fwd_mul_run<ArithU64XChk<3>, 3>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0)
+                            : emu_fwd_mul_run<ArithU64XChk<0>, 0>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
+  }
+#endif
   const bool wide = !h_f64_eligible(q);
   if(wide && !h_f64w_eligible(q)) return -2;
   std::vector<TwF64>  tf(w.size());

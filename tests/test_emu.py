@@ -589,3 +589,35 @@ def test_wide_integer_policy(oracle, emu, m, k, top):
                 assert maxb > 40, maxb        # the injection works: values do climb towards 4 + 4 * stages
         emu.set_u64x_worst(0)
     assert emu.transform(a, m, (1 << top) + 1, 3, 6, ksh=k)[0] == -2
+
+
+@pytest.mark.parametrize("m,top", [(6, 58), (12, 58), (14, 58), (14, 61), (15, 58), (16, 61)])
+def test_ntt_domain_products_wide_integer_policy(oracle, emu, m, top):
+    """dot_inv_kernel and fwd_mul_kernel with ArithU64X's stages around fast_mul_mod_q's products (class 3 below 2^58,
+    class 0 below 2^61), the checked policy with and without worst-case representatives: the inverse stages start from
+    canonical sums, the products at the forward transform's output take its unfolded values (any 64-bit word)"""
+    n = 1 << m
+    q = _prime_near(oracle, (1 << top) - 1, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    batch = 2 if m <= 14 else 1
+    a = _inputs(oracle, n, q, batch, 7300 + m)
+    fa = cx.fwd(a)
+    for worst in (0, 1):
+        emu.set_u64x_worst(worst)
+        emu.chk_stats(reset=True)
+        for k, lazy, bcast in ((1, False, False), (3, True, False), (5, False, True)):
+            a_list, b_list = _dot_operands(oracle, n, q, batch, k, 7400 + m, lazy, bcast)
+            rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=6, lazy=lazy, bcast=bcast)
+            assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q, n, bcast))), (m, hex(q), k, worst)
+        for lazy, bcast, acc in ((False, False, False), (True, False, True), (False, True, True)):
+            b = oracle.fill_uniform((1 if bcast else batch) * n, q, 7500 + m)
+            bw = b + (np.uint64(3 * q) if lazy else np.uint64(0))
+            c0 = oracle.fill_uniform(batch * n, q, 7600 + m)
+            exp = oracle.pointwise(fa, np.tile(b, batch) if bcast else b, q)
+            if acc:
+                exp = (exp + c0) % np.uint64(q)
+            rc, got = emu.fwd_mul(a, bw, m, q, w, arith=6, lazy=lazy, bcast=bcast, acc=c0 if acc else None)
+            assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc, worst)
+        assert emu.chk_stats()[0] == 0
+    emu.set_u64x_worst(0)
