@@ -90,6 +90,24 @@ int main()
       CHECK(emu_transform(got.data(), batch, cs.m, q, w, arith, 1, 0, 1, -1) == 0);
       CHECK(got == a);
     }
+    /* the wide integer policy (ArithU64X<3>, checked) for the 59-bit cases' sizes with a 57-bit modulus */
+    if(cs.q == 0) {
+      const uint64_t q57 = orc_find_prime(57, n, 0), w57 = orc_min_root(q57, n);
+      orc_ctx *      c57 = orc_ctx_new(n, q57, w57);
+      CHECK(c57 != nullptr);
+      std::vector<uint64_t> a57(batch * n), r57;
+      orc_fill_uniform(a57.data(), batch * n, q57, 0x57, cs.m);
+      r57 = a57;
+      orc_fwd_r2_batch(r57.data(), batch, c57);
+      for(int generic = 0; generic < 2; generic++) {
+        got = a57;
+        CHECK(emu_transform(got.data(), batch, cs.m, q57, w57, 6, 0, generic, 0, 3) == 0);
+        CHECK(got == r57);
+        CHECK(emu_transform(got.data(), batch, cs.m, q57, w57, 6, 1, generic, 0, 3) == 0);
+        CHECK(got == a57);
+      }
+      orc_ctx_free(c57);
+    }
     /* pointwise products, strict and lazy operands */
     std::vector<uint64_t> b(n), c(n), c2(n);
     orc_fill_uniform(b.data(), n, q, 0xb, 0);
