@@ -233,7 +233,7 @@ while time.time() < t_end:
         if m >= 15 and rng.random() < 0.5:
             nl, rb = int(rng.choice([2, 3, 4])), int(rng.choice([22, 33, 64, 70]))   # one XCD-local launch over the limbs
         if nl * rb * n <= max(args.max_coeffs, (1 << 25) if m >= 15 else 0):
-            rbits = int(rng.choice([45, 49, 50]))
+            rbits = int(rng.choice([45, 49, 50, 52, 57, 60]))    # (52: the reduce-as-scheduled FP64 policy; 57, 60: the wide integer policy)
             qs = [lib.find_prime(rbits, n, i) for i in range(nl)]
             if all(qs) and len(set(qs)) == nl:
                 ws = [lib.min_root(x, n) for x in qs]
