@@ -243,6 +243,19 @@ def test_full_size_config2_n4096(lib, oracle):
     _full_size_roundtrip(lib, oracle, 12, q, lib.min_root(q, 4096), 65536, [0, 1, 4095, 32768, 65535])
 
 
+@pytest.mark.parametrize("m,bits,batch", [(14, 57, 32768), (14, 61, 16384), (16, 59, 4096)])
+def test_full_size_integer_moduli(lib, oracle, m, bits, batch):
+    """config-4- and config-3-shaped slabs (4 GiB / 2 GiB) with moduli the FP64 policies cannot serve: the wide integer policy's
+    three headroom classes at full persistent grids -- sampled polynomials against the oracle, every polynomial's round trip by
+    checksum"""
+    n = 1 << m
+    q = lib.find_prime(bits, n)
+    p = lib.Plan(n, q, lib.min_root(q, n))
+    assert p.info()["f64_class"] == 100 + (3 if bits <= 58 else (1 if bits <= 60 else 0))
+    p.destroy()
+    _full_size_roundtrip(lib, oracle, m, q, lib.min_root(q, n), batch, [0, 1, batch // 2 + 1, batch - 1])
+
+
 def test_full_size_config3_n65536(lib, oracle, kat):
     """BASELINE config 3: N=65536, 51-bit q (reference case 17), batch=8192, fwd+inv round trip"""
     c = kat["cases"][17]
