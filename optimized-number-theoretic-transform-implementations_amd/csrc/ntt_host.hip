@@ -1233,13 +1233,19 @@ static int rns_check(int nlimbs, ntt_plan *const *plans)
 /* One launch chain for all limbs (SURVEY 8e "split primes"): possible when the limbs' plans agree in
  * everything a launch is shaped by -- size, device, arithmetic policy and headroom class (one kernel instantiation serves
  * every limb), and the plan options.  Primes of the same bit size always do.  Otherwise the limbs are looped. */
+/* plans whose kernels have MULTI variants (several limbs per launch): the FP64 policies and the wide integer policy */
+static bool multi_limb_plan(const ntt_plan *p)
+{
+  return p->arith == NTT_ARITH_F64 || (p->arith == NTT_ARITH_U64 && p->int_cls >= 0 && !p->generic);
+}
+
 static bool rns_uniform(int nlimbs, ntt_plan *const *plans)
 {
   const ntt_plan *a = plans[0];
-  if(a->arith != NTT_ARITH_F64) return false; /* the MULTI kernel variants are built for the FP64 policies */
+  if(!multi_limb_plan(a)) return false;
   for(int l = 1; l < nlimbs; l++) {
     const ntt_plan *b = plans[l];
-    if(b->arith != a->arith || b->kcls != a->kcls || b->m != a->m || b->generic != a->generic || b->block_log != a->block_log ||
+    if(b->arith != a->arith || b->kcls != a->kcls || b->int_cls != a->int_cls || b->m != a->m || b->generic != a->generic || b->block_log != a->block_log ||
        b->chunk_mib != a->chunk_mib || b->two_phase != a->two_phase || b->fused_product != a->fused_product ||
        b->max_grid != a->max_grid || b->has_fwd != a->has_fwd || b->has_inv != a->has_inv) {
       return false;
@@ -1309,6 +1315,10 @@ extern "C" int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d
   return rns_transform(nlimbs, plans, d_a, batch, true, stream);
 }
 
+static bool dot_kernel_applies(const ntt_plan *p);
+static int  inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch,
+                    unsigned flags, void *stream, const LimbSet *set, uint64_t b_limb_stride);
+
 extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
                                             uint64_t *d_b, uint64_t batch, void *stream)
 {
@@ -1322,6 +1332,22 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
       const LimbSet  ls{recs.data(), n, batch * plans[0]->N};
       const uint64_t off = (uint64_t)first * batch * plans[0]->N;
       rc                 = fused_product(plans[first], d_c + off, d_a + off, d_b + off, batch, stream, &ls);
+    }
+    return rc;
+  }
+  if(rns_uniform(nlimbs, plans) && plans[0]->arith == NTT_ARITH_U64 && dot_kernel_applies(plans[0]) && plans[0]->has_fwd &&
+     plans[0]->has_inv && d_a && d_b && d_c && rns_one_launch_pays(plans[0], batch)) {
+    /* limbs of the wide integer policy: both forward transforms (lazy words, in place -- the operands are scratch on this path
+     * as they are for a single plan) and the products inside the inverse transform's first pass, each ONE launch over all limbs */
+    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
+      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet  ls{recs.data(), n, batch * plans[0]->N};
+      const uint64_t off = (uint64_t)first * batch * plans[0]->N;
+      rc                 = run_transform(plans[first], d_a + off, batch, false, false, stream, true, &ls);
+      if(!rc && d_b != d_a) rc = run_transform(plans[first], d_b + off, batch, false, false, stream, true, &ls);
+      const uint64_t *pa = d_a + off, *pb = d_b + off;
+      if(!rc) rc = inv_dot(plans[first], d_c + off, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, &ls, ls.stride);
     }
     return rc;
   }
@@ -1379,8 +1405,8 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
   const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0, bcast = (flags & NTT_MUL_B_BROADCAST) != 0;
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   USE_DEVICE(p->device);
-  if(!dot_kernel_applies(p) || (ls.n > 1 && p->arith != NTT_ARITH_F64)) {
-    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
+  if(!dot_kernel_applies(p) || (ls.n > 1 && !multi_limb_plan(p))) {
+    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
     const uint64_t n  = batch * p->N;
     const dim3     g(grid_for(n)), t(256);
     hipStream_t    st = (hipStream_t)stream;
@@ -1477,8 +1503,18 @@ static int mul_transformed(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, cons
   if(fused_product_applies(p, d_c, d_bhat, d_a, batch)) {
     return fused_product(p, d_c, const_cast<uint64_t *>(d_bhat), d_a, batch, stream, set, true);
   }
-  if(set && set->n > 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
   const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0;
+  if(set && set->n > 1) {
+    /* a limb set of the wide integer policy: a's forward transform over the set (lazy words), then the products inside the
+     * inverse transform's first pass (dot_inv_kernel) -- two launches for all limbs */
+    if(!multi_limb_plan(p) || !dot_kernel_applies(p)) {
+      return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
+    }
+    int rcs = run_transform(p, d_a, batch, false, false, stream, true, set);
+    const uint64_t *pa = d_a;
+    if(!rcs) rcs = inv_dot(p, d_c, 1, &pa, &d_bhat, batch, NTT_MUL_LAZY_IN, stream, set, set->stride);
+    return rcs;
+  }
   int rc = p->arith == NTT_ARITH_U64_R4 ? ntt_fwd_batch(p, d_a, batch, stream) : ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc) rc = pointwise_launch(p, d_c, d_a, d_bhat, batch, stream, lazy || p->arith != NTT_ARITH_U64_R4);
   if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
@@ -1506,8 +1542,8 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
   if(acc && d_c == d_a) return fail(NTT_ERR_ARG, "an accumulator cannot alias the coefficient operand");
   const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
   USE_DEVICE(p->device);
-  if(!dot_kernel_applies(p) || (ls.n > 1 && p->arith != NTT_ARITH_F64)) {
-    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies");
+  if(!dot_kernel_applies(p) || (ls.n > 1 && !multi_limb_plan(p))) {
+    if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
     int rc = run_transform(p, d_a, batch, false, false, stream);
     if(rc) return rc;
     const uint64_t n  = batch * p->N;
@@ -1642,7 +1678,11 @@ extern "C" int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans,
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
   const uint64_t slab = batch * plans[0]->N;
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && fused_product_applies(plans[0], d_c, d_bhat, d_a, batch)) {
+  /* one launch over the limbs: the fused product kernels (FP64 policies), or -- limbs of the wide integer policy -- the forward
+   * transform and the products-inside-the-inverse launch, each over the whole set */
+  const bool int_set = plans[0]->arith == NTT_ARITH_U64 && dot_kernel_applies(plans[0]) && d_a != d_bhat && d_a && d_bhat && d_c;
+  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) &&
+     (fused_product_applies(plans[0], d_c, d_bhat, d_a, batch) || int_set)) {
     for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
       const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
       const std::vector<unsigned char> recs = rns_records(plans, first, n);

@@ -2264,8 +2264,9 @@ template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
  * policy ignores the run-time flag (its passes exchange canonical words). */
 inline int pass_lazy(const PassArgs &pa) { return pa.ends ? pa.lazy : 1; }
 
-/* the MULTI kernel variants exist for the scheduled FP64 policy and its 52-bit form */
-template <class A> constexpr bool multi_limb_built() { return A::kCompact; }
+/* the MULTI kernel variants exist for the scheduled FP64 policy, its 52-bit form and the wide integer policy (RNS bases of
+ * 54..60-bit primes: a ciphertext is a few polynomials x tens of such limbs -- one launch instead of one chain per prime) */
+template <class A> constexpr bool multi_limb_built() { return A::kCompact || A::kIntWide; }
 
 template <class A> KArgs<A> make_kargs(const PassArgs &pa)
 {
@@ -2333,9 +2334,13 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
         } else {
           return hipErrorInvalidValue;
         }
-      } else if(pa.ends && pa.lazy) {
-        hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true, true>), grid, wg, 0, pa.stream, p);
       } else {
+        if constexpr(A::kTracksBounds) { /* (lazy outputs: a kernel variant for the FP64 policies, a run-time flag for the integer ones) */
+          if(pa.ends && pa.lazy) {
+            hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, true, true>), grid, wg, 0, pa.stream, p);
+            return hipGetLastError();
+          }
+        }
         hipLaunchKernelGGL((fused_kernel<A, LOGN, false, KSH, false, false, true>), grid, wg, 0, pa.stream, p);
       }
       return hipGetLastError();

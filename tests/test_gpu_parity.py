@@ -429,8 +429,20 @@ def test_rns_one_launch_over_all_limbs(lib, oracle, logn, nlimbs, batch, monkeyp
     (kernel variants MULTI: the workgroup picks its limb's tables and constants from an array in the kernel arguments).
     Every limb of every polynomial against the oracle; the same calls with NTT_RNS_LOOP=1 (one launch chain per prime,
     the single-set kernels) must give the same words."""
+    _rns_one_launch_check(lib, oracle, monkeypatch, logn, nlimbs, batch, 50)
+
+
+@pytest.mark.parametrize("logn,nlimbs,batch,bits", [(14, 4, 2, 57), (12, 16, 1, 60), (16, 3, 2, 57), (13, 5, 3, 61), (8, 4, 9, 58)])
+def test_rns_one_launch_over_integer_limbs(lib, oracle, logn, nlimbs, batch, bits, monkeypatch):
+    """the same for limbs the FP64 policies cannot serve (54..60-bit primes, the sizes FHE libraries default to): the wide
+    integer policy's kernels have MULTI variants too, and the product of such a set is three launches (both forward
+    transforms, the products inside the inverse's first pass) instead of four per prime"""
+    _rns_one_launch_check(lib, oracle, monkeypatch, logn, nlimbs, batch, bits)
+
+
+def _rns_one_launch_check(lib, oracle, monkeypatch, logn, nlimbs, batch, bits):
     n = 1 << logn
-    qs = [lib.find_prime(50, n, k) for k in range(nlimbs)]
+    qs = [lib.find_prime(bits, n, k) for k in range(nlimbs)]
     assert len(set(qs)) == nlimbs
     roots = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
@@ -1651,9 +1663,19 @@ def test_mul_by_a_transformed_operand(lib, oracle, m, bits):
 def test_rns_products_in_the_ntt_domain(lib, oracle, logn, batch, monkeypatch):
     """the NTT-domain products over RNS limbs ([limb][batch][N]; a broadcast key: [limb][N]): one launch over the limbs
     when a limb's share cannot fill the chip, limb by limb otherwise -- both forms forced in turn, against the oracle"""
+    _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, 50)
+
+
+@pytest.mark.parametrize("logn,batch,bits", [(12, 2, 57), (14, 1, 60), (16, 2, 57), (14, 3, 61)])
+def test_rns_products_in_the_ntt_domain_integer_limbs(lib, oracle, logn, batch, bits, monkeypatch):
+    """... and over limbs of the wide integer policy"""
+    _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits)
+
+
+def _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits):
     n = 1 << logn
     nl, k = 4, 3
-    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    qs = [lib.find_prime(bits, n, i) for i in range(nl)]
     ws = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
     slab = batch * n
