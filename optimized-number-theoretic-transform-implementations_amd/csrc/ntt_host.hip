@@ -1195,6 +1195,10 @@ static bool fused_product_applies(const ntt_plan *p, const uint64_t *d_c, const 
          p->has_inv && d_a != d_b && d_a && d_b && d_c && batch;
 }
 
+static bool dot_kernel_applies(const ntt_plan *p);
+static int  inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch,
+                    unsigned flags, void *stream, const LimbSet *set, uint64_t b_limb_stride);
+
 extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
                                         uint64_t batch, void *stream)
 {
@@ -1214,6 +1218,12 @@ extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64
   if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c, d_a, d_b, batch, stream);
   int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
   if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);
+  if(!rc && p && dot_kernel_applies(p) && p->has_inv && d_c) {
+    /* the products inside the inverse transform's first pass (dot_inv_kernel): 24N bytes instead of 40N for the last two
+     * steps -- the integer policies (no one-launch product kernel), squarings, plans with the fused product switched off */
+    const uint64_t *pa = d_a, *pb = d_b;
+    return inv_dot(p, d_c, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, nullptr, 0);
+  }
   if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
   if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
   return rc;
@@ -1314,10 +1324,6 @@ extern "C" int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d
 {
   return rns_transform(nlimbs, plans, d_a, batch, true, stream);
 }
-
-static bool dot_kernel_applies(const ntt_plan *p);
-static int  inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch,
-                    unsigned flags, void *stream, const LimbSet *set, uint64_t b_limb_stride);
 
 extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
                                             uint64_t *d_b, uint64_t batch, void *stream)
