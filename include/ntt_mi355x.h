@@ -94,8 +94,9 @@ typedef enum ntt_option {
                           * three intermediates and the twiddles: the L2 retains nothing at that size) against 56N algorithmic;
                           * smaller batches of N >= 2^15: block by block between the column passes of both operands, 72N
                           * bytes); 2 = a's forward transform always as a launch of its own in front of the fused
-                          * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14); 0 = fwd, fwd, pointwise, inv (72N / 120N
-                          * bytes).  Results are identical. */
+                          * fwd(b)*a^ -> inverse kernel (40N bytes up to 2^14); 0 = fwd, fwd, then the products inside the inverse's
+                          * first pass (three launches, 56N bytes up to 2^14: what plans of the integer policies and squarings
+                          * always take).  Results are identical. */
 } ntt_option;
 
 typedef struct ntt_plan ntt_plan; /* opaque: tables for one (device, N, q, root) */
@@ -157,11 +158,12 @@ NTT_API int ntt_pointwise_mul_batch(const ntt_plan *p, uint64_t *d_c, const uint
 NTT_API int ntt_pointwise_mul_batch_lazy(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a,
                                          const uint64_t *d_b, uint64_t batch, void *stream);
 /* c = a*b in Z_q[X]/(X^N+1) for every polynomial of the batch:
- * fwd(a), fwd(b), pointwise, inv -- the chain stays in the lazy domain until the inverse's output.
+ * ONE launch (FP64 policies, NTT_OPT_FUSED_PRODUCT), else fwd(a), fwd(b) and the products inside the inverse transform's first
+ * pass -- the chain stays in the lazy domain until the inverse's output.
  * d_a is overwritten (left in the NTT domain as LAZY values in [0,4q), congruent to the reference's
  * transform -- or, large batches of N >= 2^15, holding only the column stages of it -- or, the one-launch form up to
  * 2^14, not written at all); d_b is overwritten likewise
- * (four-launch chain), overwritten by the column passes of its forward transform
+ * (three-launch chain), overwritten by the column passes of its forward transform
  * (fused product, N = 2^15 .. 2^17) or left as it was (fused product, N = 2^8 .. 2^14); callers must not rely on any of these.  Aliasing rules: d_c may alias d_a or d_b; d_a == d_b computes the square
  * a*a (the shared operand is transformed once); any other overlap is undefined.
  * NTT_ARITH_U64_R4 plans run the reference's radix-4 formulation end to end (fwd_ntt_radix4 on both operands, the
