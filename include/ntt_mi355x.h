@@ -72,13 +72,14 @@ typedef enum ntt_option {
   NTT_OPT_BLOCK_LOG = 6, /* N = 2^15, 2^16: log2 of the blocks the fused pass works on below the column pass: 12
                           * (3 or 4 column stages), 14 (1 or 2), 0 (default) = the faster one as measured.  Results
                           * are identical. */
-  NTT_OPT_XCD_LOCAL = 7,  /* N = 2^15..2^17 (FP64): 1 = both passes of a transform as items of ONE launch, every polynomial
+  NTT_OPT_XCD_LOCAL = 7,  /* N = 2^15..2^17 (FP64 policies; wide integer policy): 1 = both passes of a transform as items of ONE launch, every polynomial
                            * handled by the workgroups of one XCD, the intermediate handed over inside that XCD (MEASURED
                            * fabric traffic per transform, FETCH x2 + WRITE counters: 24N bytes at 2^15, where the L2 retains
                            * the intermediate at the shipped lag; 32N at 2^16 and 2^17, where it does not and the second pass is
                            * served by the Infinity Cache -- the gain there is one launch instead of two per chunk);
                            * 0 = one launch per pass; -1 (default) = where it measured faster: forward transforms of 512
-                           * polynomials or more.  Results are identical. */
+                           * polynomials or more (wide integer policy: +18..23 %, where the memory-bound column items overlap the
+                           * multiplier-bound row items; also its inverse at 2^17).  Results are identical. */
   NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: 10, 8, 10 at 2^15, 2^16, 2^17) */
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_INT_WIDE = 10, /* integer policy, 2^40 <= q < 2^61: 1 = transforms through the throughput form of the integer

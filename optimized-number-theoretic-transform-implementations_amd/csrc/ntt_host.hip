@@ -589,7 +589,8 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
    * transforms of 512 polynomials or more) or the two-phase kernel where it is forced -- else the pass list's length */
   {
     const bool f64big = !p->generic && p->arith == NTT_ARITH_F64;
-    const bool team   = f64big && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && p->xcd_local != 0;
+    const bool team   = (f64big || (!p->generic && p->arith == NTT_ARITH_U64 && p->int_cls >= 0)) && p->m >= kTeamBlock + 3 &&
+                      p->m <= kTeamBlock + 5 && p->xcd_local != 0;
     const bool tp     = f64big && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3 &&
                     (p->two_phase == 1 || (p->two_phase < 0 && p->m == kFusedMax + 2 && p->kcls != kWideClass));
     info[5] = (team || tp) ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
@@ -723,13 +724,18 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
 {
   if(nlimbs < 1 || nlimbs > kMaxLimbs) return false;
   batch *= (uint64_t)nlimbs; /* polynomials of the launch */
-  if(p->arith != NTT_ARITH_F64 || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy || batch < 64 ||
-     batch >= (1ull << 29)) {
+  /* the FP64 policies; transforms (not the product launch) also for the wide integer policy */
+  const bool int_wide = p->arith == NTT_ARITH_U64 && p->int_cls >= 0 && !product;
+  if((p->arith != NTT_ARITH_F64 && !int_wide) || p->generic || p->m < kTeamBlock + 3 || p->m > kTeamBlock + 5 || wide || lazy ||
+     batch < 64 || batch >= (1ull << 29)) {
     return false;
   }
   int on = p->xcd_local;
   if(on < 0) on = env_int("NTT_XCD_LOCAL", -1);
   if(on >= 0) return on == 1;
+  /* the wide integer policy (profiles/r04/ab_xcd_int.txt): forward +18..23 % at all three sizes; inverse +15 % at 2^17, none at
+   * 2^16, -14 % at 2^15 */
+  if(int_wide) return batch >= 512 && (!inverse || p->m == kTeamBlock + 5);
   /* the product launch (all transforms of a product as items of one launch) pays from 2^23 coefficients per operand on:
    * 64 / 128 / 256 polynomials at 2^17 / 2^16 / 2^15 (measured against the per-chunk launches, single limb, batches
    * 64..384: profiles/r03/ablations.txt (h)) */

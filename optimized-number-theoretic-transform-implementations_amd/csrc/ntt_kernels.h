@@ -1123,13 +1123,57 @@ __device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, 
   buffer_store_first_raw<LOGN, STAUX>(out, tid, base);
 }
 
+/* the row items of a policy without compact twiddles and LDS tables (the wide integer policy): the block body of
+ * fused_kernel's plain loop -- 16-byte records through the scalar cache and the L1/L2, which the whole batch shares -- with
+ * the cache policies of the items above (the launch's memory-order invariant does not depend on the arithmetic) */
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_row_item_fwd_plain(uint64_t *base, uint32_t blk, uint32_t tid, const Params<A> &p, typename A::val *lds)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, false, KSH>();
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX>(raw, tid, base);
+  typename A::val x[kE];
+  convert_inputs<A, false>(x, raw, false, p.c);
+  run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = decltype(gg)::value;
+    exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+    run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+  });
+  store_last_whole_lines<A, LOGN, false, STAUX>(x, tid, base, p.c, p.lazy != 0);
+}
+template <class A, int KSH, int LDAUX, int STAUX>
+__device__ __forceinline__ void team_row_item_inv_plain(uint64_t *base, uint32_t blk, uint32_t tid, const Params<A> &p, typename A::val *lds,
+                                                        bool mid_lazy)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>(); /* not the pass that ends the transform */
+  uint64_t raw[kE];
+  prefetch_last<LOGN, LDAUX>(raw, tid, base);
+  typename A::val x[kE];
+  convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
+  run_group<A, LOGN, P::NG - 1, true, MASK>(x, tid, blk, p);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = out_word<A, true, false>(x[decltype(ee)::value], mid_lazy, p.c); });
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, base);
+}
+
 template <class A, int LEAD, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
 {
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, INV, flavor_of<A>()>;
-  static_assert(A::kCompact && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5, "built for the FP64 policies on 2^12-point blocks, N = 2^15..2^17");
+  static_assert((A::kCompact || A::kIntWide) && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5,
+                "built for the FP64 policies and the wide integer policy on 2^12-point blocks, N = 2^15..2^17");
   __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
   __shared__ unsigned        s_k, s_k2[2];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
@@ -1220,7 +1264,11 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
         /* (inverse inputs arrive as 16-byte loads in runs of four coefficients per lane: two instructions share every 128-byte
          * line, so these loads must be allowed to hit the L2 -- nt; with the cache-bypassing policy of the forward
          * inputs every line crossed the fabric twice) */
-        if constexpr(INV) team_row_item_inv<A, KSH, kAuxNt, 0>(base, item, tid, p, lds, tabl, MID_LAZY);
+        if constexpr(!A::kCompact) {
+          (void)tabl;
+          if constexpr(INV) team_row_item_inv_plain<A, KSH, kAuxNt, 0>(base, item, tid, p, lds, MID_LAZY);
+          else team_row_item_fwd_plain<A, KSH, kAuxNt, kAuxSc1>(base, item, tid, p, lds);
+        } else if constexpr(INV) team_row_item_inv<A, KSH, kAuxNt, 0>(base, item, tid, p, lds, tabl, MID_LAZY);
         else team_row_item_fwd<A, KSH, kAuxNt, kAuxSc1>(base, item, tid, p, lds, tabl);
       }
       if(!second) {
@@ -2404,13 +2452,14 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
  * zeroed here.  Several limbs (an RNS set, [limb][batch][N]): the MULTI variant, the queues run over all limbs' polynomials. */
 template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const PassArgs &pa)
 {
-  if constexpr(!A::kCompact) {
+  if constexpr(!(A::kCompact || A::kIntWide)) {
     return hipErrorNotSupported;
   } else {
     const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
     if(nl > (uint64_t)kMaxLimbs || !pa.team_ctl || pa.wide || pa.lazy || nl * pa.batch >= (1ull << 31)) return hipErrorNotSupported;
     KTeam<A> kt{};
     kt.k         = make_kargs<A>(pa);
+    kt.k.lazy    = 0; /* canonical out (the integer policies read this flag at run time) */
     kt.k.lastinv = (uint32_t)pa.inverse;
     kt.k.nblocks = pa.batch;
     kt.ctl       = static_cast<TeamCtl *>(pa.team_ctl);

@@ -322,15 +322,27 @@ def test_xcd_local_two_pass_kernel(lib, oracle, m, bits):
     workgroups of one XCD (per-XCD queues, per-polynomial hand-off counters, intermediate kept in that XCD's L2).
     Forward and inverse against the oracle on every polynomial, for batches that leave queues ragged (batch mod 8 != 0),
     for every lag / residency setting, and word for word against the one-launch-per-pass path."""
+    _xcd_local_check(lib, oracle, m, bits, lib.ARITH_F64, ((64, 0, 0), (67, 1, 1), (100, 2, 3), (131, 9, 2), (77, 3, 4)))
+
+
+@pytest.mark.parametrize("m,bits", [(15, 57), (16, 60), (17, 57), (16, 61)])
+def test_xcd_local_two_pass_kernel_integer_moduli(lib, oracle, m, bits):
+    """the same launch with the wide integer policy's row and column items (moduli of 2^52 and more, N = 2^15..2^17: the
+    sizes and primes of bootstrappable CKKS parameter sets): words between the passes are lazy, the queue protocol and the
+    cache policies are the FP64 launch's"""
+    _xcd_local_check(lib, oracle, m, bits, lib.ARITH_AUTO, ((64, 0, 0), (67, 1, 1), (131, 9, 2), (77, 3, 4)))
+
+
+def _xcd_local_check(lib, oracle, m, bits, arith, settings):
     n = 1 << m
     q = lib.find_prime(bits, n, 1)
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
-    plan = lib.Plan(n, q, w, arith=lib.ARITH_F64)
-    ref = lib.Plan(n, q, w, arith=lib.ARITH_F64)
+    plan = lib.Plan(n, q, w, arith=arith)
+    ref = lib.Plan(n, q, w, arith=arith)
     ref.set_option(lib.OPT_XCD_LOCAL, 0)
     plan.set_option(lib.OPT_XCD_LOCAL, 1)
-    for batch, lag, wpc in ((64, 0, 0), (67, 1, 1), (100, 2, 3), (131, 9, 2), (77, 3, 4)):
+    for batch, lag, wpc in settings:
         plan.set_option(lib.OPT_XCD_LOCAL_LAG, lag)
         plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, wpc)
         a = _inputs(oracle, n, q, batch, 1200 + batch)
@@ -1731,14 +1743,15 @@ def _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits):
         p.destroy()
 
 
-@pytest.mark.parametrize("m,nl,batch", [(15, 4, 70), (16, 3, 64), (17, 4, 33), (16, 16, 9)])
-def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, monkeypatch):
+@pytest.mark.parametrize("m,nl,batch,bits", [(15, 4, 70, 50), (16, 3, 64, 50), (17, 4, 33, 50), (16, 16, 9, 50), (16, 3, 64, 57), (17, 4, 33, 60)])
+def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, bits, monkeypatch):
     """N = 2^15..2^17: the XCD-local launches take the limb as part of the queue entry, so a whole RNS set -- forward
     transforms, the product (both forms: both operands in coefficients; one operand transformed beforehand) -- is ONE launch
     over all limbs' polynomials.  Word for word the per-limb launches (NTT_RNS_LOOP=1), samples against the oracle; ragged
-    per-limb batches (the queues run over limb * batch + polynomial)."""
+    per-limb batches (the queues run over limb * batch + polynomial).  57- / 60-bit limbs: the wide integer policy's transforms
+    take the same launch (its products are forward transforms + the products inside the inverse)."""
     n = 1 << m
-    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    qs = [lib.find_prime(bits, n, i) for i in range(nl)]
     ws = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
     for p in plans:
