@@ -713,10 +713,11 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
   }
 }
 
-/* XCD-local two-pass launches: FP64 policies, N = 2^15..2^17, plain calls (canonical in, canonical out).
- * Automatic choice (-1), as measured (profiles/r03/sweep_xcd_local.txt): the FORWARD transform of a batch that keeps all
- * eight queues busy for several lags (+8..14 % over one launch per pass); the inverse does not gain (its first pass is
- * the heavy one: the column items wait longer than the L2 can hold their polynomials) and keeps the per-pass launches.
+/* XCD-local two-pass launches: FP64 policies and the wide integer policy, N = 2^15..2^17, plain calls (canonical in,
+ * canonical out).  Automatic choice (-1), as measured (profiles/r03/sweep_xcd_local.txt, profiles/r04/ab_xcd_*.txt): the
+ * FORWARD transform of a batch that keeps all eight queues busy for several lags (+8..14 % over one launch per pass; wide
+ * integer policy +18..23 %); the inverse only at 2^17 (+3..5 %, integer +15 %) -- at 2^15 and 2^16 its first pass is the
+ * heavy one and the column items wait longer than the L2 can hold their polynomials: per-pass launches there.
  * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it; NTT_XCD_LOCAL in the
  * environment overrides the automatic choice the same way. */
 /* nlimbs > 1: the limbs of an RNS set in ONE launch (the queues run over all limbs' polynomials): `batch` is per limb */
@@ -736,6 +737,8 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
   /* the wide integer policy (profiles/r04/ab_xcd_int.txt): forward +18..23 % at all three sizes; inverse +15 % at 2^17, none at
    * 2^16, -14 % at 2^15 */
   if(int_wide) return batch >= 512 && (!inverse || p->m == kTeamBlock + 5);
+  /* FP64 inverse (profiles/r04/ab_xcd_f64_inv.txt): slower at 2^15 and 2^16 (-21 %, -12 %), +2.6..5.5 % at 2^17 */
+  if(inverse) return p->m == kTeamBlock + 5 && batch >= 512;
   /* the product launch (all transforms of a product as items of one launch) pays from 2^23 coefficients per operand on:
    * 64 / 128 / 256 polynomials at 2^17 / 2^16 / 2^15 (measured against the per-chunk launches, single limb, batches
    * 64..384: profiles/r03/ablations.txt (h)) */
