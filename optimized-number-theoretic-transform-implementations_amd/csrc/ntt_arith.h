@@ -72,6 +72,9 @@ struct ArithU64 {
     TwU64    wninv; /* N^-1 * winv[1] merged (ntt_reference.c:55-61) */
     TwU64    r64;   /* 2^64 mod q and its precon (pointwise product)  */
     TwU64    one;   /* {1, floor(2^64/q)}: Shoup form of "t mod q"    */
+    uint64_t bmu;   /* floor(2^(64+bsh) / q): Barrett quotient of a 128-bit product (ArithU64X) */
+    uint32_t bsh;   /* bit length of q, minus 1 */
+    uint32_t pad_;
   };
   /* value-range bookkeeping is static for this policy: [0,4q) fwd, [0,2q) inv */
   static constexpr bool kTracksBounds = false;
@@ -364,6 +367,52 @@ template <int K> struct ArithU64X : ArithU64 {
   }
   static NTT_HD uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return csub(csub(v, c.q2), c.q & keep); }
   static NTT_HD val      scale_ninv(val v, const consts &c) { return shoup_est(c.ninv, v, c); }
+
+  /* ---- products of two stored words (dot_inv_kernel, fwd_mul_kernel): one Barrett reduction of the 128-bit product ----
+   * ArithU64's fast_mul_mod_q form folds hi * 2^64 + lo with two Shoup products (27 32-bit multiplies per product); here
+   *   x = a b = hi:lo < 2^(64+bsh),  q1 = floor(x / 2^bsh) < 2^64,  q3 = hi64(q1 * bmu),  r = lo - q3 q   (11 multiplies)
+   * with bmu = floor(2^(64+bsh) / q): q1 bmu / 2^64 <= x/q, and > (x/2^bsh - 1)(2^(64+bsh)/q - 1)/2^64 > x/q - 2 (x < 2^(64+bsh),
+   * 2^bsh < q), one more for the floor: x/q - 3 < q3 <= x/q, so r lies in [0,3q).  Operand ranges: canonical words (a b < q^2
+   * < 2^(2 bsh + 2)) always fit; lazy words below 4q fit as they are for K = 3 (16 q^2 < 2^(2 bsh + 6), bsh <= 57), after
+   * one / two conditional subtractions for K = 1 / K = 0.  The running sum of an inner product is NOT reduced per term:
+   * it is folded by reduce_any every kDotEvery terms (2.01 + 3 * 20 < 64, 2.01 + 3 * 4 < 16, 2.01 + 3 < 8) and at the end,
+   * which leaves a valid input of the inverse stages (< 4q; a single term, < 3q, is one as it is). */
+  static NTT_HD void mul128(uint64_t a, uint64_t b, uint64_t &hi, uint64_t &lo)
+  {
+    const uint64_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
+    const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+    const uint64_t mid = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+    lo                 = (uint32_t)p00 | (mid << 32);
+    hi                 = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+  }
+  static NTT_HD uint64_t barrett(uint64_t hi, uint64_t lo, const consts &c)
+  {
+    const uint64_t q1 = (hi << (64u - c.bsh)) | (lo >> c.bsh); /* bsh in [39,60]: the policy serves 2^40 <= q < 2^61 */
+    return lo - mulhi64(q1, c.bmu) * c.q;
+  }
+  static constexpr int kDotEvery = K == 3 ? 20 : (K == 1 ? 4 : 1);
+  static constexpr int kDotChunk = 2;
+  template <bool LAZY> static NTT_HD val dot_term(uint64_t a, uint64_t b, const consts &c)
+  {
+    if(LAZY && K <= 1) b = csub(b, c.q2);
+    if(LAZY && K == 0) a = csub(a, c.q2);
+    uint64_t hi, lo;
+    mul128(a, b, hi, lo);
+    return barrett(hi, lo, c);
+  }
+  static NTT_HD val dot_acc(val acc, val t, const consts &) { return acc + t; }
+  static NTT_HD val dot_fold(val acc, const consts &c) { return reduce_any(acc, c); }
+  /* product at the output of a forward transform: x (anything below B q) is brought below 2.01 q first */
+  template <bool LAZY> static NTT_HD val mul_out(val x, uint64_t b, const consts &c)
+  {
+    if(LAZY && K <= 1) b = csub(b, c.q2);
+    if(LAZY && K == 0) b = csub(b, c.q);
+    uint64_t hi, lo;
+    mul128(reduce_any(x, c), b, hi, lo);
+    return barrett(hi, lo, c);
+  }
+  static NTT_HD uint64_t mul_store(val r, const consts &c) { return csub(csub(r, c.q2), c.q); }
+  static NTT_HD uint64_t mul_store_acc(val r, uint64_t acc, const consts &c) { return csub(csub(r + acc, c.q2), c.q); }
 };
 
 /* ------------------------------------------------------------------ */

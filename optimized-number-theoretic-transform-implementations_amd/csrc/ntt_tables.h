@@ -128,6 +128,11 @@ inline ArithU64::consts h_consts_u64(uint64_t q, uint64_t N, const std::vector<u
   c.wninv           = h_tw_u64(mw, q);
   c.r64             = h_tw_u64((uint64_t)((((u128)1) << 64) % q), q);
   c.one             = h_tw_u64(1 % q, q);
+  /* Barrett constants of ArithU64X's products: bsh = bit length of q - 1, bmu = floor(2^(64+bsh) / q) (< 2^64: q > 2^bsh) */
+  unsigned n = 0;
+  while((q >> n) != 0) n++;
+  c.bsh = n - 1;
+  c.bmu = (uint64_t)((((u128)1) << (64 + c.bsh)) / q);
   return c;
 }
 

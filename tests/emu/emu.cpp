@@ -327,6 +327,50 @@ template <int K> struct ArithU64XChk : ArithU64X<K> {
   static uint64_t store_fwd_sel(val v, const consts &c, uint64_t keep) { return keep ? store_fwd(v, c) : store_fwd_lazy(v, c); }
   static uint64_t store_inv_sel(val v, const consts &c, uint64_t keep) { return keep ? store_inv(v, c) : store_inv_lazy(v, c); }
   static val      scale_ninv(val v, const consts &c) { return shoup_est(c.ninv, v, c); }
+  /* products of stored words: the Barrett form's preconditions and range claim */
+  static uint64_t barrett_chk(uint64_t a, uint64_t b, const consts &c)
+  {
+    const u128 x = (u128)a * b;
+    if((x >> (64 + c.bsh)) != 0) g_chk_fail++; /* q1 must fit 64 bits */
+    uint64_t hi, lo;
+    Base::mul128(a, b, hi, lo);
+    if(hi != (uint64_t)(x >> 64) || lo != (uint64_t)x) g_chk_fail++;
+    uint64_t r = Base::barrett(hi, lo, c);
+    if(r >= 3 * c.q || r % c.q != (uint64_t)(x % c.q)) g_chk_fail++;
+    if(g_u64x_worst) r += (3 * c.q - 1 - r) / c.q * c.q;
+    return r;
+  }
+  template <bool LAZY> static val dot_term(uint64_t a, uint64_t b, const consts &c)
+  {
+    if(a >= (LAZY ? 4 : 1) * c.q || b >= (LAZY ? 4 : 1) * c.q) g_chk_fail++; /* the caller's contract */
+    if(LAZY && K <= 1) b = Base::csub(b, c.q2);
+    if(LAZY && K == 0) a = Base::csub(a, c.q2);
+    return barrett_chk(a, b, c);
+  }
+  static val dot_acc(val acc, val t, const consts &c)
+  {
+    if((u128)acc + t >= (u128)kB * c.q) g_chk_fail++;
+    see(acc + t, c);
+    return acc + t;
+  }
+  static val dot_fold(val acc, const consts &c) { return reduce_any(acc, c); }
+  template <bool LAZY> static val mul_out(val x, uint64_t b, const consts &c)
+  {
+    if((u128)x >= (u128)kB * c.q || b >= (LAZY ? 4 : 1) * c.q) g_chk_fail++;
+    if(LAZY && K <= 1) b = Base::csub(b, c.q2);
+    if(LAZY && K == 0) b = Base::csub(b, c.q);
+    return barrett_chk(reduce_any(x, c), b, c);
+  }
+  static uint64_t mul_store(val r, const consts &c)
+  {
+    if(r >= 4 * c.q) g_chk_fail++;
+    return canon(r, c);
+  }
+  static uint64_t mul_store_acc(val r, uint64_t acc, const consts &c)
+  {
+    if(acc >= c.q || r + acc >= 4 * c.q) g_chk_fail++;
+    return canon(r + acc, c);
+  }
 };
 
 template <class A> struct Regs {
@@ -872,7 +916,8 @@ using WideChk = WideF64<ArithF64Chk>;
 #  define P11(KW) EMU_MUL(KW, ArithF64Chk, 1) EMU_MUL(KW, WideChk, 0)
 #  define P12(KW) EMU_RUN(KW, ArithU64XChk<0>, 0) EMU_RUN(KW, ArithU64XChk<1>, 1)
 #  define P13(KW) EMU_RUN(KW, ArithU64XChk<3>, 3)
-#  define P14(KW) EMU_DOT(KW, ArithU64XChk<3>, 3) EMU_DOT(KW, ArithU64XChk<0>, 0) EMU_MUL(KW, ArithU64XChk<3>, 3) EMU_MUL(KW, ArithU64XChk<0>, 0)
+#  define P14(KW) EMU_DOT(KW, ArithU64XChk<3>, 3) EMU_DOT(KW, ArithU64XChk<0>, 0) EMU_MUL(KW, ArithU64XChk<3>, 3) EMU_MUL(KW, ArithU64XChk<0>, 0) \
+                  EMU_DOT(KW, ArithU64XChk<1>, 1) EMU_MUL(KW, ArithU64XChk<1>, 1)
 #  if EMU_PART == 0
 P1(extern) P2(extern) P3(extern) P4(extern) P5(extern) P6(extern) P7(extern) P8(extern) P9(extern) P10(extern) P11(extern)
 P12(extern) P13(extern) P14(extern)
@@ -1155,13 +1200,14 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
     return emu_dot_run<ArithU64, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
   }
 #ifndef EMU_SAN_BUILD
-  if(arith == 6) { /* the wide integer policy, checked: class 3 below 2^58, else class 0 */
+  if(arith == 6) { /* the wide integer policy, checked, in the class of q (3 below 2^58, 1 below 2^60, else 0) */
     if(q < (1ull << 40) || q >= (1ull << 61)) return -2;
     std::vector<TwU64> tab(wix.size());
     for(size_t i = 0; i < wix.size(); i++) tab[i] = h_tw_u64(wix[i], q);
     const auto c = h_consts_u64(q, N, wi);
-    return q < (1ull << 58) ? emu_dot_run<ArithU64XChk<3>, 3>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0)
-                            : emu_dot_run<ArithU64XChk<0>, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
+    if(q < (1ull << 58)) return emu_dot_run<ArithU64XChk<3>, 3>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
+    if(q < (1ull << 60)) return emu_dot_run<ArithU64XChk<1>, 1>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
+    return emu_dot_run<ArithU64XChk<0>, 0>(out, k, pa.data(), pb.data(), batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0);
   }
 #endif
   const bool wide = !h_f64_eligible(q);
@@ -1200,8 +1246,9 @@ int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, i
     std::vector<TwU64> tab(w.size());
     for(size_t i = 0; i < w.size(); i++) tab[i] = h_tw_u64(w[i], q);
     const auto c = h_consts_u64(q, N, dummy);
-    return q < (1ull << 58) ? emu_fwd_mul_run<ArithU64XChk<3>, 3>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0)
-                            : emu_fwd_mul_run<ArithU64XChk<0>, 0>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
+    if(q < (1ull << 58)) return emu_fwd_mul_run<ArithU64XChk<3>, 3>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
+    if(q < (1ull << 60)) return emu_fwd_mul_run<ArithU64XChk<1>, 1>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
+    return emu_fwd_mul_run<ArithU64XChk<0>, 0>(out, a, b, batch, m, tab.data(), nullptr, c, lazy != 0, bcast != 0, acc != 0);
   }
 #endif
   const bool wide = !h_f64_eligible(q);

@@ -591,7 +591,27 @@ def test_wide_integer_policy(oracle, emu, m, k, top):
     assert emu.transform(a, m, (1 << top) + 1, 3, 6, ksh=k)[0] == -2
 
 
-@pytest.mark.parametrize("m,top", [(6, 58), (12, 58), (14, 58), (14, 61), (15, 58), (16, 61)])
+@pytest.mark.parametrize("top", [58, 60, 61])
+def test_inner_products_wide_integer_policy_fold_schedule(oracle, emu, top):
+    """32 operand pairs, lazy words, worst-case representatives: the running sums are folded every 20 / 4 / 1 terms
+    (kDotEvery of the three headroom classes) and never pass B q (checked policy)"""
+    m, n = 8, 256
+    q = _prime_near(oracle, (1 << top) - 1, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    for lazy in (False, True):
+        a_list, b_list = _dot_operands(oracle, n, q, 2, 32, 7700 + top, lazy, False)
+        for worst in (0, 1):
+            emu.set_u64x_worst(worst)
+            emu.chk_stats(reset=True)
+            rc, got = emu.inv_dot(a_list, b_list, m, q, w, arith=6, lazy=lazy, bcast=False)
+            assert rc == 0 and np.array_equal(got, cx.inv(oracle.dot(a_list, b_list, q, n, False))), (top, lazy, worst)
+            fails, maxb, _ = emu.chk_stats()
+            assert fails == 0 and maxb < (8 << {58: 3, 60: 1, 61: 0}[top]), (top, lazy, worst, fails, maxb)
+    emu.set_u64x_worst(0)
+
+
+@pytest.mark.parametrize("m,top", [(6, 58), (12, 58), (14, 58), (14, 61), (15, 58), (16, 61), (12, 60)])
 def test_ntt_domain_products_wide_integer_policy(oracle, emu, m, top):
     """dot_inv_kernel and fwd_mul_kernel with ArithU64X's stages around fast_mul_mod_q's products (class 3 below 2^58,
     class 0 below 2^61), the checked policy with and without worst-case representatives: the inverse stages start from
