@@ -106,6 +106,12 @@ def workload_for(config, logn=None):
         return Workload(5, 17, "rns_product", 4096, 8, "RNS products/s",
                         "FHE-style RNS negacyclic products/sec (per limb: fwd a, fwd b, pointwise, inv) at N=2^17, 4 primes, "
                         "batch 4096 over 8 GPUs; achieved HBM GB/s vs peak", 4 * (56 << 17), 2, limbs=4, qbits=50)
+    if config == 60:
+        # not a BASELINE configuration: the shape of a bootstrappable CKKS parameter set (N = 2^16, 60-bit primes), which the
+        # FP64 policies cannot serve -- the wide integer policy's XCD-local launch, reported beside the BASELINE configs
+        return Workload(60, 16, "fwd", 8192, 1, "NTT/s",
+                        "batched forward NTTs/sec at N=2^16, 60-bit q (integer arithmetic), batch 8192; achieved HBM GB/s vs peak",
+                        16 << 16, 0, qbits=60)
     raise SystemExit("bench.py: --config must be 2, 3, 4 or 5")
 
 
@@ -498,6 +504,9 @@ def kernel_chain(w, arith, f64_class):
     pol = "ArithU64" if arith != 2 else ("ArithF64W" if f64_class == 52 else "ArithF64")
     if w is None or (w.kind == "fwd" and w.logn == LOGN):
         return kernel_name(arith), 1
+    if w.kind == "fwd" and w.logn > LOGN:
+        return "team_kernel<%s,%d,fwd> (both forward passes as items of one launch)" % (
+            pol if arith == 2 else "ArithU64X", w.logn - 12), 1
     if w.kind == "fwd":
         return "fused_kernel<%s,%d,fwd>" % (pol, w.logn), 1
     if w.kind == "roundtrip":
@@ -667,7 +676,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2, 3, 4 (default, the metric) or 5")
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2, 3, 4 (default, the metric) or 5 (60: N=2^16 with a 60-bit modulus, not a BASELINE configuration)")
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: from --config and --scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
@@ -766,11 +775,12 @@ def main():
             if w.config == 4 and n == N and not args.no_also:
                 # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
                 # above): the driver only runs this default command, so their numbers ride on its line
-                for cfg in (2, 3, 5):
+                for cfg in (2, 3, 5, 60):
+                    key = "also_config%d" % cfg if cfg != 60 else "also_60_bit_q_n65536"
                     try:
-                        out["also_config%d" % cfg] = also_config(lib, cfg, steps=args.also_steps, check=check)
+                        out[key] = also_config(lib, cfg, steps=args.also_steps, check=check)
                     except Exception as e:      # a side block must never cost the headline line; a parity failure says so
-                        out["also_config%d" % cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
+                        out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, lib)
         print(json.dumps(out), flush=True)
