@@ -512,9 +512,9 @@ def kernel_chain(w, arith, f64_class):
     if w.kind == "roundtrip":
         return ("team_kernel<%s,4,fwd> (both forward passes as items of one launch) + per 256 MiB chunk "
                 "fused_kernel<%s,12,inv> + column_kernel<%s,4,inv>" % (pol, pol, pol)), 33
-    return ("per limb ONE launch: team_product_kernel<%s,5,four> (column stages of b and a, block products -- both blocks "
-            "through their twelve stages, product, inverse stages --, inverse column stages of c as items of one launch; "
-            "a^ never exists in memory)" % pol), w.limbs
+    return ("ONE launch over all limbs: team_product_kernel<%s,5,four,multi> (column stages of b and a, block products -- both "
+            "blocks through their twelve stages, product, inverse stages --, inverse column stages of c as items of one launch, "
+            "the limb in the queue entry; a^ never exists in memory)" % pol), 1
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,
