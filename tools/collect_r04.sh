@@ -32,6 +32,8 @@ if [ -f build/libntt_stamps.so ]; then NTT_LIB=build/libntt_stamps.so timeout 30
 timeout 600 python3 tools/sweep.py --logn 8 9 10 11 12 13 14 15 16 17 --ops fwd inv --qs 0x80000001c0001 --bytes 16e9 > $out/sweep_sizes.txt 2>&1
 timeout 600 python3 tools/sweep.py --logn 12 14 16 --ops fwd inv mul --arith auto u64 --qs 0xffffffff00001 --bytes 8e9 > $out/sweep_52bit_modulus.txt 2>&1
 timeout 600 python3 tools/sweep.py --logn 8 9 10 11 12 13 14 15 16 17 --ops mul --qs 0x80000001c0001 --bytes 8e9 > $out/sweep_products.txt 2>&1
+# moduli of 2^52 and more (wide integer policy): 57- and 60-bit primes that serve every size up to 2^17
+timeout 600 python3 tools/sweep.py --logn 10 12 13 14 15 16 17 --ops fwd inv mul --qs 0x1fffffffffc0001 0xffffffffffc0001 --bytes 4e9 > $out/sweep_integer_moduli.txt 2>&1
 (for loop in 1 0; do NTT_RNS_LOOP=$loop timeout 300 python3 tools/pipeline_bench.py; NTT_RNS_LOOP=$loop timeout 300 python3 tools/pipeline_bench.py --logn 16 --batch 1024; NTT_RNS_LOOP=$loop timeout 300 python3 tools/pipeline_bench.py --logn 15 --batch 2048; done; timeout 300 python3 tools/pipeline_bench.py --logn 14 --batch 4096) > $out/pipeline_rns.txt 2>&1
 (for lg in 14 16; do for limbs in 4 16; do for b in 1 2 8 64; do
   for loop in 1 0; do NTT_RNS_LOOP=$loop timeout 120 python3 tools/pipeline_bench.py --logn $lg --limbs $limbs --batch $b --steps 10; done
