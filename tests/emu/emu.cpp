@@ -1269,6 +1269,9 @@ int emu_fwd_mul(uint64_t *out, uint64_t *a, const uint64_t *b, uint64_t batch, i
   return emu_fwd_mul_run<ArithF64Chk, 0>(out, a, b, batch, m, tf.data(), tf8.data(), c, lazy != 0, bcast != 0, acc != 0);
 }
 
+/* the compile-time fold schedule of the wide integer policy (ntt_arith.h u64x_schedule), for the bound simulation in tests/test_emu.py */
+uint32_t emu_u64x_schedule(int inverse, int nstages, int k) { return u64x_schedule(inverse != 0, nstages, k); }
+
 /* the queue-entry decode of the XCD-local kernels (ntt_core.h team_decode): out = {stop, valid, pass, item, v} */
 void emu_team_decode(uint32_t k, uint32_t q, uint32_t total, uint32_t lag, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t *out)
 {

@@ -24,6 +24,8 @@ class Emu:
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
         L.emu_set_u64x_worst.argtypes = [C.c_int]
+        L.emu_u64x_schedule.restype = C.c_uint32
+        L.emu_u64x_schedule.argtypes = [C.c_int] * 3
         L.emu_set_product_both.argtypes = [C.c_int]
         L.emu_fused_product14.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.emu_expand_radix4.argtypes = [U64P, U64P, C.c_uint64, C.c_uint64]
@@ -114,6 +116,10 @@ class Emu:
         assert self.lib.emu_plan_info(logn, v.ctypes.data_as(U64P)) == 0
         keys = ("NG", "R0", "RL", "T", "ROW", "LDS_ELEMS", "wave_local", "fmask", "imask", "conflict_free")
         return dict(zip(keys, [int(x) for x in v]))
+
+    def u64x_schedule(self, inverse, nstages, k):
+        """csrc/ntt_arith.h u64x_schedule: bit s set = the stage processed at position s folds the growing operand"""
+        return int(self.lib.emu_u64x_schedule(int(inverse), nstages, k))
 
     def set_u64x_worst(self, on):
         """arith=6 (checked ArithU64X): products and reduce_any return the largest representative their claims allow, so

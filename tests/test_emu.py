@@ -641,3 +641,27 @@ def test_ntt_domain_products_wide_integer_policy(oracle, emu, m, top):
             assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc, worst)
         assert emu.chk_stats()[0] == 0
     emu.set_u64x_worst(0)
+
+
+@pytest.mark.parametrize("k", [0, 1, 3])
+def test_wide_integer_fold_schedule_bounds(emu, k):
+    """u64x_schedule, simulated with the worst-case growth of every stage: values never reach B q (B = 8, 16, 64), the
+    inverse's difference offset (B/2) q covers its subtrahend, every inverse pass ends on a folding stage, and the
+    documented shapes hold (K = 3: a 14-stage forward block never folds; its inverse folds every fourth stage)"""
+    B = 8 << k
+    for n in range(1, 18):
+        m = emu.u64x_schedule(False, n, k)
+        b = 4.0                                     # pass inputs: canonical words, lazy words below 4q, the previous pass's words
+        for s in range(n):
+            if (m >> s) & 1:
+                b = max(b - B / 2, B / 2)           # x >= (B/2) q ? x - (B/2) q : x
+            b += 4                                  # x + m and x + 4q - m with m < 4q
+            assert b <= B, (k, n, s, b)
+        mi = emu.u64x_schedule(True, n, k)
+        assert (mi >> (n - 1)) & 1                  # a pass hands on words below 4q
+        b = 4.0
+        for s in range(n):
+            assert 2 * b <= B, (k, n, s, b)         # the sum fits, (B/2) q >= y
+            b = 4.0 if (mi >> s) & 1 else 2 * b     # folded sums below 2.01 q, products below 4q
+    assert emu.u64x_schedule(False, 14, 3) == 0 and emu.u64x_schedule(True, 12, 3) == 0b100010001000
+    assert emu.u64x_schedule(False, 14, 0) == 0x3ffe and emu.u64x_schedule(True, 14, 0) == 0x3fff
