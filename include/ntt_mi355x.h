@@ -224,8 +224,10 @@ NTT_API int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, c
  * and for the wide integer policy (NTT_ARITH_AUTO plans of 2^52 <= q < 2^61; a product of such a set is three launches:
  * both forward transforms and the products inside the inverse's first pass).  At N = 2^15..2^17 (FP64 policies) large per-limb
  * batches are ONE launch over the limbs too (the XCD-local kernels take the limb as part of their queue entries); other large
- * batches and mixed sets are served limb by limb.  Results are identical either way (environment NTT_RNS_LOOP=1 forces the
- * per-limb form, =0 the one-launch form wherever it is built). ---- */
+ * batches are served limb by limb.  A modulus chain with primes of several sizes (a 60-bit first prime in front of 50-bit
+ * ones) is served as maximal RUNS of consecutive compatible limbs: one launch per pass and run, single limbs by themselves.
+ * Results are identical either way (environment NTT_RNS_LOOP=1 forces the per-limb form, =0 the one-launch form wherever it
+ * is built). ---- */
 NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,

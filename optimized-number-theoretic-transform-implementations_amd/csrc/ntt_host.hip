@@ -1258,19 +1258,47 @@ static bool multi_limb_plan(const ntt_plan *p)
   return p->arith == NTT_ARITH_F64 || (p->arith == NTT_ARITH_U64 && p->int_cls >= 0 && !p->generic);
 }
 
-static bool rns_uniform(int nlimbs, ntt_plan *const *plans)
+static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first, int n);
+static bool rns_compatible(const ntt_plan *a, const ntt_plan *b)
 {
-  const ntt_plan *a = plans[0];
-  if(!multi_limb_plan(a)) return false;
-  for(int l = 1; l < nlimbs; l++) {
-    const ntt_plan *b = plans[l];
-    if(b->arith != a->arith || b->kcls != a->kcls || b->int_cls != a->int_cls || b->m != a->m || b->generic != a->generic || b->block_log != a->block_log ||
-       b->chunk_mib != a->chunk_mib || b->two_phase != a->two_phase || b->fused_product != a->fused_product ||
-       b->max_grid != a->max_grid || b->has_fwd != a->has_fwd || b->has_inv != a->has_inv) {
-      return false;
-    }
+  return multi_limb_plan(a) && b->arith == a->arith && b->kcls == a->kcls && b->int_cls == a->int_cls && b->m == a->m &&
+         b->generic == a->generic && b->block_log == a->block_log && b->chunk_mib == a->chunk_mib && b->two_phase == a->two_phase &&
+         b->fused_product == a->fused_product && b->max_grid == a->max_grid && b->has_fwd == a->has_fwd && b->has_inv == a->has_inv;
+}
+
+/* The limb list as maximal RUNS of consecutive compatible limbs, at most kMaxLimbs each (the records one launch carries): a
+ * modulus chain with one prime of another size -- a 60-bit first prime in front of 50-bit ones -- is served as that limb by
+ * itself plus one launch per pass for the others, not limb by limb altogether.  {first, count}. */
+static std::vector<std::pair<int, int>> rns_runs(int nlimbs, ntt_plan *const *plans)
+{
+  std::vector<std::pair<int, int>> runs;
+  for(int i = 0; i < nlimbs;) {
+    int j = i + 1;
+    while(j < nlimbs && j - i < kMaxLimbs && rns_compatible(plans[i], plans[j])) j++;
+    runs.emplace_back(i, j - i);
+    i = j;
   }
-  return nlimbs > 1;
+  return runs;
+}
+
+/* calls set_fn(first, LimbSet) for every run that `pays(plan of the run's first limb, run length)` says one launch should
+ * serve, one_fn(limb) for every other limb; stops at the first error */
+template <class Pays, class SetFn, class OneFn>
+static int rns_for_runs(int nlimbs, ntt_plan *const *plans, uint64_t slab, Pays pays, SetFn set_fn, OneFn one_fn)
+{
+  int rc = NTT_OK;
+  for(const std::pair<int, int> &run : rns_runs(nlimbs, plans)) {
+    const int first = run.first, n = run.second;
+    if(n > 1 && pays(plans[first], n)) {
+      const std::vector<unsigned char> recs = rns_records(plans, first, n);
+      const LimbSet                    ls{recs.data(), n, slab};
+      rc = set_fn(first, ls);
+    } else {
+      for(int l = first; !rc && l < first + n; l++) rc = one_fn(l);
+    }
+    if(rc) break;
+  }
+  return rc;
 }
 
 /* One launch for all limbs pays when a single limb's share cannot fill the chip by itself (a ciphertext: a few
@@ -1308,20 +1336,15 @@ static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(rns_uniform(nlimbs, plans) && (rns_one_launch_pays(plans[0], batch) || rns_team_launch(plans[0], nlimbs, batch, inverse, false))) {
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet ls{recs.data(), n, batch * plans[0]->N};
-      rc = run_transform(plans[first], d_a + (uint64_t)first * batch * plans[0]->N, batch, inverse, false, stream, false, &ls);
-    }
-    return rc;
-  }
-  for(int l = 0; !rc && l < nlimbs; l++) {
-    uint64_t *d = d_a + (uint64_t)l * batch * plans[l]->N;
-    rc          = inverse ? ntt_inv_batch(plans[l], d, batch, stream) : ntt_fwd_batch(plans[l], d, batch, stream);
-  }
-  return rc;
+  const uint64_t slab = batch * plans[0]->N;
+  return rns_for_runs(
+    nlimbs, plans, slab,
+    [&](const ntt_plan *p, int n) { return rns_one_launch_pays(p, batch) || rns_team_launch(p, n, batch, inverse, false); },
+    [&](int first, const LimbSet &ls) { return run_transform(plans[first], d_a + (uint64_t)first * slab, batch, inverse, false, stream, false, &ls); },
+    [&](int l) {
+      uint64_t *d = d_a + (uint64_t)l * slab;
+      return inverse ? ntt_inv_batch(plans[l], d, batch, stream) : ntt_fwd_batch(plans[l], d, batch, stream);
+    });
 }
 
 extern "C" int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
@@ -1339,38 +1362,34 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(rns_uniform(nlimbs, plans) && fused_product_applies(plans[0], d_c, d_a, d_b, batch) &&
-     (rns_one_launch_pays(plans[0], batch) || (rns_team_launch(plans[0], nlimbs, batch, false, true) && !plans[0]->block_log))) {
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet  ls{recs.data(), n, batch * plans[0]->N};
-      const uint64_t off = (uint64_t)first * batch * plans[0]->N;
-      rc                 = fused_product(plans[first], d_c + off, d_a + off, d_b + off, batch, stream, &ls);
-    }
-    return rc;
-  }
-  if(rns_uniform(nlimbs, plans) && plans[0]->arith == NTT_ARITH_U64 && dot_kernel_applies(plans[0]) && plans[0]->has_fwd &&
-     plans[0]->has_inv && d_a && d_b && d_c && rns_one_launch_pays(plans[0], batch)) {
-    /* limbs of the wide integer policy: both forward transforms (lazy words, in place -- the operands are scratch on this path
-     * as they are for a single plan) and the products inside the inverse transform's first pass, each ONE launch over all limbs */
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet  ls{recs.data(), n, batch * plans[0]->N};
-      const uint64_t off = (uint64_t)first * batch * plans[0]->N;
-      rc                 = run_transform(plans[first], d_a + off, batch, false, false, stream, true, &ls);
-      if(!rc && d_b != d_a) rc = run_transform(plans[first], d_b + off, batch, false, false, stream, true, &ls);
+  const uint64_t slab = batch * plans[0]->N;
+  /* a run of the wide integer policy: both forward transforms (lazy words, in place -- the operands are scratch on this path as
+   * they are for a single plan) and the products inside the inverse transform's first pass, each ONE launch over the run */
+  auto int_run = [&](const ntt_plan *p) {
+    return p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && p->has_fwd && p->has_inv && d_a && d_b && d_c;
+  };
+  return rns_for_runs(
+    nlimbs, plans, slab,
+    [&](const ntt_plan *p, int n) {
+      if(fused_product_applies(p, d_c, d_a, d_b, batch)) {
+        return rns_one_launch_pays(p, batch) || (rns_team_launch(p, n, batch, false, true) && !p->block_log);
+      }
+      return int_run(p) && rns_one_launch_pays(p, batch);
+    },
+    [&](int first, const LimbSet &ls) {
+      const ntt_plan *p   = plans[first];
+      const uint64_t  off = (uint64_t)first * slab;
+      if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c + off, d_a + off, d_b + off, batch, stream, &ls);
+      int r = run_transform(p, d_a + off, batch, false, false, stream, true, &ls);
+      if(!r && d_b != d_a) r = run_transform(p, d_b + off, batch, false, false, stream, true, &ls);
       const uint64_t *pa = d_a + off, *pb = d_b + off;
-      if(!rc) rc = inv_dot(plans[first], d_c + off, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, &ls, ls.stride);
-    }
-    return rc;
-  }
-  for(int l = 0; !rc && l < nlimbs; l++) {
-    const uint64_t off = (uint64_t)l * batch * plans[l]->N;
-    rc                 = ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);
-  }
-  return rc;
+      if(!r) r = inv_dot(p, d_c + off, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, &ls, ls.stride);
+      return r;
+    },
+    [&](int l) {
+      const uint64_t off = (uint64_t)l * slab;
+      return ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);
+    });
 }
 
 /* ------------------------------------------------------------------ */
@@ -1639,20 +1658,15 @@ extern "C" int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_
   if(rc || batch == 0) return rc;
   const uint64_t N = plans[0]->N, slab = batch * N;
   const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && dot_kernel_applies(plans[0])) {
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet ls{recs.data(), n, slab};
-      rc = fwd_mul(plans[first], d_c + (uint64_t)first * slab, d_a + (uint64_t)first * slab, d_bhat + (uint64_t)first * bslab, batch, flags,
-                   stream, &ls, bslab);
-    }
-    return rc;
-  }
-  for(int l = 0; !rc && l < nlimbs; l++) {
-    rc = fwd_mul(plans[l], d_c + (uint64_t)l * slab, d_a + (uint64_t)l * slab, d_bhat + (uint64_t)l * bslab, batch, flags, stream);
-  }
-  return rc;
+  return rns_for_runs(
+    nlimbs, plans, slab, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
+    [&](int first, const LimbSet &ls) {
+      return fwd_mul(plans[first], d_c + (uint64_t)first * slab, d_a + (uint64_t)first * slab, d_bhat + (uint64_t)first * bslab, batch, flags,
+                     stream, &ls, bslab);
+    },
+    [&](int l) {
+      return fwd_mul(plans[l], d_c + (uint64_t)l * slab, d_a + (uint64_t)l * slab, d_bhat + (uint64_t)l * bslab, batch, flags, stream);
+    });
 }
 
 extern "C" int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
@@ -1663,28 +1677,17 @@ extern "C" int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_
   if(k < 1 || k > kMaxDot || !d_ahat || !d_bhat) return fail(NTT_ERR_ARG, "number of operand pairs must be 1 .. 32");
   const uint64_t N = plans[0]->N, slab = batch * N;
   const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
-  const uint64_t *la[kMaxDot], *lb[kMaxDot];
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) && dot_kernel_applies(plans[0])) {
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet ls{recs.data(), n, slab};
-      for(int i = 0; i < k; i++) {
-        la[i] = d_ahat[i] + (uint64_t)first * slab;
-        lb[i] = d_bhat[i] + (uint64_t)first * bslab;
-      }
-      rc = inv_dot(plans[first], d_c + (uint64_t)first * slab, k, la, lb, batch, flags, stream, &ls, bslab);
-    }
-    return rc;
-  }
-  for(int l = 0; !rc && l < nlimbs; l++) {
+  auto call = [&](int first, const LimbSet *ls) {
+    const uint64_t *la[kMaxDot], *lb[kMaxDot];
     for(int i = 0; i < k; i++) {
-      la[i] = d_ahat[i] + (uint64_t)l * slab;
-      lb[i] = d_bhat[i] + (uint64_t)l * bslab;
+      la[i] = d_ahat[i] + (uint64_t)first * slab;
+      lb[i] = d_bhat[i] + (uint64_t)first * bslab;
     }
-    rc = inv_dot(plans[l], d_c + (uint64_t)l * slab, k, la, lb, batch, flags, stream);
-  }
-  return rc;
+    return inv_dot(plans[first], d_c + (uint64_t)first * slab, k, la, lb, batch, flags, stream, ls, ls ? bslab : 0);
+  };
+  return rns_for_runs(
+    nlimbs, plans, slab, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
+    [&](int first, const LimbSet &ls) { return call(first, &ls); }, [&](int l) { return call(l, nullptr); });
 }
 
 extern "C" int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
@@ -1693,25 +1696,22 @@ extern "C" int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans,
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
   const uint64_t slab = batch * plans[0]->N;
-  /* one launch over the limbs: the fused product kernels (FP64 policies), or -- limbs of the wide integer policy -- the forward
-   * transform and the products-inside-the-inverse launch, each over the whole set */
-  const bool int_set = plans[0]->arith == NTT_ARITH_U64 && dot_kernel_applies(plans[0]) && d_a != d_bhat && d_a && d_bhat && d_c;
-  if(rns_uniform(nlimbs, plans) && rns_one_launch_pays(plans[0], batch) &&
-     (fused_product_applies(plans[0], d_c, d_bhat, d_a, batch) || int_set)) {
-    for(int first = 0; !rc && first < nlimbs; first += kMaxLimbs) {
-      const int n = nlimbs - first < kMaxLimbs ? nlimbs - first : kMaxLimbs;
-      const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet  ls{recs.data(), n, slab};
+  /* one launch over a run: the fused product kernels (FP64 policies), or -- limbs of the wide integer policy -- the forward
+   * transform and the products-inside-the-inverse launch, each over the whole run */
+  return rns_for_runs(
+    nlimbs, plans, slab,
+    [&](const ntt_plan *p, int) {
+      const bool int_set = p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && d_a != d_bhat && d_a && d_bhat && d_c;
+      return rns_one_launch_pays(p, batch) && (fused_product_applies(p, d_c, d_bhat, d_a, batch) || int_set);
+    },
+    [&](int first, const LimbSet &ls) {
       const uint64_t off = (uint64_t)first * slab;
-      rc                 = mul_transformed(plans[first], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &ls);
-    }
-    return rc;
-  }
-  for(int l = 0; !rc && l < nlimbs; l++) {
-    const uint64_t off = (uint64_t)l * slab;
-    rc                 = mul_transformed(plans[l], d_c + off, d_a + off, d_bhat + off, batch, flags, stream);
-  }
-  return rc;
+      return mul_transformed(plans[first], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &ls);
+    },
+    [&](int l) {
+      const uint64_t off = (uint64_t)l * slab;
+      return mul_transformed(plans[l], d_c + off, d_a + off, d_bhat + off, batch, flags, stream);
+    });
 }
 
 extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,

@@ -523,6 +523,53 @@ def test_rns_mixed_classes_fall_back_to_the_loop(lib, oracle):
         assert np.array_equal(got[s], oracle.ctx(n, q, w).fwd(a[s])), l
 
 
+@pytest.mark.parametrize("m,batch", [(12, 2), (14, 1), (16, 2)])
+def test_rns_modulus_chain_with_primes_of_several_sizes(lib, oracle, m, batch, monkeypatch):
+    """a modulus chain as FHE libraries build them -- a 60-bit first prime, three 50-bit primes, two 57-bit primes, a 30-bit
+    one: the limb list is served as maximal RUNS of consecutive compatible limbs (one launch per pass and run, single limbs
+    by themselves), in both forced forms; every entry point of the family against the oracle, limb by limb"""
+    n = 1 << m
+    qs = [lib.find_prime(60, n)] + [lib.find_prime(50, n, i) for i in range(3)] + [lib.find_prime(57, n, i) for i in range(2)] + [lib.find_prime(30, n)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    nl, slab = len(qs), batch * n
+    a = np.concatenate([oracle.fill_uniform(slab, q, 8100 + l) for l, q in enumerate(qs)])
+    b = np.concatenate([oracle.fill_uniform(slab, q, 8200 + l) for l, q in enumerate(qs)])
+    ctx = [oracle.ctx(n, q, w) for q, w in zip(qs, ws)]
+    sl = [slice(l * slab, (l + 1) * slab) for l in range(nl)]
+    fa = np.concatenate([c.fwd(a[x]) for c, x in zip(ctx, sl)])
+    fb = np.concatenate([c.fwd(b[x]) for c, x in zip(ctx, sl)])
+    prod = np.concatenate([c.inv(oracle.pointwise(fa[x], fb[x], q)) for c, x, q in zip(ctx, sl, qs)])
+    had = np.concatenate([oracle.pointwise(fa[x], fb[x], q) for x, q in zip(sl, qs)])
+    da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+    for loop in ("0", "1", None):
+        if loop is None:
+            monkeypatch.delenv("NTT_RNS_LOOP", raising=False)
+        else:
+            monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        da.upload(a)
+        lib.rns_fwd(plans, da.ptr, batch)
+        assert np.array_equal(da.download(), fa), loop
+        lib.rns_inv(plans, da.ptr, batch)
+        assert np.array_equal(da.download(), a), loop
+        da.upload(a), db.upload(b)
+        lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), prod), loop
+        da.upload(a), db.upload(fb)
+        lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), prod), loop
+        da.upload(fa), db.upload(fb)
+        lib.rns_inv_dot(plans, dc.ptr, [da.ptr], [db.ptr], batch)
+        assert np.array_equal(dc.download(), prod), loop
+        da.upload(a), db.upload(fb)
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), had), loop
+    for x in (da, db, dc):
+        x.free()
+    for p in plans:
+        p.destroy()
+
+
 def test_full_size_config5_share_rns_n131072(lib, oracle):
     """BASELINE config 5, one GPU's share: N=2^17, 4-prime RNS, 512 polynomials per GPU
     (2 GiB per operand): fwd/pointwise/inv pipeline, sampled polynomials vs the oracle,
