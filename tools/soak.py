@@ -234,7 +234,16 @@ while time.time() < t_end:
             nl, rb = int(rng.choice([2, 3, 4])), int(rng.choice([22, 33, 64, 70]))   # one XCD-local launch over the limbs
         if nl * rb * n <= max(args.max_coeffs, (1 << 25) if m >= 15 else 0):
             rbits = int(rng.choice([45, 49, 50, 52, 57, 60]))    # (52: the reduce-as-scheduled FP64 policy; 57, 60: the wide integer policy)
-            qs = [lib.find_prime(rbits, n, i) for i in range(nl)]
+            if rng.random() < 0.3:
+                # a modulus chain with primes of several sizes: served as runs of consecutive compatible limbs
+                sizes = [int(x) for x in rng.choice([45, 50, 52, 57, 60], size=nl)]
+                seen = {}
+                qs = []
+                for bts in sizes:
+                    qs.append(lib.find_prime(bts, n, seen.get(bts, 0)))
+                    seen[bts] = seen.get(bts, 0) + 1
+            else:
+                qs = [lib.find_prime(rbits, n, i) for i in range(nl)]
             if all(qs) and len(set(qs)) == nl:
                 ws = [lib.min_root(x, n) for x in qs]
                 plans = [lib.Plan(n, x, y) for x, y in zip(qs, ws)]
