@@ -7,6 +7,7 @@
  * launch and every failure is reported (status code / abort for the void
  * reference signatures).
  */
+#include <climits>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -694,10 +695,17 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
 /* ------------------------------------------------------------------ */
 /* transforms                                                          */
 /* ------------------------------------------------------------------ */
+/* A launch over several limbs runs ONE kernel instantiation: the coarsest headroom class among the limbs of the run (a coarser
+ * class is valid for every modulus a finer one serves: it only reduces / folds more often).  rns_for_runs sets the override
+ * around the run's call; every class dispatch below goes through these two. */
+static thread_local int t_run_kcls = INT_MIN, t_run_int_cls = INT_MIN;
+static int eff_kcls(const ntt_plan *p) { return (t_run_kcls != INT_MIN && p->kcls != kWideClass) ? t_run_kcls : p->kcls; }
+static int eff_int_cls(const ntt_plan *p) { return (t_run_int_cls != INT_MIN && p->int_cls >= 0) ? t_run_int_cls : p->int_cls; }
+
 static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
 {
   if(p->arith == NTT_ARITH_U64) {
-    switch(p->generic ? -1 : p->int_cls) { /* (generic = the column-pass cross-check path: the reference's butterflies) */
+    switch(p->generic ? -1 : eff_int_cls(p)) { /* (generic = the column-pass cross-check path: the reference's butterflies) */
       case 3: return launch_pass<ArithU64X<3>, 3>(pa);
       case 1: return launch_pass<ArithU64X<1>, 1>(pa);
       case 0: return launch_pass<ArithU64X<0>, 0>(pa);
@@ -705,7 +713,7 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
     }
   }
   if(p->arith == NTT_ARITH_U64_R4) return launch_pass<ArithU64R4, 0>(pa);
-  switch(p->kcls) {
+  switch(eff_kcls(p)) {
     case kWideClass: return launch_pass<ArithF64W, 0>(pa);
     case 18: return launch_pass<ArithF64, 18>(pa);
     case 1: return launch_pass<ArithF64, 1>(pa);
@@ -1143,9 +1151,10 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
       pa.team_lag    = p->team_lag ? p->team_lag : (p->m == kTeamBlock + 3 ? 20 : (p->m == kTeamBlock + 4 ? 14 : (four ? 8 : 12)));
       pa.team_wpc    = p->team_wpc;
       pa.stream      = (hipStream_t)stream;
-      hipError_t e = p->kcls == kWideClass ? launch_team_product<ArithF64W, 0>(pa)
-                     : p->kcls == 18       ? launch_team_product<ArithF64, 18>(pa)
-                     : p->kcls == 1        ? launch_team_product<ArithF64, 1>(pa)
+      const int  kc = eff_kcls(p);
+      hipError_t e = kc == kWideClass ? launch_team_product<ArithF64W, 0>(pa)
+                     : kc == 18       ? launch_team_product<ArithF64, 18>(pa)
+                     : kc == 1        ? launch_team_product<ArithF64, 1>(pa)
                                            : launch_team_product<ArithF64, 0>(pa);
       if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
       return NTT_OK;
@@ -1185,9 +1194,10 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;
     pa.stream   = (hipStream_t)stream;
-    hipError_t e = p->kcls == kWideClass ? launch_product<ArithF64W, 0>(pa)
-                   : p->kcls == 18       ? launch_product<ArithF64, 18>(pa)
-                   : p->kcls == 1        ? launch_product<ArithF64, 1>(pa)
+    const int  kc = eff_kcls(p);
+    hipError_t e = kc == kWideClass ? launch_product<ArithF64W, 0>(pa)
+                   : kc == 18       ? launch_product<ArithF64, 18>(pa)
+                   : kc == 1        ? launch_product<ArithF64, 1>(pa)
                                          : launch_product<ArithF64, 0>(pa);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     for(int k = L.n - 2; k >= 0; k--) { /* inverse column passes of c, the last one ends the transform (N^-1) */
@@ -1261,7 +1271,10 @@ static bool multi_limb_plan(const ntt_plan *p)
 static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first, int n);
 static bool rns_compatible(const ntt_plan *a, const ntt_plan *b)
 {
-  return multi_limb_plan(a) && b->arith == a->arith && b->kcls == a->kcls && b->int_cls == a->int_cls && b->m == a->m &&
+  /* (the headroom class may differ inside a policy: the run takes the coarsest one -- but the reduce-as-scheduled FP64 policy
+   * for 52-bit moduli and the reference's integer butterflies are policies of their own) */
+  return multi_limb_plan(a) && b->arith == a->arith && (b->kcls == kWideClass) == (a->kcls == kWideClass) &&
+         (b->int_cls >= 0) == (a->int_cls >= 0) && b->m == a->m &&
          b->generic == a->generic && b->block_log == a->block_log && b->chunk_mib == a->chunk_mib && b->two_phase == a->two_phase &&
          b->fused_product == a->fused_product && b->max_grid == a->max_grid && b->has_fwd == a->has_fwd && b->has_inv == a->has_inv;
 }
@@ -1292,7 +1305,15 @@ static int rns_for_runs(int nlimbs, ntt_plan *const *plans, uint64_t slab, Pays 
     if(n > 1 && pays(plans[first], n)) {
       const std::vector<unsigned char> recs = rns_records(plans, first, n);
       const LimbSet                    ls{recs.data(), n, slab};
-      rc = set_fn(first, ls);
+      int kc = plans[first]->kcls, ic = plans[first]->int_cls;
+      for(int l = first + 1; l < first + n; l++) {
+        kc = plans[l]->kcls < kc ? plans[l]->kcls : kc;
+        ic = plans[l]->int_cls < ic ? plans[l]->int_cls : ic;
+      }
+      t_run_kcls    = kc;
+      t_run_int_cls = ic;
+      rc            = set_fn(first, ls);
+      t_run_kcls = t_run_int_cls = INT_MIN;
     } else {
       for(int l = first; !rc && l < first + n; l++) rc = one_fn(l);
     }
@@ -1398,14 +1419,14 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
 static hipError_t dispatch_dot(const ntt_plan *p, const DotArgs &da)
 {
   if(p->arith == NTT_ARITH_U64) {
-    switch(p->int_cls) { /* (same tables; the wide policy's stages around fast_mul_mod_q's products) */
+    switch(eff_int_cls(p)) { /* (same tables; the wide policy's stages around its Barrett products) */
       case 3: return launch_dot<ArithU64X<3>, 3>(da);
       case 1: return launch_dot<ArithU64X<1>, 1>(da);
       case 0: return launch_dot<ArithU64X<0>, 0>(da);
       default: return launch_dot<ArithU64, 0>(da);
     }
   }
-  switch(p->kcls) {
+  switch(eff_kcls(p)) {
     case kWideClass: return launch_dot<ArithF64W, 0>(da);
     case 18: return launch_dot<ArithF64, 18>(da);
     case 1: return launch_dot<ArithF64, 1>(da);
@@ -1632,13 +1653,14 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     ma.max_grid      = p->max_grid;
     ma.num_cus       = p->num_cus;
     ma.stream        = (hipStream_t)stream;
-    hipError_t e = p->arith == NTT_ARITH_U64 ? (p->int_cls == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
-                                                : p->int_cls == 1 ? launch_fwd_mul<ArithU64X<1>, 1>(ma)
-                                                : p->int_cls == 0 ? launch_fwd_mul<ArithU64X<0>, 0>(ma)
-                                                                  : launch_fwd_mul<ArithU64, 0>(ma))
-                   : p->kcls == kWideClass   ? launch_fwd_mul<ArithF64W, 0>(ma)
-                   : p->kcls == 18           ? launch_fwd_mul<ArithF64, 18>(ma)
-                   : p->kcls == 1            ? launch_fwd_mul<ArithF64, 1>(ma)
+    const int  ic = eff_int_cls(p), kc = eff_kcls(p);
+    hipError_t e = p->arith == NTT_ARITH_U64 ? (ic == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
+                                                : ic == 1 ? launch_fwd_mul<ArithU64X<1>, 1>(ma)
+                                                : ic == 0 ? launch_fwd_mul<ArithU64X<0>, 0>(ma)
+                                                          : launch_fwd_mul<ArithU64, 0>(ma))
+                   : kc == kWideClass        ? launch_fwd_mul<ArithF64W, 0>(ma)
+                   : kc == 18                ? launch_fwd_mul<ArithF64, 18>(ma)
+                   : kc == 1                 ? launch_fwd_mul<ArithF64, 1>(ma)
                                              : launch_fwd_mul<ArithF64, 0>(ma);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   }

@@ -507,20 +507,39 @@ def test_rns_one_launch_more_limbs_than_one_launch_holds(lib, oracle, monkeypatc
         assert np.array_equal(got_p[s], cx.inv(oracle.pointwise(cx.fwd(a[s]), cx.fwd(b[s]), q))), l
 
 
-def test_rns_mixed_classes_fall_back_to_the_loop(lib, oracle):
-    """limbs whose primes need different kernel instantiations (a 30-bit and a 51-bit prime: different FP64 headroom
-    classes) cannot share a launch: served one by one, same results"""
+@pytest.mark.parametrize("sizes", [(30, 51, 45), (57, 60, 59, 61, 53), (52, 52, 50)])
+def test_rns_mixed_headroom_classes_share_a_launch(lib, oracle, sizes, monkeypatch):
+    """limbs of ONE policy whose primes fall into different headroom classes (a 30-bit, a 51-bit and a 45-bit prime: FP64
+    classes 18, 0, 1; 57- to 61-bit primes: integer classes 3, 1, 1, 0, 3) share a launch in the coarsest class of the run;
+    the 52-bit policy does not mix with the scheduled one (two runs).  Same results as limb by limb."""
+    monkeypatch.setenv("NTT_RNS_LOOP", "0")
     n, batch = 1 << 10, 2
-    qs = [lib.find_prime(30, n), lib.find_prime(51, n), lib.find_prime(45, n)]
+    seen = {}
+    qs = []
+    for bts in sizes:
+        qs.append(lib.find_prime(bts, n, seen.get(bts, 0)))
+        seen[bts] = seen.get(bts, 0) + 1
     roots = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
     a = np.concatenate([_inputs(oracle, n, q, batch, 600 + l) for l, q in enumerate(qs)])
     da = lib.DeviceBuffer(a.size).upload(a)
     lib.rns_fwd(plans, da.ptr, batch)
     got = da.download()
+    lib.rns_inv(plans, da.ptr, batch)
+    back = da.download()
+    db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(a.size)
+    lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch)        # the squares
+    sq = dc.download()
     for l, (q, w) in enumerate(zip(qs, roots)):
         s = slice(l * batch * n, (l + 1) * batch * n)
-        assert np.array_equal(got[s], oracle.ctx(n, q, w).fwd(a[s])), l
+        cx = oracle.ctx(n, q, w)
+        assert np.array_equal(got[s], cx.fwd(a[s])), l
+        assert np.array_equal(back[s], a[s]), l
+        assert np.array_equal(sq[s], cx.inv(oracle.pointwise(got[s], got[s], q))), l
+    for x in (da, db, dc):
+        x.free()
+    for p in plans:
+        p.destroy()
 
 
 @pytest.mark.parametrize("m,batch", [(12, 2), (14, 1), (16, 2)])
