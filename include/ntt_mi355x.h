@@ -219,7 +219,7 @@ NTT_API int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, c
  * an independent transform -- the reference has no counterpart; its closest
  * primitive is fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60).
  * When one limb's share alone cannot fill the GPU (a ciphertext: a few polynomials x tens of primes) and the limbs'
- * plans agree in policy and options (primes of one bit size always do), ONE launch per pass serves up to 16 limbs: a
+ * plans agree in policy and options (the headroom class may differ: the launch takes the coarsest), ONE launch per pass serves up to 16 limbs: a
  * workgroup picks its limb's tables and constants from an array in the kernel arguments -- for the FP64 policies (q < 2^52)
  * and for the wide integer policy (NTT_ARITH_AUTO plans of 2^52 <= q < 2^61; a product of such a set is three launches:
  * both forward transforms and the products inside the inverse's first pass).  At N = 2^15..2^17 (FP64 policies) large per-limb
