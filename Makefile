@@ -10,10 +10,13 @@ CSRC     = $(PKG)/csrc
 LIB      = $(PKG)/libntt_mi355x.so
 HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
             -Wall -Wextra -Wno-unused-parameter -Iinclude -Iinclude/internal -I$(CSRC) $(EXTRA_HIPFLAGS)
-OBJS     = $(CSRC)/ntt_host.o $(CSRC)/inst_u64.o $(CSRC)/inst_u64r4.o $(CSRC)/inst_u64x_k0.o $(CSRC)/inst_u64x_k1.o $(CSRC)/inst_u64x_k3.o $(CSRC)/inst_dm_u64x_k0.o $(CSRC)/inst_dm_u64x_k1.o $(CSRC)/inst_dm_u64x_k3.o $(CSRC)/inst_f64k0.o $(CSRC)/inst_f64k1.o $(CSRC)/inst_f64k18.o $(CSRC)/inst_f64w.o \
-           $(CSRC)/inst_team_f64k0.o $(CSRC)/inst_team_f64k1.o $(CSRC)/inst_team_f64k18.o $(CSRC)/inst_team_f64w.o \
+# (longest translation units first: `make -j` starts them in this order, and the four FP64 block-kernel units take two minutes each)
+OBJS     = $(CSRC)/inst_f64k0.o $(CSRC)/inst_f64k1.o $(CSRC)/inst_f64k18.o $(CSRC)/inst_f64w.o \
+           $(CSRC)/inst_dm_u64x_k0.o $(CSRC)/inst_dm_u64x_k1.o $(CSRC)/inst_dm_u64x_k3.o $(CSRC)/inst_u64x_k0.o $(CSRC)/inst_u64x_k1.o $(CSRC)/inst_u64x_k3.o \
+           $(CSRC)/inst_u64.o $(CSRC)/inst_u64r4.o \
            $(CSRC)/inst_dot_f64k0.o $(CSRC)/inst_dot_f64k1.o $(CSRC)/inst_dot_f64k18.o $(CSRC)/inst_dot_f64w.o $(CSRC)/inst_dot_u64.o \
-           $(CSRC)/inst_mul_f64k0.o $(CSRC)/inst_mul_f64k1.o $(CSRC)/inst_mul_f64k18.o $(CSRC)/inst_mul_f64w.o $(CSRC)/inst_mul_u64.o
+           $(CSRC)/inst_mul_f64k0.o $(CSRC)/inst_mul_f64k1.o $(CSRC)/inst_mul_f64k18.o $(CSRC)/inst_mul_f64w.o $(CSRC)/inst_mul_u64.o \
+           $(CSRC)/inst_team_f64k0.o $(CSRC)/inst_team_f64k1.o $(CSRC)/inst_team_f64k18.o $(CSRC)/inst_team_f64w.o $(CSRC)/ntt_host.o
 HDRS     = $(wildcard $(CSRC)/*.h) $(wildcard include/*.h) $(wildcard include/internal/*.h)
 
 lib: $(LIB)
