@@ -17,11 +17,16 @@ OBJS     = $(CSRC)/inst_f64k0.o $(CSRC)/inst_f64k1.o $(CSRC)/inst_f64k18.o $(CSR
            $(CSRC)/inst_dot_f64k0.o $(CSRC)/inst_dot_f64k1.o $(CSRC)/inst_dot_f64k18.o $(CSRC)/inst_dot_f64w.o $(CSRC)/inst_dot_u64.o \
            $(CSRC)/inst_mul_f64k0.o $(CSRC)/inst_mul_f64k1.o $(CSRC)/inst_mul_f64k18.o $(CSRC)/inst_mul_f64w.o $(CSRC)/inst_mul_u64.o \
            $(CSRC)/inst_team_f64k0.o $(CSRC)/inst_team_f64k1.o $(CSRC)/inst_team_f64k18.o $(CSRC)/inst_team_f64w.o $(CSRC)/ntt_host.o
-HDRS     = $(wildcard $(CSRC)/*.h) $(wildcard include/*.h) $(wildcard include/internal/*.h)
+# the kernel translation units see the kernel headers only; the host layer also the public headers
+KHDRS    = $(wildcard $(CSRC)/*.h)
+HDRS     = $(KHDRS) $(wildcard include/*.h) $(wildcard include/internal/*.h)
 
 lib: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+$(CSRC)/ntt_host.o: $(CSRC)/ntt_host.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(KHDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(OBJS)

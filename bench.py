@@ -52,7 +52,8 @@ SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NTT = 16 * N       # one 8-byte read + one 8-byte write per coefficient
 METRIC = "batched forward NTTs/sec at N=2^14, 50-bit q; achieved HBM GB/s vs peak"
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+TRAFFIC_DIR = os.path.join(ROOT, "profiles", "r05")
+TRAFFIC_JSON = os.path.join(TRAFFIC_DIR, "pmc_traffic.json")      # the headline launch (config 4); pmc_traffic_config{2,3,5}.json beside it
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -280,6 +281,19 @@ def measured_traffic(batch, kernel, path=None):
     return None
 
 
+def measured_traffic_config(config, batch, n, layout=None):
+    """the same for one step of BASELINE config 2, 3 or 5 (also_configN blocks): bytes of ALL kernels of a step (FETCH_SIZE x2 +
+    WRITE_SIZE summed over the step's launches, tools/pmc_traffic_json.py), valid for the batch and size the passes were taken on"""
+    try:
+        with open(os.path.join(TRAFFIC_DIR, "pmc_traffic_config%d%s.json" % (config, "_batch_major" if layout else ""))) as f:
+            t = json.load(f)
+        if t["batch"] == batch and t["N"] == n:
+            return t["hbm_bytes_per_step"]
+    except Exception:
+        pass
+    return None
+
+
 def shard_of_rank(rank, per_gpu_batch, n):
     """Shard of the global batch: GPU r owns polynomials [r*per_gpu_batch, (r+1)*per_gpu_batch);
     returns (first polynomial, first coefficient index) -- the latter seeds the device-side generator so
@@ -318,8 +332,9 @@ class GpuShard:
     (config 3); "rns_product": c = a * b per limb over [limb][batch][N] slabs (config 5) -- the product overwrites
     its operands, so every step (warm-ups included) gets its own operand pair, generated before the timed region."""
 
-    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None, kind="fwd", qs=None, roots=None, steps_total=1):
+    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None, kind="fwd", qs=None, roots=None, steps_total=1, layout=None):
         self.lib, self.device, self.index, self.batch, self.kind = lib, device, index, batch, kind
+        self.layout = layout                          # None: [limb][batch][N]; "batch_major": SURVEY 8(d)'s [batch][prime][N]
         self.n = n or N
         self.qs = qs or [q]
         self.roots = roots or [root or ROOT_W]
@@ -328,6 +343,8 @@ class GpuShard:
         self.q = self.qs[0]
         self.limbs = len(self.qs)
         self.slab = batch * self.n                     # words of one limb
+        # (limb stride, polynomial stride) in words, for the *_strided entry points
+        self.strides = (self.n, self.limbs * self.n) if layout == "batch_major" else None
         words = self.limbs * self.slab
         self.sets = steps_total if kind == "rns_product" else 1
         need = words * 8 * (2 * self.sets + 1 if kind == "rns_product" else 1)
@@ -355,6 +372,11 @@ class GpuShard:
             return
         for s in range(self.sets):
             for which in (0, 1):
+                if self.layout == "batch_major":
+                    # one fill for the interleaved slab: values below every limb's modulus
+                    self.lib.fill_uniform(self.operand_ptr(s, which), self.limbs * self.slab, min(self.qs), SEED + 2 * s + which, offset,
+                                          device=self.device, stream=self.stream)
+                    continue
                 for l, q in enumerate(self.qs):
                     self.lib.fill_uniform(self.operand_ptr(s, which) + 8 * l * self.slab, self.slab, q, SEED + 2 * s + which,
                                           offset + l * self.slab, device=self.device, stream=self.stream)
@@ -370,7 +392,7 @@ class GpuShard:
         else:
             s = self.step_no % self.sets
             self.lib.rns_negacyclic_mul(self.plans, self.out.ptr, self.operand_ptr(s, 0), self.operand_ptr(s, 1), self.batch,
-                                        stream=self.stream)
+                                        stream=self.stream, layout=self.strides)
             self.step_no += 1
 
     def sync(self):
@@ -409,6 +431,23 @@ class GpuShard:
                 best = ms
         return words * 16 / (best * 1e-3) / 1e9
 
+    def out_of_place_copy_gbs(self, reps=6):
+        """GB/s (read + written bytes) of an out-of-place 16-byte-per-lane copy of half the shard's buffer onto the other half: the
+        copy shape MI355X_MICROARCH.md quotes the achievable HBM rate for (about 6.3 TB/s).  Runs after the timed region and
+        overwrites the upper half of the buffer."""
+        half = ((self.limbs * self.slab) // 2) & ~1
+        if half == 0 or not hasattr(self.lib, "copy_probe"):
+            return None
+        best = None
+        for r in range(reps + 1):
+            self.ev0.record(self.stream)
+            self.lib.copy_probe(self.buf.ptr + 8 * half, self.buf.ptr, half, device=self.device, stream=self.stream)
+            self.ev1.record(self.stream)
+            ms = self.ev1.elapsed_ms_since(self.ev0)
+            if r and (best is None or ms < best):
+                best = ms
+        return half * 16 / (best * 1e-3) / 1e9
+
     def shape_ceiling_gbs(self, reps=6):
         """the same with the memory shape of the 2^14 block kernels themselves (ntt_shape_probe: persistent workgroups,
         next block prefetched in registers, 16-byte accesses): the best memory-only skeleton, measured in this run"""
@@ -428,7 +467,8 @@ class GpuShard:
     def polys(self, which, base=None, limb=0):
         import numpy as np
         buf = base if base is not None else self.buf
-        return np.concatenate([buf.download(self.n, limb * self.slab + p * self.n) for p in which])
+        ls, ps = self.strides if self.strides else (self.slab, self.n)
+        return np.concatenate([buf.download(self.n, limb * ls + p * ps) for p in which])
 
     def arith(self):
         return self.plan.info()["arith"]
@@ -499,11 +539,16 @@ def literal_50_bit(lib, shard, steps):
     return side_forward(lib, shard, lib.find_prime(50, shard.n), steps, "largest prime below 2^50")
 
 
-def kernel_chain(w, arith, f64_class):
-    """the device work of one step, for the report"""
+def kernel_chain(w, arith, f64_class, hbm_passes=1, batch=None):
+    """the device work of one step, for the report.  hbm_passes: ntt_plan_info()[5] -- 1 when one launch carries both passes of a
+    transform above 2^14 (the XCD-local kernel; its automatic choice needs 512 polynomials), else the pass list's length"""
     pol = "ArithU64" if arith != 2 else ("ArithF64W" if f64_class == 52 else "ArithF64")
     if w is None or (w.kind == "fwd" and w.logn == LOGN):
         return kernel_name(arith), 1
+    one_launch = hbm_passes == 1 and (batch is None or batch >= 512)
+    if w.kind == "fwd" and w.logn > LOGN and not one_launch:
+        return "per 256 MiB chunk column_kernel<%s,%d,fwd> + fused_kernel<%s,%d,fwd>" % (pol, w.logn - (12 if w.logn <= 16 else 14), pol,
+                                                                                         12 if w.logn <= 16 else 14), 2 * max(1, (batch or 0) * 8 * w.n // (256 << 20))
     if w.kind == "fwd" and w.logn > LOGN:
         return "team_kernel<%s,%d,fwd> (both forward passes as items of one launch)" % (
             pol if arith == 2 else "ArithU64X", w.logn - 12), 1
@@ -518,7 +563,7 @@ def kernel_chain(w, arith, f64_class):
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,
-                step_ms=None, f64_class=0, shape_gbs=None):
+                step_ms=None, f64_class=0, shape_gbs=None, oop_gbs=None):
     n = n or N
     w = workload
     bytes_per_unit = w.bytes_per_unit if w else 16 * n
@@ -526,7 +571,7 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     value = n_gpus * batch / (elapsed / args.steps)
     slowest = max(kernel_ms)
     achieved = batch * bytes_per_unit / (slowest * 1e-3) / 1e9
-    kname, launches = kernel_chain(w, arith, f64_class)
+    kname, launches = kernel_chain(w, arith, f64_class, hbm_passes, batch)
     scaling = getattr(args, "scaling", "weak")
     total = w.total_batch if w else TOTAL_BATCH
     shards = w.shards if w else SHARDS
@@ -547,18 +592,21 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     qdesc = ", ".join(hex(q) for q in qs)
     if cfg == 4:
         qdesc += " (51-bit, reference test case 12)"
-    traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else None
+    traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else measured_traffic_config(cfg, batch, n)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r04/pmc_traffic.json), "
+            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r05/pmc_traffic*.json), "
                               "not collected in this run" if traffic is not None else None,
             "kernel": kname, "launches_per_step": launches, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
             "algorithmic_bytes_per_step": batch * bytes_per_unit,
             "algorithmic_bytes_per_unit": bytes_per_unit,
-            # measured in this run: in-place read-modify-write of the same buffer without arithmetic (a reference
-            # point, not the ceiling: memory-only skeletons of the kernel's own shape reach 0.67-0.72 of the peak,
-            # profiles/r02/skeleton.txt)
-            "copy_probe": copy_gbs, "frac_of_copy_probe": (achieved / copy_gbs) if copy_gbs else None,
+            # measured in this run, three reference points next to the 8 TB/s specification figure, slowest first:
+            #   in-place read-modify-write of the same buffer by a plain grid-stride kernel (NOT a ceiling: the transform
+            #   kernels' own memory shape is faster, see shape_probe);
+            #   out-of-place 16-byte-per-lane copy (the shape MI355X_MICROARCH.md quotes about 6.3 TB/s for);
+            #   shape_probe below
+            "inplace_rmw_probe": copy_gbs, "frac_of_inplace_rmw_probe": (achieved / copy_gbs) if copy_gbs else None,
+            "out_of_place_copy_probe": oop_gbs, "frac_of_out_of_place_copy_probe": (achieved / oop_gbs) if oop_gbs else None,
             # measured in this run as well (ntt_shape_probe): the memory shape of the 2^14 block kernels without their
             # arithmetic -- persistent 1024-thread workgroups, register prefetch, 16-byte accesses; null when not measured
             "shape_probe": shape_gbs,
@@ -643,14 +691,14 @@ class Parity:
         self.mid["fwd_checked"] = True
 
 
-def also_config(lib, config, steps=8, warmup=3, check=True):
+def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
     """BASELINE configs 2, 3 and 5 beside the headline (only the default run is driver-timed): the
     config's one-GPU share through the same GpuShard / run_steps / Parity code as `--config N`, after the headline's timed
     region, a few steps each, parity spot-checked on the first warm-up step like the headline.  Compact block: value, unit,
     frac of 8 TB/s at the config's algorithmic bytes per unit, mean / min step time."""
     w = workload_for(config).resolve(lib)
     batch = w.per_gpu_batch("weak", 1)
-    shard = GpuShard(lib, 0, 0, batch, n=w.n, kind=w.kind, qs=w.qs, roots=w.roots, steps_total=steps + max(warmup, 1))
+    shard = GpuShard(lib, 0, 0, batch, n=w.n, kind=w.kind, qs=w.qs, roots=w.roots, steps_total=steps + max(warmup, 1), layout=layout)
     par = Parity(w, shard, batch)
     if check:
         par.capture()
@@ -659,8 +707,13 @@ def also_config(lib, config, steps=8, warmup=3, check=True):
         par.check_roundtrip_forward()
     step_ms = shard.step_ms()
     gbs = batch * w.bytes_per_unit / (kernel_ms[0] * 1e-3) / 1e9
-    kname, launches = kernel_chain(w, shard.arith(), shard.f64_class())
+    kname, launches = kernel_chain(w, shard.arith(), shard.f64_class(), shard.hbm_passes(), batch)
+    traffic = measured_traffic_config(config, batch, w.n, layout)
     out = {"value": batch / (elapsed / steps), "unit": w.unit, "frac": gbs / HBM_PEAK_GBS, "achieved_GBs": gbs,
+           # HBM-side bytes of one step from the committed counter passes (FETCH_SIZE x2 + WRITE_SIZE over the step's launches;
+           # profiles/r05/pmc_traffic_config*.json), and their ratio to the algorithmic bytes: > 1 = bytes moved twice
+           "traffic": traffic, "traffic_over_algorithmic": (traffic / (batch * w.bytes_per_unit)) if traffic else None,
+           "layout": "[batch][limb][N]" if layout else ("[limb][batch][N]" if w.kind == "rns_product" else "[batch][N]"),
            "kernel_ms": kernel_ms[0], "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": max(warmup, 1 if check else 0),
            "step_ms_min": min(step_ms), "frac_at_min": batch * w.bytes_per_unit / (min(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_unit": w.bytes_per_unit, "batch_per_gpu": batch, "N": w.n,
@@ -683,6 +736,8 @@ def main():
                     help="skip the side measurements (copy probe, other primes): profiler runs then see the step's kernels only")
     ap.add_argument("--logn", type=int, default=0, help="(experiments, config 4 only) other transform sizes")
     ap.add_argument("--no-also", action="store_true", help="default run: skip the also_config2/3/5 blocks")
+    ap.add_argument("--layout", choices=("limb-major", "batch-major"), default="limb-major",
+                    help="config 5: RNS operands as [limb][batch][N] (default) or as SURVEY 8(d) lays them out, [batch][prime][N]")
     ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each also_configN block (3 warm-ups in front)")
     args = ap.parse_args()
 
@@ -729,7 +784,8 @@ def main():
         if device >= have:
             sys.exit("bench.py: --gpus %d but only %d HIP device(s) visible" % (n_gpus, have))
         shards.append(GpuShard(lib, device, index, batch, n=n, kind=w.kind, qs=w.qs, roots=w.roots,
-                               steps_total=args.steps + max(args.warmup, 1)))
+                               steps_total=args.steps + max(args.warmup, 1),
+                               layout="batch_major" if (args.layout == "batch-major" and w.kind == "rns_product") else None))
 
     def barrier():
         for s in shards:
@@ -756,6 +812,7 @@ def main():
         dist.all_gather(allk, t)
         kernel_ms = [float(x.item()) for x in allk]
 
+    also_failed = False
     if rank == 0:
         s0 = shards[0]
         if check and w.kind == "roundtrip":
@@ -763,9 +820,10 @@ def main():
         # after the timed region, on shard 0's resident buffer
         copy_gbs = None if args.headline_only else s0.copy_ceiling_gbs()
         shape_gbs = None if args.headline_only else s0.shape_ceiling_gbs()
+        oop_gbs = None if args.headline_only else s0.out_of_place_copy_gbs()   # (last: it overwrites half of the buffer)
         slow = max(range(len(shards)), key=lambda i: kernel_ms[i] if i < len(kernel_ms) else 0) if world == 1 else 0
         out = make_report(args, n_gpus, batch, elapsed, kernel_ms, s0.arith(), s0.hbm_passes(), n=n, copy_gbs=copy_gbs,
-                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class(), shape_gbs=shape_gbs)
+                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class(), shape_gbs=shape_gbs, oop_gbs=oop_gbs)
         if n_gpus == 1 and not args.headline_only:
             if w.config == 4 and n == N:
                 out["also_literal_50_bit_q"] = literal_50_bit(lib, s0, args.steps)
@@ -775,12 +833,19 @@ def main():
             if w.config == 4 and n == N and not args.no_also:
                 # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
                 # above): the driver only runs this default command, so their numbers ride on its line
-                for cfg in (2, 3, 5, 60):
+                for cfg, lay in ((2, None), (3, None), (5, None), (5, "batch_major"), (60, None)):
                     key = "also_config%d" % cfg if cfg != 60 else "also_60_bit_q_n65536"
+                    if lay:
+                        key += "_" + lay      # config 5 with the operands as SURVEY 8(d) lays them out: [batch][prime][N]
                     try:
-                        out[key] = also_config(lib, cfg, steps=args.also_steps, check=check)
-                    except Exception as e:      # a side block must never cost the headline line; a parity failure says so
+                        out[key] = also_config(lib, cfg, steps=args.also_steps, check=check, layout=lay)
+                    except Exception as e:      # a side block must never cost the headline line ...
                         out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                        # ... but a WRONG RESULT on a BASELINE configuration must not pass unnoticed either: flagged at the top
+                        # level, and the process exits non-zero after the line is printed
+                        if isinstance(e, AssertionError):
+                            out["also_failed"] = True
+                            also_failed = True
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, lib)
         print(json.dumps(out), flush=True)
@@ -789,6 +854,8 @@ def main():
         s.close()
     if dist is not None:
         dist.destroy_process_group()
+    if also_failed:
+        sys.exit(4)      # a side block's parity check failed: the line above says which
 
 
 if __name__ == "__main__":

@@ -88,6 +88,15 @@ typedef enum ntt_option {
                           * tables, same canonical results, lazy outputs inside the same ranges but NOT the reference's lazy
                           * words; 0 = the reference's Harvey butterflies.  Default: 1 for NTT_ARITH_AUTO plans (q >= 2^52),
                           * 0 for plans created with NTT_ARITH_U64.  10 + K forces headroom class K in {0, 1, 3} (tests) */
+  NTT_OPT_RNS_LAUNCH = 12, /* ntt_rns_*: how a run of compatible limbs is launched -- 0 = ONE launch (per pass) over the run wherever
+                          * the kernels have the variant, 1 = one launch chain per limb, -1 (default) = one launch where a limb's share
+                          * alone cannot fill the chip and for the XCD-local launches.  Read from the run's first plan; results are
+                          * identical (tests, measurements) */
+  NTT_OPT_DOT_FUSED = 13, /* NTT-domain products (ntt_inv_dot_batch, ntt_fwd_mul_batch, ...): 1 (default) = the products inside the
+                          * transform's first / last pass; 0 = pointwise(-accumulate) launches around a plain transform (measurements) */
+  NTT_OPT_BLOCK_OVERSUB = 11, /* persistent block kernels: workgroups launched per resident slot (0 = default: 8 for the 2^12-point
+                          * block kernels, whose four workgroups per CU otherwise run in phase -- measured +5 % forward, +4 % inverse,
+                          * profiles/r05/grid_sweep.txt --, 1 elsewhere: 2^13 and 2^14 measured no gain) */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
                           * operands through the forward stages, multiplies in registers and runs the inverse: 24N bytes up to
                           * 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise one launch (all limbs of an RNS set
@@ -130,7 +139,8 @@ NTT_API int  ntt_plan_info(const ntt_plan *p, uint64_t info[8]);
 NTT_API int  ntt_plan_export_table(const ntt_plan *p, int which, void *h_dst, size_t bytes);
 /* force the strided multi-pass path (self-check of the fused kernels) */
 NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
-/* tuning / test knobs of one plan (ntt_option); nothing in the library reads environment variables for these */
+/* tuning / test knobs of one plan (ntt_option).  The batched API reads NO environment variable; the reference-signature entry points
+ * (which have no argument to carry a choice) read NTT_DEVICE and NTT_COMPAT_ARITH once, at their first call. */
 NTT_API int  ntt_plan_set_option(ntt_plan *p, int option, int64_t value);
 
 /* ---- batched transforms: d_a is device memory laid out [batch][N], in place ---- */
@@ -226,8 +236,7 @@ NTT_API int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, c
  * batches are ONE launch over the limbs too (the XCD-local kernels take the limb as part of their queue entries); other large
  * batches are served limb by limb.  A modulus chain with primes of several sizes (a 60-bit first prime in front of 50-bit
  * ones) is served as maximal RUNS of consecutive compatible limbs: one launch per pass and run, single limbs by themselves.
- * Results are identical either way (environment NTT_RNS_LOOP=1 forces the per-limb form, =0 the one-launch form wherever it
- * is built). ---- */
+ * Results are identical either way (NTT_OPT_RNS_LAUNCH on the limbs' plans forces either form). ---- */
 NTT_API int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
@@ -239,6 +248,36 @@ NTT_API int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, ui
                                           uint64_t batch, unsigned flags, void *stream);
 NTT_API int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
                                   uint64_t batch, unsigned flags, void *stream);
+
+/* ---- caller-native layouts (round 5).  The entry points above take RNS operands as [limb][batch][N].  SURVEY 8(d) config 5
+ * -- and every FHE library -- keeps a polynomial's limbs side by side: [batch][prime][N].  The *_strided forms take the two
+ * distances in WORDS instead of assuming either:
+ *     coefficient i of limb l of polynomial p  =  d_x[l * limb_stride + p * poly_stride + i]
+ *   [limb][batch][N]:  limb_stride = batch * N, poly_stride = N           (what the plain entry points pass)
+ *   [batch][limb][N]:  limb_stride = N,         poly_stride = nlimbs * N  (no transpose on either side of the call)
+ * Padded variants of either are accepted; strides under which two (limb, polynomial) ranges would overlap are refused
+ * (NTT_ERR_ARG).  All operands of one call (a, b, c, every a_i^ / b_i^) share the layout; a broadcast b^ (NTT_MUL_B_BROADCAST) stays
+ * [limb][N].  Same kernels, same launch choices (one launch over the limbs where it pays, the XCD-local launches for large
+ * batches of N >= 2^15), same results: the layout is one address computation per block (csrc/ntt_core.h block_offset).
+ * The reference's own batching precedent is two caller arrays side by side, fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...)
+ * (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91); these generalise it to any regular placement. ---- */
+NTT_API int ntt_rns_fwd_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t limb_stride, uint64_t poly_stride,
+                                      uint64_t batch, void *stream);
+NTT_API int ntt_rns_inv_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t limb_stride, uint64_t poly_stride,
+                                      uint64_t batch, void *stream);
+NTT_API int ntt_rns_negacyclic_mul_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
+                                                 uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, void *stream);
+NTT_API int ntt_rns_inv_dot_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                                          const uint64_t *const *d_bhat, uint64_t limb_stride, uint64_t poly_stride, uint64_t batch,
+                                          unsigned flags, void *stream);
+NTT_API int ntt_rns_mul_transformed_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                                  uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, unsigned flags, void *stream);
+NTT_API int ntt_rns_fwd_mul_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                          uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, unsigned flags, void *stream);
+/* one plan, `batch` polynomials poly_stride words apart (one limb of a [batch][limb][N] operand; a column of a caller's
+ * matrix of polynomials): ntt_transform_batch with a stride */
+NTT_API int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uint64_t poly_stride, uint64_t batch, unsigned flags,
+                                        void *stream);
 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);
@@ -267,6 +306,9 @@ NTT_API int ntt_poly_checksum(int device, uint64_t *d_out, const uint64_t *d_a, 
  * -- no arithmetic, no LDS, the same 8 B in + 8 B out per coefficient as an in-place NTT.  mask = 0 leaves the
  * data unchanged.  n must be even. */
 NTT_API int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mask, void *stream);
+/* out-of-place copy of n words (16 bytes per lane, grid-stride): the copy shape the microarchitecture guide quotes the achievable
+ * HBM rate for (about 6.3 TB/s of read + written bytes); 2 x 8 x n bytes move.  n must be even. */
+NTT_API int ntt_copy_probe(int device, uint64_t *d_dst, const uint64_t *d_src, uint64_t n, void *stream);
 /* the same measurement in the memory shape of the 2^14 block kernels themselves: one persistent 1024-thread workgroup per CU,
  * 2^14-word blocks as 16-byte loads with the next block prefetched in registers, XOR, 16-byte stores (whole KiB per wave and
  * instruction) -- the best memory-only skeleton of the transform kernels (profiles/r02/skeleton.txt), measured in the run

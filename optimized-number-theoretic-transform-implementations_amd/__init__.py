@@ -41,7 +41,8 @@ ARITH_AUTO, ARITH_U64, ARITH_F64, ARITH_U64_R4 = 0, 1, 2, 3
 FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
 MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
-OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE = 7, 8, 9, 10
+OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE, OPT_BLOCK_OVERSUB = 7, 8, 9, 10, 11
+OPT_RNS_LAUNCH, OPT_DOT_FUSED = 12, 13
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
@@ -51,10 +52,12 @@ EXPORTED_SYMBOLS = [
     "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
     "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
-    "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch",
+    "ntt_rns_fwd_batch_strided", "ntt_rns_inv_batch_strided", "ntt_rns_negacyclic_mul_batch_strided", "ntt_rns_inv_dot_batch_strided",
+    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
-    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
+    "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_copy_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
     "ntt_compat_release", "ntt_compat_cached_plans",
     # reference signatures (include/ntt_reference.h, ntt_radix4.h, ntt_radix4x4.h, ntt_seal.h)
     "fwd_ntt_ref_harvey_lazy", "inv_ntt_ref_harvey", "fwd_ntt_ref_harvey_lazy_dbl",
@@ -78,6 +81,8 @@ class MulOp(C.Structure):
 
 
 def _sig(name, restype, *argtypes):
+    if "NTT_LIB" in os.environ and not hasattr(_lib, name):
+        return None   # an older build selected for a same-box A/B (tools/build_head.sh): entry points added since are simply absent
     f = getattr(_lib, name)
     f.restype = restype
     f.argtypes = list(argtypes)
@@ -112,6 +117,15 @@ _sig("ntt_rns_inv_dot_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_int
 _sig("ntt_rns_mul_transformed_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_fwd_mul_batch", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_rns_fwd_mul_batch", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_fwd_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_rns_inv_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_rns_negacyclic_mul_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_rns_inv_dot_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64,
+     C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_mul_transformed_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64,
+     C.c_uint, VOIDP)
+_sig("ntt_rns_fwd_mul_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_transform_batch_strided", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
 _sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
@@ -127,6 +141,7 @@ _sig("ntt_fill_uniform", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, C.c_ui
 _sig("ntt_poly_checksum", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_rmw_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_shape_probe", C.c_int, C.c_int, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
+_sig("ntt_copy_probe", C.c_int, C.c_int, VOIDP, VOIDP, C.c_uint64, VOIDP)
 _sig("ntt_batch_multi", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), U64P, C.c_int)
 _sig("ntt_rns_mul_multi", C.c_int, C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.POINTER(VOIDP), C.POINTER(VOIDP), U64P)
 _sig("ntt_compat_release", None)
@@ -237,6 +252,11 @@ def shape_probe(dptr, n, mask=0, device=0, stream=None):
     _check(_lib.ntt_shape_probe(device, dptr, n, mask, stream))
 
 
+def copy_probe(ddst, dsrc, n, device=0, stream=None):
+    """out-of-place 16-byte-per-lane copy of n words (the guide's copy shape: 16 n bytes move)"""
+    _check(_lib.ntt_copy_probe(device, ddst, dsrc, n, stream))
+
+
 def stream_sync(device=0, stream=None):
     _check(_lib.ntt_stream_sync(device, stream))
 
@@ -302,6 +322,10 @@ class Plan:
         f = _lib.ntt_inv_batch_lazy if lazy else (_lib.ntt_inv_batch_wide if wide else _lib.ntt_inv_batch)
         _check(f(self.h, dptr, batch, stream))
 
+    def transform_strided(self, dptr, poly_stride, batch, flags=0, stream=None):
+        """`batch` polynomials poly_stride words apart (ntt_transform_batch_strided); flags = FLAG_*"""
+        _check(_lib.ntt_transform_batch_strided(self.h, dptr, poly_stride, batch, flags, stream))
+
     def pointwise_mul(self, dc, da, db, batch, stream=None, lazy_in=False):
         f = _lib.ntt_pointwise_mul_batch_lazy if lazy_in else _lib.ntt_pointwise_mul_batch
         _check(f(self.h, dc, da, db, batch, stream))
@@ -360,32 +384,56 @@ def _plan_array(plans):
     return (VOIDP * len(plans))(*[p.h for p in plans])
 
 
-def rns_fwd(plans, dptr, batch, stream=None):
-    """limbs laid out [limb][batch][N]"""
-    _check(_lib.ntt_rns_fwd_batch(len(plans), _plan_array(plans), dptr, batch, stream))
+def set_rns_launch(plans, mode):
+    """how ntt_rns_* launch a run of compatible limbs (NTT_OPT_RNS_LAUNCH on every plan): 0 / "0" = one launch over the run
+    wherever built, 1 / "1" = one launch chain per limb, None = the library's choice"""
+    v = -1 if mode is None else int(mode)
+    for p in plans:
+        p.set_option(OPT_RNS_LAUNCH, v)
 
 
-def rns_inv(plans, dptr, batch, stream=None):
-    _check(_lib.ntt_rns_inv_batch(len(plans), _plan_array(plans), dptr, batch, stream))
+def batch_major(plans):
+    """(limb_stride, poly_stride) of SURVEY 8(d)'s [batch][prime][N] layout for this limb list"""
+    return (plans[0].N, len(plans) * plans[0].N)
 
 
-def rns_negacyclic_mul(plans, dc, da, db, batch, stream=None):
-    _check(_lib.ntt_rns_negacyclic_mul_batch(len(plans), _plan_array(plans), dc, da, db, batch, stream))
+def rns_fwd(plans, dptr, batch, stream=None, layout=None):
+    """limbs laid out [limb][batch][N]; layout = (limb_stride, poly_stride) in words for any other placement"""
+    if layout: _check(_lib.ntt_rns_fwd_batch_strided(len(plans), _plan_array(plans), dptr, layout[0], layout[1], batch, stream))
+    else: _check(_lib.ntt_rns_fwd_batch(len(plans), _plan_array(plans), dptr, batch, stream))
 
 
-def rns_inv_dot(plans, dc, dahats, dbhats, batch, flags=0, stream=None):
+def rns_inv(plans, dptr, batch, stream=None, layout=None):
+    if layout: _check(_lib.ntt_rns_inv_batch_strided(len(plans), _plan_array(plans), dptr, layout[0], layout[1], batch, stream))
+    else: _check(_lib.ntt_rns_inv_batch(len(plans), _plan_array(plans), dptr, batch, stream))
+
+
+def rns_negacyclic_mul(plans, dc, da, db, batch, stream=None, layout=None):
+    if layout: _check(_lib.ntt_rns_negacyclic_mul_batch_strided(len(plans), _plan_array(plans), dc, da, db, layout[0], layout[1], batch, stream))
+    else: _check(_lib.ntt_rns_negacyclic_mul_batch(len(plans), _plan_array(plans), dc, da, db, batch, stream))
+
+
+def rns_inv_dot(plans, dc, dahats, dbhats, batch, flags=0, stream=None, layout=None):
     """operands laid out [limb][batch][N] (a broadcast b^: [limb][N])"""
     k = len(dahats)
-    _check(_lib.ntt_rns_inv_dot_batch(len(plans), _plan_array(plans), dc, k, (VOIDP * k)(*dahats), (VOIDP * k)(*dbhats), batch,
-                                      flags, stream))
+    if layout:
+        _check(_lib.ntt_rns_inv_dot_batch_strided(len(plans), _plan_array(plans), dc, k, (VOIDP * k)(*dahats), (VOIDP * k)(*dbhats), layout[0],
+                                                  layout[1], batch, flags, stream))
+    else:
+        _check(_lib.ntt_rns_inv_dot_batch(len(plans), _plan_array(plans), dc, k, (VOIDP * k)(*dahats), (VOIDP * k)(*dbhats), batch,
+                                          flags, stream))
 
 
-def rns_fwd_mul(plans, dc, da, dbhat, batch, flags=0, stream=None):
-    _check(_lib.ntt_rns_fwd_mul_batch(len(plans), _plan_array(plans), dc, da, dbhat, batch, flags, stream))
+def rns_fwd_mul(plans, dc, da, dbhat, batch, flags=0, stream=None, layout=None):
+    if layout: _check(_lib.ntt_rns_fwd_mul_batch_strided(len(plans), _plan_array(plans), dc, da, dbhat, layout[0], layout[1], batch, flags, stream))
+    else: _check(_lib.ntt_rns_fwd_mul_batch(len(plans), _plan_array(plans), dc, da, dbhat, batch, flags, stream))
 
 
-def rns_mul_transformed(plans, dc, da, dbhat, batch, flags=0, stream=None):
-    _check(_lib.ntt_rns_mul_transformed_batch(len(plans), _plan_array(plans), dc, da, dbhat, batch, flags, stream))
+def rns_mul_transformed(plans, dc, da, dbhat, batch, flags=0, stream=None, layout=None):
+    if layout:
+        _check(_lib.ntt_rns_mul_transformed_batch_strided(len(plans), _plan_array(plans), dc, da, dbhat, layout[0], layout[1], batch, flags, stream))
+    else:
+        _check(_lib.ntt_rns_mul_transformed_batch(len(plans), _plan_array(plans), dc, da, dbhat, batch, flags, stream))
 
 
 def batch_multi(plans, dptrs, batches, inverse=False):

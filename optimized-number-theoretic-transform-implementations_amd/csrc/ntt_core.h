@@ -255,7 +255,20 @@ template <class A> struct Params {
   uint32_t               lastinv; /* inverse: this pass ends with global stage 0  */
   uint32_t               lazy;    /* outputs of the pass that ends a transform stay in the reference's lazy range */
   uint64_t               nblocks; /* batch * 2^s0 blocks of 2^LOGN                */
+  uint64_t               pstride; /* words between consecutive polynomials of this limb: N for the dense [batch][N] slab, more
+                                   * for a caller-native layout ([polynomial][limb][N]: limbs * N) -- see block_offset */
 };
+
+/* Where block b of a pass starts, in words from the limb's first coefficient.  A pass over `batch` polynomials of 2^logn points
+ * works on batch * 2^s0 blocks of 2^LOGN points (s0 = logn - LOGN leading stages belong to column passes): block b is position
+ * b mod 2^s0 of polynomial b >> s0, and polynomial p of the limb starts p * pstride words in.  The dense layout the reference's
+ * batching precedent implies (fwd_ntt_ref_harvey_lazy_dbl's a1[], a2[] side by side, include/ntt_reference.h:44-49) has
+ * pstride = N and this is b << LOGN; SURVEY 8(d)'s [batch][prime][N] has pstride = primes * N.  One function for the kernels,
+ * the host's chunking and the CPU emulation (tests/emu). */
+template <int LOGN> NTT_HD uint64_t block_offset(uint64_t b, uint32_t s0, uint64_t pstride)
+{
+  return (b >> s0) * pstride + ((b & ((1ull << s0) - 1ull)) << LOGN);
+}
 
 NTT_HD uint32_t uniform_u32(uint32_t v)
 {

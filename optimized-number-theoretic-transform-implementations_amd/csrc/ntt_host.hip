@@ -86,11 +86,9 @@ static int fail(int code, const std::string &msg)
     }                                                                                         \
   } while(0)
 
-[[maybe_unused]] static int env_int(const char *name, int dflt)
-{
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+/* The environment is read for ONE purpose: the reference-signature entry points (void functions with the reference's argument
+ * lists: no plan, no option argument) take their device and arithmetic from NTT_DEVICE / NTT_COMPAT_ARITH -- once, at their first
+ * call (compat_config below).  Everything else is a plan option (ntt_plan_set_option). */
 
 /* Every entry point selects the plan's (or the named) device for its own HIP calls and puts the
  * caller's current device back on return, so the library can be mixed with torch / other HIP code
@@ -264,6 +262,10 @@ struct ntt_plan {
   std::mutex           team_mu;
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
+  int              rns_launch = -1; /* ntt_rns_*: 0 = one launch over a run of limbs wherever it is built, 1 = one launch chain per limb,
+                                     * -1 = where it pays (rns_one_launch_pays); read from the run's first plan */
+  int              dot_fused  = 1;  /* the NTT-domain product kernels (dot_inv_kernel, fwd_mul_kernel): 0 = pointwise launches + transform */
+  int              block_oversub = 0; /* persistent block kernels: workgroups per resident slot (0 = the kernels' defaults) */
   int              num_cus    = 256;
   int              chunk_mib  = 256; /* bytes of one multi-pass chunk (Infinity Cache residency) */
   int              block_log  = 0;     /* multi-pass transforms: block size below the column passes (0 = multi_pass_block's choice) */
@@ -439,7 +441,7 @@ static int plan_build(ntt_plan **out, int device, uint64_t N, uint64_t q, uint64
   p->arith    = ar;
   /* NTT_ARITH_AUTO on a modulus the FP64 policies cannot serve: the throughput form of the integer arithmetic; an
    * explicit NTT_ARITH_U64 keeps the reference's butterflies and lazy words (NTT_OPT_INT_WIDE switches either way) */
-  p->int_cls  = (arith == NTT_ARITH_AUTO && ar == NTT_ARITH_U64 && env_int("NTT_INT_WIDE", 1) != 0) ? int_wide_class(q) : -1;
+  p->int_cls  = (arith == NTT_ARITH_AUTO && ar == NTT_ARITH_U64) ? int_wide_class(q) : -1;
   {
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -631,6 +633,16 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       if(value < 0) return fail(NTT_ERR_ARG, "max grid must be >= 0");
       p->max_grid = (int)value;
       return NTT_OK;
+    case NTT_OPT_RNS_LAUNCH:
+      p->rns_launch = value < 0 ? -1 : (value != 0);
+      return NTT_OK;
+    case NTT_OPT_DOT_FUSED:
+      p->dot_fused = value != 0;
+      return NTT_OK;
+    case NTT_OPT_BLOCK_OVERSUB:
+      if(value < 0 || value > 256) return fail(NTT_ERR_ARG, "workgroups per resident slot: 0 (default) .. 256");
+      p->block_oversub = (int)value;
+      return NTT_OK;
     case NTT_OPT_CHUNK_MIB:
       if(value < 1) return fail(NTT_ERR_ARG, "chunk must be >= 1 MiB");
       p->chunk_mib = (int)value;
@@ -726,8 +738,7 @@ static hipError_t dispatch_pass(const ntt_plan *p, const PassArgs &pa)
  * FORWARD transform of a batch that keeps all eight queues busy for several lags (+8..14 % over one launch per pass; wide
  * integer policy +18..23 %); the inverse only at 2^17 (+3..5 %, integer +15 %) -- at 2^15 and 2^16 its first pass is the
  * heavy one and the column items wait longer than the L2 can hold their polynomials: per-pass launches there.
- * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it; NTT_XCD_LOCAL in the
- * environment overrides the automatic choice the same way. */
+ * NTT_OPT_XCD_LOCAL 1 forces the path wherever it is built (batch >= 64), 0 disables it. */
 /* nlimbs > 1: the limbs of an RNS set in ONE launch (the queues run over all limbs' polynomials): `batch` is per limb */
 static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool wide, bool lazy, int nlimbs, bool product = false)
 {
@@ -739,8 +750,7 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
      batch < 64 || batch >= (1ull << 29)) {
     return false;
   }
-  int on = p->xcd_local;
-  if(on < 0) on = env_int("NTT_XCD_LOCAL", -1);
+  const int on = p->xcd_local;
   if(on >= 0) return on == 1;
   /* the wide integer policy (profiles/r04/ab_xcd_int.txt): forward +18..23 % at all three sizes; inverse +15 % at 2^17, none at
    * 2^16, -14 % at 2^15 */
@@ -803,8 +813,11 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
 struct LimbSet {
   const void *d;
   int         n;
-  uint64_t    stride;
+  uint64_t    stride;  /* words between consecutive limbs of one polynomial */
+  uint64_t    pstride; /* words between consecutive polynomials of one limb; 0 = dense (N) */
 };
+/* the words between consecutive polynomials of a limb */
+static uint64_t poly_words(const ntt_plan *p, const LimbSet &ls) { return ls.pstride ? ls.pstride : p->N; }
 
 static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream,
                          bool lazy = false, const LimbSet *set = nullptr)
@@ -813,7 +826,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
-  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0, 0};
   const PassList L = p->arith == NTT_ARITH_U64_R4
                          ? make_passes_r4(p->m)
                          : make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
@@ -832,6 +845,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.limbs       = ls.d;
     pa.nlimbs      = ls.n;
     pa.limb_stride = ls.stride;
+    pa.poly_stride = ls.pstride;
     pa.batch       = batch;
     pa.logn        = (uint32_t)p->m;
     pa.fused       = 3;
@@ -842,6 +856,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.ends        = 1;
     pa.max_grid    = p->max_grid;
     pa.num_cus     = p->num_cus;
+    pa.oversub     = p->block_oversub;
     pa.team_ctl    = ctl;
     /* polynomials between the two passes of a queue.  The L2 keeps the intermediate while lag x polynomial size stays
      * below about 2.5 MiB (measured, FETCH_SIZE 1.0x the data: 2^15 up to lag 10, 2^16 up to 5, 2^17 not even at 2;
@@ -868,6 +883,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.limbs    = ls.d;
     pa.nlimbs   = ls.n;
     pa.limb_stride = ls.stride;
+    pa.poly_stride = ls.pstride;
     pa.batch    = batch;
     pa.logn     = (uint32_t)p->m;
     pa.fused    = 2;
@@ -880,6 +896,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.ends     = 1;
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;
+    pa.oversub  = p->block_oversub;
     pa.stream   = (hipStream_t)stream;
     hipError_t e = dispatch_pass(p, pa);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -900,11 +917,12 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     for(int k = 0; k < L.n; k++) {
       const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
       PassArgs    pa{};
-      pa.a        = d_a + first * p->N;
+      pa.a        = d_a + first * poly_words(p, ls);
       /* (radix-4 inverse: a pass that does not end the transform multiplies by 1, not by N^-1) */
       pa.limbs    = p->arith == NTT_ARITH_U64_R4 && inverse && ps.s != 0 ? (const void *)p->limbrec_mid.data() : ls.d;
       pa.nlimbs   = ls.n;
       pa.limb_stride = ls.stride;
+      pa.poly_stride = ls.pstride;
       pa.lazy     = lazy;
       pa.ends     = k == L.n - 1;
       pa.batch    = nb;
@@ -917,6 +935,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
       pa.lastinv  = inverse && ps.s == 0;
       pa.max_grid = p->max_grid;
       pa.num_cus  = p->num_cus;
+      pa.oversub  = p->block_oversub;
       pa.stream   = (hipStream_t)stream;
       hipError_t e = dispatch_pass(p, pa);
       if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -994,30 +1013,43 @@ __global__ void __launch_bounds__(256) checksum_kernel(uint64_t *out, const uint
   }
 }
 
+/* Element i of a batch of polynomials of 2^logn words: polynomial i >> logn starts (i >> logn) * stride words into its operand
+ * (ntt_core.h block_offset with whole polynomials as blocks).  pstride: a, c and every operand laid out like them; bstride: the b
+ * operand -- 0 when it is ONE polynomial shared by the batch (a broadcast key). */
+struct PwLayout {
+  uint32_t logn;
+  uint64_t pstride, bstride;
+};
+__device__ __forceinline__ uint64_t pw_index(uint64_t i, uint32_t logn, uint64_t stride)
+{
+  return (i >> logn) * stride + (i & ((1ull << logn) - 1ull));
+}
+
 /* LAZYIN: operands in [0,4q) as ntt_fwd_batch_lazy leaves them; the product is always fully reduced */
 template <class A, bool LAZYIN>
-__global__ void __launch_bounds__(256) pointwise_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n,
+__global__ void __launch_bounds__(256) pointwise_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, const PwLayout lay,
                                                         const typename A::consts k)
 {
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    c[i] = LAZYIN ? A::mulmod_full_lazy4(a[i], b[i], k) : A::mulmod_full(a[i], b[i], k);
+    const uint64_t j = pw_index(i, lay.logn, lay.pstride);
+    c[j]             = LAZYIN ? A::mulmod_full_lazy4(a[j], b[j], k) : A::mulmod_full(a[j], b[j], k);
   }
 }
 
 /* c = (ACC ? c : 0) + a * b: the unfused form of the inner product in the NTT domain (plans the fused kernel is not built
- * for: column-pass-only plans, the radix-4 formulation, N < 2^6).  bmask = N - 1 when b is ONE polynomial shared by the
- * batch, else all ones. */
+ * for: column-pass-only plans, the radix-4 formulation, N < 2^6).  lay.bstride = 0 when b is ONE polynomial shared by the batch. */
 template <class A, bool LAZYIN, bool ACC>
-__global__ void __launch_bounds__(256) pointwise_acc_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t bmask,
+__global__ void __launch_bounds__(256) pointwise_acc_kernel(uint64_t *c, const uint64_t *a, const uint64_t *b, uint64_t n, const PwLayout lay,
                                                             uint64_t q, const typename A::consts k)
 {
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t t = LAZYIN ? A::mulmod_full_lazy4(a[i], b[i & bmask], k) : A::mulmod_full(a[i], b[i & bmask], k);
+    const uint64_t j = pw_index(i, lay.logn, lay.pstride), jb = pw_index(i, lay.logn, lay.bstride);
+    const uint64_t t = LAZYIN ? A::mulmod_full_lazy4(a[j], b[jb], k) : A::mulmod_full(a[j], b[jb], k);
     if constexpr(ACC) {
-      const uint64_t v = c[i] + t; /* both canonical: < 2q < 2^64 */
-      c[i]             = v < q ? v : v - q;
+      const uint64_t v = c[j] + t; /* both canonical: < 2q < 2^64 */
+      c[j]             = v < q ? v : v - q;
     } else {
-      c[i] = t;
+      c[j] = t;
     }
   }
 }
@@ -1030,8 +1062,9 @@ static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
   return (unsigned)g;
 }
 
+/* pstride: words between consecutive polynomials of all three operands (0 = dense: N) */
 static int pointwise_launch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, uint64_t batch,
-                            void *stream, bool lazy_in)
+                            void *stream, bool lazy_in, uint64_t pstride = 0)
 {
   if(!p || !d_c || !d_a || !d_b) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
@@ -1039,12 +1072,13 @@ static int pointwise_launch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_
   const uint64_t n = batch * p->N;
   const dim3     g(grid_for(n)), t(256);
   hipStream_t    st = (hipStream_t)stream;
+  const PwLayout lay{(uint32_t)p->m, pstride ? pstride : p->N, pstride ? pstride : p->N};
   if(p->arith == NTT_ARITH_F64) {
-    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithF64, true>), g, t, 0, st, d_c, d_a, d_b, n, p->cf);
-    else hipLaunchKernelGGL((pointwise_kernel<ArithF64, false>), g, t, 0, st, d_c, d_a, d_b, n, p->cf);
+    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithF64, true>), g, t, 0, st, d_c, d_a, d_b, n, lay, p->cf);
+    else hipLaunchKernelGGL((pointwise_kernel<ArithF64, false>), g, t, 0, st, d_c, d_a, d_b, n, lay, p->cf);
   } else {
-    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithU64, true>), g, t, 0, st, d_c, d_a, d_b, n, p->cu);
-    else hipLaunchKernelGGL((pointwise_kernel<ArithU64, false>), g, t, 0, st, d_c, d_a, d_b, n, p->cu);
+    if(lazy_in) hipLaunchKernelGGL((pointwise_kernel<ArithU64, true>), g, t, 0, st, d_c, d_a, d_b, n, lay, p->cu);
+    else hipLaunchKernelGGL((pointwise_kernel<ArithU64, false>), g, t, 0, st, d_c, d_a, d_b, n, lay, p->cu);
   }
   HIP_TRY(hipGetLastError());
   return NTT_OK;
@@ -1070,6 +1104,7 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
   pa.limbs    = ls.d;
   pa.nlimbs   = ls.n;
   pa.limb_stride = ls.stride;
+  pa.poly_stride = ls.pstride;
   pa.batch    = nb;
   pa.logn     = (uint32_t)p->m;
   pa.fused    = ps.fused;
@@ -1082,6 +1117,7 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
   pa.ends     = ends;
   pa.max_grid = p->max_grid;
   pa.num_cus  = p->num_cus;
+  pa.oversub  = p->block_oversub;
   pa.stream   = (hipStream_t)stream;
   hipError_t e = dispatch_pass(p, pa);
   if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1102,14 +1138,14 @@ static int launch_one_pass(const ntt_plan *p, const Pass &ps, uint64_t *d, uint6
 static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream,
                          const LimbSet *set = nullptr, bool ahat_given = false)
 {
-  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0, 0};
   /* a^ = fwd(a).  The product kernels take a^ as lazy words v + 2q, v in (-2q, 2q); a canonical word c is the lazy word of
    * v = c - 2q, so the reduced forward transform is a valid producer too -- used where it is the faster launch (the
    * XCD-local kernel, N >= 2^15, large batches: +13..20 % over the per-pass lazy transform) */
   const bool canonical_a = team_applies(p, batch, false, false, false, ls.n, true);
   /* N >= 2^15, large batches: the chain as the item kinds of ONE launch (ntt_kernels.h: team_product_kernel) -- column
    * stages of b AND a, block products (both blocks through their twelve stages, product, inverse stages), inverse column
-   * stages of c: a^ never exists in memory (48N instead of 64N bytes across the fabric).  NTT_PRODUCT_FOUR=0 keeps a's
+   * stages of c: a^ never exists in memory (48N instead of 64N bytes across the fabric).  NTT_OPT_FUSED_PRODUCT 2 keeps a's
    * forward transform as a launch of its own in front of the three-pass form (measurements, tests). */
   void *ctl  = nullptr;
   int   rc   = NTT_OK;
@@ -1117,13 +1153,13 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch * (uint64_t)ls.n, &ctl);
     if(rc) return rc;
   }
-  const bool four = !ahat_given && ctl && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  const bool four = !ahat_given && ctl && p->fused_product != 2;
   /* N <= 2^14: a's coefficients go straight into the fused kernel, which takes both operands through the forward
    * stages (24N instead of 40N bytes, one launch; a is left as it was) */
   /* N > 2^14 below the one-launch form's batch: the same inside the block launch of every chunk -- a gets b's column
    * passes and the blocks of both operands meet in registers (72N instead of 88N bytes, 6 launches per chunk, no
    * transform of a in front) */
-  const bool both = !ahat_given && !four && p->fused_product != 2 && env_int("NTT_PRODUCT_FOUR", 1) != 0;
+  const bool both = !ahat_given && !four && p->fused_product != 2;
   if(!four && !both && !ahat_given) {
     rc = run_transform(p, d_a, batch, false, false, stream, !canonical_a, &ls);
     if(rc) return rc;
@@ -1139,11 +1175,13 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
       pa.limbs       = ls.d;
       pa.nlimbs      = ls.n;
       pa.limb_stride = ls.stride;
+      pa.poly_stride = ls.pstride;
       pa.batch       = batch;
       pa.logn        = (uint32_t)p->m;
       pa.a_lazy      = 1;
       pa.max_grid    = p->max_grid;
       pa.num_cus     = p->num_cus;
+      pa.oversub     = p->block_oversub;
       pa.team_ctl    = ctl;
       /* three passes, four workgroups per CU: the lag that keeps second- and third-pass items from waiting is larger than
        * the transform's (measured, profiles/r03/sweep_product_lag.txt: flat optimum 12-14 at 2^17, 12-20 at 2^16, 20-24 at 2^15;
@@ -1173,7 +1211,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   }
   for(uint64_t first = 0; first < batch; first += chunk) {
     const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
-    const uint64_t off = first * p->N;
+    const uint64_t off = first * poly_words(p, ls);
     for(int k = 0; k + 1 < L.n; k++) { /* forward column passes of b (every pass but the last, which is the block pass) */
       rc = launch_one_pass(p, L.p[k], d_b + off, nb, false, false, false, false, stream, ls);
       if(!rc && both) rc = launch_one_pass(p, L.p[k], d_a + off, nb, false, false, false, false, stream, ls); /* ... and of a */
@@ -1186,6 +1224,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.limbs    = ls.d;
     pa.nlimbs   = ls.n;
     pa.limb_stride = ls.stride;
+    pa.poly_stride = ls.pstride;
     pa.batch    = nb;
     pa.logn     = (uint32_t)p->m;
     pa.block_log = (uint32_t)pblk;
@@ -1193,6 +1232,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
     pa.both     = both;
     pa.max_grid = p->max_grid;
     pa.num_cus  = p->num_cus;
+    pa.oversub  = p->block_oversub;
     pa.stream   = (hipStream_t)stream;
     const int  kc = eff_kcls(p);
     hipError_t e = kc == kWideClass ? launch_product<ArithF64W, 0>(pa)
@@ -1218,34 +1258,42 @@ static bool dot_kernel_applies(const ntt_plan *p);
 static int  inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *const *a, const uint64_t *const *b, uint64_t batch,
                     unsigned flags, void *stream, const LimbSet *set, uint64_t b_limb_stride);
 
-extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
-                                        uint64_t batch, void *stream)
+/* pstride: words between consecutive polynomials of all three operands (0 = dense) */
+static int negacyclic_mul_one(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream, uint64_t pstride)
 {
   /* the chain never leaves the lazy domain: both forward transforms skip their final reduction,
    * the pointwise product takes [0,4q) operands, only the inverse's output is reduced.
    * d_a == d_b is a squaring: the operand is transformed once (transforming the shared buffer twice
    * would multiply fwd(fwd(a)) with itself) */
-  if(p && p->arith == NTT_ARITH_U64_R4) {
+  if(!p) return fail(NTT_ERR_ARG, "null argument");
+  const LimbSet own{p->limbrec.data(), 1, 0, pstride};
+  if(p->arith == NTT_ARITH_U64_R4) {
     /* the reference's radix-4 formulation end to end: fwd_ntt_radix4 on both operands (canonical outputs), the pointwise
      * product, inv_ntt_radix4 */
-    int rc4 = ntt_fwd_batch(p, d_a, batch, stream);
-    if(!rc4 && d_b != d_a) rc4 = ntt_fwd_batch(p, d_b, batch, stream);
-    if(!rc4) rc4 = pointwise_launch(p, d_c, d_a, d_b, batch, stream, false);
-    if(!rc4) rc4 = ntt_inv_batch(p, d_c, batch, stream);
+    int rc4 = run_transform(p, d_a, batch, false, false, stream, false, &own);
+    if(!rc4 && d_b != d_a) rc4 = run_transform(p, d_b, batch, false, false, stream, false, &own);
+    if(!rc4) rc4 = pointwise_launch(p, d_c, d_a, d_b, batch, stream, false, pstride);
+    if(!rc4) rc4 = run_transform(p, d_c, batch, true, false, stream, false, &own);
     return rc4;
   }
-  if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c, d_a, d_b, batch, stream);
-  int rc = ntt_fwd_batch_lazy(p, d_a, batch, stream);
-  if(!rc && d_b != d_a) rc = ntt_fwd_batch_lazy(p, d_b, batch, stream);
-  if(!rc && p && dot_kernel_applies(p) && p->has_inv && d_c) {
+  if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c, d_a, d_b, batch, stream, &own);
+  int rc = run_transform(p, d_a, batch, false, false, stream, true, &own);
+  if(!rc && d_b != d_a) rc = run_transform(p, d_b, batch, false, false, stream, true, &own);
+  if(!rc && dot_kernel_applies(p) && p->has_inv && d_c) {
     /* the products inside the inverse transform's first pass (dot_inv_kernel): 24N bytes instead of 40N for the last two
      * steps -- the integer policies (no one-launch product kernel), squarings, plans with the fused product switched off */
     const uint64_t *pa = d_a, *pb = d_b;
-    return inv_dot(p, d_c, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, nullptr, 0);
+    return inv_dot(p, d_c, 1, &pa, &pb, batch, NTT_MUL_LAZY_IN, stream, &own, 0);
   }
-  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true);
-  if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
+  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_b, batch, stream, true, pstride);
+  if(!rc) rc = run_transform(p, d_c, batch, true, false, stream, false, &own);
   return rc;
+}
+
+extern "C" int ntt_negacyclic_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
+                                        uint64_t batch, void *stream)
+{
+  return negacyclic_mul_one(p, d_c, d_a, d_b, batch, stream, 0);
 }
 
 static int rns_check(int nlimbs, ntt_plan *const *plans)
@@ -1276,7 +1324,26 @@ static bool rns_compatible(const ntt_plan *a, const ntt_plan *b)
   return multi_limb_plan(a) && b->arith == a->arith && (b->kcls == kWideClass) == (a->kcls == kWideClass) &&
          (b->int_cls >= 0) == (a->int_cls >= 0) && b->m == a->m &&
          b->generic == a->generic && b->block_log == a->block_log && b->chunk_mib == a->chunk_mib && b->two_phase == a->two_phase &&
-         b->fused_product == a->fused_product && b->max_grid == a->max_grid && b->has_fwd == a->has_fwd && b->has_inv == a->has_inv;
+         b->fused_product == a->fused_product && b->max_grid == a->max_grid && b->block_oversub == a->block_oversub && b->rns_launch == a->rns_launch && b->dot_fused == a->dot_fused && b->has_fwd == a->has_fwd && b->has_inv == a->has_inv &&
+         b->xcd_local == a->xcd_local && b->team_lag == a->team_lag && b->team_wpc == a->team_wpc;
+}
+
+/* Where the limbs and polynomials of an RNS operand live (words): polynomial p of limb l starts l * limb + p * poly words in.
+ * [limb][batch][N] (the layout of the plain ntt_rns_* entry points): {batch * N, N}; SURVEY 8(d)'s [batch][prime][N] -- what an
+ * FHE library holds: a ciphertext polynomial = its limbs side by side --: {N, limbs * N}.  Padded forms of either are fine. */
+struct Layout {
+  uint64_t limb, poly;
+};
+/* the strides must keep the (limb, polynomial) ranges apart: limb-major (a limb's polynomials inside its slab) or
+ * polynomial-major (a polynomial's limbs inside its record) */
+static int layout_check(uint64_t N, int nlimbs, uint64_t batch, const Layout &lay)
+{
+  if(lay.poly < N || lay.limb < N) return fail(NTT_ERR_ARG, "layout: strides must be at least N words");
+  if(lay.poly > (1ull << 40) || lay.limb > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: stride too large");
+  const bool limb_major = batch <= 1 || lay.limb >= (batch - 1) * lay.poly + N;
+  const bool poly_major = nlimbs <= 1 || lay.poly >= (uint64_t)(nlimbs - 1) * lay.limb + N;
+  if(!limb_major && !poly_major) return fail(NTT_ERR_ARG, "layout: limbs and polynomials overlap");
+  return NTT_OK;
 }
 
 /* The limb list as maximal RUNS of consecutive compatible limbs, at most kMaxLimbs each (the records one launch carries): a
@@ -1297,14 +1364,14 @@ static std::vector<std::pair<int, int>> rns_runs(int nlimbs, ntt_plan *const *pl
 /* calls set_fn(first, LimbSet) for every run that `pays(plan of the run's first limb, run length)` says one launch should
  * serve, one_fn(limb) for every other limb; stops at the first error */
 template <class Pays, class SetFn, class OneFn>
-static int rns_for_runs(int nlimbs, ntt_plan *const *plans, uint64_t slab, Pays pays, SetFn set_fn, OneFn one_fn)
+static int rns_for_runs(int nlimbs, ntt_plan *const *plans, const Layout &lay, Pays pays, SetFn set_fn, OneFn one_fn)
 {
   int rc = NTT_OK;
   for(const std::pair<int, int> &run : rns_runs(nlimbs, plans)) {
     const int first = run.first, n = run.second;
     if(n > 1 && pays(plans[first], n)) {
       const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet                    ls{recs.data(), n, slab};
+      const LimbSet                    ls{recs.data(), n, lay.limb, lay.poly};
       int kc = plans[first]->kcls, ic = plans[first]->int_cls;
       for(int l = first + 1; l < first + n; l++) {
         kc = plans[l]->kcls < kc ? plans[l]->kcls : kc;
@@ -1324,23 +1391,21 @@ static int rns_for_runs(int nlimbs, ntt_plan *const *plans, uint64_t slab, Pays 
 
 /* One launch for all limbs pays when a single limb's share cannot fill the chip by itself (a ciphertext: a few
  * polynomials x tens of primes); with thousands of polynomials per limb every per-limb launch fills it, and the
- * single-set kernels are the faster ones (no run-time limb index: ntt_kernels.h, MULTI).  NTT_RNS_LOOP=1 / =0 forces
- * either form (tests, measurements). */
+ * single-set kernels are the faster ones (no run-time limb index: ntt_kernels.h, MULTI).  NTT_OPT_RNS_LAUNCH 0 / 1 on the
+ * run's first plan forces the one-launch / the per-limb form (tests, measurements). */
 static bool rns_one_launch_pays(const ntt_plan *p, uint64_t batch)
 {
-  const char *env = getenv("NTT_RNS_LOOP");
-  if(env) return atoi(env) == 0;
+  if(p->rns_launch >= 0) return p->rns_launch == 0;
   const uint64_t wg_equivalents = (batch * p->N) >> 12; /* 256-thread workgroups' worth of coefficients per limb */
   return wg_equivalents < 8ull * (uint64_t)p->num_cus;
 }
 
 /* Large per-limb batches at N = 2^15..2^17: the XCD-local launches (team_kernel, team_product_kernel) take the limb as part
  * of the queue entry, so a whole RNS set is ONE launch there too -- no launch tails between the limbs (measured 3.5 % of a
- * config-5 step, profiles/r03/ablations.txt (f)).  NTT_RNS_LOOP=1 keeps the per-limb launches. */
+ * config-5 step, profiles/r03/ablations.txt (f)).  NTT_OPT_RNS_LAUNCH 1 keeps the per-limb launches. */
 static bool rns_team_launch(const ntt_plan *p, int nlimbs, uint64_t batch, bool inverse, bool product)
 {
-  const char *env = getenv("NTT_RNS_LOOP");
-  if(env && atoi(env) != 0) return false;
+  if(p->rns_launch == 1) return false;
   return team_applies(p, batch, inverse, false, false, nlimbs < kMaxLimbs ? nlimbs : kMaxLimbs, product) &&
          team_applies(p, batch, inverse, false, false, 1, product); /* (a limb's own share qualifies: same lag tuning) */
 }
@@ -1353,44 +1418,70 @@ static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first,
   return all;
 }
 
-static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, bool inverse, void *stream)
+/* the plan's own record as a one-limb set whose polynomials are lay.poly words apart */
+static LimbSet own_set(const ntt_plan *p, const Layout &lay) { return LimbSet{p->limbrec.data(), 1, 0, lay.poly}; }
+
+static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, bool inverse, void *stream, const Layout &lay)
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  const uint64_t slab = batch * plans[0]->N;
+  if(!d_a) return fail(NTT_ERR_ARG, "null argument");
+  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(rc) return rc;
   return rns_for_runs(
-    nlimbs, plans, slab,
+    nlimbs, plans, lay,
     [&](const ntt_plan *p, int n) { return rns_one_launch_pays(p, batch) || rns_team_launch(p, n, batch, inverse, false); },
-    [&](int first, const LimbSet &ls) { return run_transform(plans[first], d_a + (uint64_t)first * slab, batch, inverse, false, stream, false, &ls); },
+    [&](int first, const LimbSet &ls) { return run_transform(plans[first], d_a + (uint64_t)first * lay.limb, batch, inverse, false, stream, false, &ls); },
     [&](int l) {
-      uint64_t *d = d_a + (uint64_t)l * slab;
-      return inverse ? ntt_inv_batch(plans[l], d, batch, stream) : ntt_fwd_batch(plans[l], d, batch, stream);
+      const LimbSet own = own_set(plans[l], lay);
+      return run_transform(plans[l], d_a + (uint64_t)l * lay.limb, batch, inverse, false, stream, false, &own);
     });
+}
+
+/* [limb][batch][N]: what the plain ntt_rns_* entry points take */
+static Layout limb_major(ntt_plan *const *plans, int nlimbs, uint64_t batch)
+{
+  const uint64_t N = (nlimbs > 0 && plans && plans[0]) ? plans[0]->N : 0;
+  return Layout{batch * N, N};
 }
 
 extern "C" int ntt_rns_fwd_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
 {
-  return rns_transform(nlimbs, plans, d_a, batch, false, stream);
+  return rns_transform(nlimbs, plans, d_a, batch, false, stream, limb_major(plans, nlimbs, batch));
 }
 
 extern "C" int ntt_rns_inv_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, void *stream)
 {
-  return rns_transform(nlimbs, plans, d_a, batch, true, stream);
+  return rns_transform(nlimbs, plans, d_a, batch, true, stream, limb_major(plans, nlimbs, batch));
 }
 
-extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
-                                            uint64_t *d_b, uint64_t batch, void *stream)
+extern "C" int ntt_rns_fwd_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t limb_stride, uint64_t poly_stride,
+                                         uint64_t batch, void *stream)
+{
+  return rns_transform(nlimbs, plans, d_a, batch, false, stream, Layout{limb_stride, poly_stride});
+}
+
+extern "C" int ntt_rns_inv_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t limb_stride, uint64_t poly_stride,
+                                         uint64_t batch, void *stream)
+{
+  return rns_transform(nlimbs, plans, d_a, batch, true, stream, Layout{limb_stride, poly_stride});
+}
+
+static int rns_negacyclic_mul(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, uint64_t batch, void *stream,
+                              const Layout &lay)
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  const uint64_t slab = batch * plans[0]->N;
+  if(!d_c || !d_a || !d_b) return fail(NTT_ERR_ARG, "null argument");
+  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(rc) return rc;
   /* a run of the wide integer policy: both forward transforms (lazy words, in place -- the operands are scratch on this path as
    * they are for a single plan) and the products inside the inverse transform's first pass, each ONE launch over the run */
   auto int_run = [&](const ntt_plan *p) {
-    return p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && p->has_fwd && p->has_inv && d_a && d_b && d_c;
+    return p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && p->has_fwd && p->has_inv;
   };
   return rns_for_runs(
-    nlimbs, plans, slab,
+    nlimbs, plans, lay,
     [&](const ntt_plan *p, int n) {
       if(fused_product_applies(p, d_c, d_a, d_b, batch)) {
         return rns_one_launch_pays(p, batch) || (rns_team_launch(p, n, batch, false, true) && !p->block_log);
@@ -1399,7 +1490,7 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
     },
     [&](int first, const LimbSet &ls) {
       const ntt_plan *p   = plans[first];
-      const uint64_t  off = (uint64_t)first * slab;
+      const uint64_t  off = (uint64_t)first * lay.limb;
       if(fused_product_applies(p, d_c, d_a, d_b, batch)) return fused_product(p, d_c + off, d_a + off, d_b + off, batch, stream, &ls);
       int r = run_transform(p, d_a + off, batch, false, false, stream, true, &ls);
       if(!r && d_b != d_a) r = run_transform(p, d_b + off, batch, false, false, stream, true, &ls);
@@ -1408,9 +1499,21 @@ extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, 
       return r;
     },
     [&](int l) {
-      const uint64_t off = (uint64_t)l * slab;
-      return ntt_negacyclic_mul_batch(plans[l], d_c + off, d_a + off, d_b + off, batch, stream);
+      const uint64_t off = (uint64_t)l * lay.limb;
+      return negacyclic_mul_one(plans[l], d_c + off, d_a + off, d_b + off, batch, stream, lay.poly);
     });
+}
+
+extern "C" int ntt_rns_negacyclic_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a,
+                                            uint64_t *d_b, uint64_t batch, void *stream)
+{
+  return rns_negacyclic_mul(nlimbs, plans, d_c, d_a, d_b, batch, stream, limb_major(plans, nlimbs, batch));
+}
+
+extern "C" int ntt_rns_negacyclic_mul_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b,
+                                                    uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, void *stream)
+{
+  return rns_negacyclic_mul(nlimbs, plans, d_c, d_a, d_b, batch, stream, Layout{limb_stride, poly_stride});
 }
 
 /* ------------------------------------------------------------------ */
@@ -1437,7 +1540,7 @@ static hipError_t dispatch_dot(const ntt_plan *p, const DotArgs &da)
 /* plans the fused kernel serves: the radix-2 policies on blocks of 2^6 points and more */
 static bool dot_kernel_applies(const ntt_plan *p)
 {
-  return (p->arith == NTT_ARITH_F64 || p->arith == NTT_ARITH_U64) && !p->generic && p->m >= kFusedMin && env_int("NTT_DOT_UNFUSED", 0) == 0;
+  return (p->arith == NTT_ARITH_F64 || p->arith == NTT_ARITH_U64) && !p->generic && p->m >= kFusedMin && p->dot_fused != 0;
 }
 
 /* c = inv(sum_i a_i^ (.) b_i^).  One launch up to N = 2^14: the products are formed where the inverse transform would
@@ -1458,23 +1561,23 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
   if(batch == 0) return NTT_OK;
   if(!p->has_inv) return fail(NTT_ERR_ARG, "plan lacks the inverse table");
   const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0, bcast = (flags & NTT_MUL_B_BROADCAST) != 0;
-  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0, 0};
   USE_DEVICE(p->device);
   if(!dot_kernel_applies(p) || (ls.n > 1 && !multi_limb_plan(p))) {
     if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
     const uint64_t n  = batch * p->N;
     const dim3     g(grid_for(n)), t(256);
     hipStream_t    st = (hipStream_t)stream;
-    const uint64_t bm = bcast ? p->N - 1 : ~0ull;
+    const PwLayout lay{(uint32_t)p->m, poly_words(p, ls), bcast ? 0 : poly_words(p, ls)};
     for(int i = 0; i < k; i++) {
 #define NTT_PW_ACC(A, CONSTS)                                                                                              \
   do {                                                                                                                     \
     if(lazy) {                                                                                                             \
-      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);   \
-      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);   \
+      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, a[i], b[i], n, lay, p->q, CONSTS);  \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, a[i], b[i], n, lay, p->q, CONSTS);  \
     } else {                                                                                                               \
-      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);  \
-      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, a[i], b[i], n, bm, p->q, CONSTS);  \
+      if(i) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, a[i], b[i], n, lay, p->q, CONSTS); \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, a[i], b[i], n, lay, p->q, CONSTS); \
     }                                                                                                                      \
   } while(0)
       if(p->arith == NTT_ARITH_F64) NTT_PW_ACC(ArithF64, p->cf);
@@ -1482,7 +1585,7 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
 #undef NTT_PW_ACC
       HIP_TRY(hipGetLastError());
     }
-    return run_transform(p, d_c, batch, true, false, stream);
+    return run_transform(p, d_c, batch, true, false, stream, false, &ls);
   }
   const int      pblk  = p->m > kFusedMax ? (p->block_log ? p->block_log : multi_pass_block(p->m, true, p->arith == NTT_ARITH_F64)) : p->m;
   const PassList L     = make_passes(p->m, false, pblk);
@@ -1500,7 +1603,7 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
   const uint64_t *ca[kMaxDot], *cb[kMaxDot];
   for(uint64_t first = 0; first < batch; first += chunk) {
     const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
-    const uint64_t off = first * p->N;
+    const uint64_t off = first * poly_words(p, ls);
     for(int i = 0; i < k; i++) {
       ca[i] = a[i] + off;
       cb[i] = bcast ? b[i] : b[i] + off;
@@ -1515,12 +1618,14 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
     da.limbs         = ls.d;
     da.nlimbs        = ls.n;
     da.limb_stride   = ls.stride;
+    da.poly_stride   = ls.pstride;
     da.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
     da.batch         = nb;
     da.logn          = (uint32_t)p->m;
     da.block_log     = (uint32_t)pblk;
     da.max_grid      = p->max_grid;
     da.num_cus       = p->num_cus;
+    da.oversub       = p->block_oversub;
     da.stream        = (hipStream_t)stream;
     hipError_t e = dispatch_dot(p, da);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1570,9 +1675,10 @@ static int mul_transformed(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, cons
     if(!rcs) rcs = inv_dot(p, d_c, 1, &pa, &d_bhat, batch, NTT_MUL_LAZY_IN, stream, set, set->stride);
     return rcs;
   }
-  int rc = p->arith == NTT_ARITH_U64_R4 ? ntt_fwd_batch(p, d_a, batch, stream) : ntt_fwd_batch_lazy(p, d_a, batch, stream);
-  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_bhat, batch, stream, lazy || p->arith != NTT_ARITH_U64_R4);
-  if(!rc) rc = ntt_inv_batch(p, d_c, batch, stream);
+  const LimbSet own = set ? *set : LimbSet{p->limbrec.data(), 1, 0, 0};
+  int rc = run_transform(p, d_a, batch, false, false, stream, p->arith != NTT_ARITH_U64_R4, &own);
+  if(!rc) rc = pointwise_launch(p, d_c, d_a, d_bhat, batch, stream, lazy || p->arith != NTT_ARITH_U64_R4, own.pstride);
+  if(!rc) rc = run_transform(p, d_c, batch, true, false, stream, false, &own);
   return rc;
 }
 
@@ -1595,24 +1701,24 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
   if(!p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the forward table");
   const bool lazy = (flags & NTT_MUL_LAZY_IN) != 0, bcast = (flags & NTT_MUL_B_BROADCAST) != 0, acc = (flags & NTT_MUL_ACCUMULATE) != 0;
   if(acc && d_c == d_a) return fail(NTT_ERR_ARG, "an accumulator cannot alias the coefficient operand");
-  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0};
+  const LimbSet ls = set ? *set : LimbSet{p->limbrec.data(), 1, 0, 0};
   USE_DEVICE(p->device);
   if(!dot_kernel_applies(p) || (ls.n > 1 && !multi_limb_plan(p))) {
     if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
-    int rc = run_transform(p, d_a, batch, false, false, stream);
+    int rc = run_transform(p, d_a, batch, false, false, stream, false, &ls);
     if(rc) return rc;
     const uint64_t n  = batch * p->N;
     const dim3     g(grid_for(n)), t(256);
     hipStream_t    st = (hipStream_t)stream;
-    const uint64_t bm = bcast ? p->N - 1 : ~0ull;
+    const PwLayout lay{(uint32_t)p->m, poly_words(p, ls), bcast ? 0 : poly_words(p, ls)};
 #define NTT_PW_MUL(A, CONSTS)                                                                                              \
   do {                                                                                                                     \
     if(lazy) {                                                                                                             \
-      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);  \
-      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);   \
+      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, true, true>), g, t, 0, st, d_c, d_a, d_bhat, n, lay, p->q, CONSTS); \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, true, false>), g, t, 0, st, d_c, d_a, d_bhat, n, lay, p->q, CONSTS);  \
     } else {                                                                                                               \
-      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS); \
-      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, d_a, d_bhat, n, bm, p->q, CONSTS);  \
+      if(acc) hipLaunchKernelGGL((pointwise_acc_kernel<A, false, true>), g, t, 0, st, d_c, d_a, d_bhat, n, lay, p->q, CONSTS); \
+      else hipLaunchKernelGGL((pointwise_acc_kernel<A, false, false>), g, t, 0, st, d_c, d_a, d_bhat, n, lay, p->q, CONSTS); \
     }                                                                                                                      \
   } while(0)
     if(p->arith == NTT_ARITH_F64) NTT_PW_MUL(ArithF64, p->cf);
@@ -1631,7 +1737,7 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
   }
   for(uint64_t first = 0; first < batch; first += chunk) {
     const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
-    const uint64_t off = first * p->N;
+    const uint64_t off = first * poly_words(p, ls);
     for(int j = 0; j + 1 < L.n; j++) { /* forward column passes of a (every pass but the last, which is the block pass) */
       int rc = launch_one_pass(p, L.p[j], d_a + off, nb, false, false, false, false, stream, ls);
       if(rc) return rc;
@@ -1646,12 +1752,14 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     ma.limbs         = ls.d;
     ma.nlimbs        = ls.n;
     ma.limb_stride   = ls.stride;
+    ma.poly_stride   = ls.pstride;
     ma.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
     ma.batch         = nb;
     ma.logn          = (uint32_t)p->m;
     ma.block_log     = (uint32_t)pblk;
     ma.max_grid      = p->max_grid;
     ma.num_cus       = p->num_cus;
+    ma.oversub       = p->block_oversub;
     ma.stream        = (hipStream_t)stream;
     const int  ic = eff_int_cls(p), kc = eff_kcls(p);
     hipError_t e = p->arith == NTT_ARITH_U64 ? (ic == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
@@ -1673,67 +1781,125 @@ extern "C" int ntt_fwd_mul_batch(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a
   return fwd_mul(p, d_c, d_a, d_bhat, batch, flags, stream);
 }
 
-extern "C" int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
-                                     uint64_t batch, unsigned flags, void *stream)
+static int rns_fwd_mul(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
+                       void *stream, const Layout &lay)
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  const uint64_t N = plans[0]->N, slab = batch * N;
-  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
+  if(!d_c || !d_a || !d_bhat) return fail(NTT_ERR_ARG, "null argument"); /* (before any limb offset is added) */
+  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(rc) return rc;
+  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? plans[0]->N : lay.limb; /* a broadcast operand is [limb][N] */
   return rns_for_runs(
-    nlimbs, plans, slab, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
+    nlimbs, plans, lay, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
     [&](int first, const LimbSet &ls) {
-      return fwd_mul(plans[first], d_c + (uint64_t)first * slab, d_a + (uint64_t)first * slab, d_bhat + (uint64_t)first * bslab, batch, flags,
+      return fwd_mul(plans[first], d_c + (uint64_t)first * lay.limb, d_a + (uint64_t)first * lay.limb, d_bhat + (uint64_t)first * bslab, batch, flags,
                      stream, &ls, bslab);
     },
     [&](int l) {
-      return fwd_mul(plans[l], d_c + (uint64_t)l * slab, d_a + (uint64_t)l * slab, d_bhat + (uint64_t)l * bslab, batch, flags, stream);
+      const LimbSet own = own_set(plans[l], lay);
+      return fwd_mul(plans[l], d_c + (uint64_t)l * lay.limb, d_a + (uint64_t)l * lay.limb, d_bhat + (uint64_t)l * bslab, batch, flags, stream, &own);
     });
+}
+
+extern "C" int ntt_rns_fwd_mul_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                     uint64_t batch, unsigned flags, void *stream)
+{
+  return rns_fwd_mul(nlimbs, plans, d_c, d_a, d_bhat, batch, flags, stream, limb_major(plans, nlimbs, batch));
+}
+
+extern "C" int ntt_rns_fwd_mul_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                             uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, unsigned flags, void *stream)
+{
+  return rns_fwd_mul(nlimbs, plans, d_c, d_a, d_bhat, batch, flags, stream, Layout{limb_stride, poly_stride});
+}
+
+static int rns_inv_dot(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat, const uint64_t *const *d_bhat,
+                       uint64_t batch, unsigned flags, void *stream, const Layout &lay)
+{
+  int rc = rns_check(nlimbs, plans);
+  if(rc || batch == 0) return rc;
+  if(k < 1 || k > kMaxDot || !d_ahat || !d_bhat) return fail(NTT_ERR_ARG, "number of operand pairs must be 1 .. 32");
+  if(!d_c) return fail(NTT_ERR_ARG, "null argument");
+  for(int i = 0; i < k; i++) {
+    if(!d_ahat[i] || !d_bhat[i]) return fail(NTT_ERR_ARG, "null operand"); /* (before any limb offset is added) */
+  }
+  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(rc) return rc;
+  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? plans[0]->N : lay.limb; /* a broadcast operand is [limb][N] */
+  auto call = [&](int first, const LimbSet &ls, bool run) {
+    const uint64_t *la[kMaxDot], *lb[kMaxDot];
+    for(int i = 0; i < k; i++) {
+      la[i] = d_ahat[i] + (uint64_t)first * lay.limb;
+      lb[i] = d_bhat[i] + (uint64_t)first * bslab;
+    }
+    return inv_dot(plans[first], d_c + (uint64_t)first * lay.limb, k, la, lb, batch, flags, stream, &ls, run ? bslab : 0);
+  };
+  return rns_for_runs(
+    nlimbs, plans, lay, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
+    [&](int first, const LimbSet &ls) { return call(first, ls, true); }, [&](int l) { return call(l, own_set(plans[l], lay), false); });
 }
 
 extern "C" int ntt_rns_inv_dot_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
                                      const uint64_t *const *d_bhat, uint64_t batch, unsigned flags, void *stream)
 {
+  return rns_inv_dot(nlimbs, plans, d_c, k, d_ahat, d_bhat, batch, flags, stream, limb_major(plans, nlimbs, batch));
+}
+
+extern "C" int ntt_rns_inv_dot_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, int k, const uint64_t *const *d_ahat,
+                                             const uint64_t *const *d_bhat, uint64_t limb_stride, uint64_t poly_stride, uint64_t batch,
+                                             unsigned flags, void *stream)
+{
+  return rns_inv_dot(nlimbs, plans, d_c, k, d_ahat, d_bhat, batch, flags, stream, Layout{limb_stride, poly_stride});
+}
+
+static int rns_mul_transformed(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch,
+                               unsigned flags, void *stream, const Layout &lay)
+{
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(k < 1 || k > kMaxDot || !d_ahat || !d_bhat) return fail(NTT_ERR_ARG, "number of operand pairs must be 1 .. 32");
-  const uint64_t N = plans[0]->N, slab = batch * N;
-  const uint64_t bslab = (flags & NTT_MUL_B_BROADCAST) ? N : slab; /* a broadcast operand is [limb][N] */
-  auto call = [&](int first, const LimbSet *ls) {
-    const uint64_t *la[kMaxDot], *lb[kMaxDot];
-    for(int i = 0; i < k; i++) {
-      la[i] = d_ahat[i] + (uint64_t)first * slab;
-      lb[i] = d_bhat[i] + (uint64_t)first * bslab;
-    }
-    return inv_dot(plans[first], d_c + (uint64_t)first * slab, k, la, lb, batch, flags, stream, ls, ls ? bslab : 0);
-  };
+  if(!d_c || !d_a || !d_bhat) return fail(NTT_ERR_ARG, "null argument"); /* (before any limb offset is added) */
+  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(rc) return rc;
+  /* one launch over a run: the fused product kernels (FP64 policies), or -- limbs of the wide integer policy -- the forward
+   * transform and the products-inside-the-inverse launch, each over the whole run */
   return rns_for_runs(
-    nlimbs, plans, slab, [&](const ntt_plan *p, int) { return rns_one_launch_pays(p, batch) && dot_kernel_applies(p); },
-    [&](int first, const LimbSet &ls) { return call(first, &ls); }, [&](int l) { return call(l, nullptr); });
+    nlimbs, plans, lay,
+    [&](const ntt_plan *p, int) {
+      const bool int_set = p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && d_a != d_bhat;
+      return rns_one_launch_pays(p, batch) && (fused_product_applies(p, d_c, d_bhat, d_a, batch) || int_set);
+    },
+    [&](int first, const LimbSet &ls) {
+      const uint64_t off = (uint64_t)first * lay.limb;
+      return mul_transformed(plans[first], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &ls);
+    },
+    [&](int l) {
+      const uint64_t off = (uint64_t)l * lay.limb;
+      const LimbSet  own = own_set(plans[l], lay);
+      return mul_transformed(plans[l], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &own);
+    });
 }
 
 extern "C" int ntt_rns_mul_transformed_batch(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
                                              uint64_t batch, unsigned flags, void *stream)
 {
-  int rc = rns_check(nlimbs, plans);
-  if(rc || batch == 0) return rc;
-  const uint64_t slab = batch * plans[0]->N;
-  /* one launch over a run: the fused product kernels (FP64 policies), or -- limbs of the wide integer policy -- the forward
-   * transform and the products-inside-the-inverse launch, each over the whole run */
-  return rns_for_runs(
-    nlimbs, plans, slab,
-    [&](const ntt_plan *p, int) {
-      const bool int_set = p->arith == NTT_ARITH_U64 && dot_kernel_applies(p) && d_a != d_bhat && d_a && d_bhat && d_c;
-      return rns_one_launch_pays(p, batch) && (fused_product_applies(p, d_c, d_bhat, d_a, batch) || int_set);
-    },
-    [&](int first, const LimbSet &ls) {
-      const uint64_t off = (uint64_t)first * slab;
-      return mul_transformed(plans[first], d_c + off, d_a + off, d_bhat + off, batch, flags, stream, &ls);
-    },
-    [&](int l) {
-      const uint64_t off = (uint64_t)l * slab;
-      return mul_transformed(plans[l], d_c + off, d_a + off, d_bhat + off, batch, flags, stream);
-    });
+  return rns_mul_transformed(nlimbs, plans, d_c, d_a, d_bhat, batch, flags, stream, limb_major(plans, nlimbs, batch));
+}
+
+extern "C" int ntt_rns_mul_transformed_batch_strided(int nlimbs, ntt_plan *const *plans, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat,
+                                                     uint64_t limb_stride, uint64_t poly_stride, uint64_t batch, unsigned flags, void *stream)
+{
+  return rns_mul_transformed(nlimbs, plans, d_c, d_a, d_bhat, batch, flags, stream, Layout{limb_stride, poly_stride});
+}
+
+/* ---- one plan, polynomials poly_stride words apart (one limb of a caller-native layout) ---- */
+extern "C" int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uint64_t poly_stride, uint64_t batch, unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)(NTT_FLAG_INVERSE | NTT_FLAG_WIDE_IN | NTT_FLAG_LAZY_OUT)) return fail(NTT_ERR_ARG, "unknown flag");
+  if(!p) return fail(NTT_ERR_ARG, "null argument");
+  if(poly_stride < p->N || poly_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the polynomial stride must be at least N words");
+  const LimbSet own{p->limbrec.data(), 1, 0, poly_stride};
+  return run_transform(p, d_a, batch, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream, (flags & NTT_FLAG_LAZY_OUT) != 0, &own);
 }
 
 extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,
@@ -1785,6 +1951,25 @@ extern "C" int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mas
   USE_DEVICE(device);
   /* one workgroup per 4 KiB up to 65536 workgroups: the fastest of the grids tried (profiles/r02/skeleton.txt) */
   hipLaunchKernelGGL(rmw_probe_kernel, dim3(grid_for(n / 2, 65536)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_a, n / 2, mask);
+  HIP_TRY(hipGetLastError());
+  return NTT_OK;
+}
+
+/* out-of-place copy, 16 bytes per lane, plain grid-stride: the shape the microarchitecture guide quotes its achievable HBM rate
+ * for (MI355X_MICROARCH.md: about 6.3 TB/s of read + written bytes) */
+__global__ void __launch_bounds__(256) copy_probe_kernel(U64x2 *dst, const U64x2 *src, uint64_t n2)
+{
+  for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int ntt_copy_probe(int device, uint64_t *d_dst, const uint64_t *d_src, uint64_t n, void *stream)
+{
+  int rc = check_device(device);
+  if(rc) return rc;
+  if(!d_dst || !d_src || (n & 1) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) return fail(NTT_ERR_ARG, "copy probe: null, odd length or unaligned buffer");
+  if(n == 0) return NTT_OK;
+  USE_DEVICE(device);
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(grid_for(n / 2, 65536)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_dst, (const U64x2 *)d_src, n / 2);
   HIP_TRY(hipGetLastError());
   return NTT_OK;
 }
@@ -2174,10 +2359,25 @@ uint64_t table_key(const uint64_t *w, uint64_t n, uint64_t stride)
  *            lets the reference's own drivers exercise the throughput kernels. */
 enum CompatKind { kCompatR2 = 0, kCompatR4 = 1 };
 
+/* NTT_DEVICE / NTT_COMPAT_ARITH, read ONCE (the first reference-signature call of the process; a function-local static is
+ * initialised exactly once, also with several threads arriving together): later setenv calls of the host program neither race with
+ * the library nor change it */
+struct CompatConfig {
+  int  device;
+  bool f64;
+};
+const CompatConfig &compat_config()
+{
+  static const CompatConfig cfg = [] {
+    const char *d = getenv("NTT_DEVICE"), *a = getenv("NTT_COMPAT_ARITH");
+    return CompatConfig{d ? atoi(d) : 0, a && !strcmp(a, "f64")};
+  }();
+  return cfg;
+}
+
 int compat_arith(uint64_t q, uint64_t N, CompatKind kind, bool inverse)
 {
-  const char *env = getenv("NTT_COMPAT_ARITH");
-  if(env && !strcmp(env, "f64") && h_f64_eligible(q)) return NTT_ARITH_F64;
+  if(compat_config().f64 && h_f64_eligible(q)) return NTT_ARITH_F64;
   const int m = (int)h_log2(N);
   /* the reference's radix-4 butterflies at every size that has them (two passes above 2^14) */
   (void)inverse;
@@ -2220,7 +2420,7 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     g_err = "N must be a power of two >= 2 and the pointers non-null";
     die(fn);
   }
-  const int      device  = env_int("NTT_DEVICE", 0);
+  const int      device  = compat_config().device;
   const int      arith   = compat_arith(q, N, kind, inverse);
   const uint64_t entries = kind == kCompatR4 ? 2 * N : N;
   /* the integer policies use the caller's precomputation too: it is part of the key.  (Hashing happens outside any lock.) */

@@ -41,6 +41,9 @@
 
 namespace ntt {
 
+#ifndef NTT_WL12
+#  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
+#endif
 constexpr int kPreAlso = 12; /* forward: last group's twiddles register-resident at this size too (2^14 always) */
 constexpr int kIpreMin = 12; /* inverse: first executed group's twiddles register-resident from this size up */
 
@@ -140,6 +143,8 @@ constexpr int kMaxLimbs = 16; /* limbs of one launch (16 records of 112 bytes in
 template <class A> struct KArgs {
   uint64_t *        a;            /* limb 0's coefficients                                        */
   uint64_t          limb_stride;  /* words between the slabs of consecutive limbs                 */
+  uint64_t          poly_stride;  /* words between consecutive polynomials of one limb (N: the dense [batch][N] slab; a caller
+                                   * that keeps [polynomial][limb][N] passes limb_stride = N, poly_stride = limbs * N) */
   uint32_t          wgs_per_limb; /* grid = wgs_per_limb * limbs                                  */
   uint32_t          logn, s0, wide, lastinv, lazy;
   uint64_t          nblocks;      /* per limb                                                     */
@@ -179,7 +184,14 @@ __device__ __forceinline__ Params<A> limb_params(const KArgs<A> &k, uint32_t &bi
   p.lastinv = k.lastinv;
   p.lazy    = k.lazy;
   p.nblocks = k.nblocks;
+  p.pstride = k.poly_stride;
   return p;
+}
+
+/* word offset of block b of this launch (ntt_core.h block_offset: polynomial b >> s0 starts (b >> s0) * pstride words in) */
+template <int LOGN, class A> __device__ __forceinline__ uint64_t blk_off(const Params<A> &p, uint64_t b)
+{
+  return block_offset<LOGN>(b, p.s0, p.pstride);
 }
 
 #ifdef NTT_STAMPS
@@ -247,7 +259,10 @@ __device__ __forceinline__ void exchange(typename A::val (&x)[kE], uint32_t t, t
   }
 }
 
-constexpr int kLoadAux = 2; /* cache-policy bits of the coefficient loads: nt (measured +0.6..1 % over 0; sc0/sc1 no gain) */
+#ifndef NTT_LOAD_AUX
+#  define NTT_LOAD_AUX 2 /* (A/B builds: tools/build_tu_variant.sh) */
+#endif
+constexpr int kLoadAux = NTT_LOAD_AUX; /* cache-policy bits of the coefficient loads: nt (measured +0.6..1 % over 0; sc0/sc1 no gain) */
 /* A block seen through a buffer descriptor: the 16 row loads of a thread then share ONE
  * 32-bit lane offset (t*8) and take the row offset as a scalar operand, instead of a
  * 64-bit per-lane address each (two carry-chained VALU adds per row in the hot loop).
@@ -470,7 +485,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       __syncthreads();
     }
     uint64_t raw[kE];
-    prefetch_first<LOGN>(raw, tt, p.a + (b << LOGN));
+    prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
     pin_raw(raw);
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
@@ -490,7 +505,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
-      uint64_t *     base = p.a + (b << LOGN);
+      uint64_t *     base = p.a + blk_off<LOGN>(p, b);
       typename A::val x[kE];
       convert_inputs<A, false>(x, raw, p.wide != 0, p.c);
       {
@@ -501,7 +516,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         const bool     more = b0 + stride < p.nblocks;
         const uint64_t nb0  = more ? b0 + stride : b0;
         const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_first<LOGN>(raw, tt, p.a + (nb << LOGN), more);
+        prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, nb), more);
       }
       STAMP(0); /* wait for prefetched coefficients + convert */
       run_group<A, LOGN, 0, false, MASK>(x, tt, blk, p);
@@ -520,7 +535,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
       /* whole-line stores: measured +0.6..0.9 % at 2^14, -0.5 % at 2^12 (profiles/r02/ablations.txt) */
-      if constexpr(LOGN == 14) {
+      if constexpr(LOGN == 14 || (LOGN == 12 && NTT_WL12 != 0 && G::BPW == 1)) {
         store_last_whole_lines<A, LOGN, LAZY>(x, tid, base, p.c, p.lazy != 0);
       } else {
         if(live) global_store_last<A, LOGN, false, LAZY>(x, tt, base, p.c, p.lazy != 0);
@@ -563,14 +578,14 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     typename A::ctw pre[4][kE / 2];
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
     uint64_t raw[kE];
-    prefetch_last<LOGN>(raw, tt, p.a + (b << LOGN));
+    prefetch_last<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
     pin_raw(raw);
     if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
-      uint64_t *     base = p.a + (b << LOGN);
+      uint64_t *     base = p.a + blk_off<LOGN>(p, b);
       typename A::val x[kE];
       convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
       {
@@ -578,7 +593,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         const bool     more = b0 + stride < p.nblocks;
         const uint64_t nb0  = more ? b0 + stride : b0;
         const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_last<LOGN>(raw, tt, p.a + (nb << LOGN), more);
+        prefetch_last<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, nb), more);
       }
       if constexpr(IPRE) {
         run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
@@ -616,7 +631,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     const bool live = b < p.nblocks;
     if(!live) b = p.nblocks - 1; /* idle lanes shadow a real block, never store */
     const uint32_t blk  = (uint32_t)b & bmask;
-    uint64_t *     base = p.a + (b << LOGN);
+    uint64_t *     base = p.a + blk_off<LOGN>(p, b);
     typename A::val x[kE];
     if constexpr(!INV) {
       global_load_first<A, LOGN, false>(x, t, base, p.wide != 0, p.c);
@@ -814,7 +829,7 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
   constexpr bool MID_LAZY = !A::kTracksBounds;
 
   for(uint64_t poly = bid; poly < p.nblocks; poly += gdim) {
-    uint64_t *const base = p.a + (poly << (LOGN + LEAD));
+    uint64_t *const base = p.a + poly * p.pstride;
     if constexpr(!INV) {
       twophase_columns<A, LEAD, false, KSH>(base, tid, p, p.wide != 0, MID_LAZY);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1232,7 +1247,7 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
         pl                  = pidx - limb * batch;
         team_limb<A, INV>(p, kt.k, limb);
       }
-      uint64_t *poly = p.a + ((uint64_t)pl << logn);
+      uint64_t *poly = p.a + (uint64_t)pl * p.pstride;
       if(second) {
         if(tid == 0) {
 #ifdef NTT_TEAM_WATCHDOG
@@ -1376,7 +1391,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
   __syncthreads();
   uint64_t raw[kE];
-  prefetch_first<LOGN>(raw, tid, (BOTH ? pp.ahat : pf.a) + (b << LOGN));
+  prefetch_first<LOGN>(raw, tid, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, b));
   pin_raw(raw);
   for(; b < pf.nblocks; b += stride) {
     /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
@@ -1407,7 +1422,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     typename A::val xa[BOTH ? kE : 1];
     if constexpr(BOTH) {
       convert_inputs<A, false>(xa, raw, false, pf.c);
-      prefetch_first<LOGN>(raw, tl, pf.a + (b << LOGN)); /* b's words travel during a's forward stages */
+      prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b)); /* b's words travel during a's forward stages */
       forward(xa);
       /* (b's words are converted after a's last stage, not before: interleaved by the scheduler, x, xa and the raw words
        * lived side by side and spilled) */
@@ -1416,7 +1431,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     } else {
       convert_inputs<A, false>(x, raw, false, pf.c);
       /* a^ in the last group's layout: requested now, used after the 14 forward stages */
-      prefetch_last<LOGN>(raw, tl, pp.ahat + (b << LOGN));
+      prefetch_last<LOGN>(raw, tl, pp.ahat + blk_off<LOGN>(pf, b));
     }
     forward(x);
     /* the inverse's first group: its twiddles land while the product is computed */
@@ -1433,7 +1448,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     {
       const bool     more = b + stride < pf.nblocks;
       const uint64_t nb   = more ? b + stride : b;
-      prefetch_first<LOGN>(raw, tl, (BOTH ? pp.ahat : pf.a) + (nb << LOGN), more);
+      prefetch_first<LOGN>(raw, tl, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, nb), more);
     }
     run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -1450,7 +1465,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     });
     uint64_t out[kE];
     static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
-    buffer_store_first_raw<LOGN>(out, tl, pp.out + (b << LOGN));
+    buffer_store_first_raw<LOGN>(out, tl, pp.out + blk_off<LOGN>(pf, b));
   }
 }
 
@@ -1674,9 +1689,10 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
         }
         __syncthreads();
       }
-      uint64_t *      bpoly = pf.a + loff + ((uint64_t)pl << logn);
-      const uint64_t *apoly = pp.ahat + loff + ((uint64_t)pl << logn);
-      uint64_t *      cpoly = pp.out + loff + ((uint64_t)pl << logn);
+      const uint64_t  poff  = loff + (uint64_t)pl * pf.pstride;
+      uint64_t *      bpoly = pf.a + poff;
+      const uint64_t *apoly = pp.ahat + poff;
+      uint64_t *      cpoly = pp.out + poff;
       if(pass == 0) {
         uint64_t *const src = FOUR && item >= NCOL ? const_cast<uint64_t *>(apoly) : bpoly; /* (a is an operand buffer of the caller's: written here) */
         team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(src, (item & (NCOL - 1u)) * kTeamCols + tid, logn, pf, MID_LAZY);
@@ -1751,15 +1767,15 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     if constexpr(BOTH) {
       /* a's coefficients through the same forward stages first; a^ waits in registers (the ones a^'s words occupy otherwise) */
       typename A::val xa[kE];
-      global_load_first<A, LOGN, false>(xa, t, pp.ahat + (b << LOGN), false, pf.c);
-      prefetch_first<LOGN>(raw, t, pf.a + (b << LOGN));
+      global_load_first<A, LOGN, false>(xa, t, pp.ahat + blk_off<LOGN>(pf, b), false, pf.c);
+      prefetch_first<LOGN>(raw, t, pf.a + blk_off<LOGN>(pf, b));
       forward(xa);
       convert_inputs<A, false>(x, raw, false, pf.c);
       forward(x);
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
     } else {
-      global_load_first<A, LOGN, false>(x, t, pf.a + (b << LOGN), false, pf.c);
-      prefetch_last<LOGN>(raw, t, pp.ahat + (b << LOGN));
+      global_load_first<A, LOGN, false>(x, t, pf.a + blk_off<LOGN>(pf, b), false, pf.c);
+      prefetch_last<LOGN>(raw, t, pp.ahat + blk_off<LOGN>(pf, b));
       forward(x);
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
     }
@@ -1770,7 +1786,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
       exchange<A, LOGN, GI, GI - 1>(x, t, lds);
       run_group<A, LOGN, GI - 1, true, MASKI, (G::TBL(GI - 1) > 0), (G::TBL(GI - 1) > 0)>(x, t, 0u, pi, gtw + G::TBL_OFF(GI - 1));
     });
-    if(live) global_store_first<A, LOGN, true>(x, t, pp.out + (b << LOGN), pf.c, false);
+    if(live) global_store_first<A, LOGN, true>(x, t, pp.out + blk_off<LOGN>(pf, b), pf.c, false);
   }
 }
 
@@ -1867,14 +1883,15 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
      * twiddle request to arrive. */
     constexpr bool IPRE = stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
     uint64_t ra[kE], rb[kE];
-    prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tid, kd.a[0] + aoff + (b << LOGN));
-    prefetch_last_b<LOGN>(rb, tid, kd.b[0] + boff + ((bc ? (b & bmask) : b) << LOGN));
+    prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tid, kd.a[0] + aoff + blk_off<LOGN>(p, b));
+    prefetch_last_b<LOGN>(rb, tid, kd.b[0] + boff + (bc ? ((b & bmask) << LOGN) : blk_off<LOGN>(p, b)));
     pin_raw(ra);
     pin_raw(rb);
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
-      const uint64_t bb   = bc ? (uint64_t)blk : b;
-      uint64_t *     base = p.a + (b << LOGN);
+      const uint64_t offa = blk_off<LOGN>(p, b);                    /* operands a_i^ and c: the launch's layout */
+      const uint64_t offb = bc ? ((uint64_t)blk << LOGN) : offa;    /* a broadcast b_i^ is one dense polynomial */
+      uint64_t *     base = p.a + offa;
       /* (an opaque copy of the thread id ties the per-block twiddle request and every lane-dependent address to the
        * iteration: hoisted, they would stay in registers -- or scratch -- for the whole launch; see fused_product_kernel) */
       uint32_t tl = tid;
@@ -1886,8 +1903,8 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
       for(uint32_t i = 0; i + 1 < np; i++) {
         if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
         dot_tile<A, 0, kE, NTT_DOT_LOOP_CHUNK>(x, ra, rb, lazy, p.c);
-        prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tl, kd.a[i + 1] + aoff + (b << LOGN));
-        prefetch_last_b<LOGN>(rb, tl, kd.b[i + 1] + boff + (bb << LOGN));
+        prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tl, kd.a[i + 1] + aoff + offa);
+        prefetch_last_b<LOGN>(rb, tl, kd.b[i + 1] + boff + offb);
         sched_fence();
       }
       if(np > 1 && (np - 1) % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
@@ -1916,7 +1933,7 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
           uint32_t t2 = tid;
           asm volatile("" : "+v"(t2));
           sched_fence();
-          prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, t2, kd.a[0] + aoff + (nb << LOGN), more);
+          prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, t2, kd.a[0] + aoff + blk_off<LOGN>(p, nb), more);
           sched_fence();
         }
         if constexpr(G::TBL(GI - 1) > 0) {
@@ -1930,7 +1947,7 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
         uint32_t t3 = tid;
         asm volatile("" : "+v"(t3));
         sched_fence();
-        prefetch_last_b<LOGN>(rb, t3, kd.b[0] + boff + ((bc ? (nb & bmask) : nb) << LOGN), more);
+        prefetch_last_b<LOGN>(rb, t3, kd.b[0] + boff + (bc ? ((nb & bmask) << LOGN) : blk_off<LOGN>(p, nb)), more);
         sched_fence();
       }
       uint64_t out[kE];
@@ -1953,8 +1970,9 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
       const bool live = b < p.nblocks;
       if(!live) b = p.nblocks - 1; /* idle sub-blocks shadow a real block (barriers are workgroup-wide), never store */
       const uint32_t blk  = (uint32_t)b & bmask;
-      const uint64_t bb   = bc ? (uint64_t)blk : b;
-      uint64_t *     base = p.a + (b << LOGN);
+      const uint64_t offa = blk_off<LOGN>(p, b);
+      const uint64_t offb = bc ? ((uint64_t)blk << LOGN) : offa;
+      uint64_t *     base = p.a + offa;
       typename A::val x[kE];
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = typename A::val{}; });
 #pragma unroll 1
@@ -1965,8 +1983,8 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
           constexpr int H = decltype(hh)::value;
           uint64_t      ra[kE], rb[kE];
           sched_fence();
-          load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, t, kd.a[i] + aoff + (b << LOGN));
-          load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, t, kd.b[i] + boff + (bb << LOGN));
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, t, kd.a[i] + aoff + offa);
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, t, kd.b[i] + boff + offb);
           dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
         });
       }
@@ -2088,14 +2106,14 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       __syncthreads();
     }
     uint64_t raw[kE];
-    prefetch_first<LOGN>(raw, tt, p.a + (b << LOGN));
+    prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
     pin_raw(raw);
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t  blk   = (uint32_t)b & bmask;
-      const uint64_t *bblk  = bptr + ((bc ? (uint64_t)blk : b) << LOGN);
-      uint64_t *      cblk  = cptr + (b << LOGN);
+      const uint64_t *bblk  = bptr + (bc ? ((uint64_t)blk << LOGN) : blk_off<LOGN>(p, b));
+      uint64_t *      cblk  = cptr + blk_off<LOGN>(p, b);
       uint32_t        tl    = tt;
       asm volatile("" : "+v"(tl)); /* ties the per-block requests to the iteration (see dot_inv_kernel) */
       typename A::val x[kE];
@@ -2104,7 +2122,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
         const bool     more = b0 + stride < p.nblocks;
         const uint64_t nb0  = more ? b0 + stride : b0;
         const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_first<LOGN>(raw, tl, p.a + (nb << LOGN), more);
+        prefetch_first<LOGN>(raw, tl, p.a + blk_off<LOGN>(p, nb), more);
       }
       run_group<A, LOGN, 0, false, MASK>(x, tl, blk, p);
       typename A::ctw pre[4][kE / 2];
@@ -2170,14 +2188,14 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       const bool live = b < p.nblocks;
       if(!live) b = p.nblocks - 1;
       const uint32_t  blk  = (uint32_t)b & bmask;
-      const uint64_t *bblk = bptr + ((bc ? (uint64_t)blk : b) << LOGN);
-      uint64_t *      cblk = cptr + (b << LOGN);
+      const uint64_t *bblk = bptr + (bc ? ((uint64_t)blk << LOGN) : blk_off<LOGN>(p, b));
+      uint64_t *      cblk = cptr + blk_off<LOGN>(p, b);
       /* (an opaque copy of the thread id per block: the integer policy's per-lane twiddle addresses would otherwise be
        * computed once for the launch and sit in registers -- or scratch -- throughout) */
       uint32_t tg = t;
       asm volatile("" : "+v"(tg));
       typename A::val x[kE];
-      global_load_first<A, LOGN, false>(x, tg, p.a + (b << LOGN), false, p.c);
+      global_load_first<A, LOGN, false>(x, tg, p.a + blk_off<LOGN>(p, b), false, p.c);
       run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tg, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
@@ -2214,9 +2232,9 @@ __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
     if constexpr(A::kRadix4) {
       /* (even stage count: launch_pass refuses anything else for this policy) */
-      if constexpr(R % 2 == 0) column_pass_thread_r4<A, R, INV>(p.a + (poly << p.logn), col, p.logn, p.s0, p.tw, p.c, p.lazy != 0);
+      if constexpr(R % 2 == 0) column_pass_thread_r4<A, R, INV>(p.a + poly * p.pstride, col, p.logn, p.s0, p.tw, p.c, p.lazy != 0);
     } else {
-      column_pass_thread<A, R, INV, MASK>(p.a + (poly << p.logn), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
+      column_pass_thread<A, R, INV, MASK>(p.a + poly * p.pstride, col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
     }
   }
 }
@@ -2229,6 +2247,7 @@ struct PassArgs {
   const void *limbs;       /* HOST array of LimbRec<A>, one per limb (copied into the kernel arguments) */
   int         nlimbs;      /* >= 1 */
   uint64_t    limb_stride; /* words between consecutive limbs' slabs   */
+  uint64_t    poly_stride; /* words between consecutive polynomials of a limb (0 = dense: N) */
   uint64_t    batch;       /* polynomials per limb                     */
   uint32_t    logn;   /* whole transform                   */
   int         fused;  /* Pass::fused; 2 = both passes of a 2^16 / 2^17 transform in one workgroup (r = m - 14); 3 = both passes as
@@ -2242,6 +2261,7 @@ struct PassArgs {
   int         ends;     /* this pass is the last one of the transform */
   int         max_grid; /* cap on workgroups (0 = default) */
   int         num_cus;  /* compute units of the device     */
+  int         oversub;  /* persistent block kernels: workgroups per resident slot (0 = block_oversub's default) */
   void *      team_ctl; /* fused == 3: device memory for the queues and counters (TeamCtl + batch counters) */
   int         team_lag, team_wpc;
   hipStream_t stream;
@@ -2257,11 +2277,13 @@ struct ProdArgs {
   const void *    limbs;       /* HOST array of LimbRec<A> */
   int             nlimbs;
   uint64_t        limb_stride;
+  uint64_t        poly_stride; /* words between consecutive polynomials of a limb, the same for all three operands (0 = dense: N) */
   uint64_t        batch;       /* per limb */
   uint32_t        logn;
   uint32_t        block_log; /* N > 2^14: log2 of the blocks (12, 13 or 14); the column passes around the launch cover logn - block_log stages */
   int             a_lazy;
   int             max_grid, num_cus;
+  int             oversub;  /* as PassArgs::oversub */
   void *          team_ctl; /* launch_team_product: device memory for the queues and 2 * batch counters */
   int             team_lag, team_wpc;
   int             four; /* launch_team_product: ahat holds a's COEFFICIENTS; the launch transforms both operands */
@@ -2281,10 +2303,12 @@ struct DotArgs {
   const void *           limbs; /* HOST array of LimbRec<A> */
   int                    nlimbs;
   uint64_t               limb_stride, b_limb_stride;
+  uint64_t               poly_stride; /* words between consecutive polynomials of a limb: every a_i^, c, and every b_i^ that is not broadcast (0 = dense: N) */
   uint64_t               batch;     /* per limb */
   uint32_t               logn;
   uint32_t               block_log; /* N > 2^14: log2 of the blocks (12 or 14); the inverse column passes follow as launches of their own */
   int                    max_grid, num_cus;
+  int                    oversub; /* as PassArgs::oversub */
   hipStream_t            stream;
 };
 template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
@@ -2298,10 +2322,12 @@ struct MulArgs {
   const void *    limbs; /* HOST array of LimbRec<A> */
   int             nlimbs;
   uint64_t        limb_stride, b_limb_stride;
+  uint64_t        poly_stride; /* words between consecutive polynomials of a limb: a, c^, and b^ unless broadcast (0 = dense: N) */
   uint64_t        batch;
   uint32_t        logn;
   uint32_t        block_log; /* N > 2^14: log2 of the blocks (12 or 14) */
   int             max_grid, num_cus;
+  int             oversub; /* as PassArgs::oversub */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
@@ -2316,6 +2342,23 @@ inline int pass_lazy(const PassArgs &pa) { return pa.ends ? pa.lazy : 1; }
  * 54..60-bit primes: a ciphertext is a few polynomials x tens of such limbs -- one launch instead of one chain per prime) */
 template <class A> constexpr bool multi_limb_built() { return A::kCompact || A::kIntWide; }
 
+/* Workgroups launched per resident slot of a persistent block kernel.  One workgroup per slot (the r01..r04 grids) lets the four
+ * 256-thread workgroups that share a CU at 2^12 run IN PHASE for the whole launch: they start together, do identical work and
+ * meet at the memory system, the LDS pipe and their barriers at the same time.  With several times as many workgroups as
+ * slots a slot is refilled whenever its workgroup runs out of blocks, at a time of its own, and the phases of a CU's workgroups
+ * decorrelate: measured (profiles/r05/grid_sweep.txt, three alternating repetitions on one box) 2^12 forward 0.592 -> 0.622 of
+ * the roofline at 8 workgroups per slot, inverse 0.617 -> 0.641, flat from 8 to 16, 0.61 with one block per workgroup (no
+ * prefetch across blocks left); the 1024-thread kernels (2^13, 2^14: one workgroup per CU, 16 waves in step by construction)
+ * measured no gain (0.591 at 1, 2, 4 per slot, 0.586 at 8) and keep one.  requested > 0 (NTT_OPT_BLOCK_OVERSUB) overrides. */
+template <int LOGN, int WG> constexpr int block_oversub_default(bool whole_polynomials)
+{
+  return (LOGN == 12 && WG == 256 && whole_polynomials) ? 8 : 1;
+}
+template <int LOGN, int WG> inline uint64_t block_oversub(int requested, bool whole_polynomials)
+{
+  return (uint64_t)(requested > 0 ? requested : block_oversub_default<LOGN, WG>(whole_polynomials));
+}
+
 template <class A> KArgs<A> make_kargs(const PassArgs &pa)
 {
   KArgs<A> k{};
@@ -2323,6 +2366,7 @@ template <class A> KArgs<A> make_kargs(const PassArgs &pa)
   const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
   for(int l = 0; l < (pa.nlimbs > 0 ? pa.nlimbs : 1) && l < kMaxLimbs; l++) k.limbs[l] = recs[l];
   k.limb_stride  = pa.limb_stride;
+  k.poly_stride  = pa.poly_stride ? pa.poly_stride : (1ull << pa.logn);
   k.wgs_per_limb = 1;
   k.logn         = pa.logn;
   k.s0           = 0;
@@ -2349,7 +2393,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     constexpr int by_lds    = G::WG_PER_CU0;
     constexpr int by_waves  = (G::WPS * 4 * 64) / G::WG;
     constexpr int per_cu    = by_lds < by_waves ? by_lds : by_waves;
-    cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+    cap                     = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * block_oversub<LOGN, G::WG>(pa.oversub, pa.s == 0);
   }
   if(!G::PERSISTENT && G::LDS_TW > 0) {
     /* tables are filled once per workgroup: a few workgroups per resident slot, each looping */
@@ -2518,6 +2562,7 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
     for(int l = 0; l < (pa.nlimbs > 0 ? pa.nlimbs : 1) && l < kMaxLimbs; l++) pp.f.limbs[l] = recs[l];
     pp.f.limb_stride  = pa.limb_stride;
+    pp.f.poly_stride  = pa.poly_stride ? pa.poly_stride : (1ull << pa.logn);
     pp.f.wgs_per_limb = 1;
     pp.f.logn         = pa.logn;
     pp.f.s0           = s0;
@@ -2571,7 +2616,9 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(blog == 12) {
       using G12 = Geom<12, false, 3>;
       constexpr int per_cu = G12::WG_PER_CU0 < G12::WPS ? G12::WG_PER_CU0 : G12::WPS; /* 256-thread workgroups: one wave per SIMD each */
-      uint64_t      cap12  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * per_cu;
+      /* (whole polynomials: several workgroups per resident slot, as for the transforms -- block_oversub; measured 0.369 -> 0.401 of
+       * the 24N roofline at 8 per slot, profiles/r05/oversub_sweep.txt) */
+      uint64_t      cap12  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * per_cu * block_oversub<12, G12::WG>(pa.oversub, s0 == 0);
       if(pa.max_grid > 0) cap12 = (uint64_t)pa.max_grid;
       cap12 = cap12 / nl > 0 ? cap12 / nl : 1;
       if(cap12 < (1ull << s0)) cap12 = 1ull << s0;
@@ -2650,6 +2697,7 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(pa.limbs);
     for(uint64_t l = 0; l < nl; l++) kt.k.f.limbs[l] = recs[l];
     kt.k.f.limb_stride  = nl > 1 ? pa.limb_stride : 0;
+    kt.k.f.poly_stride  = pa.poly_stride ? pa.poly_stride : (1ull << pa.logn);
     kt.k.f.logn         = pa.logn;
     kt.k.f.s0           = pa.logn - kTeamBlock;
     kt.k.f.nblocks      = pa.batch;
@@ -2700,6 +2748,7 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
   const uint64_t    nl   = (uint64_t)(da.nlimbs > 0 ? da.nlimbs : 1);
   for(uint64_t l = 0; l < nl && l < (uint64_t)kMaxLimbs; l++) kd.k.limbs[l] = recs[l];
   kd.k.limb_stride = da.limb_stride;
+  kd.k.poly_stride = da.poly_stride ? da.poly_stride : (1ull << da.logn);
   kd.k.logn        = da.logn;
   kd.k.s0          = da.logn - (uint32_t)LOGN;
   kd.k.lastinv     = LASTINV ? 1u : 0u;
@@ -2720,7 +2769,7 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
     constexpr int by_lds   = G::WG_PER_CU0;
     constexpr int by_waves = (G::WPS * 4 * 64) / G::WG;
     constexpr int per_cu   = by_lds < by_waves ? by_lds : by_waves;
-    cap                    = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+    cap                    = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * block_oversub<LOGN, G::WG>(da.oversub, kd.k.s0 == 0);
   }
   if(!G::PERSISTENT && G::LDS_TW > 0) {
     if(kd.k.s0 != 0) return hipErrorInvalidValue;
@@ -2775,6 +2824,7 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
   const uint64_t    nl   = (uint64_t)(ma.nlimbs > 0 ? ma.nlimbs : 1);
   for(uint64_t l = 0; l < nl && l < (uint64_t)kMaxLimbs; l++) km.k.limbs[l] = recs[l];
   km.k.limb_stride = ma.limb_stride;
+  km.k.poly_stride = ma.poly_stride ? ma.poly_stride : (1ull << ma.logn);
   km.k.logn        = ma.logn;
   km.k.s0          = ma.logn - (uint32_t)LOGN;
   km.k.nblocks     = ma.batch << km.k.s0;
@@ -2791,7 +2841,7 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
     constexpr int by_lds   = G::WG_PER_CU0;
     constexpr int by_waves = (G::WPS * 4 * 64) / G::WG;
     constexpr int per_cu   = by_lds < by_waves ? by_lds : by_waves;
-    cap                    = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (per_cu > 0 ? per_cu : 1);
+    cap                    = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * block_oversub<LOGN, G::WG>(ma.oversub, km.k.s0 == 0);
   }
   if(!G::PERSISTENT && G::LDS_TW > 0) {
     if(km.k.s0 != 0) return hipErrorInvalidValue;

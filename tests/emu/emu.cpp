@@ -31,6 +31,12 @@ using namespace ntt;
 /* ArithF64Chk: the FP64 policy with every exactness claim of DESIGN.md */
 /* section 4 asserted at run time against 128-bit integer arithmetic.   */
 /* ------------------------------------------------------------------ */
+/* words between consecutive polynomials for the next calls (emu_set_poly_stride; 0 = dense: N) -- the caller-native layouts of
+ * the library's *_strided entry points, through the same block_offset the kernels use */
+inline uint64_t g_pstride = 0;
+static inline uint64_t emu_pstride(int m) { return g_pstride ? g_pstride : (1ull << m); }
+inline uint64_t g_opstride = 0; /* emu_inv_dot: words between consecutive operands of the a / b arrays (0 = batch * N: dense) */
+
 inline uint64_t g_chk_fail  = 0;   /* number of violated claims          (inline: one copy for all parts) */
 inline double   g_chk_maxb  = 0;   /* largest |value|/q seen             */
 inline double   g_chk_maxr  = 0;   /* largest |product|/q seen           */
@@ -385,7 +391,7 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false>
   std::vector<Regs<A>>         regs(P::T);
   for(uint64_t b = 0; b < p.nblocks; b++) {
     const uint32_t blk  = (uint32_t)(b & ((1ull << p.s0) - 1));
-    uint64_t *     base = p.a + (b << LOGN);
+    uint64_t *     base = p.a + block_offset<LOGN>(b, p.s0, p.pstride); /* as the kernels: csrc/ntt_kernels.h blk_off */
     if constexpr(!INV) {
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
         global_load_first<A, LOGN, false>(regs[t].x, t, base, p.wide, p.c);
@@ -611,15 +617,16 @@ void emu_dot_blocks(const Params<A> &p, int k, const uint64_t *const *a, const u
   const uint64_t bmask = (1ull << p.s0) - 1;
   for(uint64_t blkid = 0; blkid < p.nblocks; blkid++) {
     const uint32_t blk  = (uint32_t)(blkid & bmask);
-    const uint64_t bb   = bcast ? (uint64_t)blk : blkid;
-    uint64_t *     base = p.a + (blkid << LOGN);
+    const uint64_t offa = block_offset<LOGN>(blkid, p.s0, p.pstride);
+    const uint64_t offb = bcast ? ((uint64_t)blk << LOGN) : offa; /* a broadcast operand is one dense polynomial */
+    uint64_t *     base = p.a + offa;
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
       typename A::val(&x)[kE] = regs[t].x;
       for(int e = 0; e < kE; e++) x[e] = typename A::val{};
       for(int i = 0; i < k; i++) {
         uint64_t ra[kE], rb[kE];
-        load_last_raw<LOGN>(ra, t, a[i] + (blkid << LOGN));
-        load_last_raw<LOGN>(rb, t, b[i] + (bb << LOGN));
+        load_last_raw<LOGN>(ra, t, a[i] + offa);
+        load_last_raw<LOGN>(rb, t, b[i] + offb);
         if(i != 0 && i % A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
         dot_tile<A>(x, ra, rb, lazy, p.c);
       }
@@ -664,10 +671,11 @@ void emu_fwd_mul_blocks(const Params<A> &p, const uint64_t *bhat, uint64_t *out,
   const uint64_t bmask = (1ull << p.s0) - 1;
   for(uint64_t blkid = 0; blkid < p.nblocks; blkid++) {
     const uint32_t  blk  = (uint32_t)(blkid & bmask);
-    const uint64_t *bblk = bhat + ((bcast ? (uint64_t)blk : blkid) << LOGN);
-    uint64_t *      cblk = out + (blkid << LOGN);
+    const uint64_t  offa = block_offset<LOGN>(blkid, p.s0, p.pstride);
+    const uint64_t *bblk = bhat + (bcast ? ((uint64_t)blk << LOGN) : offa);
+    uint64_t *      cblk = out + offa;
     for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
-      global_load_first<A, LOGN, false>(regs[t].x, t, p.a + (blkid << LOGN), false, p.c);
+      global_load_first<A, LOGN, false>(regs[t].x, t, p.a + offa, false, p.c);
       run_group<A, LOGN, 0, false, MASK>(regs[t].x, t, blk, p);
     }
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -722,6 +730,7 @@ int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t b
   p.tw8     = tab8;
   p.c       = c;
   p.logn    = (uint32_t)m;
+  p.pstride = emu_pstride(m);
   p.s0      = (uint32_t)(m - pblk);
   p.nblocks = batch << p.s0;
   switch(pblk) {
@@ -752,6 +761,7 @@ int emu_dot_run(uint64_t *out, int k, const uint64_t *const *a, const uint64_t *
   p.tw8     = tab8;
   p.c       = c;
   p.logn    = (uint32_t)m;
+  p.pstride = emu_pstride(m);
   p.s0      = (uint32_t)(m - pblk);
   p.lastinv = m <= kFusedMax;
   p.nblocks = batch << p.s0;
@@ -795,7 +805,7 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
   const uint64_t     cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
     for(uint64_t col = 0; col < cols; col++) {
-      column_pass_thread<A, R, INV, MASK>(a + (pidx << logn), (uint32_t)col, logn, S, wide, lastinv, tab, c, lazy_out);
+      column_pass_thread<A, R, INV, MASK>(a + pidx * emu_pstride((int)logn), (uint32_t)col, logn, S, wide, lastinv, tab, c, lazy_out);
     }
   }
 }
@@ -806,7 +816,7 @@ static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S
 {
   const uint64_t cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
-    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R, INV>(a + (pidx << logn), (uint32_t)col, logn, S, tab, c, lazy_out);
+    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R, INV>(a + pidx * emu_pstride((int)logn), (uint32_t)col, logn, S, tab, c, lazy_out);
   }
 }
 
@@ -839,6 +849,7 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
         if(INV && ps.s != 0) p.c.ninv = h_tw_u64(1, c.q);
       }
       p.logn    = (uint32_t)m;
+      p.pstride = emu_pstride(m);
       p.s0      = (uint32_t)ps.s;
       p.wide    = w;
       p.lastinv = lastinv;
@@ -1080,6 +1091,8 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 }
 
 void emu_set_lazy(int on) { g_lazy = on != 0; }
+void emu_set_poly_stride(uint64_t words) { g_pstride = words; }
+void emu_set_operand_stride(uint64_t words) { g_opstride = words; }
 void emu_set_u64x_worst(int on) { g_u64x_worst = on != 0; }
 void emu_set_product_both(int on) { g_prod_both = on != 0; }
 
@@ -1190,8 +1203,8 @@ int emu_inv_dot(uint64_t *out, int k, const uint64_t *a, const uint64_t *b, uint
   const auto     wix  = h_with_folded_ninv(wi, h_powmod(N % q, q - 2, q), q);
   std::vector<const uint64_t *> pa(k), pb(k);
   for(int i = 0; i < k; i++) {
-    pa[i] = a + (uint64_t)i * batch * N;
-    pb[i] = b + (uint64_t)i * (bcast ? N : batch * N);
+    pa[i] = a + (uint64_t)i * (g_opstride ? g_opstride : batch * N);
+    pb[i] = b + (uint64_t)i * (bcast ? N : (g_opstride ? g_opstride : batch * N));
   }
   if(arith == 0) {
     std::vector<TwU64> tab(wix.size());

@@ -23,6 +23,8 @@ class Emu:
         L.emu_chk_stats.argtypes = [U64P, C.c_int]
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
+        L.emu_set_poly_stride.argtypes = [C.c_uint64]
+        L.emu_set_operand_stride.argtypes = [C.c_uint64]
         L.emu_set_u64x_worst.argtypes = [C.c_int]
         L.emu_u64x_schedule.restype = C.c_uint32
         L.emu_u64x_schedule.argtypes = [C.c_int] * 3
@@ -44,6 +46,39 @@ class Emu:
                                     int(generic), int(wide), ksh)
         self.lib.emu_set_lazy(0)
         return rc, a
+
+    def transform_limb(self, buf, limb, nlimbs, batch, m, q, root, arith, inverse=False, ksh=-1):
+        """limb `limb` of a [batch][nlimbs][N] buffer (SURVEY 8(d)'s layout: polynomials nlimbs * N words apart), in place, through
+        the block_offset addressing of the kernels (csrc/ntt_core.h); returns the status"""
+        n = 1 << m
+        assert buf.dtype == np.uint64 and buf.flags["C_CONTIGUOUS"] and buf.size == batch * nlimbs * n
+        self.lib.emu_set_poly_stride(nlimbs * n)
+        ptr = C.cast(buf.ctypes.data + 8 * limb * n, U64P)
+        rc = self.lib.emu_transform(ptr, batch, m, q, root, arith, int(inverse), 0, 0, ksh)
+        self.lib.emu_set_poly_stride(0)
+        return rc
+
+    def inv_dot_limb(self, out, a, b, limb, nlimbs, k, batch, m, q, root, arith=1, lazy=False):
+        """limb `limb` of c = inv(sum_i a_i (.) b_i) with a, b laid out [k][batch][nlimbs][N] and out [batch][nlimbs][N]"""
+        n = 1 << m
+        self.lib.emu_set_poly_stride(nlimbs * n)
+        self.lib.emu_set_operand_stride(batch * nlimbs * n)
+        off = 8 * limb * n
+        rc = self.lib.emu_inv_dot(C.cast(out.ctypes.data + off, U64P), k, C.cast(a.ctypes.data + off, U64P), C.cast(b.ctypes.data + off, U64P),
+                                  batch, m, q, root, arith, int(lazy), 0)
+        self.lib.emu_set_poly_stride(0)
+        self.lib.emu_set_operand_stride(0)
+        return rc
+
+    def fwd_mul_limb(self, out, a, bhat, limb, nlimbs, batch, m, q, root, arith=1, acc=False):
+        """limb `limb` of c^ (+)= fwd(a) (.) b^, all three laid out [batch][nlimbs][N] (a is scratch above 2^14)"""
+        n = 1 << m
+        self.lib.emu_set_poly_stride(nlimbs * n)
+        off = 8 * limb * n
+        rc = self.lib.emu_fwd_mul(C.cast(out.ctypes.data + off, U64P), C.cast(a.ctypes.data + off, U64P), C.cast(bhat.ctypes.data + off, U64P),
+                                  batch, m, q, root, arith, 0, 0, int(acc))
+        self.lib.emu_set_poly_stride(0)
+        return rc
 
     def fused_product14(self, ahat, b, q, root, a_lazy=False, chk=False, both=False):
         """inv(fwd(b) * ahat) as the fused product kernel computes it (N = 2^14); both: `ahat` holds a's COEFFICIENTS and

@@ -665,3 +665,46 @@ def test_wide_integer_fold_schedule_bounds(emu, k):
             b = 4.0 if (mi >> s) & 1 else 2 * b     # folded sums below 2.01 q, products below 4q
     assert emu.u64x_schedule(False, 14, 3) == 0 and emu.u64x_schedule(True, 12, 3) == 0b100010001000
     assert emu.u64x_schedule(False, 14, 0) == 0x3ffe and emu.u64x_schedule(True, 14, 0) == 0x3fff
+
+
+@pytest.mark.parametrize("m,q", [(8, 0x7fffffffe0001), (12, 0x80000001c0001), (13, 0x3ffffffdf0001), (15, 0x7fffffffe0001)])
+def test_caller_native_layout_block_offsets(oracle, emu, m, q):
+    """SURVEY 8(d)'s [batch][prime][N] layout through csrc/ntt_core.h block_offset -- the address computation the kernels and the
+    library's *_strided entry points share: limb l of a [batch][3][N] buffer is transformed in place with polynomials 3 N words
+    apart (whole-polynomial blocks, blocks below a column pass at 2^15, the column pass itself); the other limbs' words must
+    stay untouched and every polynomial must equal the oracle's transform.  Forward, inverse, the NTT-domain inner product and
+    the forward transform times a transformed operand."""
+    n, batch, nl = 1 << m, 3, 3
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    rng = np.random.default_rng(m)
+    buf = (rng.integers(0, q, size=(batch, nl, n), dtype=np.uint64)).copy()
+    buf[0, 1, :4] = q - 1
+    orig = buf.copy()
+    limb = 1
+    assert emu.transform_limb(buf.reshape(-1), limb, nl, batch, m, q, w, F64) == 0
+    for l in range(nl):
+        for p in range(batch):
+            exp = cx.fwd(orig[p, l].copy()) if l == limb else orig[p, l]
+            assert np.array_equal(buf[p, l], exp), (p, l)
+    fwd = buf.copy()
+    assert emu.transform_limb(buf.reshape(-1), limb, nl, batch, m, q, w, F64, inverse=True) == 0
+    assert np.array_equal(buf, orig)
+    # c = inv(a0^ b0^ + a1^ b1^) on the limb, operands [k][batch][nl][N]
+    k = 2
+    a = rng.integers(0, q, size=(k, batch, nl, n), dtype=np.uint64)
+    b = rng.integers(0, q, size=(k, batch, nl, n), dtype=np.uint64)
+    out = np.full((batch, nl, n), 7, dtype=np.uint64)
+    assert emu.inv_dot_limb(out.reshape(-1), a.reshape(-1), b.reshape(-1), limb, nl, k, batch, m, q, w) == 0
+    for p in range(batch):
+        s = oracle.pointwise(a[0, p, limb].copy(), b[0, p, limb].copy(), q)
+        s = (s + oracle.pointwise(a[1, p, limb].copy(), b[1, p, limb].copy(), q)) % np.uint64(q)
+        assert np.array_equal(out[p, limb], cx.inv(s)), p
+        assert (out[p, 0] == 7).all() and (out[p, 2] == 7).all()
+    # c^ = fwd(a) (.) b^ on the limb
+    acoef = orig.copy()
+    out2 = np.full((batch, nl, n), 9, dtype=np.uint64)
+    assert emu.fwd_mul_limb(out2.reshape(-1), acoef.reshape(-1), b[0].copy().reshape(-1), limb, nl, batch, m, q, w) == 0
+    for p in range(batch):
+        assert np.array_equal(out2[p, limb], oracle.pointwise(fwd[p, limb].copy(), b[0, p, limb].copy(), q)), p
+        assert (out2[p, 0] == 9).all()

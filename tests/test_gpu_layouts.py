@@ -1,0 +1,270 @@
+"""GPU (-m gpu): caller-native layouts.  SURVEY 8(d) config 5 keeps RNS operands as [batch][prime][N] (a polynomial's limbs side
+by side -- what FHE libraries hold); the plain ntt_rns_* entry points take [limb][batch][N].  The *_strided forms take both
+distances in words; every entry point is compared with the oracle polynomial by polynomial in the batch-major layout, in a
+padded layout, with one launch over the limbs and limb by limb, at sizes that reach every kernel family (several blocks per
+workgroup, persistent block kernels, column passes, the XCD-local one-launch kernels), and with the untouched words checked.
+The reference's batching precedent is two caller arrays, fwd_ntt_ref_harvey_lazy_dbl (include/ntt_reference.h:44-49)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GUARD = np.uint64(0xDEADBEEFCAFEF00D)
+
+
+def _primes(lib, n, nlimbs, bits):
+    qs = [lib.find_prime(bits, n, k) for k in range(nlimbs)]
+    assert len(set(qs)) == nlimbs
+    return qs, [lib.min_root(q, n) for q in qs]
+
+
+class _Layout:
+    """a host image of an RNS operand: polynomial p of limb l at l * limb + p * poly (words), guard words everywhere else"""
+
+    def __init__(self, n, nlimbs, batch, limb, poly):
+        self.n, self.nl, self.batch, self.limb, self.poly = n, nlimbs, batch, limb, poly
+        self.words = (nlimbs - 1) * limb + (batch - 1) * poly + n
+
+    def scatter(self, dense):
+        """dense[l][p][:] -> image"""
+        img = np.full(self.words, GUARD, dtype=np.uint64)
+        for l in range(self.nl):
+            for p in range(self.batch):
+                o = l * self.limb + p * self.poly
+                img[o:o + self.n] = dense[l, p]
+        return img
+
+    def gather(self, img):
+        out = np.empty((self.nl, self.batch, self.n), dtype=np.uint64)
+        mask = np.ones(self.words, dtype=bool)
+        for l in range(self.nl):
+            for p in range(self.batch):
+                o = l * self.limb + p * self.poly
+                out[l, p] = img[o:o + self.n]
+                mask[o:o + self.n] = False
+        assert (img[mask] == GUARD).all(), "words outside the operand's polynomials were written"
+        return out
+
+    @property
+    def strides(self):
+        return (self.limb, self.poly)
+
+
+def _layouts(n, nlimbs, batch):
+    return {
+        "batch_major": _Layout(n, nlimbs, batch, n, nlimbs * n),                       # [batch][prime][N]
+        "batch_major_padded": _Layout(n, nlimbs, batch, n + 64, nlimbs * (n + 64) + 128),
+        "limb_major_padded": _Layout(n, nlimbs, batch, batch * (n + 32) + 256, n + 32),
+    }
+
+
+def _dense_inputs(oracle, n, qs, batch, seed):
+    d = np.empty((len(qs), batch, n), dtype=np.uint64)
+    for l, q in enumerate(qs):
+        d[l] = oracle.fill_uniform(batch * n, q, seed + l).reshape(batch, n)
+        d[l, 0, :4] = q - 1
+        d[l, -1, -1] = q - 1
+        d[l, 0, 4:8] = 0
+    return d
+
+
+def _expected(oracle, n, qs, roots, a, b):
+    ctxs = [oracle.ctx(n, q, w) for q, w in zip(qs, roots)]
+    fa = np.stack([cx.fwd(a[l].reshape(-1)).reshape(a[l].shape) for l, cx in enumerate(ctxs)])
+    fb = np.stack([cx.fwd(b[l].reshape(-1)).reshape(b[l].shape) for l, cx in enumerate(ctxs)])
+    prod = np.stack([cx.inv(oracle.pointwise(fa[l].reshape(-1), fb[l].reshape(-1), q)).reshape(a[l].shape)
+                     for l, (cx, q) in enumerate(zip(ctxs, qs))])
+    return ctxs, fa, fb, prod
+
+
+CASES = [
+    # logn, nlimbs, batch, bits            what it reaches
+    (8, 3, 5, 50),      # several blocks per workgroup (per-lane block addresses), ragged tail
+    (12, 4, 3, 50),     # persistent 2^12 kernels, MULTI variants
+    (13, 3, 2, 52),     # two blocks per workgroup (forward), the 52-bit policy
+    (14, 4, 2, 50),     # the headline kernels
+    (14, 3, 2, 57),     # wide integer policy
+    (15, 3, 2, 50),     # blocks below a column pass, chunks
+    (16, 2, 3, 52),
+    (17, 2, 2, 50),
+    (5, 2, 3, 45),      # column passes only
+]
+
+
+def _run_entry_points(lib, oracle, monkeypatch, logn, nlimbs, batch, bits, lay_name, loop):
+    n = 1 << logn
+    qs, roots = _primes(lib, n, nlimbs, bits)
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    lay = _layouts(n, nlimbs, batch)[lay_name]
+    a, b = _dense_inputs(oracle, n, qs, batch, 4100), _dense_inputs(oracle, n, qs, batch, 4200)
+    ctxs, fa, fb, prod = _expected(oracle, n, qs, roots, a, b)
+    lib.set_rns_launch(plans, loop)
+    da, db, dc = (lib.DeviceBuffer(lay.words) for _ in range(3))
+    try:
+        # transforms
+        da.upload(lay.scatter(a))
+        lib.rns_fwd(plans, da.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(da.download()), fa), "forward"
+        lib.rns_inv(plans, da.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(da.download()), a), "inverse"
+        # coefficient-domain product, c its own buffer and c aliasing a
+        db.upload(lay.scatter(b)), dc.upload(np.full(lay.words, GUARD, dtype=np.uint64))
+        lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(dc.download()), prod), "product"
+        da.upload(lay.scatter(a)), db.upload(lay.scatter(b))
+        lib.rns_negacyclic_mul(plans, da.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(da.download()), prod), "product, c aliasing a"
+        # NTT-domain products: c = inv(a^ b^ + b^ a^') with canonical words, then with a broadcast key [limb][N]
+        da.upload(lay.scatter(fa)), db.upload(lay.scatter(fb)), dc.upload(np.full(lay.words, GUARD, dtype=np.uint64))
+        lib.rns_inv_dot(plans, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], batch, layout=lay.strides)
+        pw = np.stack([oracle.pointwise(fa[l].reshape(-1), fb[l].reshape(-1), q).reshape(a[l].shape) for l, q in enumerate(qs)])
+        pw2 = np.stack([(pw[l] + pw[l]) % np.uint64(q) for l, q in enumerate(qs)])                  # (q < 2^61: no overflow)
+        exp2 = np.stack([cx.inv(pw2[l].reshape(-1)).reshape(a[l].shape) for l, cx in enumerate(ctxs)])
+        assert np.array_equal(lay.gather(dc.download()), exp2), "inner product, k = 2"
+        key = np.stack([fb[l, 0] for l in range(nlimbs)])                      # [limb][N]
+        dk = lib.DeviceBuffer(key.size).upload(key.reshape(-1))
+        lib.rns_inv_dot(plans, dc.ptr, [da.ptr], [dk.ptr], batch, flags=lib.MUL_B_BROADCAST, layout=lay.strides)
+        expk = np.stack([cx.inv(oracle.pointwise(fa[l].reshape(-1), np.tile(key[l], batch), q)).reshape(a[l].shape)
+                         for l, (cx, q) in enumerate(zip(ctxs, qs))])
+        assert np.array_equal(lay.gather(dc.download()), expk), "product with a broadcast key"
+        # c = inv(fwd(a) b^)
+        da.upload(lay.scatter(a)), db.upload(lay.scatter(fb))
+        lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(dc.download()), prod), "fwd(a) times a transformed operand, inverse"
+        # c^ = fwd(a) b^, then c^ += fwd(a) b^
+        da.upload(lay.scatter(a))
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+        assert np.array_equal(lay.gather(dc.download()), pw), "forward transform times a transformed operand"
+        da.upload(lay.scatter(a))
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch, flags=lib.MUL_ACCUMULATE, layout=lay.strides)
+        assert np.array_equal(lay.gather(dc.download()), pw2), "... accumulated"
+        dk.free()
+    finally:
+        for x in (da, db, dc):
+            x.free()
+        for p in plans:
+            p.destroy()
+
+
+@pytest.mark.parametrize("loop", ["0", "1"])
+@pytest.mark.parametrize("logn,nlimbs,batch,bits", CASES)
+def test_rns_entry_points_in_batch_major_layout(lib, oracle, monkeypatch, logn, nlimbs, batch, bits, loop):
+    """every ntt_rns_*_strided entry point on [batch][prime][N] operands, one launch over the limbs (loop 0) and limb by limb (1)"""
+    _run_entry_points(lib, oracle, monkeypatch, logn, nlimbs, batch, bits, "batch_major", loop)
+
+
+@pytest.mark.parametrize("lay_name", ["batch_major_padded", "limb_major_padded"])
+@pytest.mark.parametrize("logn,nlimbs,batch,bits", [(8, 3, 5, 50), (12, 4, 3, 50), (14, 3, 2, 57), (15, 3, 2, 50)])
+def test_rns_entry_points_in_padded_layouts(lib, oracle, monkeypatch, logn, nlimbs, batch, bits, lay_name):
+    _run_entry_points(lib, oracle, monkeypatch, logn, nlimbs, batch, bits, lay_name, "0")
+
+
+@pytest.mark.parametrize("arith", ["u64", "r4", "generic"])
+def test_strided_layout_plans_without_the_fused_kernels(lib, oracle, monkeypatch, arith):
+    """the reference's butterflies (NTT_ARITH_U64), its radix-4 formulation and column-pass-only plans: per-limb launches and the
+    unfused pointwise products honour the layout too"""
+    n, nlimbs, batch = 1 << 10, 3, 3
+    qs, roots = _primes(lib, n, nlimbs, 50)
+    ar = {"u64": lib.ARITH_U64, "r4": lib.ARITH_U64_R4, "generic": lib.ARITH_AUTO}[arith]
+    plans = [lib.Plan(n, q, w, arith=ar) for q, w in zip(qs, roots)]
+    if arith == "generic":
+        for p in plans:
+            p.set_generic(True)
+    lay = _layouts(n, nlimbs, batch)["batch_major"]
+    a, b = _dense_inputs(oracle, n, qs, batch, 5100), _dense_inputs(oracle, n, qs, batch, 5200)
+    ctxs, fa, fb, prod = _expected(oracle, n, qs, roots, a, b)
+    da, db, dc = (lib.DeviceBuffer(lay.words) for _ in range(3))
+    da.upload(lay.scatter(a)), db.upload(lay.scatter(b)), dc.upload(np.full(lay.words, GUARD, dtype=np.uint64))
+    lib.rns_fwd(plans, da.ptr, batch, layout=lay.strides)
+    assert np.array_equal(lay.gather(da.download()), fa)
+    lib.rns_inv(plans, da.ptr, batch, layout=lay.strides)
+    assert np.array_equal(lay.gather(da.download()), a)
+    lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+    assert np.array_equal(lay.gather(dc.download()), prod)
+    da.upload(lay.scatter(fa)), db.upload(lay.scatter(fb))
+    lib.rns_inv_dot(plans, dc.ptr, [da.ptr], [db.ptr], batch, layout=lay.strides)
+    assert np.array_equal(lay.gather(dc.download()), prod)
+    da.upload(lay.scatter(a))
+    lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+    pw = np.stack([oracle.pointwise(fa[l].reshape(-1), fb[l].reshape(-1), q).reshape(a[l].shape) for l, q in enumerate(qs)])
+    assert np.array_equal(lay.gather(dc.download()), pw)
+
+
+@pytest.mark.parametrize("m,nl,batch,bits", [(15, 3, 90, 50), (16, 2, 160, 52), (17, 4, 33, 50), (16, 3, 180, 57)])
+def test_xcd_local_launches_in_batch_major_layout(lib, oracle, m, nl, batch, bits):
+    """large batches of N >= 2^15: the XCD-local one-launch kernels (queue entry = limb and polynomial) on [batch][prime][N]
+    operands; every polynomial of the forward transform and of the product against the limb-major call on the same data,
+    samples against the oracle"""
+    n = 1 << m
+    qs, roots = _primes(lib, n, nl, bits)
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    for p in plans:
+        p.set_option(lib.OPT_XCD_LOCAL, 1)
+    a, b = _dense_inputs(oracle, n, qs, batch, 6100), _dense_inputs(oracle, n, qs, batch, 6200)
+    lay = _layouts(n, nl, batch)["batch_major"]
+    da, db, dc = (lib.DeviceBuffer(lay.words) for _ in range(3))
+    ea, eb, ec = (lib.DeviceBuffer(nl * batch * n) for _ in range(3))
+    da.upload(lay.scatter(a)), ea.upload(a.reshape(-1))
+    lib.rns_fwd(plans, da.ptr, batch, layout=lay.strides)
+    lib.rns_fwd(plans, ea.ptr, batch)
+    f_bm, f_lm = lay.gather(da.download()), ea.download().reshape(nl, batch, n)
+    assert np.array_equal(f_bm, f_lm)
+    for l in (0, nl - 1):
+        cx = oracle.ctx(n, qs[l], roots[l])
+        for p in (0, batch // 2, batch - 1):
+            assert np.array_equal(f_bm[l, p], cx.fwd(a[l, p].copy())), (l, p)
+    lib.rns_inv(plans, da.ptr, batch, layout=lay.strides)
+    assert np.array_equal(lay.gather(da.download()), a)
+    db.upload(lay.scatter(b)), ea.upload(a.reshape(-1)), eb.upload(b.reshape(-1))
+    lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lay.strides)
+    lib.rns_negacyclic_mul(plans, ec.ptr, ea.ptr, eb.ptr, batch)
+    p_bm, p_lm = lay.gather(dc.download()), ec.download().reshape(nl, batch, n)
+    assert np.array_equal(p_bm, p_lm)
+    cx = oracle.ctx(n, qs[1], roots[1])
+    for p in (0, batch - 1):
+        assert np.array_equal(p_bm[1, p], cx.inv(oracle.pointwise(cx.fwd(a[1, p].copy()), cx.fwd(b[1, p].copy()), qs[1]))), p
+    for x in (da, db, dc, ea, eb, ec):
+        x.free()
+
+
+@pytest.mark.parametrize("m,bits", [(9, 50), (14, 51), (14, 60), (16, 50)])
+def test_single_plan_strided_transform(lib, oracle, m, bits):
+    """ntt_transform_batch_strided: one limb of a [batch][3][N] operand, every flag combination"""
+    n, batch = 1 << m, 5
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w)
+    cx = oracle.ctx(n, q, w)
+    stride = 3 * n
+    a = oracle.fill_uniform(batch * n, q, 7100).reshape(batch, n)
+    img = np.full(batch * stride, GUARD, dtype=np.uint64)
+    for p in range(batch):
+        img[p * stride + n:p * stride + 2 * n] = a[p]
+    d = lib.DeviceBuffer(img.size).upload(img)
+    plan.transform_strided(d.ptr + 8 * n, stride, batch)
+    got = d.download().reshape(batch, 3, n)
+    assert (got[:, 0] == GUARD).all() and (got[:, 2] == GUARD).all()
+    assert np.array_equal(got[:, 1], cx.fwd(a.reshape(-1)).reshape(batch, n))
+    plan.transform_strided(d.ptr + 8 * n, stride, batch, lib.FLAG_INVERSE)
+    assert np.array_equal(d.download().reshape(batch, 3, n)[:, 1], a)
+    plan.transform_strided(d.ptr + 8 * n, stride, batch, lib.FLAG_LAZY_OUT)
+    lz = d.download().reshape(batch, 3, n)[:, 1]
+    assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), cx.fwd(a.reshape(-1)).reshape(batch, n))
+    plan.transform_strided(d.ptr + 8 * n, stride, batch, lib.FLAG_INVERSE | lib.FLAG_WIDE_IN)
+    assert np.array_equal(d.download().reshape(batch, 3, n)[:, 1], a)
+    d.free()
+
+
+def test_layouts_that_overlap_are_refused(lib, oracle):
+    n, nl, batch = 1 << 8, 3, 4
+    qs, roots = _primes(lib, n, nl, 50)
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    d = lib.DeviceBuffer(nl * batch * n * 2)
+    for limb, poly in ((n, n), (n, 2 * n), (n - 1, nl * n), (batch * n - 1, n), (0, 0)):
+        with pytest.raises(lib.NttError):
+            lib.rns_fwd(plans, d.ptr, batch, layout=(limb, poly))
+    with pytest.raises(lib.NttError):
+        plans[0].transform_strided(d.ptr, n - 1, batch)
+    # the two canonical layouts pass
+    lib.rns_fwd(plans, d.ptr, batch, layout=(batch * n, n))
+    lib.rns_fwd(plans, d.ptr, batch, layout=(n, nl * n))
+    d.free()

@@ -439,7 +439,7 @@ def test_xcd_local_full_size_round_trip_and_cross_check(lib, oracle):
 def test_rns_one_launch_over_all_limbs(lib, oracle, logn, nlimbs, batch, monkeypatch):
     """ntt_rns_{fwd,inv,negacyclic_mul}_batch with a small per-limb batch: ONE launch (per pass) serves every limb
     (kernel variants MULTI: the workgroup picks its limb's tables and constants from an array in the kernel arguments).
-    Every limb of every polynomial against the oracle; the same calls with NTT_RNS_LOOP=1 (one launch chain per prime,
+    Every limb of every polynomial against the oracle; the same calls with NTT_OPT_RNS_LAUNCH 1 (one launch chain per prime,
     the single-set kernels) must give the same words."""
     _rns_one_launch_check(lib, oracle, monkeypatch, logn, nlimbs, batch, 50)
 
@@ -467,7 +467,7 @@ def _rns_one_launch_check(lib, oracle, monkeypatch, logn, nlimbs, batch, bits):
     exp_p = np.concatenate([cx.inv(oracle.pointwise(cx.fwd(a[s]), cx.fwd(b[s]), q)) for cx, s, q in zip(ctxs, sl, qs)])
     results = {}
     for loop in ("0", "1"):
-        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        lib.set_rns_launch(plans, loop)
         da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
         lib.rns_fwd(plans, da.ptr, batch)
         f = da.download()
@@ -493,7 +493,7 @@ def test_rns_one_launch_more_limbs_than_one_launch_holds(lib, oracle, monkeypatc
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
     a = np.concatenate([_inputs(oracle, n, q, batch, 700 + l) for l, q in enumerate(qs)])
     b = np.concatenate([_inputs(oracle, n, q, batch, 750 + l) for l, q in enumerate(qs)])
-    monkeypatch.setenv("NTT_RNS_LOOP", "0")
+    lib.set_rns_launch(plans, 0)
     da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
     lib.rns_fwd(plans, da.ptr, batch)
     got_f = da.download()
@@ -512,7 +512,6 @@ def test_rns_mixed_headroom_classes_share_a_launch(lib, oracle, sizes, monkeypat
     """limbs of ONE policy whose primes fall into different headroom classes (a 30-bit, a 51-bit and a 45-bit prime: FP64
     classes 18, 0, 1; 57- to 61-bit primes: integer classes 3, 1, 1, 0, 3) share a launch in the coarsest class of the run;
     the 52-bit policy does not mix with the scheduled one (two runs).  Same results as limb by limb."""
-    monkeypatch.setenv("NTT_RNS_LOOP", "0")
     n, batch = 1 << 10, 2
     seen = {}
     qs = []
@@ -521,6 +520,7 @@ def test_rns_mixed_headroom_classes_share_a_launch(lib, oracle, sizes, monkeypat
         seen[bts] = seen.get(bts, 0) + 1
     roots = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    lib.set_rns_launch(plans, 0)
     a = np.concatenate([_inputs(oracle, n, q, batch, 600 + l) for l, q in enumerate(qs)])
     da = lib.DeviceBuffer(a.size).upload(a)
     lib.rns_fwd(plans, da.ptr, batch)
@@ -563,9 +563,9 @@ def test_rns_modulus_chain_with_primes_of_several_sizes(lib, oracle, m, batch, m
     da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
     for loop in ("0", "1", None):
         if loop is None:
-            monkeypatch.delenv("NTT_RNS_LOOP", raising=False)
+            lib.set_rns_launch(plans, None)
         else:
-            monkeypatch.setenv("NTT_RNS_LOOP", loop)
+            lib.set_rns_launch(plans, loop)
         da.upload(a)
         lib.rns_fwd(plans, da.ptr, batch)
         assert np.array_equal(da.download(), fa), loop
@@ -1791,7 +1791,7 @@ def _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits):
     dc = lib.DeviceBuffer(nl * slab)
     outs = []
     for loop in ("0", "1"):
-        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        lib.set_rns_launch(plans, loop)
         lib.rns_inv_dot(plans, dc.ptr, [x.ptr for x in da], [x.ptr for x in dk], batch, lib.MUL_B_BROADCAST)
         got = dc.download()
         outs.append(got)
@@ -1807,7 +1807,7 @@ def _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits):
     dco, dbh = lib.DeviceBuffer(a_co.size), lib.DeviceBuffer(bh.size).upload(bh)
     outs = []
     for loop in ("0", "1"):
-        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        lib.set_rns_launch(plans, loop)
         dco.upload(a_co)
         lib.rns_mul_transformed(plans, dc.ptr, dco.ptr, dbh.ptr, batch)
         outs.append(dc.download())
@@ -1827,7 +1827,7 @@ def _rns_ntt_domain_check(lib, oracle, monkeypatch, logn, batch, bits):
 def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, bits, monkeypatch):
     """N = 2^15..2^17: the XCD-local launches take the limb as part of the queue entry, so a whole RNS set -- forward
     transforms, the product (both forms: both operands in coefficients; one operand transformed beforehand) -- is ONE launch
-    over all limbs' polynomials.  Word for word the per-limb launches (NTT_RNS_LOOP=1), samples against the oracle; ragged
+    over all limbs' polynomials.  Word for word the per-limb launches (NTT_OPT_RNS_LAUNCH 1), samples against the oracle; ragged
     per-limb batches (the queues run over limb * batch + polynomial).  57- / 60-bit limbs: the wide integer policy's transforms
     take the same launch (its products are forward transforms + the products inside the inverse)."""
     n = 1 << m
@@ -1842,7 +1842,7 @@ def test_rns_one_xcd_local_launch_over_the_limbs(lib, oracle, m, nl, batch, bits
     da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
     res = {}
     for loop in ("1", "0"):
-        monkeypatch.setenv("NTT_RNS_LOOP", loop)
+        lib.set_rns_launch(plans, loop)
         da.upload(a)
         lib.rns_fwd(plans, da.ptr, batch)
         res["fwd", loop] = da.download()

@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--arith", default="auto")
 ap.add_argument("--no-broadcast", action="store_true")
 ap.add_argument("--chunk-mib", type=int, default=0)
+ap.add_argument("--oversub", type=int, default=0, help="persistent block kernels: workgroups per resident slot (0 = the library's choice)")
 a = ap.parse_args()
 AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64}
 
@@ -41,6 +42,10 @@ for bits in a.bits:
         plan = lib.Plan(n, q, lib.min_root(q, n), arith=AR[a.arith])
         if a.chunk_mib:
             plan.set_option(lib.OPT_CHUNK_MIB, a.chunk_mib)
+        if a.oversub:
+            plan.set_option(lib.OPT_BLOCK_OVERSUB, a.oversub)
+        if os.environ.get("NTT_INT_WIDE") == "0" and plan.info()["arith"] == lib.ARITH_U64:
+            plan.set_option(lib.OPT_INT_WIDE, 0)   # (tools/ab_int_wide_domain.sh)
         kmax = max(a.k)
         batch = max(1, int(a.bytes / (8 * n)))
         abufs = [lib.DeviceBuffer(batch * n) for _ in range(kmax)]
@@ -53,11 +58,11 @@ for bits in a.bits:
                 flags = lib.MUL_B_BROADCAST if bcast else 0
                 ap_, bp_ = [x.ptr for x in abufs[:k]], [x.ptr for x in bbufs[:k]]
                 run = lambda: plan.inv_dot(c.ptr, ap_, bp_, batch, flags)
-                os.environ.pop("NTT_DOT_UNFUSED", None)
+                plan.set_option(lib.OPT_DOT_FUSED, 1)
                 ms = timed(run, a.steps)
-                os.environ["NTT_DOT_UNFUSED"] = "1"          # k pointwise(-accumulate) launches + the inverse transform
+                plan.set_option(lib.OPT_DOT_FUSED, 0)            # k pointwise(-accumulate) launches + the inverse transform
                 ms0 = timed(run, max(2, a.steps // 2))
-                os.environ.pop("NTT_DOT_UNFUSED", None)
+                plan.set_option(lib.OPT_DOT_FUSED, 1)
                 byts = ((8 if bcast else 16) * k + 8) * n * batch   # operands in, c out (a broadcast key comes from the L2)
                 print("%-5d %-5d %-3d %-9s %8d %10.3f %10.3f %8.2f %14.3f %7.3f"
                       % (ln, bits, k, "bcast b^" if bcast else "a^, b^", batch, ms, ms0, ms0 / ms, batch / ms / 1e3, byts / ms / 1e6 / 8000))
@@ -74,11 +79,11 @@ for bits in a.bits:
         for bcast, acc in ((False, False), (True, False), (False, True), (True, True)):
             flags = (lib.MUL_B_BROADCAST if bcast else 0) | (lib.MUL_ACCUMULATE if acc else 0)
             run = lambda: plan.fwd_mul(c.ptr, abufs[0].ptr, bbufs[0].ptr, batch, flags)
-            os.environ.pop("NTT_DOT_UNFUSED", None)
+            plan.set_option(lib.OPT_DOT_FUSED, 1)
             ms = timed(run, a.steps)
-            os.environ["NTT_DOT_UNFUSED"] = "1"              # forward transform, then a pointwise (accumulate) launch
+            plan.set_option(lib.OPT_DOT_FUSED, 0)                # forward transform, then a pointwise (accumulate) launch
             ms0 = timed(run, max(2, a.steps // 2))
-            os.environ.pop("NTT_DOT_UNFUSED", None)
+            plan.set_option(lib.OPT_DOT_FUSED, 1)
             byts = (16 + (0 if bcast else 8) + (8 if acc else 0)) * n * batch
             print("%-5d %-5d %-3s %-9s %8d %10.3f %10.3f %8.2f %14.3f %7.3f"
                   % (ln, bits, "mac" if acc else "mul", "fwd(a)" + (".key" if bcast else ".b^"), batch, ms, ms0, ms0 / ms, batch / ms / 1e3,

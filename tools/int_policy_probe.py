@@ -35,6 +35,8 @@ for m in a.logn:
         w = orc.min_root(q, n)
         cx = orc.ctx(n, q, w)
         plan = lib.Plan(n, q, w, arith=ARITH)
+        if os.environ.get("NTT_INT_WIDE") == "0" and plan.info()["arith"] == lib.ARITH_U64:
+            plan.set_option(lib.OPT_INT_WIDE, 0)   # (tools/ab_int_wide.sh: the reference's butterflies; the library reads no environment)
         host = orc.fill_uniform(batch * n, q, 31 + m)
         d = torch.from_numpy(host.view(np.int64)).cuda()
         picks = [0, batch // 2, batch - 1]

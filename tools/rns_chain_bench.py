@@ -23,7 +23,7 @@ for ln in a.logn:
                 for l, q in enumerate(qs):
                     lib.fill_uniform(b.ptr + 8 * l * per, per, q, 1000 + i, l * per)
         for loop in ("1", "0"):
-            os.environ["NTT_RNS_LOOP"] = loop
+            lib.set_rns_launch(plans, loop)
             fill(); lib.rns_negacyclic_mul(plans, bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, batch); lib.stream_sync()
             e0, e1 = lib.Event(), lib.Event()
             tot = 0.0

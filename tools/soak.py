@@ -249,7 +249,8 @@ while time.time() < t_end:
                 plans = [lib.Plan(n, x, y) for x, y in zip(qs, ws)]
                 ra = np.concatenate([orc.fill_uniform(rb * n, x, int(rng.integers(1, 1 << 40))) for x in qs])
                 rbv = np.concatenate([orc.fill_uniform(rb * n, x, int(rng.integers(1, 1 << 40))) for x in qs])
-                os.environ["NTT_RNS_LOOP"] = str(int(rng.integers(0, 2)))
+                rloop = int(rng.integers(0, 2))
+                lib.set_rns_launch(plans, rloop)
                 da, db, dc = lib.DeviceBuffer(ra.size).upload(ra), lib.DeviceBuffer(ra.size).upload(rbv), lib.DeviceBuffer(ra.size)
                 lib.rns_fwd(plans, da.ptr, rb)
                 f = da.download()
@@ -271,8 +272,7 @@ while time.time() < t_end:
                        not np.array_equal(pr[sl], c2.inv(orc.pointwise(fa, c2.fwd(rbv[sl]), x))) or \
                        not np.array_equal(sq[sl], c2.inv(orc.pointwise(fa, fa, x))) or \
                        not np.array_equal(dt[sl], c2.inv(orc.dot([fa, fa], [fa, fa], x))):
-                        fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=os.environ["NTT_RNS_LOOP"], q=hex(x))
-                del os.environ["NTT_RNS_LOOP"]
+                        fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=rloop, q=hex(x))
                 for d in (da, db, dc):
                     d.free()
                 for pl in plans:

@@ -18,6 +18,8 @@ ap.add_argument("--fused-product", type=int, default=1, help="ntt_negacyclic_mul
 ap.add_argument("--xcd-local", type=int, default=-1, help="N=2^15..2^17: 1 = both passes as items of one launch, intermediate kept in the XCD's L2; 0 = per-pass launches")
 ap.add_argument("--lag", type=int, default=0, help="--xcd-local 1: polynomials between the two passes (0 = default)")
 ap.add_argument("--wpc", type=int, default=0, help="--xcd-local 1: workgroups per CU (0 = default)")
+ap.add_argument("--max-grid", type=int, default=0, help="cap on workgroups per launch (0 = the kernels' own choice)")
+ap.add_argument("--oversub", type=int, default=0, help="persistent block kernels: workgroups per resident slot (0 = the library's choice)")
 ap.add_argument("--block-log", type=int, default=0, help="N=2^15, 2^16: block size below the column pass (12, 14, 0 = library's choice)")
 a = ap.parse_args()
 ap2 = None
@@ -40,6 +42,11 @@ for qs in a.qs:
             plan.set_option(lib.OPT_XCD_LOCAL, a.xcd_local)
             plan.set_option(lib.OPT_XCD_LOCAL_LAG, a.lag)
             plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, a.wpc)
+            if a.max_grid: plan.set_option(lib.OPT_MAX_GRID, a.max_grid)
+            if os.environ.get("NTT_DOT_UNFUSED") == "1": plan.set_option(lib.OPT_DOT_FUSED, 0)   # (tools/ab_product_tail.sh)
+            if a.oversub and hasattr(lib, "OPT_BLOCK_OVERSUB"):
+                try: plan.set_option(lib.OPT_BLOCK_OVERSUB, a.oversub)
+                except lib.NttError: pass     # (an older build of the library under NTT_LIB)
             if a.block_log and ln in (15, 16): plan.set_option(lib.OPT_BLOCK_LOG, a.block_log)
             nb = 3 if "mul" in a.ops else 1
             bufs = [lib.DeviceBuffer(batch * n) for _ in range(nb)]
