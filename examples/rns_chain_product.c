@@ -3,7 +3,9 @@
  * first prime (served by the integer arithmetic in its throughput form), three 50-bit primes (FP64 arithmetic) and two 57-bit
  * primes; the primes and their roots come from the library's own parameter generation (ntt_find_prime / ntt_min_root, the
  * reference's "minimum root" rule, tests/test_cases.h:113-142).  The limb list is served as runs of compatible limbs, one
- * launch per pass and run.  Layout [limb][batch][N].
+ * launch per pass and run.  Layout [limb][batch][N] first; then the same product with the operands as an FHE library holds them --
+ * [batch][limb][N]: a polynomial's limbs side by side -- through the *_strided entry points, no transpose; then two
+ * RNS polynomials handed over as a pointer batch (the reference's one-array-per-polynomial form, include/ntt_reference.h:44-49).
  *
  *   gcc -O2 -std=gnu11 -Iinclude examples/rns_chain_product.c \
  *       -Loptimized-number-theoretic-transform-implementations_amd -lntt_mi355x -o build/rns_chain_product
@@ -91,6 +93,40 @@ int main(void)
   CHECK(ntt_d2h(0, c, d_c, LIMBS * slab * 8));
   for(int l = 0; l < LIMBS; l++) ok = ok && c[l * slab + N + k] == expect[l];
   printf("multiply-accumulate in the NTT domain + inverse: %s\n", ok ? "same coefficients" : "MISMATCH");
+
+  /* the same product with the operands laid out [batch][limb][N]: limb l of polynomial p at (p * LIMBS + l) * N.  The two
+   * strides (words) are all the library needs: limb_stride = N, poly_stride = LIMBS * N. */
+  uint64_t *abm = malloc(LIMBS * slab * 8), *bbm = malloc(LIMBS * slab * 8);
+  for(int l = 0; l < LIMBS; l++) {
+    for(uint64_t p = 0; p < batch; p++) {
+      for(uint64_t i = 0; i < N; i++) {
+        abm[(p * LIMBS + l) * N + i] = a[l * slab + p * N + i];
+        bbm[(p * LIMBS + l) * N + i] = b[l * slab + p * N + i];
+      }
+    }
+  }
+  CHECK(ntt_h2d(0, d_a, abm, LIMBS * slab * 8));
+  CHECK(ntt_h2d(0, d_b, bbm, LIMBS * slab * 8));
+  CHECK(ntt_rns_negacyclic_mul_batch_strided(LIMBS, plans, d_c, d_a, d_b, N, LIMBS * N, batch, NULL));
+  CHECK(ntt_stream_sync(0, NULL));
+  CHECK(ntt_d2h(0, c, d_c, LIMBS * slab * 8));
+  int ok_bm = 1;
+  for(int l = 0; l < LIMBS; l++) ok_bm = ok_bm && c[(1 * LIMBS + l) * N + k] == expect[l];
+  printf("the product on [batch][limb][N] operands (ntt_rns_negacyclic_mul_batch_strided): %s\n", ok_bm ? "same coefficients" : "MISMATCH");
+
+  /* a pointer batch: the two RNS polynomials of d_a as two pointers (each [limb][N]); forward and back */
+  CHECK(ntt_h2d(0, d_a, abm, LIMBS * slab * 8));
+  uint64_t *polys[2] = {d_a + LIMBS * N, d_a}; /* (any order) */
+  CHECK(ntt_rns_transform_ptrs(LIMBS, plans, polys, 2, N, 0, NULL));
+  CHECK(ntt_rns_transform_ptrs(LIMBS, plans, polys, 2, N, NTT_FLAG_INVERSE, NULL));
+  CHECK(ntt_stream_sync(0, NULL));
+  CHECK(ntt_d2h(0, c, d_a, LIMBS * slab * 8));
+  int ok_ptr = 1;
+  for(uint64_t i = 0; i < LIMBS * slab; i++) ok_ptr = ok_ptr && c[i] == abm[i];
+  printf("pointer batch of two RNS polynomials, forward and inverse (ntt_rns_transform_ptrs): %s\n", ok_ptr ? "round trip exact" : "MISMATCH");
+  ok = ok && ok_bm && ok_ptr;
+  free(abm);
+  free(bbm);
 
   ntt_dev_free(0, d_a);
   ntt_dev_free(0, d_b);

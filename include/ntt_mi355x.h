@@ -94,6 +94,10 @@ typedef enum ntt_option {
                           * identical (tests, measurements) */
   NTT_OPT_DOT_FUSED = 13, /* NTT-domain products (ntt_inv_dot_batch, ntt_fwd_mul_batch, ...): 1 (default) = the products inside the
                           * transform's first / last pass; 0 = pointwise(-accumulate) launches around a plain transform (measurements) */
+  NTT_OPT_MAX_BATCH_HINT = 14, /* polynomials x limbs of the largest batched call the plan will serve: the control blocks of the
+                          * XCD-local launches (N >= 2^15) are sized for it -- for the null stream at once, for any other stream at its
+                          * first call or by ntt_plan_reserve -- so that no later call allocates (an allocation synchronises the device).
+                          * 0 (default): sized by the first call, doubled when outgrown */
   NTT_OPT_BLOCK_OVERSUB = 11, /* persistent block kernels: workgroups launched per resident slot (0 = default: 8 for the 2^12-point
                           * block kernels, whose four workgroups per CU otherwise run in phase -- measured +5 % forward, +4 % inverse,
                           * profiles/r05/grid_sweep.txt --, 1 elsewhere: 2^13 and 2^14 measured no gain) */
@@ -142,6 +146,11 @@ NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
 /* tuning / test knobs of one plan (ntt_option).  The batched API reads NO environment variable; the reference-signature entry points
  * (which have no argument to carry a choice) read NTT_DEVICE and NTT_COMPAT_ARITH once, at their first call. */
 NTT_API int  ntt_plan_set_option(ntt_plan *p, int option, int64_t value);
+/* Allocates the control blocks (queue heads + one counter per polynomial, 4 bytes each; the direct one and the one captured
+ * launches use) the XCD-local launches of this plan need on `stream` for batches of up to `polys` polynomials x limbs.  The
+ * batched entry points take a const plan; these blocks are the one thing they may create or grow (under the plan's mutex), and
+ * after this call they do not.  Call it outside stream capture. */
+NTT_API int  ntt_plan_reserve(const ntt_plan *p, void *stream, uint64_t polys);
 
 /* ---- batched transforms: d_a is device memory laid out [batch][N], in place ---- */
 NTT_API int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
@@ -278,6 +287,19 @@ NTT_API int ntt_rns_fwd_mul_batch_strided(int nlimbs, ntt_plan *const *plans, ui
  * matrix of polynomials): ntt_transform_batch with a stride */
 NTT_API int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uint64_t poly_stride, uint64_t batch, unsigned flags,
                                         void *stream);
+
+/* ---- pointer batches: one DEVICE pointer per polynomial, in a HOST array.  The reference's own batch form is one array per
+ * polynomial -- fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...) (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91) --; this is
+ * that form for `count` polynomials resident on the device.  The polynomials are independent and transformed in place, so the
+ * call is free to reorder them: the pointers are sorted and cut into maximal arithmetic progressions, each of which is ONE strided
+ * launch chain (separately allocated ciphertexts out of a pool, the rows of a matrix of polynomials, two arrays a fixed distance
+ * apart: one launch; no regularity at all: one launch chain per polynomial -- prefer ntt_transform_batch_strided when the placement is
+ * known).  Pointers must be 8-byte aligned; overlapping polynomials (or a pointer listed twice) are refused.  flags = NTT_FLAG_*.
+ * ntt_rns_transform_ptrs: h_polys[i] points at limb 0 of RNS polynomial i, whose limbs are limb_stride words apart ([limb][N] per
+ * polynomial: limb_stride = N); flags: NTT_FLAG_INVERSE only. ---- */
+NTT_API int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, uint64_t count, unsigned flags, void *stream);
+NTT_API int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64_t *const *h_polys, uint64_t count, uint64_t limb_stride,
+                                   unsigned flags, void *stream);
 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);

@@ -42,19 +42,19 @@ FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
 MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
 OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE, OPT_BLOCK_OVERSUB = 7, 8, 9, 10, 11
-OPT_RNS_LAUNCH, OPT_DOT_FUSED = 12, 13
+OPT_RNS_LAUNCH, OPT_DOT_FUSED, OPT_MAX_BATCH_HINT = 12, 13, 14
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
     "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
-    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option", "ntt_plan_export_table",
+    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option", "ntt_plan_reserve", "ntt_plan_export_table",
     "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
     "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
     "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch",
     "ntt_rns_fwd_batch_strided", "ntt_rns_inv_batch_strided", "ntt_rns_negacyclic_mul_batch_strided", "ntt_rns_inv_dot_batch_strided",
-    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_dev_malloc", "ntt_dev_free",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_copy_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
@@ -98,6 +98,7 @@ _sig("ntt_plan_destroy", None, VOIDP)
 _sig("ntt_plan_info", C.c_int, VOIDP, U64P)
 _sig("ntt_plan_set_generic", C.c_int, VOIDP, C.c_int)
 _sig("ntt_plan_set_option", C.c_int, VOIDP, C.c_int, C.c_int64)
+_sig("ntt_plan_reserve", C.c_int, VOIDP, VOIDP, C.c_uint64)
 _sig("ntt_plan_export_table", C.c_int, VOIDP, C.c_int, VOIDP, C.c_size_t)
 for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide", "ntt_fwd_batch_lazy",
            "ntt_inv_batch_lazy"):
@@ -126,6 +127,8 @@ _sig("ntt_rns_mul_transformed_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP)
      C.c_uint, VOIDP)
 _sig("ntt_rns_fwd_mul_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_transform_batch_strided", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_transform_ptrs", C.c_int, VOIDP, C.POINTER(VOIDP), C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_transform_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
 _sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
@@ -308,6 +311,10 @@ class Plan:
     def set_option(self, option, value):
         _check(_lib.ntt_plan_set_option(self.h, option, value))
 
+    def reserve(self, polys, stream=None):
+        """ntt_plan_reserve: the control blocks of the XCD-local launches on `stream`, sized for `polys` polynomials x limbs"""
+        _check(_lib.ntt_plan_reserve(self.h, stream, polys))
+
     def fwd(self, dptr, batch, stream=None, wide=False, lazy=False):
         if wide and lazy:
             _check(_lib.ntt_transform_batch(self.h, dptr, batch, FLAG_WIDE_IN | FLAG_LAZY_OUT, stream))
@@ -325,6 +332,11 @@ class Plan:
     def transform_strided(self, dptr, poly_stride, batch, flags=0, stream=None):
         """`batch` polynomials poly_stride words apart (ntt_transform_batch_strided); flags = FLAG_*"""
         _check(_lib.ntt_transform_batch_strided(self.h, dptr, poly_stride, batch, flags, stream))
+
+    def transform_ptrs(self, ptrs, flags=0, stream=None):
+        """one device pointer per polynomial (ntt_transform_ptrs)"""
+        k = len(ptrs)
+        _check(_lib.ntt_transform_ptrs(self.h, (VOIDP * k)(*ptrs), k, flags, stream))
 
     def pointwise_mul(self, dc, da, db, batch, stream=None, lazy_in=False):
         f = _lib.ntt_pointwise_mul_batch_lazy if lazy_in else _lib.ntt_pointwise_mul_batch
@@ -390,6 +402,12 @@ def set_rns_launch(plans, mode):
     v = -1 if mode is None else int(mode)
     for p in plans:
         p.set_option(OPT_RNS_LAUNCH, v)
+
+
+def rns_transform_ptrs(plans, ptrs, limb_stride, flags=0, stream=None):
+    """one device pointer per RNS polynomial (its limbs limb_stride words apart): ntt_rns_transform_ptrs"""
+    k = len(ptrs)
+    _check(_lib.ntt_rns_transform_ptrs(len(plans), _plan_array(plans), (VOIDP * k)(*ptrs), k, limb_stride, flags, stream))
 
 
 def batch_major(plans):

@@ -1,5 +1,5 @@
 /* inst_dm_u64x_k0.hip -- instantiates the NTT-domain product kernels (dot_inv_kernel, fwd_mul_kernel) for ArithU64X<0>:
- * the products themselves are fast_mul_mod_q's (inherited from ArithU64), the transform stages around them the wide policy's. */
+ * the products themselves are one Barrett reduction per 128-bit product (ArithU64X::dot_term / mul_out), the transform stages around them the wide policy's. */
 #include "ntt_kernels.h"
 
 namespace ntt {

@@ -269,7 +269,7 @@ struct ArithU64R4 : ArithU64 {
  *      in a 14-stage block for K = 3 (4 + 4 * 14 = 60 < 64), every other stage for K = 1, every stage but the first
  *      for K = 0.  The Shoup product takes ANY 64-bit y.  Inverse: s = x + y doubles, d = x - y + (B/2) q stays below
  *      B q, the product comes back below 4q; the sum is brought below 4q by reduce_any (one 32-bit multiply estimates
- *      s / q) where the schedule says so: every third stage for K = 3, every second for K = 1, and the LAST stage of
+ *      s / q) where the schedule says so: every fourth stage for K = 3, every second for K = 1, and the LAST stage of
  *      every pass, so that a pass hands on words below 4q whatever it computed.
  * Per butterfly: 19 VALU instructions (9 multiplies) against ArithU64's 28 (10); measured +16..17 % at 2^12 / 2^14 on the
  * forward transform (profiles/r04/ab_int_wide.txt), where the multiplies are 56 % of the issue time.
@@ -741,26 +741,50 @@ template <class Base> struct WideF64 : Base {
     x               = xr + m;
     y               = xr - m;
   }
+  /* RED (round 5): reduce the difference before the product.  RED = false is chosen (ntt_core.h bfly_reduces) where both inputs
+   * are REDUCED SUMS of the stage before, |x|, |y| <= q/2 + 2: then |d| <= q + 4, the true quotient Q = d w / q is at most
+   * q/2 + 2 in magnitude, its estimate -- a stored w/q, or a compact twiddle through the two-word reciprocal (mulmod_c2) --
+   * is within 2 |Q| 2^-53 < theta2 (1 + 2^-50) of it, so |y'| <= (1/2 + theta2) q + 2 <= q - N + 3 for an NTT-friendly
+   * q <= 2^52 - 2N + 1 (theta2 = q / 2^53 <= 1/2 - N / 2^52); h - k q is an integer below 1.13 q: exact.  Two such products
+   * add up to at most 2q - 2N + 6 < 2^53, the next stage's sum and difference are exact, and that stage reduces both.
+   * 11 instead of 14 instructions (12 with a compact twiddle: mulmod_c's one-word estimate would be 1.5 times looser and
+   * leave products up to 1.25 q).  The checked policy of tests/emu runs these very functions (test_wide_fp64_policy_52_bit_moduli). */
   template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, const tw &t, const consts &c)
   {
     const double s = x + y;
     const double d = x - y;
     x              = Base::reduce(s, c);
-    y              = Base::mulmod(t, Base::reduce(d, c), c);
+    y              = Base::mulmod(t, RED ? Base::reduce(d, c) : d, c);
   }
   template <bool RED> static NTT_HD void inv_bfly(val &x, val &y, ctw w, const consts &c)
   {
     const double s = x + y;
     const double d = x - y;
     x              = Base::reduce(s, c);
-    y              = Base::mulmod_c(w, Base::reduce(d, c), c);
+    y              = RED ? Base::mulmod_c(w, Base::reduce(d, c), c) : Base::mulmod_c2(w, d, c);
   }
   template <bool RED> static NTT_HD void inv_bfly_mirror(val &x, val &y, ctw wneg, const consts &c)
   {
     const double s = x + y;
     const double d = y - x;
     x              = Base::reduce(s, c);
-    y              = Base::mulmod_c(wneg, Base::reduce(d, c), c);
+    y              = RED ? Base::mulmod_c(wneg, Base::reduce(d, c), c) : Base::mulmod_c2(wneg, d, c);
+  }
+  /* the block kernels' form (ntt_core.h w52_inv_plan): REDD as RED above; REDS = false leaves the sum of two REDUCED inputs
+   * unreduced (|s| <= q + 4: the next stage adds or subtracts two such values, at most 2q + 8 < 2^53, and reduces both) */
+  template <bool REDD, bool REDS> static NTT_HD void inv_bfly2(val &x, val &y, const tw &t, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = REDS ? Base::reduce(s, c) : s;
+    y              = Base::mulmod(t, REDD ? Base::reduce(d, c) : d, c);
+  }
+  template <bool REDD, bool REDS> static NTT_HD void inv_bfly2(val &x, val &y, ctw w, const consts &c)
+  {
+    const double s = x + y;
+    const double d = x - y;
+    x              = REDS ? Base::reduce(s, c) : s;
+    y              = REDD ? Base::mulmod_c(w, Base::reduce(d, c), c) : Base::mulmod_c2(w, d, c);
   }
   static NTT_HD void inv_bfly_last(val &x, val &y, const consts &c)
   {

@@ -452,6 +452,10 @@ constexpr uint32_t kRedPlanFlag = 0x80000000u;
  * Compile-time rather than a kernel argument: with a run-time branch both variants of the
  * last group live in one kernel and the 2^14 inverse spills. */
 constexpr uint32_t kLastInvFlag = 0x40000000u;
+/* MASK bit (inverse, moduli up to 2^52): the first executed group's inputs are CANONICAL words of the caller (or of the pass
+ * before): 0 <= x, y < q, so their difference is below q in magnitude like that of two reduced sums (bfly_reduces).  Set by the
+ * transform kernels; not by the kernels whose inverse half starts from products (fused products, NTT-domain products). */
+constexpr uint32_t kCanonInFlag = 0x20000000u;
 
 struct RedPlan {
   uint8_t red[4][4]; /* [group][local stage]: bit b => butterfly b reduces its sum */
@@ -498,15 +502,63 @@ template <class A, int LOGN, int KSH> constexpr RedPlan make_inv_red_plan()
   return rp;
 }
 
+/* Inverse butterflies for moduli up to 2^52 (WideF64, ntt_arith.h): which of the two reductions a butterfly needs.
+ * A Gentleman-Sande stage pairs two slots with the same history (they differ only in the bit the stage processes), so both
+ * inputs of a butterfly are of one kind:
+ *   REDUCED  |.| <= q/2 + 2    a sum the stage before reduced
+ *   other    |.| <= q - N + 3  a product, a sum of two reduced values left unreduced, or anything a previous stage GROUP left
+ *                              (across an LDS exchange the bit the last stage processed is a lane bit: the history differs from lane
+ *                              to lane and is not a compile-time property of the slot)
+ * Two REDUCED inputs: s = x + y and d = x - y are at most q + 4 in magnitude.  The sum is left as it is (kind "other"; the next
+ * stage adds two of them: <= 2q + 8 < 2^53 for an NTT-friendly q <= 2^52 - 2N + 1) and the difference is multiplied unreduced
+ * (|product| <= q - N + 3, WideF64::inv_bfly2): 8 (9 with a compact twiddle) instead of 14 instructions.  Any other pair: both are
+ * reduced first (14).  CANONICAL inputs (0 <= x, y < q: the first stage of a transform kernel, kCanonInFlag): |d| < q, the
+ * difference goes unreduced, the sum (up to 2q) is reduced.  Plan per group of four stages: first stage 8 full butterflies, then
+ * 4 + 2 + 3 of 8 take the short form -- 12.3 instructions per butterfly on average (12.6 with compact twiddles) where rounds 3 and
+ * 4 spent 14. */
+struct W52Bfly {
+  bool red_d, red_s;
+};
+template <int LOGN> constexpr bool w52_inputs_reduced(int g, int j, int e0)
+{
+  using P = Plan<LOGN>;
+  if(j + 1 >= P::R(g)) return false;                              /* first executed stage of the group: unknown history */
+  const int jp = j + 1;                                            /* the stage executed before */
+  if((e0 >> P::ABIT(g, jp)) & 1) return false;                     /* a product of that stage */
+  return !w52_inputs_reduced<LOGN>(g, jp, e0);                     /* a sum: reduced unless its butterfly took the short form */
+}
+template <int LOGN, uint32_t MASK> constexpr W52Bfly w52_inv_plan(int g, int j, int b)
+{
+  using P         = Plan<LOGN>;
+  const int  e0   = P::BFLY_E0(g, j, b);
+  const bool red  = w52_inputs_reduced<LOGN>(g, j, e0);
+  const bool canon = (MASK & kCanonInFlag) != 0 && g == P::NG - 1 && j + 1 >= P::R(g);
+  return W52Bfly{!(red || canon), !red};
+}
+
 template <class A, int LOGN, bool INV, uint32_t MASK> constexpr bool bfly_reduces(int g, int j, int b)
 {
-  if constexpr(INV && (MASK & kRedPlanFlag) != 0) {
+  if constexpr(INV && A::kWide52) {
+    return w52_inv_plan<LOGN, MASK>(g, j, b).red_d; /* (moduli up to 2^52: the flag of inv_bfly<RED> = "reduce the difference") */
+  } else if constexpr(INV && (MASK & kRedPlanFlag) != 0) {
     constexpr RedPlan rp = make_inv_red_plan<A, LOGN, (int)(MASK & 0xFFu)>();
     static_assert(rp.ok, "inverse reduction plan exceeds the FP64 exactness limit");
     return (rp.red[g][j] >> b) & 1u;
   } else {
     const int sl = Plan<LOGN>::S(g) + j;
     return (MASK >> (INV ? (LOGN - 1 - sl) : sl)) & 1u;
+  }
+}
+
+/* butterfly B of local stage J of group G of an inverse block pass, with the reductions the policy's plan gives it */
+template <class A, int LOGN, uint32_t MASK, int G, int J, int B, class TW>
+NTT_HD void inv_butterfly(typename A::val &x, typename A::val &y, const TW &w, const typename A::consts &c)
+{
+  if constexpr(A::kWide52) {
+    constexpr W52Bfly pl = w52_inv_plan<LOGN, MASK>(G, J, B);
+    A::template inv_bfly2<pl.red_d, pl.red_s>(x, y, w, c);
+  } else {
+    A::template inv_bfly<bfly_reduces<A, LOGN, true, MASK>(G, J, B)>(x, y, w, c);
   }
 }
 
@@ -550,10 +602,9 @@ NTT_HD void run_group0_folded(typename A::val (&x)[kE], uint32_t ib, uint32_t bl
       constexpr int      B   = decltype(bb)::value;
       constexpr int      E0  = P::BFLY_E0(0, J, B);
       constexpr int      E1  = E0 | (1 << AB);
-      constexpr bool     RED = bfly_reduces<A, LOGN, true, MASK>(0, J, B);
       constexpr uint32_t OFF = P::IOFF(0, E0) >> (LOGN - SL);
       if constexpr((E0 & DONE) != 0) {
-        A::template inv_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, 0, J, true, B>(w, p.c), p.c);
+        inv_butterfly<A, LOGN, MASK, 0, J, B>(x[E0], x[E1], stage_tw<A, LOGN, 0, J, true, B>(w, p.c), p.c);
       } else if constexpr(SL == 0) {
         A::inv_bfly_last(x[E0], x[E1], p.c); /* slot 0: explicit N^-1 on the sum */
       } else {
@@ -562,7 +613,7 @@ NTT_HD void run_group0_folded(typename A::val (&x)[kE], uint32_t ib, uint32_t bl
          * these 7 records are re-read from the scalar cache per block instead of being
          * hoisted into 28 more SGPRs for the whole launch (which spilled) */
         const typename A::tw wn = load_tw<A, true, 0>(p.tw, uniform_u32((1u << p.logn) + (blk << SL) + (1u << SL) + OFF));
-        A::template inv_bfly<RED>(x[E0], x[E1], wn, p.c);
+        inv_butterfly<A, LOGN, MASK, 0, J, B>(x[E0], x[E1], wn, p.c);
       }
     });
   });
@@ -718,12 +769,12 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
         if constexpr(MIRROR) {
           A::template inv_bfly_mirror<RED>(x[E0], x[E1], wcur.c[F], p.c);
         } else if constexpr(INV) {
-          A::template inv_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);
+          inv_butterfly<A, LOGN, MASK, G, J, B>(x[E0], x[E1], wcur.c[F], p.c);
         } else {
           A::template fwd_bfly<RED>(x[E0], x[E1], wcur.c[F], p.c);
         }
       } else if constexpr(INV) {
-        A::template inv_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
+        inv_butterfly<A, LOGN, MASK, G, J, B>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
       } else {
         A::template fwd_bfly<RED>(x[E0], x[E1], stage_tw<A, LOGN, G, J, INV, B>(wcur, p.c), p.c);
       }
@@ -791,7 +842,7 @@ NTT_HD void run_group_preloaded(typename A::val (&x)[kE], const typename A::ctw 
       constexpr bool RED = bfly_reduces<A, LOGN, INV, MASK>(G, J, B);
       const typename A::ctw w = pre[J][P::BFLY_FIRST(G, J, B)];
       if constexpr(INV) {
-        A::template inv_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
+        inv_butterfly<A, LOGN, MASK, G, J, B>(x[E0], x[E0 | (1 << AB)], w, p.c);
       } else {
         A::template fwd_bfly<RED>(x[E0], x[E0 | (1 << AB)], w, p.c);
       }
@@ -1259,7 +1310,9 @@ template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
   } else if constexpr(!A::kTracksBounds) {
     return 0;
   } else if constexpr(A::kWide52) {
-    return INV ? 0u : f64w_fwd_schedule(R, 1.0, 0u).mask; /* (column passes read full records) */
+    /* forward: the stages that also reduce the multiplied operand; inverse: every stage reduces its difference (the passes are
+     * memory-bound: the per-slot plan of the block kernels, bfly_reduces, is not worth a second form here) */
+    return INV ? ((1u << R) - 1u) : f64w_fwd_schedule(R, 1.0, 0u).mask; /* (column passes read full records) */
   } else {
     return f64_schedule(INV, R, KSH, 1.0).mask;
   }

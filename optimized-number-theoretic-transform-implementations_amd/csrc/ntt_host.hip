@@ -7,6 +7,7 @@
  * launch and every failure is reported (status code / abort for the void
  * reference signatures).
  */
+#include <algorithm>
 #include <climits>
 #include <hip/hip_runtime.h>
 
@@ -257,9 +258,12 @@ struct ntt_plan {
                      * freed, regrown or shared with direct launches before the plan is destroyed */
     size_t gbytes;
   };
-  std::vector<TeamBuf> team_bufs;
-  std::vector<void *>  team_retired; /* outgrown direct blocks: launches still queued may use them, freed with the plan */
-  std::mutex           team_mu;
+  /* The control blocks are the ONE piece of plan state a batched call (const ntt_plan *) may touch: mutable, every access
+   * under team_mu.  ntt_plan_reserve / NTT_OPT_MAX_BATCH_HINT size them ahead of time so that no batched call allocates. */
+  mutable std::vector<TeamBuf> team_bufs;
+  mutable std::vector<void *>  team_retired; /* outgrown direct blocks: launches still queued may use them, freed with the plan */
+  mutable std::mutex           team_mu;
+  uint64_t                     batch_hint = 0; /* NTT_OPT_MAX_BATCH_HINT: polynomials x limbs of the largest call; blocks of new streams start at this size */
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              rns_launch = -1; /* ntt_rns_*: 0 = one launch over a run of limbs wherever it is built, 1 = one launch chain per limb,
@@ -639,6 +643,10 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
     case NTT_OPT_DOT_FUSED:
       p->dot_fused = value != 0;
       return NTT_OK;
+    case NTT_OPT_MAX_BATCH_HINT:
+      if(value < 0) return fail(NTT_ERR_ARG, "batch hint must be >= 0");
+      p->batch_hint = (uint64_t)value;
+      return value ? ntt_plan_reserve(p, nullptr, (uint64_t)value) : NTT_OK;
     case NTT_OPT_BLOCK_OVERSUB:
       if(value < 0 || value > 256) return fail(NTT_ERR_ARG, "workgroups per resident slot: 0 (default) .. 256");
       p->block_oversub = (int)value;
@@ -773,9 +781,9 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
  * Nothing here synchronises the device: an outgrown direct block is retired, not freed (launches still queued may be
  * using it), and released with the plan.  While capturing nothing is allocated (not capturable): without a graph block of
  * sufficient size *out stays null and the caller takes the per-pass launches. */
-static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
+static int team_buffer(const ntt_plan *p, void *stream, uint64_t batch, void **out)
 {
-  const size_t need = sizeof(TeamCtl) + (size_t)batch * sizeof(unsigned);
+  const size_t need = sizeof(TeamCtl) + (size_t)(batch > 2 * p->batch_hint ? batch : 2 * p->batch_hint) * sizeof(unsigned);
   std::lock_guard<std::mutex> lock(p->team_mu);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
@@ -793,11 +801,13 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
     tb = &p->team_bufs.back();
   }
   if(tb->bytes < need) {
+    /* a reserved size is taken as given, an outgrown one doubled */
+    const size_t grow = p->batch_hint && !tb->d ? need : need * 2;
     void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, need * 2));
+    HIP_TRY(hipMalloc(&d, grow));
     if(tb->d) p->team_retired.push_back(tb->d);
     tb->d     = d;
-    tb->bytes = need * 2;
+    tb->bytes = grow;
   }
   if(!tb->g) {
     /* the graph block is sized once, by the first direct call (run the largest batch once before capturing) */
@@ -806,6 +816,21 @@ static int team_buffer(ntt_plan *p, void *stream, uint64_t batch, void **out)
   }
   *out = tb->d;
   return NTT_OK;
+}
+
+/* Sizes the (plan, stream) control blocks for calls of up to `polys` polynomials x limbs (products count their operands:
+ * twice that many entries) -- the allocation an XCD-local launch would otherwise make on its first call, an implicit device
+ * synchronisation inside a call documented as asynchronous.  Not while the stream is being captured. */
+extern "C" int ntt_plan_reserve(const ntt_plan *p, void *stream, uint64_t polys)
+{
+  if(!p) return fail(NTT_ERR_ARG, "null plan");
+  if(polys == 0) return NTT_OK;
+  USE_DEVICE(p->device);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if(hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(NTT_ERR_ARG, "reserve before the capture begins");
+  void *ctl = nullptr;
+  return team_buffer(p, stream, 2 * polys, &ctl);
 }
 
 /* The limbs one launch serves: the plan's own record (every ordinary call), or an RNS set's records (host array, copied
@@ -836,7 +861,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     /* the queue heads and counters live in a buffer the plan keeps per stream; it is allocated on first use -- except
      * while the stream is being captured into a HIP graph (allocation is not capturable): the call then takes the
      * per-pass launches, which need no memory of their own */
-    int rc = team_buffer(const_cast<ntt_plan *>(p), stream, batch * (uint64_t)ls.n, &ctl);
+    int rc = team_buffer(p, stream, batch * (uint64_t)ls.n, &ctl);
     if(rc) return rc;
   }
   if(ctl) {
@@ -1150,7 +1175,7 @@ static int fused_product(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, uint64
   void *ctl  = nullptr;
   int   rc   = NTT_OK;
   if(canonical_a && !p->block_log) {
-    rc = team_buffer(const_cast<ntt_plan *>(p), stream, 2 * batch * (uint64_t)ls.n, &ctl);
+    rc = team_buffer(p, stream, 2 * batch * (uint64_t)ls.n, &ctl);
     if(rc) return rc;
   }
   const bool four = !ahat_given && ctl && p->fused_product != 2;
@@ -1543,6 +1568,30 @@ static bool dot_kernel_applies(const ntt_plan *p)
   return (p->arith == NTT_ARITH_F64 || p->arith == NTT_ARITH_U64) && !p->generic && p->m >= kFusedMin && p->dot_fused != 0;
 }
 
+/* the automatic choice between the one-launch form of the NTT-domain products at N = 2^15..2^17 and the per-chunk launches, as
+ * measured (profiles/r05/domain_bench_xcd_local.txt) */
+static bool dot_team_pays(const ntt_plan *p, uint64_t polys, int k, bool bcast)
+{
+  /* a shared key at 2^17 with three pairs and more: the one launch measured -4 % */
+  if(bcast && p->m == kTeamBlock + 5 && k >= 3) return false;
+  return polys >= 512;
+}
+
+/* Polynomials between the two passes of a queue in team_dot_kernel.  Its first-pass items stream k operand pairs past the L2,
+ * so only c competes for it, and the optimum sits where lag x polynomial size is 5-6 MiB per queue -- well above the plain
+ * transform's (team_kernel: 8-10 polynomials): too short and second-pass items wait for rows still in flight, too long and c has
+ * left the Infinity Cache slice when it is read back.  Fine sweep, k = 1..4, three operand kinds:
+ * profiles/r05/teamdot_lag_fine.txt, teamdot_lag_other.txt (a lag two steps off the optimum costs 5-15 %). */
+static int dot_team_lag(const ntt_plan *p, int k, bool bcast)
+{
+  const bool longer = k <= 2 || bcast || p->arith == NTT_ARITH_U64;
+  switch(p->m - kTeamBlock) {
+    case 3: return longer ? 24 : 20;
+    case 4: return bcast ? 14 : longer ? 12 : 10;
+    default: return (k == 1 || bcast) ? 8 : 6;
+  }
+}
+
 /* c = inv(sum_i a_i^ (.) b_i^).  One launch up to N = 2^14: the products are formed where the inverse transform would
  * convert its input words (dot_inv_kernel).  Above: per 256 MiB chunk of c that kernel over the blocks (the product rides in
  * the inverse's first pass), then the inverse's column passes on c -- 16kN + 24N bytes instead of 24kN + 32N.  Plans the
@@ -1586,6 +1635,48 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
       HIP_TRY(hipGetLastError());
     }
     return run_transform(p, d_c, batch, true, false, stream, false, &ls);
+  }
+  /* N = 2^15..2^17, batches that keep the eight queues busy: the blocks with the products AND the inverse's column stages as
+   * the items of ONE launch (team_dot_kernel) instead of two launches per 128 / 256 MiB chunk.  NTT_OPT_XCD_LOCAL 1 / 0 forces
+   * either form; while a stream is being captured without a control block of its own the per-chunk launches serve (team_buffer). */
+  {
+    const bool int_wide = p->arith == NTT_ARITH_U64 && p->int_cls >= 0;
+    const uint64_t polys = batch * (uint64_t)ls.n;
+    bool team = (p->arith == NTT_ARITH_F64 || int_wide) && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && !p->block_log && polys >= 64 &&
+                polys < (1ull << 29) && ls.n <= kMaxLimbs;
+    if(team && p->xcd_local >= 0) team = p->xcd_local == 1;
+    else if(team) team = dot_team_pays(p, polys, k, bcast);
+    void *ctl = nullptr;
+    if(team) {
+      int rc = team_buffer(p, stream, polys, &ctl);
+      if(rc) return rc;
+    }
+    if(ctl) {
+      DotArgs da{};
+      da.out           = d_c;
+      da.a             = a;
+      da.b             = b;
+      da.npairs        = k;
+      da.lazy_in       = lazy;
+      da.b_bcast       = bcast;
+      da.limbs         = ls.d;
+      da.nlimbs        = ls.n;
+      da.limb_stride   = ls.stride;
+      da.poly_stride   = ls.pstride;
+      da.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
+      da.batch         = batch;
+      da.logn          = (uint32_t)p->m;
+      da.block_log     = (uint32_t)kTeamBlock;
+      da.max_grid      = p->max_grid;
+      da.num_cus       = p->num_cus;
+      da.team_ctl      = ctl;
+      da.team_lag      = p->team_lag ? p->team_lag : dot_team_lag(p, k, bcast);
+      da.team_wpc      = p->team_wpc;
+      da.stream        = (hipStream_t)stream;
+      hipError_t e = dispatch_dot(p, da);
+      if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+      return NTT_OK;
+    }
   }
   const int      pblk  = p->m > kFusedMax ? (p->block_log ? p->block_log : multi_pass_block(p->m, true, p->arith == NTT_ARITH_F64)) : p->m;
   const PassList L     = make_passes(p->m, false, pblk);
@@ -1900,6 +1991,74 @@ extern "C" int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uin
   if(poly_stride < p->N || poly_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the polynomial stride must be at least N words");
   const LimbSet own{p->limbrec.data(), 1, 0, poly_stride};
   return run_transform(p, d_a, batch, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream, (flags & NTT_FLAG_LAZY_OUT) != 0, &own);
+}
+
+/* ---- pointer batches: one device pointer per polynomial (host array) ----
+ * The reference's batching precedent hands over one array per polynomial: fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...)
+ * (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91).  Generalised to `count` pointers: the polynomials are independent
+ * and transformed in place, so their order is free -- the pointers are sorted and cut into maximal arithmetic progressions,
+ * and every progression is ONE strided launch chain (a pool of equally spaced ciphertexts, the rows of a caller's matrix, two
+ * arrays a fixed distance apart: one launch; pointers with no regularity: one launch chain each).  Overlapping polynomials are
+ * refused. */
+static int ptr_runs(uint64_t N, uint64_t span_words, uint64_t *const *h_polys, uint64_t count, std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> &runs)
+{
+  if(!h_polys) return fail(NTT_ERR_ARG, "null argument");
+  std::vector<uintptr_t> v(count);
+  for(uint64_t i = 0; i < count; i++) {
+    if(!h_polys[i] || ((uintptr_t)h_polys[i] & 7)) return fail(NTT_ERR_ARG, "pointer batch: null or misaligned polynomial pointer");
+    v[i] = (uintptr_t)h_polys[i];
+  }
+  std::sort(v.begin(), v.end());
+  for(uint64_t i = 0; i + 1 < count; i++) {
+    if(v[i + 1] - v[i] < span_words * 8) return fail(NTT_ERR_ARG, "pointer batch: polynomials overlap (or a pointer is listed twice)");
+  }
+  (void)N;
+  for(uint64_t i = 0; i < count;) {
+    uint64_t j = i, d = 0;
+    if(i + 1 < count) {
+      d = (uint64_t)(v[i + 1] - v[i]);
+      j = i + 1;
+      while(j + 1 < count && (uint64_t)(v[j + 1] - v[j]) == d) j++;
+    }
+    /* {first polynomial, {word stride (0: a single polynomial), polynomials}} */
+    runs.push_back({reinterpret_cast<uint64_t *>(v[i]), {d / 8, j - i + 1}});
+    i = j + 1;
+  }
+  return NTT_OK;
+}
+
+extern "C" int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, uint64_t count, unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)(NTT_FLAG_INVERSE | NTT_FLAG_WIDE_IN | NTT_FLAG_LAZY_OUT)) return fail(NTT_ERR_ARG, "unknown flag");
+  if(!p) return fail(NTT_ERR_ARG, "null argument");
+  if(count == 0) return NTT_OK;
+  std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
+  int rc = ptr_runs(p->N, p->N, h_polys, count, runs);
+  for(size_t r = 0; !rc && r < runs.size(); r++) {
+    const LimbSet own{p->limbrec.data(), 1, 0, runs[r].second.first};
+    rc = run_transform(p, runs[r].first, runs[r].second.second, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream,
+                       (flags & NTT_FLAG_LAZY_OUT) != 0, &own);
+  }
+  return rc;
+}
+
+/* the same for RNS polynomials: h_polys[i] points at limb 0 of polynomial i, its limbs limb_stride words apart */
+extern "C" int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64_t *const *h_polys, uint64_t count, uint64_t limb_stride,
+                                      unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)NTT_FLAG_INVERSE) return fail(NTT_ERR_ARG, "unknown flag (RNS transforms take NTT_FLAG_INVERSE only)");
+  int rc = rns_check(nlimbs, plans);
+  if(rc || count == 0) return rc;
+  const uint64_t N = plans[0]->N;
+  if(limb_stride < N || limb_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the limb stride must be at least N words");
+  const uint64_t span = (uint64_t)(nlimbs - 1) * limb_stride + N; /* words one RNS polynomial covers */
+  std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
+  rc = ptr_runs(N, span, h_polys, count, runs);
+  for(size_t r = 0; !rc && r < runs.size(); r++) {
+    const uint64_t d = runs[r].second.first ? runs[r].second.first : span;
+    rc = rns_transform(nlimbs, plans, runs[r].first, runs[r].second.second, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, d});
+  }
+  return rc;
 }
 
 extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,

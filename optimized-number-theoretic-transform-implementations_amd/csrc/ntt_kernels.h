@@ -41,6 +41,9 @@
 
 namespace ntt {
 
+#ifndef NTT_BLOCK_PERM
+#  define NTT_BLOCK_PERM 0 /* A/B builds: 1 = the small-block loop walks the blocks in a permuted order */
+#endif
 #ifndef NTT_WL12
 #  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
 #endif
@@ -164,9 +167,15 @@ template <class A, bool INV, bool MULTI>
 __device__ __forceinline__ Params<A> limb_params(const KArgs<A> &k, uint32_t &bid, uint32_t &gdim, uint32_t &limb)
 {
   if constexpr(MULTI) {
-    limb = blockIdx.x / k.wgs_per_limb; /* wave-uniform: scalar arithmetic, once per workgroup */
-    bid  = blockIdx.x - limb * k.wgs_per_limb;
-    gdim = k.wgs_per_limb;
+    /* A two-dimensional grid: blockIdx.y is the limb, blockIdx.x the block id inside the limb's share -- both arrive in scalar
+     * registers.  Rounds 3 and 4 launched a flat grid and computed limb = blockIdx.x / wgs_per_limb: a 32-bit division by a
+     * run-time value is expanded into VALU float instructions, its result lives in a VGPR, and everything derived from it --
+     * the block id and the loop counters of the persistent loops, the limb's record address, the slab pointer, every buffer
+     * descriptor (then a "waterfall" loop around each buffer_load) -- followed it there (a readfirstlane on a provably uniform
+     * value is folded away by the compiler): that, not the run-time index as such, was what these variants spilled on. */
+    limb = blockIdx.y;
+    bid  = blockIdx.x;
+    gdim = gridDim.x;
   } else {
     limb = 0;
     bid  = blockIdx.x;
@@ -443,7 +452,8 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
   using P                 = Plan<LOGN>;
   using G                 = Geom<LOGN, INV, flavor_of<A>()>;
   static_assert(!LAZY || (!INV && A::kTracksBounds), "the LAZY variant exists for the FP64 forward kernels only");
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u);
+  /* (kCanonInFlag: a transform kernel's inputs are canonical words, also after the fold of `wide` inputs -- ntt_core.h bfly_reduces) */
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u) | (INV && A::kWide52 ? kCanonInFlag : 0u);
   constexpr int LDS_TW = G::LDS_TW;
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
@@ -627,7 +637,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     __syncthreads();
   }
   for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gdim * G::BPW) {
+#if NTT_BLOCK_PERM
+    /* experiment (profiles/r05/small_size_modes.txt): the workgroups in flight touch blocks spread over the whole buffer
+     * instead of one contiguous window -- a multiplicative permutation of the workgroup-sized groups of blocks */
+    const uint64_t groups = (p.nblocks + G::BPW - 1) / G::BPW;
+    const uint64_t gidx   = b0 / G::BPW;
+    const uint64_t pidx   = groups % 1000003ull ? (gidx * 1000003ull) % groups : gidx;
+    uint64_t       b      = pidx * G::BPW + sub;
+#else
     uint64_t   b    = b0 + sub;
+#endif
     const bool live = b < p.nblocks;
     if(!live) b = p.nblocks - 1; /* idle lanes shadow a real block, never store */
     const uint32_t blk  = (uint32_t)b & bmask;
@@ -987,7 +1006,26 @@ template <class A> struct KTeam {
   TeamCtl *ctl;    /* zeroed before the launch */
   uint32_t lag;    /* polynomials between a first-pass item and the second-pass items of the same queue */
   uint32_t nlimbs; /* MULTI kernels: limbs of the launch (polynomial v of the queues = limb * batch + polynomial) */
+  uint64_t split_rcp; /* MULTI kernels: floor(2^64 / D) + 1 for the divisor D of team_split (batch, or nlimbs when poly_major): the
+                       * quotient as a scalar multiply-high, exact for every v (v D < 2^64) -- a division would run in the VALU */
+  uint32_t poly_major; /* MULTI kernels: v = polynomial * nlimbs + limb instead -- the numbering that follows the ADDRESSES when a
+                        * polynomial's limbs lie side by side ([batch][limb][N]): the queues then walk memory as they do in the
+                        * limb-major layout (which polynomials are in flight together decides the HBM channel mix) */
 };
+/* queue polynomial v -> (limb, polynomial inside the limb) */
+__device__ __forceinline__ void team_split(uint32_t v, uint32_t batch, uint32_t nlimbs, uint32_t poly_major, uint64_t rcp, uint32_t &limb, uint32_t &pl)
+{
+  /* (v is wave-uniform: the multiply-high stays in scalar registers, see limb_params; rcp = floor(2^64 / D) + 1 gives the exact quotient) */
+  const uint32_t quo = rcp ? (uint32_t)__umul64hi((uint64_t)v, rcp) : v; /* (rcp == 0: divisor 1) */
+  if(poly_major) {
+    pl   = quo;
+    limb = v - pl * nlimbs;
+  } else {
+    limb = quo;
+    pl   = v - limb * batch;
+  }
+}
+inline uint64_t team_split_rcp(uint64_t divisor) { return divisor > 1 ? ~0ull / divisor + 1 : 0; /* (D = 1: the quotient is v itself, see callers) */ }
 
 /* MULTI (several RNS limbs in one launch): the item's limb picks the tables, the constants and the slab.  The items of these
  * kernels fetch their tables per item anyway, so a limb that changes from item to item costs scalar loads only. */
@@ -1107,7 +1145,7 @@ __device__ __forceinline__ void team_row_item_inv(uint64_t *base, uint32_t blk, 
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, true, flavor_of<A>()>;
   constexpr int GL   = P::NG - 1;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>(); /* not the pass that ends the transform */
+  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (A::kWide52 ? kCanonInFlag : 0u); /* not the pass that ends the transform; canonical inputs */
   const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
   uint64_t raw[kE];
   prefetch_last<LOGN, LDAUX>(raw, tid, base);
@@ -1243,8 +1281,8 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
       const uint32_t pidx   = ti.v;
       uint32_t       pl     = pidx; /* the polynomial inside its limb */
       if constexpr(MULTI) {
-        const uint32_t limb = pidx / batch;
-        pl                  = pidx - limb * batch;
+        uint32_t limb;
+        team_split(pidx, batch, kt.nlimbs, kt.poly_major, kt.split_rcp, limb, pl);
         team_limb<A, INV>(p, kt.k, limb);
       }
       uint64_t *poly = p.a + (uint64_t)pl * p.pstride;
@@ -1608,6 +1646,8 @@ template <class A> struct KTeamProd {
   TeamProdCtl *ctl;    /* zeroed before the launch */
   uint32_t     lag;
   uint32_t     nlimbs; /* MULTI kernels: limbs of the launch */
+  uint64_t     split_rcp;  /* as KTeam::split_rcp */
+  uint32_t     poly_major; /* as KTeam::poly_major */
 };
 
 template <class A, int LEAD, int KSH, bool FOUR = false, bool MULTI = false>
@@ -1670,8 +1710,8 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       const uint32_t pass = ti.pass, item = ti.item, pidx = ti.v;
       uint32_t       pl   = pidx; /* the polynomial inside its limb */
       if constexpr(MULTI) {
-        const uint32_t limb = pidx / batch;
-        pl                  = pidx - limb * batch;
+        uint32_t limb;
+        team_split(pidx, batch, kt.nlimbs, kt.poly_major, kt.split_rcp, limb, pl);
         loff                = (uint64_t)limb * kt.k.f.limb_stride;
         const LimbRec<A> &r = kt.k.f.limbs[limb];
         pf.tw  = r.tw_f;
@@ -2002,6 +2042,167 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
 }
 
 /* ------------------------------------------------------------------ */
+/* NTT-domain products at N = 2^15 .. 2^17 as items of ONE launch       */
+/* ------------------------------------------------------------------ */
+/*
+ * c = inv( sum_i a_i^ (.) b_i^ ) for polynomials larger than a block: per 128 / 256 MiB chunk the library used to launch
+ * dot_inv_kernel over the blocks (the products ride in the inverse's first pass) and then the inverse's column pass -- at
+ * 4 GB per operand sixty launches of some 60 us, every one with its own ramp and tail.  Here both passes are the ITEMS of one
+ * persistent launch in team_kernel's scheme (per-XCD in-order queues, a per-polynomial counter between the passes, a later
+ * pass `lag` polynomials behind: see team_kernel for the protocol and its memory-order invariant):
+ *   pass 0  row item   : one 2^12-point block -- the k operand pairs' words of the block, products and their sum in registers
+ *                        (A::dot_term / dot_acc / dot_fold), the twelve inverse block stages, intermediate words to c;
+ *   pass 1  column item: 256 adjacent columns of c through the LEAD leading inverse stages, N^-1 folded in, final stores.
+ * The row item reads its operands' block and writes c's block at the same position, so c may alias an operand for k = 1
+ * exactly as in dot_inv_kernel (the item that overwrites a line is the only one that ever read it).  A broadcast b_i^ (one
+ * polynomial per limb shared by the batch) is read from the L2 by every item.
+ * Reference primitive: fast_mul_mod_q (include/internal/fast_mul_operators.h:56-60) in front of inv_ntt_* (src/ntt_reference.c:33-66).
+ */
+template <class A> struct KTeamDot {
+  KDot<A>  d;       /* d.k.a = c (limb 0), d.k.nblocks = polynomials PER LIMB; operand pointers, flags, strides as for dot_inv_kernel */
+  TeamCtl *ctl;     /* zeroed before the launch */
+  uint64_t split_rcp;
+  uint32_t lag, nlimbs, poly_major;
+};
+
+/* row item: block `blk` of one polynomial; offa / offb = word offsets of the block inside the a-like operands (and c) / the b operands */
+template <class A, int KSH>
+__device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa, uint64_t offb, uint32_t blk, uint32_t tid0, const Params<A> &p,
+                                                  const KDot<A> &kd, uint64_t aoff, uint64_t boff, typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, true, flavor_of<A>()>;
+  constexpr int GL   = P::NG - 1;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>(); /* not the pass that ends the transform; inputs are products, not canonical words */
+  constexpr bool     MID_LAZY = !A::kTracksBounds;
+  /* (an opaque copy of the thread id ties every lane-dependent address to the item: see team_product_item) */
+  uint32_t tl = tid0;
+  asm volatile("" : "+v"(tl));
+  const uint32_t tid  = tl;
+  const uint32_t np   = kd.npairs;
+  const bool     lazy = kd.lazy_in != 0;
+  [[maybe_unused]] const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  constexpr bool IPRE = A::kCompact && stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0 && KSH != 1;
+  [[maybe_unused]] typename A::ctw pre[4][kE / 2];
+  if constexpr(A::kCompact) fill_lds_tables<A, LOGN, true>(tabl, p, blk, tid);
+  typename A::val x[kE];
+  static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = typename A::val{}; });
+#pragma unroll 1
+  for(uint32_t i = 0; i < np; i++) {
+    if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
+    /* half a tile at a time: 32 registers of words next to the 32 running sums (dot_inv_kernel's plain loop) */
+    static_for<0, 2>([&](auto hh) {
+      constexpr int H = decltype(hh)::value;
+      uint64_t      ra[kE], rb[kE];
+      sched_fence();
+      load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, tid, kd.a[i] + aoff + offa);
+      load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
+      dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
+    });
+  }
+  if(np > 1) dot_fold_tile<A>(x, p.c);
+  /* (the first group's twiddles: requested behind the products, whose 64 registers of words are free again) */
+  if constexpr(A::kCompact && IPRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+  if constexpr(A::kCompact) __syncthreads(); /* the LDS table is read after a wave-local exchange: it needs a barrier of its own */
+  if constexpr(A::kCompact && IPRE) {
+    run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+  } else {
+    run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+  }
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    exchange<A, LOGN, GI, GI - 1>(x, tid, lds);
+    if constexpr(A::kCompact && G::TBL(GI - 1) > 0) {
+      run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
+    } else {
+      run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+    }
+  });
+  uint64_t out[kE];
+  static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = out_word<A, true, false>(x[decltype(ee)::value], MID_LAZY, p.c); });
+  buffer_store_first_raw<LOGN, 0>(out, tid, cblk);
+}
+
+template <class A, int LEAD, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, true, flavor_of<A>()>;
+  static_assert((A::kCompact || A::kIntWide) && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5,
+                "built for the FP64 policies and the wide integer policy on 2^12-point blocks, N = 2^15..2^17");
+  __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
+  __shared__ unsigned        s_k, s_k2[2];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
+  const uint32_t         tid  = threadIdx.x;
+  uint32_t               bid_, gdim_, limb_;
+  Params<A>              p = limb_params<A, true, false>(kt.d.k, bid_, gdim_, limb_);
+  p.s0                     = LEAD;
+  constexpr uint32_t CMASK = column_mask<A, LEAD, true, KSH>();
+  const uint32_t logn  = LOGN + LEAD;
+  const uint32_t batch = (uint32_t)p.nblocks; /* polynomials per limb */
+  const uint32_t total = MULTI ? batch * kt.nlimbs : batch;
+  constexpr uint32_t NCOL = 1u << (LOGN - 8), NROW = 1u << LEAD;
+  TeamCtl *const ctl = kt.ctl;
+  const uint32_t lag = kt.lag;
+  const uint32_t my  = xcc_id();
+  const bool     bc  = kt.d.b_bcast != 0;
+  uint64_t       aoff = 0, boff = 0; /* the item's limb: word offsets of its slabs (MULTI) */
+  for(uint32_t qq = 0; qq < 8; qq++) {
+    const uint32_t q = (my + qq) & 7u;
+    if(tid == 0) {
+      const unsigned prev = atomicCAS(&ctl->owner[q][0], 0u, my + 1u);
+      s_k                 = (prev == 0u || prev == my + 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = s_k != 0;
+    __syncthreads();
+    if(!mine) continue;
+    constexpr uint32_t kNoSignal = 0xffffffffu;
+    uint32_t           sig       = kNoSignal;
+    for(uint32_t it = 0;; it ^= 1u) {
+      /* (lane-0 blocks are followed at once by a workgroup barrier: see team_kernel) */
+      if(tid == 0) {
+        if(sig != kNoSignal) __hip_atomic_fetch_add(&ctl->done[sig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_k2[it] = atomicAdd(&ctl->next[q][0], 1u);
+      }
+      sig = kNoSignal;
+      __syncthreads();
+      const TeamItem ti = team_decode(uniform_u32(s_k2[it]), q, total, lag, NROW, NCOL, 0u);
+      if(ti.stop) break;
+      if(!ti.valid) continue;
+      const bool     second = ti.pass != 0;
+      const uint32_t item = ti.item, pidx = ti.v;
+      uint32_t       pl   = pidx;
+      if constexpr(MULTI) {
+        uint32_t limb;
+        team_split(pidx, batch, kt.nlimbs, kt.poly_major, kt.split_rcp, limb, pl);
+        team_limb<A, true>(p, kt.d.k, limb);
+        aoff = (uint64_t)limb * kt.d.k.limb_stride;
+        boff = (uint64_t)limb * kt.d.b_limb_stride;
+      }
+      const uint64_t poff = (uint64_t)pl * p.pstride; /* the polynomial inside its limb: c and every operand laid out like it */
+      uint64_t *     poly = p.a + poff;
+      if(second) {
+        if(tid == 0) {
+          while(__hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NROW) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        team_column_item<A, LEAD, true, CMASK, kAuxNt, kAuxSc1>(poly, item * kTeamCols + tid, logn, p, false);
+      } else {
+        const uint64_t offa = poff + ((uint64_t)item << LOGN);
+        const uint64_t offb = bc ? ((uint64_t)item << LOGN) : offa;
+        team_dot_row_item<A, KSH>(poly + ((uint64_t)item << LOGN), offa, offb, item, tid, p, kt.d, aoff, boff, lds, tabl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sig = pidx;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
 /* forward transform with the product at its output: c^ = fwd(a) (.) b^ (+ c^) */
 /* ------------------------------------------------------------------ */
 /*
@@ -2309,6 +2510,8 @@ struct DotArgs {
   uint32_t               block_log; /* N > 2^14: log2 of the blocks (12 or 14); the inverse column passes follow as launches of their own */
   int                    max_grid, num_cus;
   int                    oversub; /* as PassArgs::oversub */
+  void *                 team_ctl; /* N = 2^15..2^17: non-null = both passes as items of ONE launch (team_dot_kernel); TeamCtl + nlimbs * batch counters */
+  int                    team_lag, team_wpc;
   hipStream_t            stream;
 };
 template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
@@ -2413,8 +2616,7 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   p.wgs_per_limb = (uint32_t)wgs;
-  wgs *= nl;
-  const dim3 grid((unsigned)wgs), wg(G::WG);
+  const dim3 grid((unsigned)wgs, (unsigned)nl), wg(G::WG); /* (MULTI variants: blockIdx.y is the limb) */
   if(nl > 1) {
     /* several limbs in one launch: the MULTI variants, built for the FP64 policies (the ones RNS bases use) */
     if constexpr(multi_limb_built<A>()) {
@@ -2509,6 +2711,8 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const Pas
     kt.ctl       = static_cast<TeamCtl *>(pa.team_ctl);
     kt.lag       = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 6);
     kt.nlimbs    = (uint32_t)nl;
+    kt.poly_major = nl > 1 && kt.k.poly_stride > kt.k.limb_stride;
+    kt.split_rcp  = team_split_rcp(kt.poly_major ? nl : pa.batch);
     const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * pa.batch) * sizeof(unsigned);
     hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
     if(e != hipSuccess) return e;
@@ -2538,7 +2742,7 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
   p.wgs_per_limb = (uint32_t)wgs;
   if(nl > 1) {
     if constexpr(multi_limb_built<A>()) {
-      hipLaunchKernelGGL((column_kernel<A, R, INV, KSH, true>), dim3((unsigned)(wgs * nl)), dim3(256), 0, pa.stream, p);
+      hipLaunchKernelGGL((column_kernel<A, R, INV, KSH, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(256), 0, pa.stream, p);
       return hipGetLastError();
     } else {
       return hipErrorNotSupported;
@@ -2597,11 +2801,11 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(g > gcap) g = gcap;                                                                                          \
     pp.f.wgs_per_limb = (unsigned)g;                                                                                \
     if(pa.both) {                                                                                                   \
-      if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true, true>), dim3((unsigned)(g * nl)), dim3(GS::WG), 0, pa.stream, pp); \
+      if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true, true>), dim3((unsigned)g, (unsigned)nl), dim3(GS::WG), 0, pa.stream, pp); \
       else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
       return hipGetLastError();                                                                                     \
     }                                                                                                               \
-    if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true>), dim3((unsigned)(g * nl)), dim3(GS::WG), 0, pa.stream, pp); \
+    if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true>), dim3((unsigned)g, (unsigned)nl), dim3(GS::WG), 0, pa.stream, pp); \
     else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
     return hipGetLastError();                                                                                       \
   }
@@ -2627,17 +2831,17 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       pp.f.wgs_per_limb = (uint32_t)wgs;
       if(pa.both) {
         if(s0 == 0) {
-          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
           else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
         } else {
-          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+          if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
           else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, false, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
         }
         return hipGetLastError();
       }
       if(nl > 1) {
-        if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
-        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(G12::WG), 0, pa.stream, pp);
+        if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
       } else {
         if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, false>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
@@ -2650,28 +2854,28 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
       pp.f.wgs_per_limb = (uint32_t)wgs;
       if(pa.both) {
-        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G13::WG), 0, pa.stream, pp);
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G13::WG), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
         return hipGetLastError();
       }
-      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(G13::WG), 0, pa.stream, pp);
+      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G13::WG), 0, pa.stream, pp);
       else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
       return hipGetLastError();
     }
     pp.f.wgs_per_limb = (uint32_t)wgs;
     if(pa.both) {
       if(s0 == 0) {
-        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
       } else {
-        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, false, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
       }
       return hipGetLastError();
     }
     if(nl > 1) {
-      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
-      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true>), dim3((unsigned)(wgs * nl)), dim3(1024), 0, pa.stream, pp);
+      if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
     } else {
       if(s0 == 0) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
       else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, false>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
@@ -2707,6 +2911,8 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     kt.ctl              = static_cast<TeamProdCtl *>(pa.team_ctl);
     kt.lag              = (uint32_t)(pa.team_lag > 0 ? pa.team_lag : 8);
     kt.nlimbs           = (uint32_t)nl;
+    kt.poly_major       = nl > 1 && kt.k.f.poly_stride > kt.k.f.limb_stride;
+    kt.split_rcp        = team_split_rcp(kt.poly_major ? nl : pa.batch);
     const size_t bytes = sizeof(TeamProdCtl) + 2 * (size_t)(nl * pa.batch) * sizeof(unsigned);
     hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
     if(e != hipSuccess) return e;
@@ -2787,7 +2993,7 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
   kd.k.wgs_per_limb = (uint32_t)wgs;
   if(nl > 1) {
     if constexpr(multi_limb_built<A>()) {
-      hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, LASTINV, true>), dim3((unsigned)(wgs * nl)), dim3(G::WG), 0, da.stream, kd);
+      hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, LASTINV, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, da.stream, kd);
       return hipGetLastError();
     } else {
       return hipErrorNotSupported;
@@ -2797,9 +3003,67 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
   return hipGetLastError();
 }
 
+/* the NTT-domain product at N = 2^15..2^17 as ONE launch (team_dot_kernel); da.team_ctl: TeamCtl + nlimbs * batch counters, zeroed here */
+template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
+{
+  if constexpr(!(A::kCompact || A::kIntWide)) {
+    return hipErrorNotSupported;
+  } else {
+    const uint64_t nl = (uint64_t)(da.nlimbs > 0 ? da.nlimbs : 1);
+    if(nl > (uint64_t)kMaxLimbs || !da.team_ctl || da.logn < (uint32_t)kTeamBlock + 3 || da.logn > (uint32_t)kTeamBlock + 5 ||
+       nl * da.batch >= (1ull << 31) || da.npairs < 1 || da.npairs > kMaxDot) {
+      return hipErrorNotSupported;
+    }
+    KTeamDot<A> kt{};
+    kt.d.k.a                = da.out;
+    const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(da.limbs);
+    for(uint64_t l = 0; l < nl; l++) kt.d.k.limbs[l] = recs[l];
+    kt.d.k.limb_stride = nl > 1 ? da.limb_stride : 0;
+    kt.d.k.poly_stride = da.poly_stride ? da.poly_stride : (1ull << da.logn);
+    kt.d.k.logn        = da.logn;
+    kt.d.k.s0          = da.logn - (uint32_t)kTeamBlock;
+    kt.d.k.lastinv     = 1;
+    kt.d.k.lazy        = 0;
+    kt.d.k.nblocks     = da.batch;
+    kt.d.npairs        = (uint32_t)da.npairs;
+    kt.d.lazy_in       = (uint32_t)da.lazy_in;
+    kt.d.b_bcast       = (uint32_t)da.b_bcast;
+    kt.d.b_limb_stride = nl > 1 ? da.b_limb_stride : 0;
+    for(int i = 0; i < da.npairs; i++) {
+      kt.d.a[i] = da.a[i];
+      kt.d.b[i] = da.b[i];
+    }
+    kt.ctl        = static_cast<TeamCtl *>(da.team_ctl);
+    kt.lag        = (uint32_t)(da.team_lag > 0 ? da.team_lag : 8);
+    kt.nlimbs     = (uint32_t)nl;
+    kt.poly_major = nl > 1 && kt.d.k.poly_stride > kt.d.k.limb_stride;
+    kt.split_rcp  = team_split_rcp(kt.poly_major ? nl : da.batch);
+    const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * da.batch) * sizeof(unsigned);
+    hipError_t   e     = hipMemsetAsync(da.team_ctl, 0, bytes, da.stream);
+    if(e != hipSuccess) return e;
+    uint64_t wgs = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (da.team_wpc > 0 ? da.team_wpc : 4);
+    if(da.max_grid > 0) wgs = (uint64_t)da.max_grid;
+    kt.d.k.wgs_per_limb = (uint32_t)wgs;
+    const dim3 g((unsigned)wgs), t(256);
+#define NTT_TEAM_DOT(LEADV)                                                                                  \
+  do {                                                                                                       \
+    if(nl > 1) hipLaunchKernelGGL((team_dot_kernel<A, LEADV, KSH, true>), g, t, 0, da.stream, kt);           \
+    else hipLaunchKernelGGL((team_dot_kernel<A, LEADV, KSH, false>), g, t, 0, da.stream, kt);                \
+  } while(0)
+    switch(da.logn - kTeamBlock) {
+      case 3: NTT_TEAM_DOT(3); break;
+      case 4: NTT_TEAM_DOT(4); break;
+      default: NTT_TEAM_DOT(5); break;
+    }
+#undef NTT_TEAM_DOT
+    return hipGetLastError();
+  }
+}
+
 template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
 {
   if(da.npairs < 1 || da.npairs > kMaxDot || da.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(da.team_ctl) return launch_team_dot<A, KSH>(da);
   if(da.logn > (uint32_t)kFusedMax) {
     if(da.block_log == (uint32_t)kFusedSmallBlock) return launch_dot_blocks<A, kFusedSmallBlock, KSH, false>(da);
     if(da.block_log == (uint32_t)kFusedLarge) return launch_dot_blocks<A, kFusedLarge, KSH, false>(da);
@@ -2860,7 +3124,7 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
   km.k.wgs_per_limb = (uint32_t)wgs;
   if(nl > 1) {
     if constexpr(multi_limb_built<A>()) {
-      hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, true>), dim3((unsigned)(wgs * nl)), dim3(G::WG), 0, ma.stream, km);
+      hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, ma.stream, km);
       return hipGetLastError();
     } else {
       return hipErrorNotSupported;

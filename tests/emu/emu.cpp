@@ -386,7 +386,7 @@ template <class A> struct Regs {
 template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false> static void emu_fused(const Params<A> &p)
 {
   using P                 = Plan<LOGN>;
-  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u);
+  constexpr uint32_t MASK = fused_mask<A, LOGN, INV, KSH, LAZY>() | (INV && LASTINV ? kLastInvFlag : 0u) | (INV && A::kWide52 ? kCanonInFlag : 0u); /* as fused_kernel */
   std::vector<typename A::val> lds(P::LDS_ELEMS);
   std::vector<Regs<A>>         regs(P::T);
   for(uint64_t b = 0; b < p.nblocks; b++) {

@@ -188,13 +188,17 @@ def test_headline_kernels_do_not_spill():
     import check_spills
     every = check_spills.all_kernels()
     # the MULTI variants (several RNS limbs in one launch: the limb's tables are picked at run time from an array in the
-    # kernel arguments) are exempt: a run-time limb index costs the register-tight ones 2-6 spilled VGPRs, which is why
-    # the host only takes them when one limb's share alone cannot fill the chip (ntt_host.hip rns_one_launch_pays)
+    # kernel arguments) spilled 2-6 VGPRs in rounds 3 and 4 -- not because of the run-time index but because the limb came out
+    # of a VALU division and dragged every address after it into vector registers; since round 5 (the limb is blockIdx.y, the
+    # queue kernels split with a scalar multiply-high: csrc/ntt_kernels.h limb_params, team_split) they are held to the same rule
     multi = [k for k in every if _last_template_bool_is_multi(k["name"])]
     ks = [k for k in every if k not in multi]
     assert len(ks) >= 80 and len(multi) >= 40
     for k in multi:
-        assert k["vgpr_spill_count"] <= 8, k
+        if "fused_product_kernel" in k["name"] and "WideF64" in k["name"] and "ELi14E" in k["name"]:
+            assert k["vgpr_spill_count"] <= 4, k      # (the same known exception as its single-set twin below)
+        else:
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
     fused = [k for k in ks if "fused_kernel" in k["name"] and "ArithF64" in k["name"]]
     big = [k for k in fused if any(("ELi%dE" % ln) in k["name"] for ln in (12, 13, 14))]
     # 3 block sizes x (3 headroom classes + the wide policy for q up to 2^52) x {fwd, fwd with lazy outputs, inv},

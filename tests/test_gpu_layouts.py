@@ -268,3 +268,87 @@ def test_layouts_that_overlap_are_refused(lib, oracle):
     lib.rns_fwd(plans, d.ptr, batch, layout=(batch * n, n))
     lib.rns_fwd(plans, d.ptr, batch, layout=(n, nl * n))
     d.free()
+
+
+@pytest.mark.parametrize("m,bits", [(8, 50), (12, 51), (14, 60), (15, 50)])
+def test_pointer_batch_of_polynomials(lib, oracle, m, bits):
+    """ntt_transform_ptrs: one device pointer per polynomial (the reference's fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...) form,
+    include/ntt_reference.h:44-49, for any number of device-resident polynomials): three equally spaced polynomials of one
+    buffer (one strided launch), two at irregular places -- one of them only 8-byte aligned, as the reference's unaligned bench
+    passes its arrays (tests/bench.c:160-186) --, two in a second allocation; listed in scrambled order.  Every polynomial
+    against the oracle, every other word untouched; forward, lazy forward, inverse."""
+    n = 1 << m
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    plan, cx = lib.Plan(n, q, w), oracle.ctx(n, q, w)
+    words1, words2 = 12 * n + 64, 3 * n
+    offs1 = [0, 3 * n, 6 * n, 8 * n + 16, 10 * n + 33]        # (the last one: odd word offset)
+    offs2 = [8, n + 24]
+    polys = [oracle.fill_uniform(n, q, 9000 + i) for i in range(7)]
+    img1, img2 = np.full(words1, GUARD, dtype=np.uint64), np.full(words2, GUARD, dtype=np.uint64)
+    for o, a in zip(offs1, polys[:5]):
+        img1[o:o + n] = a
+    for o, a in zip(offs2, polys[5:]):
+        img2[o:o + n] = a
+    d1, d2 = lib.DeviceBuffer(words1).upload(img1), lib.DeviceBuffer(words2).upload(img2)
+    ptrs = [d1.ptr + 8 * o for o in offs1] + [d2.ptr + 8 * o for o in offs2]
+    order = [3, 6, 0, 2, 5, 1, 4]
+
+    def gather():
+        g1, g2 = d1.download(), d2.download()
+        m1, m2 = np.ones(words1, dtype=bool), np.ones(words2, dtype=bool)
+        out = []
+        for o in offs1:
+            out.append(g1[o:o + n]); m1[o:o + n] = False
+        for o in offs2:
+            out.append(g2[o:o + n]); m2[o:o + n] = False
+        assert (g1[m1] == GUARD).all() and (g2[m2] == GUARD).all(), "words outside the listed polynomials were written"
+        return out
+
+    plan.transform_ptrs([ptrs[i] for i in order])
+    for i, got in enumerate(gather()):
+        assert np.array_equal(got, cx.fwd(polys[i].copy())), i
+    plan.transform_ptrs([ptrs[i] for i in order], lib.FLAG_INVERSE)
+    for i, got in enumerate(gather()):
+        assert np.array_equal(got, polys[i]), i
+    plan.transform_ptrs(ptrs, lib.FLAG_LAZY_OUT)
+    for i, got in enumerate(gather()):
+        assert int(got.max()) < 4 * q and np.array_equal(got % np.uint64(q), cx.fwd(polys[i].copy())), i
+    # overlapping polynomials, a pointer listed twice, a misaligned pointer: refused
+    for bad in ([ptrs[0], ptrs[0] + 8 * (n - 1)], [ptrs[1], ptrs[1]], [ptrs[0] + 4]):
+        with pytest.raises(lib.NttError):
+            plan.transform_ptrs(bad)
+    d1.free(), d2.free()
+
+
+@pytest.mark.parametrize("m,nl,bits", [(12, 3, 50), (14, 4, 57), (16, 2, 50)])
+def test_pointer_batch_of_rns_polynomials(lib, oracle, m, nl, bits):
+    """ntt_rns_transform_ptrs: separately allocated RNS polynomials ([limb][N] each, the unit an FHE library allocates) as one
+    call: five out of a pool at equal spacing (one launch over limbs and polynomials), one by itself"""
+    n = 1 << m
+    qs, roots = _primes(lib, n, nl, bits)
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    ctxs = [oracle.ctx(n, q, w) for q, w in zip(qs, roots)]
+    span, gap = nl * n, nl * n + 128
+    pool = lib.DeviceBuffer(5 * gap)
+    lone = lib.DeviceBuffer(span)
+    data = [np.stack([oracle.fill_uniform(n, q, 9500 + 10 * i + l) for l, q in enumerate(qs)]) for i in range(6)]
+    img = np.full(5 * gap, GUARD, dtype=np.uint64)
+    for i in range(5):
+        img[i * gap:i * gap + span] = data[i].reshape(-1)
+    pool.upload(img), lone.upload(data[5].reshape(-1))
+    ptrs = [pool.ptr + 8 * i * gap for i in range(5)] + [lone.ptr]
+    lib.rns_transform_ptrs(plans, ptrs[::-1], n)
+    got = pool.download()
+    for i in range(5):
+        for l in range(nl):
+            assert np.array_equal(got[i * gap + l * n:i * gap + (l + 1) * n], ctxs[l].fwd(data[i][l].copy())), (i, l)
+        assert (got[i * gap + span:(i + 1) * gap] == GUARD).all()
+    gl = lone.download()
+    for l in range(nl):
+        assert np.array_equal(gl[l * n:(l + 1) * n], ctxs[l].fwd(data[5][l].copy())), l
+    lib.rns_transform_ptrs(plans, ptrs, n, lib.FLAG_INVERSE)
+    assert np.array_equal(pool.download(), img) and np.array_equal(lone.download(), data[5].reshape(-1))
+    with pytest.raises(lib.NttError):
+        lib.rns_transform_ptrs(plans, [ptrs[0], ptrs[0] + 8 * n], n)      # two RNS polynomials that overlap
+    pool.free(), lone.free()

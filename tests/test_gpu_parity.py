@@ -1321,7 +1321,8 @@ def test_c_example_rns_modulus_chain_runs():
                            "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("schoolbook") == 6 and "same coefficients" in out.stdout
+    assert out.stdout.count("schoolbook") == 6 and out.stdout.count("same coefficients") == 2 and "round trip exact" in out.stdout
+    assert "MISMATCH" not in out.stdout
 
 
 def test_torch_tensors_and_streams_interoperate():
@@ -1470,8 +1471,8 @@ def test_single_launch_two_pass_transform_captured_in_a_hip_graph():
     """The single-launch two-pass transform (N = 2^15, 512 polynomials: its default range) keeps queue heads and counters
     in a buffer the plan allocates per stream on first use.  Allocation cannot be captured, so (cold) a capture on a stream
     the plan has not seen takes the per-pass launches, and (warm) a capture on a stream that already owns a buffer records
-    the memset + the one launch.  Both graphs, replayed on fresh inputs, equal the oracle on sampled polynomials and each
-    other on all of them; so does the product chain."""
+    the memset + the one launch; so does one on a stream ntt_plan_reserve prepared.  All three graphs, replayed on fresh inputs,
+    equal the oracle on sampled polynomials and each other on all of them; so does the product chain."""
     import sys
     code = """
 import sys
@@ -1486,12 +1487,14 @@ n, batch, q = 1 << 15, 512, 0x7fffffffe0001
 w = lib.min_root(q, n)
 cx = orc.ctx(n, q, w)
 outs = {}
-for mode in ("cold", "warm"):
+for mode in ("cold", "warm", "reserved"):
     plan = lib.Plan(n, q, w, device=0)
     ta = torch.zeros(batch * n, dtype=torch.int64, device="cuda:0")
     tb, tc, sa, sb = torch.zeros_like(ta), torch.zeros_like(ta), torch.zeros_like(ta), torch.zeros_like(ta)
     g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
     s.wait_stream(torch.cuda.current_stream())
+    if mode == "reserved":
+        plan.reserve(batch, stream=s.cuda_stream)         # ntt_plan_reserve: the control blocks exist before the capture begins
     if mode == "warm":
         with torch.cuda.stream(s):
             plan.fwd(ta.data_ptr(), batch, stream=s.cuda_stream)
@@ -1518,6 +1521,7 @@ for mode in ("cold", "warm"):
         outs[(mode, seed)] = prod.copy()
 for seed in (1, 2):
     assert np.array_equal(outs[("cold", seed)], outs[("warm", seed)]), seed
+    assert np.array_equal(outs[("cold", seed)], outs[("reserved", seed)]), seed
 print("graph ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
@@ -1670,18 +1674,22 @@ def test_inv_dot_in_the_ntt_domain(lib, oracle, m, cls):
     plan.destroy()
 
 
-@pytest.mark.parametrize("m,arith", [(4, "auto"), (10, "generic"), (12, "r4"), (15, "generic"), (16, "u64")])
+@pytest.mark.parametrize("m,arith", [(4, "auto"), (10, "generic"), (12, "r4"), (15, "generic"), (16, "u64"), (10, "generic52"),
+                                     (12, "unfused52"), (15, "unfused52")])
 def test_inv_dot_plans_without_the_fused_kernel(lib, oracle, m, arith):
     """plans the fused kernel is not built for (N < 2^6, column-pass-only plans, the radix-4 formulation) accumulate the
     products with pointwise launches and run their own inverse; the integer policy above 2^14 takes the kernel's
-    two-pass form: same results"""
+    two-pass form: same results.  *52: a 52-bit modulus, whose lazy words ([0,4q)) exceed 2^53 -- the pointwise kernels fold
+    them with integer operations before the conversion (ArithF64::mulmod_full_lazy4); unfused52: NTT_OPT_DOT_FUSED = 0"""
     n = 1 << m
-    q = lib.find_prime(50 if arith != "u64" else 59, n)
+    q = lib.find_prime(52 if arith.endswith("52") else 50 if arith != "u64" else 59, n)
     w = lib.min_root(q, n)
     cx = oracle.ctx(n, q, w)
     plan = lib.Plan(n, q, w, arith={"r4": lib.ARITH_U64_R4, "u64": lib.ARITH_U64}.get(arith, lib.ARITH_AUTO))
-    if arith == "generic":
+    if arith.startswith("generic"):
         plan.set_generic(True)
+    if arith == "unfused52":
+        plan.set_option(lib.OPT_DOT_FUSED, 0)
     for k, batch, lazy, bcast in ((1, 3, False, False), (3, 2, True, False), (4, 3, False, True)):
         a_list, b_list = _ntt_domain_operands(oracle, n, q, batch, k, 5100 + m, lazy, bcast)
         expect = cx.inv(oracle.dot(a_list, b_list, q, n, bcast))
@@ -1693,6 +1701,40 @@ def test_inv_dot_plans_without_the_fused_kernel(lib, oracle, m, arith):
         assert np.array_equal(dc.download(), expect), (k, batch, lazy, bcast)
         for x in da + db + [dc]:
             x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("m,batch,k,bits", [(15, 640, 1, 51), (16, 520, 2, 52), (17, 513, 1, 60)])
+def test_ntt_domain_products_automatic_form_at_large_batches(lib, oracle, m, batch, k, bits):
+    """batches of 512 polynomials and more at N >= 2^15 take the one-launch form by themselves (dot_team_pays) with the measured
+    default lags (24 / 12 / 8 polynomials: queues much longer than the lag here, unlike the ragged cases above); the control
+    block comes from NTT_OPT_MAX_BATCH_HINT, not from the first call.  Every polynomial against the forced per-chunk form,
+    samples against the oracle."""
+    n = 1 << m
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    plan.set_option(lib.OPT_MAX_BATCH_HINT, batch)
+    da = [lib.DeviceBuffer(batch * n) for _ in range(k)]
+    db = [lib.DeviceBuffer(batch * n) for _ in range(k)]
+    for i in range(k):
+        lib.fill_uniform(da[i].ptr, batch * n, q, 7100 + i)
+        lib.fill_uniform(db[i].ptr, batch * n, q, 7200 + i)
+    dc = lib.DeviceBuffer(batch * n)
+    res = {}
+    for form in (-1, 0):
+        plan.set_option(lib.OPT_XCD_LOCAL, form)
+        dc.upload(np.zeros(batch * n, dtype=np.uint64))
+        plan.inv_dot(dc.ptr, [x.ptr for x in da], [x.ptr for x in db], batch, 0)
+        res[form] = dc.download()
+    assert np.array_equal(res[-1], res[0])
+    for p_ in (0, 7, batch // 2, batch - 9, batch - 1):
+        a_l = [x.download(n, p_ * n) for x in da]
+        b_l = [x.download(n, p_ * n) for x in db]
+        assert np.array_equal(res[-1][p_ * n:(p_ + 1) * n], cx.inv(oracle.dot(a_l, b_l, q, n))), p_
+    for x in da + db + [dc]:
+        x.free()
     plan.destroy()
 
 
@@ -2072,3 +2114,86 @@ def test_key_switching_inner_product_digit_by_digit(lib, oracle):
         plan.destroy()
     for x in (dacc, dd, dk):
         x.free()
+
+
+@pytest.mark.parametrize("cls", ["f64_class0", "f64_52bit", "u64_57bit", "u64_60bit"])
+@pytest.mark.parametrize("m", [15, 16, 17])
+def test_xcd_local_ntt_domain_products(lib, oracle, m, cls):
+    """N = 2^15..2^17: c = inv(sum a_i^ (.) b_i^) with BOTH passes as items of ONE launch (team_dot_kernel: row items = the products
+    and the inverse block stages, column items behind a per-polynomial counter; round 5) against the per-chunk launches
+    (NTT_OPT_XCD_LOCAL 0), every polynomial, and samples against the oracle: k = 1 and 3, canonical and lazy words, a broadcast
+    key, c aliasing a^ and b^, ragged batches (queues of unequal length)"""
+    n = 1 << m
+    bits = {"f64_class0": 51, "f64_52bit": 52, "u64_57bit": 57, "u64_60bit": 60}[cls]
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    for k, batch, lazy, bcast in ((1, 67, False, False), (3, 70, True, False), (2, 65, False, True), (1, 64, True, False)):
+        a_list, b_list = _ntt_domain_operands(oracle, n, q, batch, k, 5600 + 5 * m + k, lazy, bcast)
+        flags = (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0)
+        da = [lib.DeviceBuffer(a.size).upload(a) for a in a_list]
+        db = [lib.DeviceBuffer(b.size).upload(b) for b in b_list]
+        dc = lib.DeviceBuffer(batch * n)
+        res = {}
+        for form in (0, 1):
+            plan.set_option(lib.OPT_XCD_LOCAL, form)
+            dc.upload(np.zeros(batch * n, dtype=np.uint64))
+            plan.inv_dot(dc.ptr, [x.ptr for x in da], [x.ptr for x in db], batch, flags)
+            res[form] = dc.download()
+        assert np.array_equal(res[0], res[1]), (k, batch, lazy, bcast)
+        for p_ in (0, batch // 2, batch - 1):
+            sl = slice(p_ * n, (p_ + 1) * n)
+            exp = cx.inv(oracle.dot([a[sl] for a in a_list], [b if bcast else b[sl] for b in b_list], q, n, bcast))
+            assert np.array_equal(res[1][sl], exp), (k, batch, lazy, bcast, p_)
+        if k == 1:
+            plan.set_option(lib.OPT_XCD_LOCAL, 1)
+            plan.inv_product(da[0].ptr, da[0].ptr, db[0].ptr, batch, flags)          # c aliases a^
+            assert np.array_equal(da[0].download(), res[0]), ("alias a", batch, lazy)
+            da[0].upload(a_list[0])
+            plan.inv_product(db[0].ptr, da[0].ptr, db[0].ptr, batch, flags)          # c aliases b^
+            assert np.array_equal(db[0].download(), res[0]), ("alias b", batch, lazy)
+        for x in da + db + [dc]:
+            x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("m,nl,batch,bits,layout", [(15, 3, 30, 50, None), (16, 4, 20, 50, "bm"), (17, 2, 40, 57, "bm"), (16, 16, 5, 52, None)])
+def test_xcd_local_ntt_domain_products_over_rns_limbs(lib, oracle, m, nl, batch, bits, layout):
+    """the same over the limbs of an RNS set (the limb in the queue entry: MULTI variant), in [limb][batch][N] and in
+    [batch][limb][N] layout, against the per-limb per-chunk form, every word; samples against the oracle"""
+    n = 1 << m
+    qs = [lib.find_prime(bits, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    k = 2
+    rng = np.random.default_rng(m)
+    # operands [k][limb][batch][n] dense, values below the smallest modulus
+    ops_a = rng.integers(0, min(qs), size=(k, nl, batch, n), dtype=np.uint64)
+    ops_b = rng.integers(0, min(qs), size=(k, nl, batch, n), dtype=np.uint64)
+    lay = (n, nl * n) if layout == "bm" else None
+
+    def place(x):       # [limb][batch][n] -> the layout's image
+        return np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(-1) if layout == "bm" else x.reshape(-1)
+
+    da = [lib.DeviceBuffer(nl * batch * n).upload(place(ops_a[i])) for i in range(k)]
+    db = [lib.DeviceBuffer(nl * batch * n).upload(place(ops_b[i])) for i in range(k)]
+    dc = lib.DeviceBuffer(nl * batch * n)
+    res = {}
+    for form in (0, 1):
+        for p in plans:
+            p.set_option(lib.OPT_XCD_LOCAL, form)
+        lib.set_rns_launch(plans, 1 - form)            # per limb and per chunk  /  one launch over the limbs
+        lib.rns_inv_dot(plans, dc.ptr, [x.ptr for x in da], [x.ptr for x in db], batch, layout=lay)
+        res[form] = dc.download()
+    assert np.array_equal(res[0], res[1])
+    got = res[1].reshape(batch, nl, n).transpose(1, 0, 2) if layout == "bm" else res[1].reshape(nl, batch, n)
+    for l in (0, nl - 1):
+        cx = oracle.ctx(n, qs[l], ws[l])
+        for p_ in (0, batch - 1):
+            exp = cx.inv(oracle.dot([ops_a[i, l, p_].copy() for i in range(k)], [ops_b[i, l, p_].copy() for i in range(k)], qs[l], n))
+            assert np.array_equal(got[l, p_], exp), (l, p_)
+    for x in da + db + [dc]:
+        x.free()
+    for p in plans:
+        p.destroy()

@@ -11,18 +11,19 @@ def short(name):
     return re.sub(r"\s+", " ", name)[:96]
 
 
-for cfg in (4, 2, 3, 5):
+for cfg in ("4", "2", "3", "5", "5_bm"):
+    if not glob.glob("%s/kt%s" % (root, cfg)): continue
     dur = collections.defaultdict(list)
-    for f in glob.glob("%s/kt%d/**/*kernel_trace.csv" % (root, cfg), recursive=True):
+    for f in glob.glob("%s/kt%s/**/*kernel_trace.csv" % (root, cfg), recursive=True):
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        for f in glob.glob("%s/pmc%d/%s/**/*counter_collection.csv" % (root, cfg, c), recursive=True):
+        for f in glob.glob("%s/pmc%s/%s/**/*counter_collection.csv" % (root, cfg, c), recursive=True):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == c:
                     ctr[short(r["Kernel_Name"])][c].append(float(r["Counter_Value"]))
-    print("# config %d : kernel | launches | avg ms (min) | FETCH_SIZE x2 MiB | WRITE_SIZE MiB  (per dispatch, full-size dispatches)" % cfg)
+    print("# config %s : kernel | launches | avg ms (min) | FETCH_SIZE x2 MiB | WRITE_SIZE MiB  (per dispatch, full-size dispatches)" % cfg)
     for k in sorted(dur, key=lambda k: -sum(dur[k])):
         d = dur[k]
         big = [x for x in d if x > 0.3 * max(d)]

@@ -8,6 +8,8 @@ lib = ontt.load()
 ap = argparse.ArgumentParser()
 ap.add_argument("--logn", type=int, default=9)
 ap.add_argument("--gib", type=float, default=8.0)
+ap.add_argument("--max-grid", type=int, nargs="+", default=[0], help="workgroup caps to try (0 = the library's grid)")
+ap.add_argument("--allocs", type=int, default=2, help="allocations of --gib each to visit")
 a = ap.parse_args()
 n = 1 << a.logn
 q = 0x80000001c0001
@@ -17,7 +19,8 @@ batch = words // n
 pad = (64 << 20) // 8
 buf = lib.DeviceBuffer(words + pad)
 lib.fill_uniform(buf.ptr, words + pad, q, 3)
-def rate(ptr):
+def rate(ptr, grid=0):
+    plan.set_option(lib.OPT_MAX_GRID, grid)
     for _ in range(2): plan.fwd(ptr, batch)
     e0, e1 = lib.Event(), lib.Event()
     lib.stream_sync(); e0.record()
@@ -28,6 +31,9 @@ print("pid %d base %#x (mod 2 MiB: %#x)" % (os.getpid(), buf.ptr, buf.ptr % (2 <
 for rep in range(2):
     for off in (0, 4096, 65536, 1 << 20, 2 << 20, (2 << 20) + 4096, 32 << 20, 48 << 20):
         print("  rep %d offset %9d B: frac %.3f" % (rep, off, rate(buf.ptr + off)))
-b2 = lib.DeviceBuffer(words)
-lib.fill_uniform(b2.ptr, words, q, 4)
-print("second allocation base %#x: frac %.3f, first again: %.3f" % (b2.ptr, rate(b2.ptr), rate(buf.ptr)))
+bufs = [buf] + [lib.DeviceBuffer(words) for _ in range(a.allocs - 1)]
+for b in bufs[1:]: lib.fill_uniform(b.ptr, words, q, 4)
+print("library %s" % os.environ.get("NTT_LIB", "(tree)"))
+for g in a.max_grid:
+    print("grid cap %6d: " % g + "  ".join("alloc %d (base %#x) %.3f" % (i, b.ptr, rate(b.ptr, g)) for i, b in enumerate(bufs))
+          + "  | again: " + " ".join("%.3f" % rate(b.ptr, g) for b in bufs))
