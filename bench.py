@@ -332,7 +332,8 @@ class GpuShard:
     (config 3); "rns_product": c = a * b per limb over [limb][batch][N] slabs (config 5) -- the product overwrites
     its operands, so every step (warm-ups included) gets its own operand pair, generated before the timed region."""
 
-    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None, kind="fwd", qs=None, roots=None, steps_total=1, layout=None):
+    def __init__(self, lib, device, index, batch, n=None, q=Q, root=None, kind="fwd", qs=None, roots=None, steps_total=1, layout=None,
+                 warm_steps=None):
         self.lib, self.device, self.index, self.batch, self.kind = lib, device, index, batch, kind
         self.layout = layout                          # None: [limb][batch][N]; "batch_major": SURVEY 8(d)'s [batch][prime][N]
         self.n = n or N
@@ -346,7 +347,11 @@ class GpuShard:
         # (limb stride, polynomial stride) in words, for the *_strided entry points
         self.strides = (self.n, self.limbs * self.n) if layout == "batch_major" else None
         words = self.limbs * self.slab
-        self.sets = steps_total if kind == "rns_product" else 1
+        # rns_product: every TIMED step and the first (parity-checked) warm-up get an operand pair of their own; the other warm-ups
+        # share one (what a product leaves in its operands are canonical residues again: valid inputs of unknown meaning)
+        self.warm_steps = steps_total if warm_steps is None else warm_steps
+        self.warm_sets = min(self.warm_steps, 2)
+        self.sets = (steps_total - self.warm_steps + self.warm_sets) if kind == "rns_product" else 1
         need = words * 8 * (2 * self.sets + 1 if kind == "rns_product" else 1)
         if need > 230 * 2**30:
             raise SystemExit("bench.py: config needs %.0f GiB of operands on one GPU (reduce --steps)" % (need / 2**30))
@@ -390,7 +395,8 @@ class GpuShard:
             self.plan.fwd(self.buf.ptr, self.batch, stream=self.stream)
             self.plan.inv(self.buf.ptr, self.batch, stream=self.stream)
         else:
-            s = self.step_no % self.sets
+            i = self.step_no
+            s = (min(i, self.warm_sets - 1) if i < self.warm_steps else i - self.warm_steps + self.warm_sets) % self.sets
             self.lib.rns_negacyclic_mul(self.plans, self.out.ptr, self.operand_ptr(s, 0), self.operand_ptr(s, 1), self.batch,
                                         stream=self.stream, layout=self.strides)
             self.step_no += 1
@@ -698,7 +704,8 @@ def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
     frac of 8 TB/s at the config's algorithmic bytes per unit, mean / min step time."""
     w = workload_for(config).resolve(lib)
     batch = w.per_gpu_batch("weak", 1)
-    shard = GpuShard(lib, 0, 0, batch, n=w.n, kind=w.kind, qs=w.qs, roots=w.roots, steps_total=steps + max(warmup, 1), layout=layout)
+    shard = GpuShard(lib, 0, 0, batch, n=w.n, kind=w.kind, qs=w.qs, roots=w.roots, steps_total=steps + max(warmup, 1), layout=layout,
+                     warm_steps=max(warmup, 1))
     par = Parity(w, shard, batch)
     if check:
         par.capture()
@@ -727,7 +734,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps (the first carries the parity check; eight = 50 ms of work behind it, see also_config's note on settling clocks)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2, 3, 4 (default, the metric) or 5 (60: N=2^16 with a 60-bit modulus, not a BASELINE configuration)")
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: from --config and --scaling)")
@@ -738,7 +745,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="default run: skip the also_config2/3/5 blocks")
     ap.add_argument("--layout", choices=("limb-major", "batch-major"), default="limb-major",
                     help="config 5: RNS operands as [limb][batch][N] (default) or as SURVEY 8(d) lays them out, [batch][prime][N]")
-    ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each also_configN block (3 warm-ups in front)")
+    ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each also_configN block (warm-ups covering >= 60 ms of work in front)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -771,8 +778,8 @@ def main():
     w = workload_for(args.config, args.logn or None).resolve(lib)
     n = w.n
     batch = args.batch or w.per_gpu_batch(args.scaling, n_gpus)
-    if w.kind == "rns_product" and args.steps + args.warmup > 24 and not args.batch:
-        sys.exit("bench.py: config 5 keeps one operand pair per step resident: use --steps + --warmup <= 24")
+    if w.kind == "rns_product" and args.steps + min(args.warmup, 2) > 24 and not args.batch:
+        sys.exit("bench.py: config 5 keeps one operand pair per timed step resident: use --steps <= 22")
 
     have = lib.device_count()
     shards = []
@@ -784,7 +791,7 @@ def main():
         if device >= have:
             sys.exit("bench.py: --gpus %d but only %d HIP device(s) visible" % (n_gpus, have))
         shards.append(GpuShard(lib, device, index, batch, n=n, kind=w.kind, qs=w.qs, roots=w.roots,
-                               steps_total=args.steps + max(args.warmup, 1),
+                               steps_total=args.steps + max(args.warmup, 1), warm_steps=max(args.warmup, 1),
                                layout="batch_major" if (args.layout == "batch-major" and w.kind == "rns_product") else None))
 
     def barrier():
@@ -837,9 +844,13 @@ def main():
                     key = "also_config%d" % cfg if cfg != 60 else "also_60_bit_q_n65536"
                     if lay:
                         key += "_" + lay      # config 5 with the operands as SURVEY 8(d) lays them out: [batch][prime][N]
-                    # (config 2's step is half a millisecond: forty of them after ten warm-ups, so that the block's mean is as
-                    # steady as the others' -- eight such steps read anywhere between the mean and +8 %)
-                    st, wu = (max(args.also_steps, 40), 10) if cfg == 2 else (args.also_steps, 3)
+                    # Warm-ups cover >= 60 ms of device work in every block: the first one carries the parity check (the GPU idles
+                    # while the oracle runs on the host), and for about 20 ms after an idle gap the clocks are still settling --
+                    # the operation measured first in a process reads 10 % low over 20 ms, 1.5 % low over 160 ms, whichever
+                    # operation it is (profiles/r05/clock_settling_after_idle.txt).  Config 2's step is one millisecond: a hundred
+                    # of them, so that its mean is as steady as the others'.
+                    st, wu = {2: (max(args.also_steps, 100), 80), 3: (args.also_steps, 9), 5: (args.also_steps, 18),
+                              60: (args.also_steps, 12)}[cfg]
                     try:
                         out[key] = also_config(lib, cfg, steps=st, warmup=wu, check=check, layout=lay)
                     except Exception as e:      # a side block must never cost the headline line ...

@@ -1572,9 +1572,13 @@ static bool dot_kernel_applies(const ntt_plan *p)
  * measured (profiles/r05/domain_bench_xcd_local.txt) */
 static bool dot_team_pays(const ntt_plan *p, uint64_t polys, int k, bool bcast)
 {
-  /* a shared key at 2^17 with three pairs and more: the one launch measured -4 % */
-  if(bcast && p->m == kTeamBlock + 5 && k >= 3) return false;
-  return polys >= 512;
+  /* (profiles/r05/domain_bench_xcd_local.txt, _batch.txt: +11..26 % from 2^25 coefficients per operand on -- 1024 / 512 / 512
+   * polynomials at 2^15 / 2^16 / 2^17; half of that is even or a loss, the queues then being as long as the lag) */
+  if(polys < 512 || (polys << p->m) < (1ull << 25)) return false;
+  /* a key shared by the batch: its words come from the L2 and the row items get short -- the gain ends at three pairs (2^17: -3 %,
+   * eight pairs -18 %) and between four and eight pairs at 2^16 (+12 % at three, -12 % at eight); 2^15 keeps +6 % at eight */
+  if(bcast) return p->m == kTeamBlock + 3 || k <= (p->m == kTeamBlock + 4 ? 4 : 2);
+  return true;
 }
 
 /* Polynomials between the two passes of a queue in team_dot_kernel.  Its first-pass items stream k operand pairs past the L2,

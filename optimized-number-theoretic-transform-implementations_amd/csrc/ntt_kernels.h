@@ -44,6 +44,21 @@ namespace ntt {
 #ifndef NTT_BLOCK_PERM
 #  define NTT_BLOCK_PERM 0 /* A/B builds: 1 = the small-block loop walks the blocks in a permuted order */
 #endif
+#ifndef NTT_STAGGER
+#define NTT_STAGGER 0 /* A/B builds: the 2^12 persistent loops start (slot & 3) * NTT_STAGGER * 1024 clocks apart, slot = the workgroup's TG_ID on its CU */
+#endif
+#if NTT_STAGGER
+__device__ __forceinline__ void stagger_start()
+{
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 16, 4)" : "=s"(v));
+  for(uint32_t i = 0; i < (v & 3u) * (uint32_t)NTT_STAGGER; i++) __builtin_amdgcn_s_sleep(16);
+}
+#endif
+/* a < b for block counts (both far below 2^63) as a subtraction and a sign test: the 64-bit unsigned comparison has no scalar
+ * instruction, so the compiler copies b into two VGPRs for the whole kernel (v_cmp_lt_u64) -- in the 52-bit class's one-launch
+ * product at 2^14 those were the two registers that spilled */
+__device__ __forceinline__ bool below(uint64_t a, uint64_t b) { return (int64_t)(a - b) < 0; }
 #ifndef NTT_WL12
 #  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
 #endif
@@ -511,6 +526,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
       pin_preloaded<A, LOGN, GL>(pre);
     }
+#if NTT_STAGGER
+    if constexpr(LOGN == 12 && G::WG == 256) stagger_start();
+#endif
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
@@ -591,6 +609,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     prefetch_last<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
     pin_raw(raw);
     if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
+#if NTT_STAGGER
+    if constexpr(LOGN == 12 && G::WG == 256) stagger_start();
+#endif
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
@@ -1425,13 +1446,15 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   const uint64_t stride = gdim;
   uint64_t       b      = bid;
   if(b >= pf.nblocks) return;
+  /* (the loop's comparisons as scalar subtractions where the two VGPRs of a vector comparison are the ones that spill: `below`) */
+  constexpr bool SCMP = BOTH && A::kWide52 && LOGN == 14;
   const uint32_t blk = WHOLE ? 0u : ((uint32_t)b & ((1u << pf.s0) - 1u)); /* the same for every block of this workgroup */
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
   __syncthreads();
   uint64_t raw[kE];
   prefetch_first<LOGN>(raw, tid, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, b));
   pin_raw(raw);
-  for(; b < pf.nblocks; b += stride) {
+  for(; SCMP ? below(b, pf.nblocks) : b < pf.nblocks; b += stride) {
     /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
      * of registers and are therefore requested per block.  They do not depend on the block, so the
      * compiler would hoist both sets (and their 24 lane offsets) out of the loop and spill; the opaque copy of
@@ -1442,8 +1465,15 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     asm volatile("" : "+v"(tl));
     typename A::ctw pre[4][kE / 2];
     preload_group_tw<A, LOGN, GL>(pre, tl, blk, pf);
-    const auto forward = [&](typename A::val(&v)[kE]) {
+    /* (52-bit class, BOTH at 2^14: b's words are requested behind a's first stage group instead of in front of it -- the
+     * reduce-both-operands butterflies of that group need the registers: 2 spilled VGPRs otherwise) */
+    constexpr bool LATE_B = BOTH && A::kWide52 && LOGN == 14;
+    const auto forward = [&](typename A::val(&v)[kE], auto late) {
       run_group<A, LOGN, 0, false, MASKF>(v, tl, blk, pf);
+      if constexpr(decltype(late)::value) {
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b));
+      }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(v, tl, lds_all);
@@ -1460,8 +1490,8 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     typename A::val xa[BOTH ? kE : 1];
     if constexpr(BOTH) {
       convert_inputs<A, false>(xa, raw, false, pf.c);
-      prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b)); /* b's words travel during a's forward stages */
-      forward(xa);
+      if constexpr(!LATE_B) prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b)); /* b's words travel during a's forward stages */
+      forward(xa, std::integral_constant<bool, LATE_B>{});
       /* (b's words are converted after a's last stage, not before: interleaved by the scheduler, x, xa and the raw words
        * lived side by side and spilled) */
       __builtin_amdgcn_sched_barrier(0);
@@ -1471,7 +1501,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
       /* a^ in the last group's layout: requested now, used after the 14 forward stages */
       prefetch_last<LOGN>(raw, tl, pp.ahat + blk_off<LOGN>(pf, b));
     }
-    forward(x);
+    forward(x, std::false_type{});
     /* the inverse's first group: its twiddles land while the product is computed */
     asm volatile("" : "+v"(tl));
     preload_group_tw<A, LOGN, GL>(pre, tl, blk, pi);
@@ -1484,7 +1514,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
      * the scheduler, the two lived side by side and spilled) */
     __builtin_amdgcn_sched_barrier(0);
     {
-      const bool     more = b + stride < pf.nblocks;
+      const bool     more = SCMP ? below(b + stride, pf.nblocks) : b + stride < pf.nblocks;
       const uint64_t nb   = more ? b + stride : b;
       prefetch_first<LOGN>(raw, tl, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, nb), more);
     }
@@ -2602,7 +2632,14 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
     /* tables are filled once per workgroup: a few workgroups per resident slot, each looping */
     if(pa.s != 0) return hipErrorInvalidValue;
     constexpr int per_cu = G::WG_PER_CU0 < 8 ? G::WG_PER_CU0 : 8;
-    cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
+    /* Workgroups that loop over the slab in step produce their loads and stores in bursts; how well the memory system takes
+     * them depends on the allocation (the "two modes" of 2^8..2^10: 0.63 or 0.72 of the roofline from one hipMalloc block to
+     * the next, profiles/r05/small_size_modes.txt).  At 2^8 and 2^9, where a table fill is cheap, sixteen times as many
+     * workgroups (one or two iterations each on a 6 GiB slab) lift the slow mode by 5-7 % (0.633 -> 0.678, 0.636 -> 0.667;
+     * inverse +4.5 %) and leave the fast one where it was; 2^10 and 2^11 lose what the larger tables cost, 2^6 and 2^7 are mixed:
+     * unchanged (profiles/r05/small_size_grid.txt). */
+    constexpr int per_slot = (LOGN == 8 || LOGN == 9) ? 64 : 4;
+    cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * per_slot;
   }
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   cap = cap / nl > 0 ? cap / nl : 1; /* the limbs of one launch share the resident workgroups */

@@ -195,10 +195,7 @@ def test_headline_kernels_do_not_spill():
     ks = [k for k in every if k not in multi]
     assert len(ks) >= 80 and len(multi) >= 40
     for k in multi:
-        if "fused_product_kernel" in k["name"] and "WideF64" in k["name"] and "ELi14E" in k["name"]:
-            assert k["vgpr_spill_count"] <= 4, k      # (the same known exception as its single-set twin below)
-        else:
-            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
     fused = [k for k in ks if "fused_kernel" in k["name"] and "ArithF64" in k["name"]]
     big = [k for k in fused if any(("ELi%dE" % ln) in k["name"] for ln in (12, 13, 14))]
     # 3 block sizes x (3 headroom classes + the wide policy for q up to 2^52) x {fwd, fwd with lazy outputs, inv},
@@ -206,12 +203,8 @@ def test_headline_kernels_do_not_spill():
     assert len(big) == 3 * 4 * 3 + 4 + 4
     for k in big:
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
-    # one known exception among the single-set kernels: the one-launch product at 2^14 for 52-bit moduli (both operands
-    # through the reduce-both-operands butterflies) keeps 4 spilled VGPRs (measured faster than the
-    # two-launch form all the same)
-    known = [k for k in ks if "fused_product_kernel" in k["name"] and "WideF64" in k["name"] and "ELi14E" in k["name"] and k["vgpr_spill_count"]]
-    assert len(known) <= 1 and all(k["vgpr_spill_count"] <= 4 for k in known)
+    # (rounds 2-4 had one exception, the one-launch product at 2^14 for 52-bit moduli: its two spilled VGPRs were the block count,
+    # copied into vector registers for a 64-bit unsigned comparison that has no scalar form -- csrc/ntt_kernels.h `below`)
     for k in ks:
         assert k["group_segment_fixed_size"] <= 160 * 1024, k
-        if k not in known:
-            assert k["vgpr_spill_count"] == 0, k      # no other kernel of the library spills vector registers
+        assert k["vgpr_spill_count"] == 0, k   # no kernel of the library spills vector registers

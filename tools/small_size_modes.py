@@ -10,6 +10,8 @@ ap.add_argument("--logn", type=int, default=9)
 ap.add_argument("--gib", type=float, default=8.0)
 ap.add_argument("--max-grid", type=int, nargs="+", default=[0], help="workgroup caps to try (0 = the library's grid)")
 ap.add_argument("--allocs", type=int, default=2, help="allocations of --gib each to visit")
+ap.add_argument("--ops", nargs="+", default=["fwd"], choices=["fwd", "inv"])
+ap.add_argument("--no-offsets", action="store_true", help="skip the byte-offset walk over the first allocation")
 a = ap.parse_args()
 n = 1 << a.logn
 q = 0x80000001c0001
@@ -19,21 +21,23 @@ batch = words // n
 pad = (64 << 20) // 8
 buf = lib.DeviceBuffer(words + pad)
 lib.fill_uniform(buf.ptr, words + pad, q, 3)
-def rate(ptr, grid=0):
+def rate(ptr, grid=0, op="fwd"):
     plan.set_option(lib.OPT_MAX_GRID, grid)
-    for _ in range(2): plan.fwd(ptr, batch)
+    run = plan.fwd if op == "fwd" else plan.inv
+    for _ in range(4): run(ptr, batch)
     e0, e1 = lib.Event(), lib.Event()
     lib.stream_sync(); e0.record()
-    for _ in range(10): plan.fwd(ptr, batch)
+    for _ in range(10): run(ptr, batch)
     e1.record(); ms = e1.elapsed_ms_since(e0) / 10
     return 16 * n * batch / ms / 1e6 / 8000
 print("pid %d base %#x (mod 2 MiB: %#x)" % (os.getpid(), buf.ptr, buf.ptr % (2 << 20)))
-for rep in range(2):
+for rep in range(0 if a.no_offsets else 2):
     for off in (0, 4096, 65536, 1 << 20, 2 << 20, (2 << 20) + 4096, 32 << 20, 48 << 20):
         print("  rep %d offset %9d B: frac %.3f" % (rep, off, rate(buf.ptr + off)))
 bufs = [buf] + [lib.DeviceBuffer(words) for _ in range(a.allocs - 1)]
 for b in bufs[1:]: lib.fill_uniform(b.ptr, words, q, 4)
 print("library %s" % os.environ.get("NTT_LIB", "(tree)"))
-for g in a.max_grid:
-    print("grid cap %6d: " % g + "  ".join("alloc %d (base %#x) %.3f" % (i, b.ptr, rate(b.ptr, g)) for i, b in enumerate(bufs))
-          + "  | again: " + " ".join("%.3f" % rate(b.ptr, g) for b in bufs))
+for op in a.ops:
+    for g in a.max_grid:
+        print("%s grid cap %6d: " % (op, g) + "  ".join("alloc %d (base %#x) %.3f" % (i, b.ptr, rate(b.ptr, g, op)) for i, b in enumerate(bufs))
+              + "  | again: " + " ".join("%.3f" % rate(b.ptr, g, op) for b in bufs))
