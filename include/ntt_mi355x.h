@@ -79,8 +79,13 @@ typedef enum ntt_option {
                            * served by the Infinity Cache -- the gain there is one launch instead of two per chunk);
                            * 0 = one launch per pass; -1 (default) = where it measured faster: forward transforms of 512
                            * polynomials or more (wide integer policy: +18..23 %, where the memory-bound column items overlap the
-                           * multiplier-bound row items; also its inverse at 2^17).  Results are identical. */
-  NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: 10, 8, 10 at 2^15, 2^16, 2^17) */
+                           * multiplier-bound row items; also its inverse at 2^17).  The NTT-domain products (ntt_inv_product_batch,
+                           * ntt_inv_dot_batch, their RNS forms) follow the same switch: 1 = the k products with the inverse's block
+                           * stages and the inverse's column stages as the items of one launch, 0 = two launches per 128 / 256 MiB
+                           * chunk, -1 = one launch from 2^25 coefficients per operand on (measured +11..26 %,
+                           * profiles/r05/domain_bench_xcd_local.txt).  Results are identical. */
+  NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: transforms 10, 8, 10 at 2^15,
+                                     * 2^16, 2^17; NTT-domain products 20-24, 10-14, 6-8 -- about 5-6 MiB of c per queue) */
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */
   NTT_OPT_INT_WIDE = 10, /* integer policy, 2^40 <= q < 2^61: 1 = transforms through the throughput form of the integer
                           * arithmetic (estimated Shoup quotient, no conditional subtraction per butterfly: the bits between q

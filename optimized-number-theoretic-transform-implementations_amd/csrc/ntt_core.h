@@ -896,6 +896,17 @@ struct alignas(16) u64x2 {
  * issue them (ntt_kernels.h, buffer loads).  These generic helpers stay plain. */
 NTT_HD uint64_t stream_load(const uint64_t *p) { return *p; }
 NTT_HD u64x2    stream_load2(const uint64_t *p) { return *reinterpret_cast<const u64x2 *>(p); }
+/* the same marked non-temporal (global_load_dwordx4 ... nt: the line is the first the L2 gives up) */
+NTT_HD u64x2 stream_load2_nt(const uint64_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+  const v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(p));
+  return u64x2{v.x, v.y};
+#else
+  return stream_load2(p);
+#endif
+}
 NTT_HD void     stream_store(uint64_t *p, uint64_t v) { *p = v; }
 NTT_HD void     stream_store2(uint64_t *p, u64x2 v) { *reinterpret_cast<u64x2 *>(p) = v; }
 
@@ -1017,7 +1028,7 @@ template <class A> NTT_HD void dot_fold_tile(typename A::val (&x)[kE], const typ
   static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::dot_fold(x[decltype(ee)::value], c); });
 }
 /* raw words of a block in the last-kind layout (runs of 2^RL consecutive indices per lane, 16-byte loads), slots [E0, E1) */
-template <int LOGN, int E0 = 0, int E1 = kE> NTT_HD void load_last_raw(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
+template <int LOGN, int E0 = 0, int E1 = kE, bool NT = false> NTT_HD void load_last_raw(uint64_t (&raw)[kE], uint32_t t, const uint64_t *blk)
 {
   using P           = Plan<LOGN>;
   constexpr int G   = P::NG - 1;
@@ -1025,7 +1036,7 @@ template <int LOGN, int E0 = 0, int E1 = kE> NTT_HD void load_last_raw(uint64_t 
   static_assert(E0 % 2 == 0 && E1 % 2 == 0, "slots come in pairs");
   static_for<E0 / 2, E1 / 2>([&](auto hh) {
     constexpr int E = 2 * decltype(hh)::value;
-    const u64x2   v = stream_load2(coef_at(blk + P::IOFF(G, E), ib));
+    const u64x2   v = NT ? stream_load2_nt(coef_at(blk + P::IOFF(G, E), ib)) : stream_load2(coef_at(blk + P::IOFF(G, E), ib));
     raw[E]          = v.a;
     raw[E + 1]      = v.b;
   });

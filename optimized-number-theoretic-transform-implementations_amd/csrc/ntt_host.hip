@@ -1581,11 +1581,11 @@ static bool dot_team_pays(const ntt_plan *p, uint64_t polys, int k, bool bcast)
   return true;
 }
 
-/* Polynomials between the two passes of a queue in team_dot_kernel.  Its first-pass items stream k operand pairs past the L2,
- * so only c competes for it, and the optimum sits where lag x polynomial size is 5-6 MiB per queue -- well above the plain
- * transform's (team_kernel: 8-10 polynomials): too short and second-pass items wait for rows still in flight, too long and c has
- * left the Infinity Cache slice when it is read back.  Fine sweep, k = 1..4, three operand kinds:
- * profiles/r05/teamdot_lag_fine.txt, teamdot_lag_other.txt (a lag two steps off the optimum costs 5-15 %). */
+/* Polynomials between the two passes of a queue in team_dot_kernel.  Measured optimum: lag x polynomial size = 5-6 MiB per
+ * queue at all three sizes (24 / 12 / 6 polynomials), a little more for one or two pairs, a shared key and the integer policy,
+ * whose row items are short -- too short a lag and second-pass items wait for rows still in flight, too long and c has left the
+ * Infinity Cache slice when it is read back.  Fine sweep, k = 1..4, three operand kinds: profiles/r05/teamdot_lag_fine.txt,
+ * teamdot_lag_other.txt (a lag two steps off the optimum costs 5-15 %; the plain transform's 8-10 polynomials lose 22 % at 2^15). */
 static int dot_team_lag(const ntt_plan *p, int k, bool bcast)
 {
   const bool longer = k <= 2 || bcast || p->arith == NTT_ARITH_U64;

@@ -59,6 +59,9 @@ __device__ __forceinline__ void stagger_start()
  * instruction, so the compiler copies b into two VGPRs for the whole kernel (v_cmp_lt_u64) -- in the 52-bit class's one-launch
  * product at 2^14 those were the two registers that spilled */
 __device__ __forceinline__ bool below(uint64_t a, uint64_t b) { return (int64_t)(a - b) < 0; }
+#ifndef NTT_TEAMDOT_NT
+#define NTT_TEAMDOT_NT 0 /* A/B builds: team_dot_kernel's operand loads non-temporal (1: a and a per-polynomial b; 2: a only) */
+#endif
 #ifndef NTT_WL12
 #  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
 #endif
@@ -2126,8 +2129,9 @@ __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa,
       constexpr int H = decltype(hh)::value;
       uint64_t      ra[kE], rb[kE];
       sched_fence();
-      load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, tid, kd.a[i] + aoff + offa);
-      load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
+      load_last_raw<LOGN, 8 * H, 8 * H + 8, (NTT_TEAMDOT_NT != 0)>(ra, tid, kd.a[i] + aoff + offa);
+      if(NTT_TEAMDOT_NT == 1 && !kd.b_bcast) load_last_raw<LOGN, 8 * H, 8 * H + 8, true>(rb, tid, kd.b[i] + boff + offb);
+      else load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
       dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
     });
   }

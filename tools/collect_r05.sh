@@ -9,7 +9,8 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 900 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 for c in 4 2 3 5 5_bm; do
   cfg=${c%_bm}; lay=""; [ $c = 5_bm ] && lay="--layout batch-major"
-  st="--steps 20 --warmup 3"; [ $cfg = 5 ] && st="--steps 10 --warmup 2"; [ $cfg = 2 ] && st="--steps 40 --warmup 10"
+  # warm-ups cover >= 60 ms of device work (the clocks settle for ~20 ms after the idle gap of the parity check: clock_settling_after_idle.txt)
+  st="--steps 20 --warmup 9"; [ $cfg = 5 ] && st="--steps 10 --warmup 18"; [ $cfg = 2 ] && st="--steps 100 --warmup 80"
   timeout 900 python3 bench.py --config $cfg $lay $st --no-also > $out/bench_config$c.json 2> $out/bench_config$c.err
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt$c -- python3 bench.py --config $cfg $lay $st --no-cpu-baseline --headline-only > $out/bench_config${c}_under_rocprofv3.json 2> $out/kt$c.log
   for ctr in FETCH_SIZE WRITE_SIZE; do

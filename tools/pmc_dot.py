@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""NTT-domain product kernels under rocprofv3 (tools/collect_r04.sh: tools/domain_bench.py --logn 14 16 --k 1 3 --steps 4):
+"""NTT-domain product kernels under rocprofv3 (tools/collect_r05.sh: tools/domain_bench.py --logn 14 16 --k 1 3 --steps 4):
 duration from the kernel trace, FETCH_SIZE (x2: gfx950 reports half of a coalesced streaming read, MI355X_MICROARCH.md) and
 WRITE_SIZE from the two PMC passes, PER CALL of ntt_inv_dot_batch.  domain_bench.py issues, per size, 6 fused calls (2 warm-ups
 + 4 timed) for each of (k=1), (k=1, broadcast b^), (k=3), (k=3, broadcast b^) in that order: the dispatches of a kernel are
@@ -30,7 +30,7 @@ ctr = {c: rows("%s/pmc_dot/%s/**/*counter_collection.csv" % (root, c), lambda r,
        for c in ("FETCH_SIZE", "WRITE_SIZE")}
 print("# kernel | operands | dispatches per call | ms per call | FETCH_SIZE x2 MiB per call | WRITE_SIZE MiB per call")
 for k in sorted(dur):
-    if "dot_inv_kernel" not in k:
+    if "dot_inv_kernel" not in k and "team_dot_kernel" not in k:      # (round 5: above 2^14 the whole call is ONE team_dot_kernel launch)
         continue
     d = dur[k]
     if len(d) % (CALLS * len(GROUPS)):
