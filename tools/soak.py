@@ -4,7 +4,8 @@
 Every round draws a transform size 2^1..2^18, a prime of 20..60 bits with 2N | q-1, an arithmetic policy the
 library offers for it, a ragged batch (with a bias to the persistent grids' edges: 255, 256, 257, 511, ...), plan
 options (chunk size, grid cap, two-phase, XCD-local launch with random lag and residency, column-only engine, fused
-product on/off), now and then an RNS set (one launch over all limbs or the per-prime loop) and checks, bit for bit against
+product on/off, workgroups per resident slot), now and then an RNS set (one launch over all limbs or the per-prime loop, in
+[limb][batch][N] or [batch][limb][N] layout) or a shuffled pointer batch and checks, bit for bit against
 the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms, the products of
 operands given in the NTT domain (inner products of k pairs, canonical / lazy / broadcast; one operand transformed beforehand).
 usage: python3 tools/soak.py [--seconds 300] [--seed 1] [--max-coeffs 2^22]"""
@@ -79,13 +80,16 @@ while time.time() < t_end:
         opts["block"] = int(rng.choice([12, 14]))
         plan.set_option(lib.OPT_BLOCK_LOG, opts["block"])
     if rng.random() < 0.3:
+        opts["oversub"] = int(rng.choice([1, 2, 3, 8, 16, 64]))      # workgroups per resident slot of the persistent block kernels
+        plan.set_option(lib.OPT_BLOCK_OVERSUB, opts["oversub"])
+    if rng.random() < 0.3:
         opts["fused_product"] = int(rng.choice([0, 0, 2]))      # 2: a's forward transform as a launch of its own
         plan.set_option(lib.OPT_FUSED_PRODUCT, opts["fused_product"])
     if m in (15, 16, 17) and rng.random() < 0.6:
         # both passes as items of one launch (needs batch >= 64; forced on for both directions, random lag / residency)
         opts["xcd_local"] = int(rng.choice([1, 1, 0]))
         plan.set_option(lib.OPT_XCD_LOCAL, opts["xcd_local"])
-        opts["lag"], opts["wpc"] = int(rng.integers(0, 13)), int(rng.integers(0, 5))
+        opts["lag"], opts["wpc"] = int(rng.choice(list(range(13)) + [16, 24, 32, 48])), int(rng.integers(0, 5))
         plan.set_option(lib.OPT_XCD_LOCAL_LAG, opts["lag"])
         plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, opts["wpc"])
         if opts["xcd_local"] == 1:
@@ -127,6 +131,23 @@ while time.time() < t_end:
     if int(out.max()) >= 2 * q or not np.array_equal(out % np.uint64(q), a):
         fail("inv lazy", **ctxt)
     checks += 6
+    if rng.random() < 0.25 and batch >= 2:
+        # the same batch as separately placed polynomials: a pointer per polynomial, shuffled, over a padded pool (ntt_transform_ptrs)
+        gap = int(rng.choice([0, 0, 8, n, 3 * n + 2]))
+        pool = lib.DeviceBuffer(batch * (n + gap))
+        order = rng.permutation(batch)
+        host = np.zeros(batch * (n + gap), dtype=np.uint64)
+        for i, slot in enumerate(order):
+            host[slot * (n + gap): slot * (n + gap) + n] = a[i * n:(i + 1) * n]
+        pool.upload(host)
+        plan.transform_ptrs([pool.ptr + 8 * int(slot) * (n + gap) for slot in order])
+        res = pool.download()
+        for i in (0, batch // 2, batch - 1):
+            slot = int(order[i])
+            if not np.array_equal(res[slot * (n + gap): slot * (n + gap) + n], want[i * n:(i + 1) * n]):
+                fail("transform_ptrs", gap=gap, poly=i, **ctxt)
+        pool.free()
+        checks += 1
     if True:   # every policy has a product chain (radix-4: its own transforms around the pointwise product, N <= 2^14)
         b = orc.fill_uniform(batch * n, q, int(rng.integers(1, 1 << 40)))
         prod = cx.inv(orc.pointwise(want, cx.fwd(b), q))
@@ -251,19 +272,28 @@ while time.time() < t_end:
                 rbv = np.concatenate([orc.fill_uniform(rb * n, x, int(rng.integers(1, 1 << 40))) for x in qs])
                 rloop = int(rng.integers(0, 2))
                 lib.set_rns_launch(plans, rloop)
-                da, db, dc = lib.DeviceBuffer(ra.size).upload(ra), lib.DeviceBuffer(ra.size).upload(rbv), lib.DeviceBuffer(ra.size)
-                lib.rns_fwd(plans, da.ptr, rb)
-                f = da.download()
-                lib.rns_inv(plans, da.ptr, rb)
-                back = da.download()
-                lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, rb)
-                pr = dc.download()
-                da.upload(ra), db.upload(f)
-                lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, rb)        # inv(fwd(a) (.) fwd(a)): the square
-                sq = dc.download()
-                da.upload(f), db.upload(f)
-                lib.rns_inv_dot(plans, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], rb)   # inv(2 a^ (.) a^)
-                dt = dc.download()
+                # half of the rounds in the caller-native layout [batch][limb][N] (the *_strided entry points)
+                bm = bool(rng.random() < 0.5)
+                lay = (n, nl * n) if bm else None
+
+                def place(x):      # [limb][batch][N] -> the layout's image, and back
+                    return np.ascontiguousarray(x.reshape(nl, rb, n).transpose(1, 0, 2)).reshape(-1) if bm else x
+
+                def gather(x):
+                    return np.ascontiguousarray(x.reshape(rb, nl, n).transpose(1, 0, 2)).reshape(-1) if bm else x
+                da, db, dc = lib.DeviceBuffer(ra.size).upload(place(ra)), lib.DeviceBuffer(ra.size).upload(place(rbv)), lib.DeviceBuffer(ra.size)
+                lib.rns_fwd(plans, da.ptr, rb, layout=lay)
+                f = gather(da.download())
+                lib.rns_inv(plans, da.ptr, rb, layout=lay)
+                back = gather(da.download())
+                lib.rns_negacyclic_mul(plans, dc.ptr, da.ptr, db.ptr, rb, layout=lay)
+                pr = gather(dc.download())
+                da.upload(place(ra)), db.upload(place(f))
+                lib.rns_mul_transformed(plans, dc.ptr, da.ptr, db.ptr, rb, layout=lay)        # inv(fwd(a) (.) fwd(a)): the square
+                sq = gather(dc.download())
+                da.upload(place(f)), db.upload(place(f))
+                lib.rns_inv_dot(plans, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], rb, layout=lay)   # inv(2 a^ (.) a^)
+                dt = gather(dc.download())
                 for l, (x, y) in enumerate(zip(qs, ws)):
                     c2 = orc.ctx(n, x, y)
                     sl = slice(l * rb * n, (l + 1) * rb * n)
@@ -272,7 +302,7 @@ while time.time() < t_end:
                        not np.array_equal(pr[sl], c2.inv(orc.pointwise(fa, c2.fwd(rbv[sl]), x))) or \
                        not np.array_equal(sq[sl], c2.inv(orc.pointwise(fa, fa, x))) or \
                        not np.array_equal(dt[sl], c2.inv(orc.dot([fa, fa], [fa, fa], x))):
-                        fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=rloop, q=hex(x))
+                        fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=rloop, batch_major=bm, q=hex(x))
                 for d in (da, db, dc):
                     d.free()
                 for pl in plans:
