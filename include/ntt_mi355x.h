@@ -301,7 +301,8 @@ NTT_API int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uint64
  * apart: one launch; no regularity at all: one launch chain per polynomial -- prefer ntt_transform_batch_strided when the placement is
  * known).  Pointers must be 8-byte aligned; overlapping polynomials (or a pointer listed twice) are refused.  flags = NTT_FLAG_*.
  * ntt_rns_transform_ptrs: h_polys[i] points at limb 0 of RNS polynomial i, whose limbs are limb_stride words apart ([limb][N] per
- * polynomial: limb_stride = N); flags: NTT_FLAG_INVERSE only. ---- */
+ * polynomial: limb_stride = N; pointers INTO a [limb][batch][N] slab: limb_stride = batch * N -- the polynomials then interleave
+ * without overlapping, which the check, made limb image by limb image, accepts); flags: NTT_FLAG_INVERSE only. ---- */
 NTT_API int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, uint64_t count, unsigned flags, void *stream);
 NTT_API int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64_t *const *h_polys, uint64_t count, uint64_t limb_stride,
                                    unsigned flags, void *stream);

@@ -2004,7 +2004,8 @@ extern "C" int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uin
  * and every progression is ONE strided launch chain (a pool of equally spaced ciphertexts, the rows of a caller's matrix, two
  * arrays a fixed distance apart: one launch; pointers with no regularity: one launch chain each).  Overlapping polynomials are
  * refused. */
-static int ptr_runs(uint64_t N, uint64_t span_words, uint64_t *const *h_polys, uint64_t count, std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> &runs)
+static int ptr_runs(uint64_t N, int nlimbs, uint64_t limb_stride, uint64_t *const *h_polys, uint64_t count,
+                    std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> &runs)
 {
   if(!h_polys) return fail(NTT_ERR_ARG, "null argument");
   std::vector<uintptr_t> v(count);
@@ -2013,10 +2014,24 @@ static int ptr_runs(uint64_t N, uint64_t span_words, uint64_t *const *h_polys, u
     v[i] = (uintptr_t)h_polys[i];
   }
   std::sort(v.begin(), v.end());
-  for(uint64_t i = 0; i + 1 < count; i++) {
-    if(v[i + 1] - v[i] < span_words * 8) return fail(NTT_ERR_ARG, "pointer batch: polynomials overlap (or a pointer is listed twice)");
+  /* overlap: every limb image [pointer + l * limb_stride, + N) of every polynomial is an interval of N words; sorted by start,
+   * two of them intersect iff two neighbours do.  (Exact also for pointers INTO a [limb][batch][N] slab, whose polynomials
+   * interleave without overlapping.) */
+  {
+    std::vector<uintptr_t> img;
+    const std::vector<uintptr_t> *starts = &v;
+    if(nlimbs > 1) {
+      img.reserve((size_t)count * (size_t)nlimbs);
+      for(uint64_t i = 0; i < count; i++) {
+        for(int l = 0; l < nlimbs; l++) img.push_back(v[i] + (uintptr_t)l * (uintptr_t)limb_stride * 8u);
+      }
+      std::sort(img.begin(), img.end());
+      starts = &img;
+    }
+    for(size_t i = 0; i + 1 < starts->size(); i++) {
+      if((*starts)[i + 1] - (*starts)[i] < N * 8) return fail(NTT_ERR_ARG, "pointer batch: polynomials overlap (or a pointer is listed twice)");
+    }
   }
-  (void)N;
   for(uint64_t i = 0; i < count;) {
     uint64_t j = i, d = 0;
     if(i + 1 < count) {
@@ -2037,7 +2052,7 @@ extern "C" int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, u
   if(!p) return fail(NTT_ERR_ARG, "null argument");
   if(count == 0) return NTT_OK;
   std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
-  int rc = ptr_runs(p->N, p->N, h_polys, count, runs);
+  int rc = ptr_runs(p->N, 1, 0, h_polys, count, runs);
   for(size_t r = 0; !rc && r < runs.size(); r++) {
     const LimbSet own{p->limbrec.data(), 1, 0, runs[r].second.first};
     rc = run_transform(p, runs[r].first, runs[r].second.second, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream,
@@ -2057,10 +2072,21 @@ extern "C" int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64
   if(limb_stride < N || limb_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the limb stride must be at least N words");
   const uint64_t span = (uint64_t)(nlimbs - 1) * limb_stride + N; /* words one RNS polynomial covers */
   std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
-  rc = ptr_runs(N, span, h_polys, count, runs);
+  rc = ptr_runs(N, nlimbs, limb_stride, h_polys, count, runs);
   for(size_t r = 0; !rc && r < runs.size(); r++) {
-    const uint64_t d = runs[r].second.first ? runs[r].second.first : span;
-    rc = rns_transform(nlimbs, plans, runs[r].first, runs[r].second.second, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, d});
+    uint64_t *first = runs[r].first;
+    uint64_t  d = runs[r].second.first ? runs[r].second.first : span, cnt = runs[r].second.second;
+    /* a progression the strided entry point takes whole is limb-major (the limbs' slabs apart: pointers into a [limb][batch][N]
+     * slab) or polynomial-major (every polynomial's limbs inside its own record); any other spacing is legal here -- the
+     * images were checked one by one above -- but not expressible as ONE layout: polynomial by polynomial then */
+    const bool whole = cnt <= 1 || limb_stride >= (cnt - 1) * d + N || d >= span;
+    if(whole) {
+      rc = rns_transform(nlimbs, plans, first, cnt, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, cnt > 1 ? d : span});
+    } else {
+      for(uint64_t i = 0; !rc && i < cnt; i++) {
+        rc = rns_transform(nlimbs, plans, first + i * d, 1, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, span});
+      }
+    }
   }
   return rc;
 }

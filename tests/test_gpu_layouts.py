@@ -352,3 +352,39 @@ def test_pointer_batch_of_rns_polynomials(lib, oracle, m, nl, bits):
     with pytest.raises(lib.NttError):
         lib.rns_transform_ptrs(plans, [ptrs[0], ptrs[0] + 8 * n], n)      # two RNS polynomials that overlap
     pool.free(), lone.free()
+    # pointers INTO a [limb][batch][N] slab (limb stride = batch * N): the polynomials interleave without overlapping; all of them
+    # (one progression = one limb-major launch), then an irregular subset (polynomial by polynomial), against the slab call
+    batch = 7
+    slab = np.stack([oracle.fill_uniform(batch * n, q, 9700 + l) for l, q in enumerate(qs)])           # [limb][batch * n]
+    d = lib.DeviceBuffer(nl * batch * n).upload(slab.reshape(-1))
+    lib.rns_transform_ptrs(plans, [d.ptr + 8 * i * n for i in (3, 0, 6, 1, 5, 2, 4)], batch * n)
+    got = d.download().reshape(nl, batch * n)
+    for l in (0, nl - 1):
+        assert np.array_equal(got[l], ctxs[l].fwd(slab[l].copy())), l
+    d.upload(slab.reshape(-1))
+    lib.rns_transform_ptrs(plans, [d.ptr + 8 * i * n for i in (0, 1, 3, 6)], batch * n)
+    got = d.download().reshape(nl, batch, n)
+    for l in range(nl):
+        exp = slab[l].reshape(batch, n).copy()
+        for i in (0, 1, 3, 6):
+            exp[i] = ctxs[l].fwd(exp[i].copy())
+        assert np.array_equal(got[l], exp), l
+    with pytest.raises(lib.NttError):
+        lib.rns_transform_ptrs(plans, [d.ptr, d.ptr + 8 * (n // 2)], batch * n)          # limb images that do overlap
+    d.free()
+    # a spacing that is neither limb-major nor polynomial-major but still disjoint (two limbs 3N apart, polynomials 2N apart:
+    # images {0, 3N}, {2N, 5N}, {4N, 7N}): served polynomial by polynomial
+    two = plans[:2]
+    words = np.full(8 * n, GUARD, dtype=np.uint64)
+    polys = [[oracle.fill_uniform(n, qs[l], 9800 + 10 * i + l) for l in range(2)] for i in range(3)]
+    for i in range(3):
+        for l in range(2):
+            words[(2 * i + 3 * l) * n:(2 * i + 3 * l + 1) * n] = polys[i][l]
+    d = lib.DeviceBuffer(8 * n).upload(words)
+    lib.rns_transform_ptrs(two, [d.ptr + 8 * 2 * i * n for i in range(3)], 3 * n)
+    got = d.download()
+    for i in range(3):
+        for l in range(2):
+            assert np.array_equal(got[(2 * i + 3 * l) * n:(2 * i + 3 * l + 1) * n], ctxs[l].fwd(polys[i][l].copy())), (i, l)
+    assert (got[n:2 * n] == GUARD).all() and (got[6 * n:7 * n] == GUARD).all()
+    d.free()
