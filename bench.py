@@ -722,6 +722,9 @@ def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
            "traffic": traffic, "traffic_over_algorithmic": (traffic / (batch * w.bytes_per_unit)) if traffic else None,
            "layout": "[batch][limb][N]" if layout else ("[limb][batch][N]" if w.kind == "rns_product" else "[batch][N]"),
            "kernel_ms": kernel_ms[0], "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": max(warmup, 1 if check else 0),
+           # (what the untimed steps amounted to: the first carries the parity check, the rest must outlast the ~20 ms the clocks
+           # need after that idle gap -- profiles/r05/clock_settling_after_idle.txt, bench_warmup_length.txt)
+           "warmup_device_ms": kernel_ms[0] * max(warmup - 1, 0),
            "step_ms_min": min(step_ms), "frac_at_min": batch * w.bytes_per_unit / (min(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_unit": w.bytes_per_unit, "batch_per_gpu": batch, "N": w.n,
            "q": [hex(q) for q in w.qs], "parity_checked": bool(check), "kernel": kname, "launches_per_step": launches,

@@ -162,7 +162,13 @@ def test_bench_report_for_other_configs():
     assert rep["unit"] == "round trips/s" and rep["metric"] == w3.metric and rep["config"]["workload"].startswith("config3")
     assert rep["value"] == pytest.approx(8192 / (0.02 / 4))
     r = rep["roofline"]
-    assert r["algorithmic_bytes_per_step"] == 8192 * 32 * 65536 and r["traffic"] is None and r["traffic_source"] is None
+    # the traffic figure is the committed counter pass of THIS configuration and batch (profiles/r05/pmc_traffic_config3.json:
+    # 2.00 x the algorithmic bytes at 2^16) -- and absent for any other batch: no stale figure
+    assert r["algorithmic_bytes_per_step"] == 8192 * 32 * 65536
+    assert r["traffic"] == bench.measured_traffic_config(3, 8192, 65536) and 1.9 < r["traffic"] / r["algorithmic_bytes_per_step"] < 2.1
+    assert "pmc_traffic" in r["traffic_source"]
+    other = bench.make_report(args, 1, 4096, 0.02, [5.0], 2, 2, n=w3.n, workload=w3, step_ms=[5.2, 4.9, 5.0, 5.1], f64_class=52)["roofline"]
+    assert other["traffic"] is None and other["traffic_source"] is None
     assert r["step_ms_min"] == 4.9 and r["step_ms_median"] == pytest.approx(5.05) and r["launches_per_step"] == 33
     assert r["frac"] == pytest.approx(8192 * 32 * 65536 / 5.0e-3 / 1e9 / 8000.0)
     assert "reduced" in rep["config"]["arith"]
