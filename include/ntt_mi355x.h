@@ -83,7 +83,9 @@ typedef enum ntt_option {
                            * ntt_inv_dot_batch, their RNS forms) follow the same switch: 1 = the k products with the inverse's block
                            * stages and the inverse's column stages as the items of one launch, 0 = two launches per 128 / 256 MiB
                            * chunk, -1 = one launch from 2^25 coefficients per operand on (measured +11..26 %,
-                           * profiles/r05/domain_bench_xcd_local.txt).  Results are identical. */
+                           * profiles/r05/domain_bench_xcd_local.txt); so does ntt_fwd_mul_batch (the forward column stages of a and
+                           * the blocks with the product as one launch: +8..28 %, automatic from 2^26 coefficients on).  Results are
+                           * identical. */
   NTT_OPT_XCD_LOCAL_LAG = 8,        /* tuning: polynomials between the two passes of a queue (0 = default: transforms 10, 8, 10 at 2^15,
                                      * 2^16, 2^17; NTT-domain products 20-24, 10-14, 6-8 -- about 5-6 MiB of c per queue) */
   NTT_OPT_XCD_LOCAL_WGS_PER_CU = 9, /* tuning: resident workgroups per CU, 1..4 (0 = default 4) */

@@ -1787,6 +1787,19 @@ extern "C" int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint6
  * reduce and store its outputs (fwd_mul_kernel).  One launch up to N = 2^14; above, the forward column passes run on a in
  * place (a is scratch there) and the product rides in the block pass, the forward transform's last one.  Plans without the
  * kernel: forward transform of a in place, then a pointwise (accumulate) launch. */
+/* the one-launch form of c^ = fwd(a) (.) b^ (+ c^) at N = 2^15..2^17 against the per-chunk launches: the automatic choice and the lag
+ * between the two passes of a queue, as measured (profiles/r05/domain_bench_xcd_local_mul.txt) */
+static bool mul_team_pays(const ntt_plan *p, uint64_t polys, bool bcast, bool acc)
+{
+  /* +8..16 % (FP64), +16..28 % (wide integer policy) on large batches, all four operand kinds alike; even at 2^26 coefficients
+   * per operand (2048 / 1024 / 512 polynomials at 2^15 / 2^16 / 2^17: +0 / +5 / +9 %), a loss below
+   * (domain_bench_xcd_local_mul_batch.txt) */
+  (void)bcast, (void)acc;
+  return polys >= 512 && (polys << p->m) >= (1ull << 26);
+}
+/* (flat between 8 and 16 polynomials at 2^15 and 2^16; 2^17 loses 1-2 % per step beyond 8) */
+static int mul_team_lag(const ntt_plan *p) { return p->m == kTeamBlock + 3 ? 10 : 8; }
+
 static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64_t *d_bhat, uint64_t batch, unsigned flags,
                    void *stream, const LimbSet *set = nullptr, uint64_t b_limb_stride = 0)
 {
@@ -1830,6 +1843,59 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     if(chunk < 1) chunk = 1;
     if(chunk > batch) chunk = batch;
   }
+  const int ic = eff_int_cls(p), kc = eff_kcls(p);
+  const auto dispatch = [&](const MulArgs &ma) {
+    return p->arith == NTT_ARITH_U64 ? (ic == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
+                                        : ic == 1 ? launch_fwd_mul<ArithU64X<1>, 1>(ma)
+                                        : ic == 0 ? launch_fwd_mul<ArithU64X<0>, 0>(ma)
+                                                  : launch_fwd_mul<ArithU64, 0>(ma))
+           : kc == kWideClass        ? launch_fwd_mul<ArithF64W, 0>(ma)
+           : kc == 18                ? launch_fwd_mul<ArithF64, 18>(ma)
+           : kc == 1                 ? launch_fwd_mul<ArithF64, 1>(ma)
+                                     : launch_fwd_mul<ArithF64, 0>(ma);
+  };
+  /* N = 2^15..2^17, batches that keep the eight queues busy: the forward column stages of a and the blocks with the product as
+   * the items of ONE launch (team_mul_kernel) instead of two launches per chunk.  NTT_OPT_XCD_LOCAL 1 / 0 forces either form; a
+   * stream being captured without a control block of its own takes the per-chunk launches (team_buffer). */
+  {
+    const bool     int_wide = p->arith == NTT_ARITH_U64 && p->int_cls >= 0;
+    const uint64_t polys    = batch * (uint64_t)ls.n;
+    bool team = (p->arith == NTT_ARITH_F64 || int_wide) && p->m >= kTeamBlock + 3 && p->m <= kTeamBlock + 5 && !p->block_log && polys >= 64 &&
+                polys < (1ull << 29) && ls.n <= kMaxLimbs;
+    if(team && p->xcd_local >= 0) team = p->xcd_local == 1;
+    else if(team) team = mul_team_pays(p, polys, bcast, acc);
+    void *ctl = nullptr;
+    if(team) {
+      int rc = team_buffer(p, stream, polys, &ctl);
+      if(rc) return rc;
+    }
+    if(ctl) {
+      MulArgs ma{};
+      ma.a             = d_a;
+      ma.b             = d_bhat;
+      ma.out           = d_c;
+      ma.lazy_in       = lazy;
+      ma.b_bcast       = bcast;
+      ma.accumulate    = acc;
+      ma.limbs         = ls.d;
+      ma.nlimbs        = ls.n;
+      ma.limb_stride   = ls.stride;
+      ma.poly_stride   = ls.pstride;
+      ma.b_limb_stride = ls.n > 1 ? b_limb_stride : 0;
+      ma.batch         = batch;
+      ma.logn          = (uint32_t)p->m;
+      ma.block_log     = (uint32_t)kTeamBlock;
+      ma.max_grid      = p->max_grid;
+      ma.num_cus       = p->num_cus;
+      ma.team_ctl      = ctl;
+      ma.team_lag      = p->team_lag ? p->team_lag : mul_team_lag(p);
+      ma.team_wpc      = p->team_wpc;
+      ma.stream        = (hipStream_t)stream;
+      hipError_t e = dispatch(ma);
+      if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+      return NTT_OK;
+    }
+  }
   for(uint64_t first = 0; first < batch; first += chunk) {
     const uint64_t nb  = batch - first < chunk ? batch - first : chunk;
     const uint64_t off = first * poly_words(p, ls);
@@ -1856,15 +1922,7 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     ma.num_cus       = p->num_cus;
     ma.oversub       = p->block_oversub;
     ma.stream        = (hipStream_t)stream;
-    const int  ic = eff_int_cls(p), kc = eff_kcls(p);
-    hipError_t e = p->arith == NTT_ARITH_U64 ? (ic == 3   ? launch_fwd_mul<ArithU64X<3>, 3>(ma)
-                                                : ic == 1 ? launch_fwd_mul<ArithU64X<1>, 1>(ma)
-                                                : ic == 0 ? launch_fwd_mul<ArithU64X<0>, 0>(ma)
-                                                          : launch_fwd_mul<ArithU64, 0>(ma))
-                   : kc == kWideClass        ? launch_fwd_mul<ArithF64W, 0>(ma)
-                   : kc == 18                ? launch_fwd_mul<ArithF64, 18>(ma)
-                   : kc == 1                 ? launch_fwd_mul<ArithF64, 1>(ma)
-                                             : launch_fwd_mul<ArithF64, 0>(ma);
+    hipError_t e = dispatch(ma);
     if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   }
   return NTT_OK;

@@ -2453,6 +2453,164 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* c^ = fwd(a) (.) b^ (+ c^) at N = 2^15 .. 2^17 as ONE launch            */
+/* ------------------------------------------------------------------ */
+/*
+ * team_kernel's forward scheme (column items of polynomial j, row items of polynomial j - lag in the same XCD's queue, a
+ * per-polynomial counter between them) with fwd_mul_kernel's epilogue in the row items: where the forward block stages would
+ * reduce and store their outputs, b^ (and the accumulator) are read by the lane that owns the words and c^ is written --
+ * instead of a column launch and a block launch per 256 MiB chunk.  a is scratch (its column stages run in place), c^ may
+ * alias a (a block's words are consumed before its products are stored; not when accumulating) or b^.
+ */
+template <class A> struct KTeamMul {
+  KMul<A>  m;       /* m.k.a = a (limb 0), m.k.nblocks = polynomials PER LIMB; b^, c^, flags and strides as for fwd_mul_kernel */
+  TeamCtl *ctl;     /* zeroed before the launch */
+  uint64_t split_rcp;
+  uint32_t lag, nlimbs, poly_major;
+};
+
+template <class A, int KSH, int LDAUX>
+__device__ __forceinline__ void team_mul_row_item(const uint64_t *ablk, const uint64_t *bblk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
+                                                  const Params<A> &p, bool lazy, bool acc, typename A::val *lds, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, flavor_of<A>()>;
+  constexpr uint32_t MASK = fused_mask<A, LOGN, false, KSH>();
+  /* (an opaque copy of the thread id ties every lane-dependent address to the item: see team_product_item) */
+  uint32_t tl = tid0;
+  asm volatile("" : "+v"(tl));
+  const uint32_t tid = tl;
+  uint64_t raw[kE];
+  prefetch_first<LOGN, LDAUX>(raw, tid, ablk);
+  typename A::val x[kE];
+  if constexpr(A::kCompact) {
+    constexpr int GL = P::NG - 1;
+    static_assert(G::TBL(GL - 1) > 0 && G::TBL(GL) == 0 && !P::WAVE_LOCAL(0, 1), "twiddle placement / barrier this item assumes");
+    const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+    typename A::ctw      pre[4][kE / 2];
+    preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+    fill_lds_tables<A, LOGN, false>(tabl, p, blk, tid); /* (published by the first exchange's barriers) */
+    convert_inputs<A, false>(x, raw, false, p.c);
+    run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+      if constexpr(GI + 1 == GL) {
+        run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+      } else if constexpr(G::TBL(GI + 1) > 0) {
+        run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
+      } else {
+        run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+      }
+    });
+  } else {
+    (void)tabl;
+    convert_inputs<A, false>(x, raw, false, p.c);
+    run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+    static_for<0, P::NG - 1>([&](auto gg) {
+      constexpr int GI = decltype(gg)::value;
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds);
+      run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+    });
+  }
+  /* the products, a quarter of the tile at a time (fwd_mul_kernel's plain loop) */
+  uint32_t t2 = tid0;
+  asm volatile("" : "+v"(t2));
+  static_for<0, 4>([&](auto qq) {
+    constexpr int Q = decltype(qq)::value;
+    uint64_t      rb[kE], rc[kE], u[kE];
+    sched_fence();
+    load_last_raw<LOGN, 4 * Q, 4 * Q + 4>(rb, t2, bblk);
+    if(acc) load_last_raw<LOGN, 4 * Q, 4 * Q + 4>(rc, t2, cblk);
+    else static_for<4 * Q, 4 * Q + 4>([&](auto ee) { rc[decltype(ee)::value] = 0; });
+    mul_out_tile<A, 4 * Q, 4 * Q + 4, 1>(u, x, rb, rc, lazy, p.c);
+    store_last_raw<LOGN, 4 * Q, 4 * Q + 4>(u, t2, cblk);
+    sched_fence();
+  });
+}
+
+template <class A, int LEAD, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__(256, 4) team_mul_kernel(const KTeamMul<A> kt)
+{
+  constexpr int LOGN = kTeamBlock;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, flavor_of<A>()>;
+  static_assert((A::kCompact || A::kIntWide) && P::T == kTeamCols && LEAD >= 3 && LEAD <= 5,
+                "built for the FP64 policies and the wide integer policy on 2^12-point blocks, N = 2^15..2^17");
+  __shared__ typename A::val lds[P::LDS_ELEMS + G::LDS_TW];
+  __shared__ unsigned        s_k, s_k2[2];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds + P::LDS_ELEMS);
+  const uint32_t         tid  = threadIdx.x;
+  uint32_t               bid_, gdim_, limb_;
+  Params<A>              p = limb_params<A, false, false>(kt.m.k, bid_, gdim_, limb_);
+  p.s0                     = LEAD;
+  constexpr uint32_t CMASK    = column_mask<A, LEAD, false, KSH>();
+  constexpr bool     MID_LAZY = !A::kTracksBounds; /* words between the passes: canonical for the FP64 policies */
+  const uint32_t logn  = LOGN + LEAD;
+  const uint32_t batch = (uint32_t)p.nblocks; /* polynomials per limb */
+  const uint32_t total = MULTI ? batch * kt.nlimbs : batch;
+  constexpr uint32_t NCOL = 1u << (LOGN - 8), NROW = 1u << LEAD;
+  TeamCtl *const ctl = kt.ctl;
+  const uint32_t lag = kt.lag;
+  const uint32_t my  = xcc_id();
+  const bool     bc  = kt.m.b_bcast != 0, lazy = kt.m.lazy_in != 0, acc = kt.m.accumulate != 0;
+  uint64_t       boff = 0, coff = 0; /* the item's limb: word offsets of its b^ and c^ slabs (MULTI) */
+  for(uint32_t qq = 0; qq < 8; qq++) {
+    const uint32_t q = (my + qq) & 7u;
+    if(tid == 0) {
+      const unsigned prev = atomicCAS(&ctl->owner[q][0], 0u, my + 1u);
+      s_k                 = (prev == 0u || prev == my + 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = s_k != 0;
+    __syncthreads();
+    if(!mine) continue;
+    constexpr uint32_t kNoSignal = 0xffffffffu;
+    uint32_t           sig       = kNoSignal;
+    for(uint32_t it = 0;; it ^= 1u) {
+      /* (lane-0 blocks are followed at once by a workgroup barrier: see team_kernel) */
+      if(tid == 0) {
+        if(sig != kNoSignal) __hip_atomic_fetch_add(&ctl->done[sig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_k2[it] = atomicAdd(&ctl->next[q][0], 1u);
+      }
+      sig = kNoSignal;
+      __syncthreads();
+      const TeamItem ti = team_decode(uniform_u32(s_k2[it]), q, total, lag, NCOL, NROW, 0u);
+      if(ti.stop) break;
+      if(!ti.valid) continue;
+      const bool     second = ti.pass != 0;
+      const uint32_t item = ti.item, pidx = ti.v;
+      uint32_t       pl   = pidx;
+      if constexpr(MULTI) {
+        uint32_t limb;
+        team_split(pidx, batch, kt.nlimbs, kt.poly_major, kt.split_rcp, limb, pl);
+        team_limb<A, false>(p, kt.m.k, limb);
+        boff = (uint64_t)limb * kt.m.b_limb_stride;
+        coff = (uint64_t)limb * kt.m.k.limb_stride;
+      }
+      const uint64_t poff = (uint64_t)pl * p.pstride; /* the polynomial inside its limb: a, c^ and a per-polynomial b^ alike */
+      uint64_t *     poly = p.a + poff;
+      if(!second) {
+        /* inputs -> intermediate (kept dirty in the L2), as in team_kernel */
+        team_column_item<A, LEAD, false, CMASK, kAuxSc0Sc1, 0>(poly, item * kTeamCols + tid, logn, p, MID_LAZY);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sig = pidx;
+      } else {
+        if(tid == 0) {
+          while(__hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NCOL) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        const uint64_t ioff = (uint64_t)item << LOGN;
+        team_mul_row_item<A, KSH, kAuxNt>(poly + ioff, kt.m.b + boff + (bc ? ioff : poff + ioff), kt.m.out + coff + poff + ioff, item, tid, p, lazy,
+                                           acc, lds, tabl);
+      }
+    }
+  }
+}
+
 template <class A, int R, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
 {
@@ -2565,6 +2723,8 @@ struct MulArgs {
   uint32_t        block_log; /* N > 2^14: log2 of the blocks (12 or 14) */
   int             max_grid, num_cus;
   int             oversub; /* as PassArgs::oversub */
+  void *          team_ctl; /* N = 2^15..2^17: non-null = column items and row items with the product as ONE launch (team_mul_kernel); a = the caller's coefficients */
+  int             team_lag, team_wpc;
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
@@ -3175,9 +3335,63 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
   return hipGetLastError();
 }
 
+template <class A, int KSH> hipError_t launch_team_mul(const MulArgs &ma)
+{
+  if constexpr(!(A::kCompact || A::kIntWide)) {
+    return hipErrorNotSupported;
+  } else {
+    const uint64_t nl = (uint64_t)(ma.nlimbs > 0 ? ma.nlimbs : 1);
+    if(nl > (uint64_t)kMaxLimbs || !ma.team_ctl || ma.logn < (uint32_t)kTeamBlock + 3 || ma.logn > (uint32_t)kTeamBlock + 5 ||
+       nl * ma.batch >= (1ull << 31)) {
+      return hipErrorNotSupported;
+    }
+    KTeamMul<A> kt{};
+    kt.m.k.a               = ma.a;
+    const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(ma.limbs);
+    for(uint64_t l = 0; l < nl; l++) kt.m.k.limbs[l] = recs[l];
+    kt.m.k.limb_stride = nl > 1 ? ma.limb_stride : 0;
+    kt.m.k.poly_stride = ma.poly_stride ? ma.poly_stride : (1ull << ma.logn);
+    kt.m.k.logn        = ma.logn;
+    kt.m.k.s0          = ma.logn - (uint32_t)kTeamBlock;
+    kt.m.k.lazy        = 0;
+    kt.m.k.nblocks     = ma.batch;
+    kt.m.b             = ma.b;
+    kt.m.out           = ma.out;
+    kt.m.b_limb_stride = nl > 1 ? ma.b_limb_stride : 0;
+    kt.m.lazy_in       = (uint32_t)ma.lazy_in;
+    kt.m.b_bcast       = (uint32_t)ma.b_bcast;
+    kt.m.accumulate    = (uint32_t)ma.accumulate;
+    kt.ctl             = static_cast<TeamCtl *>(ma.team_ctl);
+    kt.lag             = (uint32_t)(ma.team_lag > 0 ? ma.team_lag : 8);
+    kt.nlimbs          = (uint32_t)nl;
+    kt.poly_major      = nl > 1 && kt.m.k.poly_stride > kt.m.k.limb_stride;
+    kt.split_rcp       = team_split_rcp(kt.poly_major ? nl : ma.batch);
+    const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * ma.batch) * sizeof(unsigned);
+    hipError_t   e     = hipMemsetAsync(ma.team_ctl, 0, bytes, ma.stream);
+    if(e != hipSuccess) return e;
+    uint64_t wgs = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (ma.team_wpc > 0 ? ma.team_wpc : 4);
+    if(ma.max_grid > 0) wgs = (uint64_t)ma.max_grid;
+    kt.m.k.wgs_per_limb = (uint32_t)wgs;
+    const dim3 g((unsigned)wgs), t(256);
+#define NTT_TEAM_MUL(LEADV)                                                                                  \
+  do {                                                                                                       \
+    if(nl > 1) hipLaunchKernelGGL((team_mul_kernel<A, LEADV, KSH, true>), g, t, 0, ma.stream, kt);           \
+    else hipLaunchKernelGGL((team_mul_kernel<A, LEADV, KSH, false>), g, t, 0, ma.stream, kt);                \
+  } while(0)
+    switch(ma.logn - kTeamBlock) {
+      case 3: NTT_TEAM_MUL(3); break;
+      case 4: NTT_TEAM_MUL(4); break;
+      default: NTT_TEAM_MUL(5); break;
+    }
+#undef NTT_TEAM_MUL
+    return hipGetLastError();
+  }
+}
+
 template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 {
   if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(ma.team_ctl) return launch_team_mul<A, KSH>(ma);
   if(ma.logn > (uint32_t)kFusedMax) {
     if(ma.block_log == (uint32_t)kFusedSmallBlock) return launch_fwd_mul_blocks<A, kFusedSmallBlock, KSH>(ma);
     if(ma.block_log == (uint32_t)kFusedLarge) return launch_fwd_mul_blocks<A, kFusedLarge, KSH>(ma);

@@ -1733,6 +1733,18 @@ def test_ntt_domain_products_automatic_form_at_large_batches(lib, oracle, m, bat
         a_l = [x.download(n, p_ * n) for x in da]
         b_l = [x.download(n, p_ * n) for x in db]
         assert np.array_equal(res[-1][p_ * n:(p_ + 1) * n], cx.inv(oracle.dot(a_l, b_l, q, n))), p_
+    # the forward-side counterpart (team_mul_kernel; automatic from 2^26 coefficients per operand on): c^ = fwd(a) (.) b^
+    res = {}
+    for form in (-1, 0):
+        plan.set_option(lib.OPT_XCD_LOCAL, form)
+        lib.fill_uniform(da[0].ptr, batch * n, q, 7300)
+        plan.fwd_mul(dc.ptr, da[0].ptr, db[0].ptr, batch, 0)
+        res[form] = dc.download()
+    assert np.array_equal(res[-1], res[0])
+    lib.fill_uniform(da[0].ptr, batch * n, q, 7300)
+    for p_ in (0, batch // 2, batch - 1):
+        a_ = da[0].download(n, p_ * n)
+        assert np.array_equal(res[-1][p_ * n:(p_ + 1) * n], oracle.pointwise(cx.fwd(a_), db[0].download(n, p_ * n), q)), p_
     for x in da + db + [dc]:
         x.free()
     plan.destroy()
@@ -2156,6 +2168,102 @@ def test_xcd_local_ntt_domain_products(lib, oracle, m, cls):
         for x in da + db + [dc]:
             x.free()
     plan.destroy()
+
+
+@pytest.mark.parametrize("cls", ["f64_class0", "f64_class1", "f64_52bit", "u64_57bit", "u64_60bit"])
+@pytest.mark.parametrize("m", [15, 16, 17])
+def test_xcd_local_forward_transform_times_a_transformed_operand(lib, oracle, m, cls):
+    """N = 2^15..2^17: c^ = fwd(a) (.) b^ (+ c^) with the forward column stages of a and the blocks with the product as items of ONE
+    launch (team_mul_kernel, round 5) against the two launches per chunk (NTT_OPT_XCD_LOCAL 0), every word, and samples against
+    the oracle: canonical / lazy b^, a broadcast key, the accumulator, c^ aliasing a and b^, ragged batches (queues of unequal
+    length, much shorter than the lag)"""
+    n = 1 << m
+    bits = {"f64_class0": 51, "f64_class1": 50, "f64_52bit": 52, "u64_57bit": 57, "u64_60bit": 60}[cls]
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    rng = np.random.default_rng(100 + m)
+    for batch, lazy, bcast, acc in ((67, False, False, False), (70, True, False, True), (65, False, True, True), (64, True, True, False)):
+        a = oracle.fill_uniform(batch * n, q, 7600 + m)
+        a[:3] = [q - 1, 0, q // 2]
+        b = oracle.fill_uniform((1 if bcast else batch) * n, q, 7700 + m)
+        b[:4] = [q - 1, 0, q // 2, 1]
+        lz = 4 if (4 * q < (1 << 64)) else 1
+        bw = b + (rng.integers(0, lz, b.size).astype(np.uint64) * np.uint64(q) if lazy else np.uint64(0))
+        c0 = oracle.fill_uniform(batch * n, q, 7800 + m)
+        flags = (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0) | (lib.MUL_ACCUMULATE if acc else 0)
+        da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(bw.size), lib.DeviceBuffer(a.size)
+        res = {}
+        for form in (0, 1):
+            plan.set_option(lib.OPT_XCD_LOCAL, form)
+            da.upload(a), db.upload(bw), dc.upload(c0)
+            plan.fwd_mul(dc.ptr, da.ptr, db.ptr, batch, flags)
+            res[form] = dc.download()
+            assert np.array_equal(db.download(), bw)                                   # b^ is only read
+        assert np.array_equal(res[0], res[1]), (batch, lazy, bcast, acc)
+        for p_ in (0, batch // 2, batch - 1):
+            sl = slice(p_ * n, (p_ + 1) * n)
+            exp = oracle.pointwise(cx.fwd(a[sl].copy()), b if bcast else b[sl], q)
+            if acc:
+                exp = (exp + c0[sl]) % np.uint64(q)
+            assert np.array_equal(res[1][sl], exp), (batch, lazy, bcast, acc, p_)
+        plan.set_option(lib.OPT_XCD_LOCAL, 1)
+        if not acc:
+            da.upload(a)
+            plan.fwd_mul(da.ptr, da.ptr, db.ptr, batch, flags)                          # c^ aliases a
+            assert np.array_equal(da.download(), res[0]), ("alias a", batch, lazy, bcast)
+        if not bcast:
+            da.upload(a), db.upload(bw)
+            plan.fwd_mul(db.ptr, da.ptr, db.ptr, batch, flags & ~lib.MUL_ACCUMULATE)     # c^ aliases b^
+            plan.set_option(lib.OPT_XCD_LOCAL, 0)
+            da.upload(a), dc.upload(c0)
+            db2 = lib.DeviceBuffer(bw.size).upload(bw)
+            plan.fwd_mul(dc.ptr, da.ptr, db2.ptr, batch, flags & ~lib.MUL_ACCUMULATE)
+            assert np.array_equal(db.download(), dc.download()), ("alias b^", batch, lazy)
+            db2.free()
+        for x in (da, db, dc):
+            x.free()
+    plan.destroy()
+
+
+@pytest.mark.parametrize("m,nl,batch,bits,layout", [(15, 3, 30, 50, None), (16, 4, 20, 50, "bm"), (17, 2, 40, 57, "bm"), (16, 16, 5, 52, None)])
+def test_xcd_local_fwd_mul_over_rns_limbs(lib, oracle, m, nl, batch, bits, layout):
+    """the same over the limbs of an RNS set (the limb in the queue entry), [limb][batch][N] and [batch][limb][N], a broadcast key
+    ([limb][N]) accumulated onto c^: against the per-limb per-chunk form, every word; samples against the oracle"""
+    n = 1 << m
+    qs = [lib.find_prime(bits, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    rng = np.random.default_rng(200 + m)
+    a = rng.integers(0, min(qs), size=(nl, batch, n), dtype=np.uint64)
+    key = rng.integers(0, min(qs), size=(nl, n), dtype=np.uint64)
+    c0 = rng.integers(0, min(qs), size=(nl, batch, n), dtype=np.uint64)
+    lay = (n, nl * n) if layout == "bm" else None
+
+    def place(x):
+        return np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(-1) if layout == "bm" else x.reshape(-1)
+
+    da, dk, dc = lib.DeviceBuffer(nl * batch * n), lib.DeviceBuffer(nl * n).upload(key.reshape(-1)), lib.DeviceBuffer(nl * batch * n)
+    res = {}
+    for form in (0, 1):
+        for p in plans:
+            p.set_option(lib.OPT_XCD_LOCAL, form)
+        lib.set_rns_launch(plans, 1 - form)
+        da.upload(place(a)), dc.upload(place(c0))
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, dk.ptr, batch, lib.MUL_B_BROADCAST | lib.MUL_ACCUMULATE, layout=lay)
+        res[form] = dc.download()
+    assert np.array_equal(res[0], res[1])
+    got = res[1].reshape(batch, nl, n).transpose(1, 0, 2) if layout == "bm" else res[1].reshape(nl, batch, n)
+    for l in (0, nl - 1):
+        cx = oracle.ctx(n, qs[l], ws[l])
+        for p_ in (0, batch - 1):
+            exp = (oracle.pointwise(cx.fwd(a[l, p_].copy()), key[l].copy(), qs[l]) + c0[l, p_]) % np.uint64(qs[l])
+            assert np.array_equal(got[l, p_], exp), (l, p_)
+    for x in (da, dk, dc):
+        x.free()
+    for p in plans:
+        p.destroy()
 
 
 @pytest.mark.parametrize("m,nl,batch,bits,layout", [(15, 3, 30, 50, None), (16, 4, 20, 50, "bm"), (17, 2, 40, 57, "bm"), (16, 16, 5, 52, None)])
