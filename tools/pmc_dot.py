@@ -48,6 +48,24 @@ for k in sorted(dur):
             else:
                 line += "  %10s" % "-"
         print(line)
+# c^ = fwd(a) (.) b^ (+ c^): domain_bench.py issues 6 fused calls each of (multiply), (multiply, broadcast key), (accumulate), (accumulate, key)
+MGROUPS = ["mul", "mul key", "mac", "mac key"]
+for k in sorted(dur):
+    if "fwd_mul_kernel" not in k and "team_mul_kernel" not in k:
+        continue
+    d = dur[k]
+    if len(d) % (CALLS * len(MGROUPS)):
+        print("  %s: %d dispatches do not split into %d groups of %d calls" % (k, len(d), len(MGROUPS), CALLS))
+        continue
+    per = len(d) // (CALLS * len(MGROUPS))
+    for g, name in enumerate(MGROUPS):
+        lo, hi = g * CALLS * per, (g + 1) * CALLS * per
+        ms = sum(d[lo + 2 * per:hi]) / (CALLS - 2)
+        line = "  %-70s %-10s %3d  %8.3f" % (k, name, per, ms)
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            v = ctr[c].get(k, [])
+            line += ("  %10.1f" % ((2 if c == "FETCH_SIZE" else 1) * sum(v[lo:hi]) / CALLS / 1024)) if len(v) == len(d) else ("  %10s" % "-")
+        print(line)
 for k in sorted(dur):
     if "column_kernel" in k or "pointwise_acc" in k:
         d = dur[k]
