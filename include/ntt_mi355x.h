@@ -105,6 +105,8 @@ typedef enum ntt_option {
                           * XCD-local launches (N >= 2^15) are sized for it -- for the null stream at once, for any other stream at its
                           * first call or by ntt_plan_reserve -- so that no later call allocates (an allocation synchronises the device).
                           * 0 (default): sized by the first call, doubled when outgrown */
+  NTT_OPT_CTL_ALLOCATIONS = 15, /* READ-ONLY (ntt_plan_get_option): device allocations the plan has made for its control blocks so far --
+                          * unchanged across a call = that call did not allocate (what ntt_plan_reserve promises) */
   NTT_OPT_BLOCK_OVERSUB = 11, /* persistent block kernels: workgroups launched per resident slot (0 = default: 8 for the 2^12-point
                           * block kernels, whose four workgroups per CU otherwise run in phase -- measured +5 % forward, +4 % inverse,
                           * profiles/r05/grid_sweep.txt --, 1 elsewhere: 2^13 and 2^14 measured no gain) */
@@ -153,6 +155,7 @@ NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
 /* tuning / test knobs of one plan (ntt_option).  The batched API reads NO environment variable; the reference-signature entry points
  * (which have no argument to carry a choice) read NTT_DEVICE and NTT_COMPAT_ARITH once, at their first call. */
 NTT_API int  ntt_plan_set_option(ntt_plan *p, int option, int64_t value);
+NTT_API int  ntt_plan_get_option(const ntt_plan *p, int option, int64_t *value); /* the value in force (0 / -1 = the default, as set) */
 /* Allocates the control blocks (queue heads + one counter per polynomial, 4 bytes each; the direct one and the one captured
  * launches use) the XCD-local launches of this plan need on `stream` for batches of up to `polys` polynomials x limbs.  The
  * batched entry points take a const plan; these blocks are the one thing they may create or grow (under the plan's mutex), and
@@ -314,6 +317,7 @@ NTT_API int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64_t 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);
 NTT_API int ntt_dev_free(int device, void *d_ptr);
+NTT_API int ntt_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo */
 NTT_API int ntt_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
 NTT_API int ntt_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
 NTT_API int ntt_stream_create(int device, void **stream);

@@ -42,19 +42,19 @@ FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
 MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
 OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE, OPT_BLOCK_OVERSUB = 7, 8, 9, 10, 11
-OPT_RNS_LAUNCH, OPT_DOT_FUSED, OPT_MAX_BATCH_HINT = 12, 13, 14
+OPT_RNS_LAUNCH, OPT_DOT_FUSED, OPT_MAX_BATCH_HINT, OPT_CTL_ALLOCATIONS = 12, 13, 14, 15
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
     "ntt_last_error", "ntt_device_count", "ntt_version", "ntt_plan_create",
-    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option", "ntt_plan_reserve", "ntt_plan_export_table",
+    "ntt_plan_create_from_tables", "ntt_plan_destroy", "ntt_plan_info", "ntt_plan_set_generic", "ntt_plan_set_option", "ntt_plan_get_option", "ntt_plan_reserve", "ntt_plan_export_table",
     "ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide",
     "ntt_fwd_batch_lazy", "ntt_inv_batch_lazy", "ntt_transform_batch",
     "ntt_pointwise_mul_batch", "ntt_pointwise_mul_batch_lazy", "ntt_negacyclic_mul_batch", "ntt_rns_fwd_batch", "ntt_rns_inv_batch",
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch",
     "ntt_rns_fwd_batch_strided", "ntt_rns_inv_batch_strided", "ntt_rns_negacyclic_mul_batch_strided", "ntt_rns_inv_dot_batch_strided",
-    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_dev_malloc", "ntt_dev_free",
+    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_dev_malloc", "ntt_dev_free", "ntt_dev_mem_info",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_copy_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
@@ -99,6 +99,7 @@ _sig("ntt_plan_info", C.c_int, VOIDP, U64P)
 _sig("ntt_plan_set_generic", C.c_int, VOIDP, C.c_int)
 _sig("ntt_plan_set_option", C.c_int, VOIDP, C.c_int, C.c_int64)
 _sig("ntt_plan_reserve", C.c_int, VOIDP, VOIDP, C.c_uint64)
+_sig("ntt_plan_get_option", C.c_int, VOIDP, C.c_int, C.POINTER(C.c_int64))
 _sig("ntt_plan_export_table", C.c_int, VOIDP, C.c_int, VOIDP, C.c_size_t)
 for _n in ("ntt_fwd_batch", "ntt_inv_batch", "ntt_fwd_batch_wide", "ntt_inv_batch_wide", "ntt_fwd_batch_lazy",
            "ntt_inv_batch_lazy"):
@@ -130,6 +131,7 @@ _sig("ntt_transform_batch_strided", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint6
 _sig("ntt_transform_ptrs", C.c_int, VOIDP, C.POINTER(VOIDP), C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_rns_transform_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
+_sig("ntt_dev_mem_info", C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
 _sig("ntt_h2d", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
 _sig("ntt_d2h", C.c_int, C.c_int, VOIDP, VOIDP, C.c_size_t)
@@ -237,6 +239,13 @@ class DeviceBuffer:
             pass
 
 
+def mem_info(device=0):
+    """(free, total) bytes of device memory: hipMemGetInfo"""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(_lib.ntt_dev_mem_info(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
 def fill_uniform(dptr, n, q, seed, offset=0, device=0, stream=None):
     _check(_lib.ntt_fill_uniform(device, dptr, n, q, seed, offset, stream))
 
@@ -310,6 +319,11 @@ class Plan:
 
     def set_option(self, option, value):
         _check(_lib.ntt_plan_set_option(self.h, option, value))
+
+    def get_option(self, option):
+        v = C.c_int64()
+        _check(_lib.ntt_plan_get_option(self.h, option, C.byref(v)))
+        return v.value
 
     def reserve(self, polys, stream=None):
         """ntt_plan_reserve: the control blocks of the XCD-local launches on `stream`, sized for `polys` polynomials x limbs"""

@@ -264,6 +264,7 @@ struct ntt_plan {
   mutable std::vector<void *>  team_retired; /* outgrown direct blocks: launches still queued may use them, freed with the plan */
   mutable std::mutex           team_mu;
   uint64_t                     batch_hint = 0; /* NTT_OPT_MAX_BATCH_HINT: polynomials x limbs of the largest call; blocks of new streams start at this size */
+  mutable uint64_t             ctl_allocs = 0; /* hipMalloc calls team_buffer has made for this plan (NTT_OPT_CTL_ALLOCATIONS, read-only) */
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              rns_launch = -1; /* ntt_rns_*: 0 = one launch over a run of limbs wherever it is built, 1 = one launch chain per limb,
@@ -712,6 +713,33 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
   }
 }
 
+extern "C" int ntt_plan_get_option(const ntt_plan *p, int option, int64_t *value)
+{
+  if(!p || !value) return fail(NTT_ERR_ARG, "null argument");
+  switch(option) {
+    case NTT_OPT_MAX_GRID: *value = p->max_grid; return NTT_OK;
+    case NTT_OPT_CHUNK_MIB: *value = p->chunk_mib; return NTT_OK;
+    case NTT_OPT_F64_CLASS: *value = p->arith == NTT_ARITH_F64 ? p->kcls : -1; return NTT_OK;
+    case NTT_OPT_TWO_PHASE: *value = p->two_phase; return NTT_OK;
+    case NTT_OPT_FUSED_PRODUCT: *value = p->fused_product; return NTT_OK;
+    case NTT_OPT_BLOCK_LOG: *value = p->block_log; return NTT_OK;
+    case NTT_OPT_XCD_LOCAL: *value = p->xcd_local; return NTT_OK;
+    case NTT_OPT_XCD_LOCAL_LAG: *value = p->team_lag; return NTT_OK;
+    case NTT_OPT_XCD_LOCAL_WGS_PER_CU: *value = p->team_wpc; return NTT_OK;
+    case NTT_OPT_INT_WIDE: *value = p->arith == NTT_ARITH_U64 ? (p->int_cls < 0 ? 0 : 10 + p->int_cls) : -1; return NTT_OK;
+    case NTT_OPT_BLOCK_OVERSUB: *value = p->block_oversub; return NTT_OK;
+    case NTT_OPT_RNS_LAUNCH: *value = p->rns_launch; return NTT_OK;
+    case NTT_OPT_DOT_FUSED: *value = p->dot_fused; return NTT_OK;
+    case NTT_OPT_MAX_BATCH_HINT: *value = (int64_t)p->batch_hint; return NTT_OK;
+    case NTT_OPT_CTL_ALLOCATIONS: {
+      std::lock_guard<std::mutex> lock(p->team_mu);
+      *value = (int64_t)p->ctl_allocs;
+      return NTT_OK;
+    }
+    default: return fail(NTT_ERR_ARG, "unknown option");
+  }
+}
+
 /* ------------------------------------------------------------------ */
 /* transforms                                                          */
 /* ------------------------------------------------------------------ */
@@ -805,6 +833,7 @@ static int team_buffer(const ntt_plan *p, void *stream, uint64_t batch, void **o
     const size_t grow = p->batch_hint && !tb->d ? need : need * 2;
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, grow));
+    p->ctl_allocs++;
     if(tb->d) p->team_retired.push_back(tb->d);
     tb->d     = d;
     tb->bytes = grow;
@@ -812,6 +841,7 @@ static int team_buffer(const ntt_plan *p, void *stream, uint64_t batch, void **o
   if(!tb->g) {
     /* the graph block is sized once, by the first direct call (run the largest batch once before capturing) */
     HIP_TRY(hipMalloc(&tb->g, tb->bytes));
+    p->ctl_allocs++;
     tb->gbytes = tb->bytes;
   }
   *out = tb->d;
@@ -2309,6 +2339,13 @@ extern "C" int ntt_dev_malloc(int device, void **d_ptr, size_t bytes)
   hipError_t e = hipMalloc(d_ptr, bytes);
   if(e == hipErrorOutOfMemory) return fail(NTT_ERR_NOMEM, "hipMalloc: out of device memory");
   HIP_TRY(e);
+  return NTT_OK;
+}
+extern "C" int ntt_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes)
+{
+  DEV_PROLOG(device);
+  if(!free_bytes || !total_bytes) return fail(NTT_ERR_ARG, "null argument");
+  HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
   return NTT_OK;
 }
 extern "C" int ntt_dev_free(int device, void *d_ptr)

@@ -1750,6 +1750,51 @@ def test_ntt_domain_products_automatic_form_at_large_batches(lib, oracle, m, bat
     plan.destroy()
 
 
+def test_no_batched_call_allocates_after_reserve(lib, oracle):
+    """ntt_plan_reserve / NTT_OPT_MAX_BATCH_HINT (round 5): once the control blocks of the XCD-local launches are sized, no batched
+    call allocates -- read from the plan's own counter (NTT_OPT_CTL_ALLOCATIONS; hipMemGetInfo does not move for allocations of a
+    few KiB) -- transforms, products, NTT-domain products, on the null stream and on a stream of its own, growing batches up to the
+    reserved size; an unreserved plan allocates its two blocks at its first XCD-local call"""
+    import ctypes as C
+    n, q = 1 << 15, 0x7fffffffe0001
+    w = lib.min_root(q, n)
+    batch = 600
+    bufs = [lib.DeviceBuffer(batch * n) for _ in range(3)]
+    for i, b in enumerate(bufs):
+        lib.fill_uniform(b.ptr, batch * n, q, 8100 + i)
+    h = C.c_void_p()
+    lib._check(lib._lib.ntt_stream_create(0, C.byref(h)))
+    plan = lib.Plan(n, q, w)
+    plan.set_option(lib.OPT_XCD_LOCAL, 1)
+    assert plan.get_option(lib.OPT_CTL_ALLOCATIONS) == 0 and plan.get_option(lib.OPT_XCD_LOCAL) == 1
+    plan.set_option(lib.OPT_MAX_BATCH_HINT, batch)          # the null stream: direct block + graph block
+    plan.reserve(batch, stream=h.value)                     # and this one
+    reserved = plan.get_option(lib.OPT_CTL_ALLOCATIONS)
+    assert reserved == 4 and plan.get_option(lib.OPT_MAX_BATCH_HINT) == batch
+    for st in (None, h.value):
+        for nb in (64, 200, batch):
+            plan.fwd(bufs[0].ptr, nb, stream=st)
+            plan.inv(bufs[0].ptr, nb, stream=st)
+            plan.negacyclic_mul(bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, nb, stream=st)
+            plan.inv_product(bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, nb, stream=st)
+            plan.fwd_mul(bufs[2].ptr, bufs[0].ptr, bufs[1].ptr, nb, stream=st)
+            assert plan.get_option(lib.OPT_CTL_ALLOCATIONS) == reserved, (st, nb)
+    lib.stream_sync(0, h.value)
+    plan2 = lib.Plan(n, q, w)
+    plan2.set_option(lib.OPT_XCD_LOCAL, 1)
+    plan2.fwd(bufs[0].ptr, 64)
+    first = plan2.get_option(lib.OPT_CTL_ALLOCATIONS)
+    assert first == 2                                       # the first XCD-local call of an unreserved plan allocates its two blocks
+    plan2.fwd(bufs[0].ptr, 100)
+    assert plan2.get_option(lib.OPT_CTL_ALLOCATIONS) == first        # (sized with a factor of two: no regrowth yet; regrowth itself:
+    #                                                                   test_captured_xcd_local_launch_survives_regrowth_and_concurrent_direct_calls)
+    lib.stream_sync(0, None)
+    plan.destroy(), plan2.destroy()
+    lib._lib.ntt_stream_destroy(0, h.value)
+    for b in bufs:
+        b.free()
+
+
 def test_inv_dot_bad_arguments(lib, oracle):
     n, q = 256, 0x1e01
     plan = lib.Plan(n, q, lib.min_root(q, n))
