@@ -802,7 +802,7 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
 
 /* The stream's control block, at least sizeof(TeamCtl) + batch counters.
  * A (plan, stream) pair owns TWO blocks, both allocated by the first direct (uncaptured) call: one for direct launches
- * and one for launches captured into HIP graphs.  A captured launch bakes the block's address into its memset and kernel
+ * and one for launches captured into HIP graphs.  A captured launch bakes the block's address into its clearing-kernel and kernel
  * nodes, so the graph block is never freed or regrown while the plan lives, and direct launches never touch it: a graph
  * replayed on another stream cannot collide with direct calls on the capture stream.  (Two graphs captured on the same
  * plan and stream share the graph block: replay them one after the other, not concurrently -- INTEGRATION.md.)

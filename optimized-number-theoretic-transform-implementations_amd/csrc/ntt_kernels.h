@@ -2897,6 +2897,25 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
 
 /* pa.r = LEAD (3..5), pa.batch polynomials of 2^(12 + LEAD) points per limb; pa.team_ctl: TeamCtl with nlimbs * batch counters,
  * zeroed here.  Several limbs (an RNS set, [limb][batch][N]): the MULTI variant, the queues run over all limbs' polynomials. */
+/* Zeroes a control block (queue heads, owners, per-polynomial counters) in front of an XCD-local launch -- as a KERNEL, not as an
+ * asynchronous memset: captured into a HIP graph, a memset node in front of the kernel node did not always take effect before the
+ * kernel's first workgroups read the counters (stale counters of the previous replay: second-pass items that do not wait, or
+ * queues that look exhausted -- found by replaying a captured NTT-domain product between other work, round 5:
+ * tests/test_gpu_parity.py::test_one_launch_ntt_domain_products_captured_in_a_hip_graph).  A kernel in front of a kernel on the
+ * same stream is ordered in a graph exactly as outside one. */
+static __global__ void __launch_bounds__(256) team_ctl_clear_kernel(unsigned *w, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) w[i] = 0u;
+}
+static inline hipError_t team_ctl_clear(void *ctl, size_t bytes, hipStream_t stream)
+{
+  const size_t n = (bytes + 3) / 4;
+  size_t       g = (n + 255) / 256;
+  if(g > 64) g = 64;
+  hipLaunchKernelGGL(team_ctl_clear_kernel, dim3((unsigned)g), dim3(256), 0, stream, static_cast<unsigned *>(ctl), n);
+  return hipGetLastError();
+}
+
 template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const PassArgs &pa)
 {
   if constexpr(!(A::kCompact || A::kIntWide)) {
@@ -2915,7 +2934,7 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_team(const Pas
     kt.poly_major = nl > 1 && kt.k.poly_stride > kt.k.limb_stride;
     kt.split_rcp  = team_split_rcp(kt.poly_major ? nl : pa.batch);
     const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * pa.batch) * sizeof(unsigned);
-    hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
+    hipError_t   e     = team_ctl_clear(pa.team_ctl, bytes, pa.stream);
     if(e != hipSuccess) return e;
     /* four workgroups per CU: 40,580 bytes of LDS each (32.9 KB exchange buffer + 7.5 KB table), at most 128 VGPRs */
     uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
@@ -3115,7 +3134,7 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     kt.poly_major       = nl > 1 && kt.k.f.poly_stride > kt.k.f.limb_stride;
     kt.split_rcp        = team_split_rcp(kt.poly_major ? nl : pa.batch);
     const size_t bytes = sizeof(TeamProdCtl) + 2 * (size_t)(nl * pa.batch) * sizeof(unsigned);
-    hipError_t   e     = hipMemsetAsync(pa.team_ctl, 0, bytes, pa.stream);
+    hipError_t   e     = team_ctl_clear(pa.team_ctl, bytes, pa.stream);
     if(e != hipSuccess) return e;
     /* four workgroups per CU (121 VGPRs, 40.6 KB of LDS each) */
     uint64_t wgs = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (pa.team_wpc > 0 ? pa.team_wpc : 4);
@@ -3240,7 +3259,7 @@ template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
     kt.poly_major = nl > 1 && kt.d.k.poly_stride > kt.d.k.limb_stride;
     kt.split_rcp  = team_split_rcp(kt.poly_major ? nl : da.batch);
     const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * da.batch) * sizeof(unsigned);
-    hipError_t   e     = hipMemsetAsync(da.team_ctl, 0, bytes, da.stream);
+    hipError_t   e     = team_ctl_clear(da.team_ctl, bytes, da.stream);
     if(e != hipSuccess) return e;
     uint64_t wgs = (uint64_t)(da.num_cus > 0 ? da.num_cus : 256) * (da.team_wpc > 0 ? da.team_wpc : 4);
     if(da.max_grid > 0) wgs = (uint64_t)da.max_grid;
@@ -3367,7 +3386,7 @@ template <class A, int KSH> hipError_t launch_team_mul(const MulArgs &ma)
     kt.poly_major      = nl > 1 && kt.m.k.poly_stride > kt.m.k.limb_stride;
     kt.split_rcp       = team_split_rcp(kt.poly_major ? nl : ma.batch);
     const size_t bytes = sizeof(TeamCtl) + (size_t)(nl * ma.batch) * sizeof(unsigned);
-    hipError_t   e     = hipMemsetAsync(ma.team_ctl, 0, bytes, ma.stream);
+    hipError_t   e     = team_ctl_clear(ma.team_ctl, bytes, ma.stream);
     if(e != hipSuccess) return e;
     uint64_t wgs = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256) * (ma.team_wpc > 0 ? ma.team_wpc : 4);
     if(ma.max_grid > 0) wgs = (uint64_t)ma.max_grid;

@@ -1471,7 +1471,7 @@ def test_single_launch_two_pass_transform_captured_in_a_hip_graph():
     """The single-launch two-pass transform (N = 2^15, 512 polynomials: its default range) keeps queue heads and counters
     in a buffer the plan allocates per stream on first use.  Allocation cannot be captured, so (cold) a capture on a stream
     the plan has not seen takes the per-pass launches, and (warm) a capture on a stream that already owns a buffer records
-    the memset + the one launch; so does one on a stream ntt_plan_reserve prepared.  All three graphs, replayed on fresh inputs,
+    the clearing kernel + the one launch; so does one on a stream ntt_plan_reserve prepared.  All three graphs, replayed on fresh inputs,
     equal the oracle on sampled polynomials and each other on all of them; so does the product chain."""
     import sys
     code = """
@@ -1522,6 +1522,104 @@ for mode in ("cold", "warm", "reserved"):
 for seed in (1, 2):
     assert np.array_equal(outs[("cold", seed)], outs[("warm", seed)]), seed
     assert np.array_equal(outs[("cold", seed)], outs[("reserved", seed)]), seed
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_captured_xcd_local_launches_replayed_between_other_work():
+    """Round 5 found that a captured hipMemsetAsync in front of a captured XCD-local launch does not reliably take effect before the
+    kernel's first workgroups read the control block when the graph is replayed between other GPU work (the round-4 library returns
+    96 of 96 wrong polynomials here from the second replay on: profiles/r05/graph_replay_control_block_clear.txt); the block is now
+    cleared by a kernel.  A graph that BEGINS with the XCD-local launches (forward transform, product), six replays with 2 GiB of
+    unrelated traffic between them, every polynomial against the oracle."""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, batch, q = 1 << 16, 96, 0x7fffffffe0001
+w = lib.min_root(q, n)
+cx = orc.ctx(n, q, w)
+plan = lib.Plan(n, q, w, device=0)
+plan.set_option(lib.OPT_XCD_LOCAL, 1)
+z = lambda: torch.zeros(batch * n, dtype=torch.int64, device="cuda:0")
+ta, tb, tc = z(), z(), z()
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+plan.reserve(batch, stream=s.cuda_stream)
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    plan.fwd(ta.data_ptr(), batch, stream=st)                                               # ta = fwd(a)
+    plan.negacyclic_mul(tc.data_ptr(), tb.data_ptr(), tb.data_ptr(), batch, stream=st)      # tc = b * b
+for seed in (1, 2, 3, 1, 2, 3):
+    a = orc.fill_uniform(batch * n, q, 30 * seed); b = orc.fill_uniform(batch * n, q, 30 * seed + 1)
+    ta.copy_(torch.from_numpy(a.view(np.int64))); tb.copy_(torch.from_numpy(b.view(np.int64)))
+    g.replay(); torch.cuda.synchronize()
+    got_f, got_p = ta.cpu().numpy().view(np.uint64), tc.cpu().numpy().view(np.uint64)
+    for j in range(batch):
+        sl = slice(j * n, (j + 1) * n)
+        fb = cx.fwd(b[sl].copy())
+        assert np.array_equal(got_f[sl], cx.fwd(a[sl].copy())), ("forward", seed, j)
+        assert np.array_equal(got_p[sl], cx.inv(orc.pointwise(fb, fb, q))), ("product", seed, j)
+    big = torch.empty(1 << 28, dtype=torch.int64, device="cuda:0"); big.fill_(1); torch.cuda.synchronize(); del big
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_one_launch_ntt_domain_products_captured_in_a_hip_graph():
+    """round 5's one-launch kernels (team_dot_kernel, team_mul_kernel) inside a HIP graph: control blocks from ntt_plan_reserve, the
+    capture records the clearing kernel + one launch per call; two replays on fresh inputs with direct (uncaptured, per-chunk) calls
+    between them -- the interleaving that exposed the unreliable captured memset -- every word, and one polynomial against the oracle"""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, batch, q = 1 << 16, 96, 0x7fffffffe0001
+w = lib.min_root(q, n)
+cx = orc.ctx(n, q, w)
+plan, ref = lib.Plan(n, q, w, device=0), lib.Plan(n, q, w, device=0)
+plan.set_option(lib.OPT_XCD_LOCAL, 1); ref.set_option(lib.OPT_XCD_LOCAL, 0)
+z = lambda: torch.zeros(batch * n, dtype=torch.int64, device="cuda:0")
+sa, sb, ta, tb, tc, td = z(), z(), z(), z(), z(), z()
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+plan.reserve(batch, stream=s.cuda_stream)
+before = plan.get_option(lib.OPT_CTL_ALLOCATIONS)
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    ta.copy_(sa); tb.copy_(sb)
+    plan.inv_product(tc.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=st)     # tc = inv(a^ . b^)
+    plan.fwd_mul(td.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=st)         # td = fwd(a) . b^   (ta is scratch)
+assert plan.get_option(lib.OPT_CTL_ALLOCATIONS) == before
+for seed in (1, 2):
+    a = orc.fill_uniform(batch * n, q, 20 * seed); b = orc.fill_uniform(batch * n, q, 20 * seed + 1)
+    sa.copy_(torch.from_numpy(a.view(np.int64))); sb.copy_(torch.from_numpy(b.view(np.int64)))
+    g.replay(); torch.cuda.synchronize()
+    got_c, got_d = tc.cpu().numpy().view(np.uint64).copy(), td.cpu().numpy().view(np.uint64).copy()
+    da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+    ref.inv_product(dc.ptr, da.ptr, db.ptr, batch)
+    assert np.array_equal(got_c, dc.download()), seed
+    ref.fwd_mul(dc.ptr, da.ptr, db.ptr, batch)
+    assert np.array_equal(got_d, dc.download()), seed
+    j = batch - 1
+    sl = slice(j * n, (j + 1) * n)
+    assert np.array_equal(got_c[sl], cx.inv(orc.pointwise(a[sl], b[sl], q))) and np.array_equal(got_d[sl], orc.pointwise(cx.fwd(a[sl]), b[sl], q))
+    for x in (da, db, dc): x.free()
 print("graph ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
