@@ -1,3 +1,7 @@
+"""tools/dbg_graph2.py MODE FORM BETWEEN: a HIP graph of the NTT-domain products (MODE dot | mul | both; FORM 1 = one launch, 0 = per chunk) replayed six
+times on fresh inputs with something between the replays (BETWEEN none | alloc | direct[_other|_fwd|_same|_pw|_nodl] | flush, suffix _outside = the
+input copies outside the graph); every word against the oracle.  What found the unreliable captured memset
+(profiles/r05/graph_replay_control_block_clear.txt)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
