@@ -320,7 +320,7 @@ NTT_API int ntt_dev_free(int device, void *d_ptr);
 NTT_API int ntt_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo */
 NTT_API int ntt_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
 NTT_API int ntt_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
-NTT_API int ntt_stream_create(int device, void **stream);
+NTT_API int ntt_stream_create(int device, void **stream); /* hipStreamNonBlocking: does NOT synchronise with the null stream (ntt_h2d / ntt_d2h are blocking copies on the null stream: ntt_stream_sync first) */
 NTT_API int ntt_stream_destroy(int device, void *stream);
 NTT_API int ntt_stream_sync(int device, void *stream);
 NTT_API int ntt_event_create(int device, void **event);

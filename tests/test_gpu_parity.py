@@ -1664,6 +1664,62 @@ def test_concurrent_host_threads_on_their_own_streams(lib, oracle, kat):
         assert np.array_equal(got, oracle.ctx(n, q, w).fwd(a)), idx
 
 
+def test_one_plan_shared_by_host_threads_on_their_own_streams(lib, oracle):
+    """ONE plan, three host threads, each with a stream of its own, all issuing XCD-local launches at once (transforms, an NTT-domain
+    product, a forward-side product: team_kernel, team_dot_kernel, team_mul_kernel): the (plan, stream) pairs own separate control
+    blocks, created under the plan's mutex by whichever call comes first; every result against the oracle"""
+    import ctypes as C
+    import threading
+    n, q, batch = 1 << 15, 0x7fffffffe0001, 80
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    plan.set_option(lib.OPT_XCD_LOCAL, 1)
+    errors, results = [], {}
+
+    def work(idx):
+        try:
+            h = C.c_void_p()
+            lib._check(lib._lib.ntt_stream_create(0, C.byref(h)))
+            a = oracle.fill_uniform(batch * n, q, 8300 + idx)
+            b = oracle.fill_uniform(batch * n, q, 8400 + idx)
+            da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+            for _ in range(8):
+                if idx == 0:
+                    plan.fwd(da.ptr, batch, stream=h.value)
+                    plan.inv(da.ptr, batch, stream=h.value)
+                elif idx == 1:
+                    plan.inv_product(dc.ptr, da.ptr, db.ptr, batch, stream=h.value)
+                else:
+                    lib.stream_sync(0, h.value)                    # (the upload is a blocking copy on the null stream: the streams
+                    da.upload(a)                                   #  here do not synchronise with it; a is scratch above 2^14)
+                    plan.fwd_mul(dc.ptr, da.ptr, db.ptr, batch, stream=h.value)
+            if idx == 0:
+                plan.fwd(da.ptr, batch, stream=h.value)
+            lib.stream_sync(0, h.value)
+            results[idx] = ((da if idx == 0 else dc).download(), a, b)
+            for x in (da, db, dc):
+                x.free()
+            lib._lib.ntt_stream_destroy(0, h.value)
+        except Exception as e:                      # noqa: BLE001 -- reported by the main thread
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert plan.get_option(lib.OPT_CTL_ALLOCATIONS) == 6       # three streams x (direct block + graph block)
+    for idx, (got, a, b) in results.items():
+        for j in (0, batch // 2, batch - 1):
+            sl = slice(j * n, (j + 1) * n)
+            exp = cx.fwd(a[sl].copy()) if idx == 0 else (cx.inv(oracle.pointwise(a[sl], b[sl], q)) if idx == 1 else
+                                                          oracle.pointwise(cx.fwd(a[sl].copy()), b[sl], q))
+            assert np.array_equal(got[sl], exp), (idx, j)
+    plan.destroy()
+
+
 @pytest.mark.parametrize("m", [15, 16])
 @pytest.mark.parametrize("arith", ["u64", "f64", "f64_52bit"])
 def test_block_sizes_below_the_column_pass_agree(lib, oracle, m, arith):
