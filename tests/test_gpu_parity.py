@@ -1575,6 +1575,70 @@ print("graph ok")
     assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
+def test_rns_xcd_local_launches_over_limbs_captured_in_a_hip_graph():
+    """the same for ONE launch over the limbs of an RNS set in the caller-native layout [batch][limb][N] (MULTI variants: the limb in the
+    queue entry, control block of the run's first plan): product, NTT-domain inner product and forward-side product captured after
+    ntt_plan_reserve on the first plan, replayed between unrelated traffic, every word against the uncaptured per-limb per-chunk
+    calls, samples against the oracle"""
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, nl, batch = 1 << 15, 3, 40
+qs = [lib.find_prime(50, n, i) for i in range(nl)]
+ws = [lib.min_root(q, n) for q in qs]
+plans = [lib.Plan(n, q, w, device=0) for q, w in zip(qs, ws)]
+refs = [lib.Plan(n, q, w, device=0) for q, w in zip(qs, ws)]
+for p in plans: p.set_option(lib.OPT_XCD_LOCAL, 1)
+for p in refs: p.set_option(lib.OPT_XCD_LOCAL, 0)
+lib.set_rns_launch(plans, 0); lib.set_rns_launch(refs, 1)
+lay = (n, nl * n)                                    # [batch][limb][N]
+words = nl * batch * n
+z = lambda: torch.zeros(words, dtype=torch.int64, device="cuda:0")
+sa, sb, ta, tb, tc, td, te = z(), z(), z(), z(), z(), z(), z()
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+plans[0].reserve(nl * batch, stream=s.cuda_stream)
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rns_inv_dot(plans, tc.data_ptr(), [sa.data_ptr(), sb.data_ptr()], [sb.data_ptr(), sa.data_ptr()], batch, stream=st, layout=lay)   # inv(2 a^ . b^)
+    ta.copy_(sa); tb.copy_(sb)
+    lib.rns_negacyclic_mul(plans, td.data_ptr(), ta.data_ptr(), tb.data_ptr(), batch, stream=st, layout=lay)                              # a * b
+    ta.copy_(sa)
+    lib.rns_fwd_mul(plans, te.data_ptr(), ta.data_ptr(), sb.data_ptr(), batch, stream=st, layout=lay)                                      # fwd(a) . b^
+rng = np.random.default_rng(5)
+for rep in range(3):
+    a = rng.integers(0, min(qs), size=words, dtype=np.uint64); b = rng.integers(0, min(qs), size=words, dtype=np.uint64)
+    sa.copy_(torch.from_numpy(a.view(np.int64))); sb.copy_(torch.from_numpy(b.view(np.int64)))
+    g.replay(); torch.cuda.synchronize()
+    got = [x.cpu().numpy().view(np.uint64).copy() for x in (tc, td, te)]
+    da, db, dc = lib.DeviceBuffer(words).upload(a), lib.DeviceBuffer(words).upload(b), lib.DeviceBuffer(words)
+    lib.rns_inv_dot(refs, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], batch, layout=lay)
+    assert np.array_equal(got[0], dc.download()), ("inv_dot", rep)
+    lib.rns_negacyclic_mul(refs, dc.ptr, da.ptr, db.ptr, batch, layout=lay)
+    assert np.array_equal(got[1], dc.download()), ("mul", rep)
+    da.upload(a); db.upload(b)                         # (a product leaves scratch in both operands above 2^14)
+    lib.rns_fwd_mul(refs, dc.ptr, da.ptr, db.ptr, batch, layout=lay)
+    assert np.array_equal(got[2], dc.download()), ("fwd_mul", rep)
+    l, p_ = nl - 1, batch - 1
+    cx = orc.ctx(n, qs[l], ws[l])
+    sl = slice((p_ * nl + l) * n, (p_ * nl + l + 1) * n)
+    assert np.array_equal(got[1][sl], cx.inv(orc.pointwise(cx.fwd(a[sl].copy()), cx.fwd(b[sl].copy()), qs[l])))
+    assert np.array_equal(got[2][sl], orc.pointwise(cx.fwd(a[sl].copy()), b[sl], qs[l]))
+    for x in (da, db, dc): x.free()
+    big = torch.empty(1 << 27, dtype=torch.int64, device="cuda:0"); big.fill_(1); torch.cuda.synchronize(); del big
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_one_launch_ntt_domain_products_captured_in_a_hip_graph():
     """round 5's one-launch kernels (team_dot_kernel, team_mul_kernel) inside a HIP graph: control blocks from ntt_plan_reserve, the
     capture records the clearing kernel + one launch per call; two replays on fresh inputs with direct (uncaptured, per-chunk) calls
