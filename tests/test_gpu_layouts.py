@@ -270,6 +270,42 @@ def test_layouts_that_overlap_are_refused(lib, oracle):
     d.free()
 
 
+def test_empty_inputs_and_bad_arguments_of_the_round_5_entry_points(lib, oracle):
+    """empty batches and counts are no-ops (no launch, NTT_OK); null and misaligned pointers, unknown flags, strides below N and a
+    reserve during capture-less misuse are refused with an error, never a crash"""
+    n, nl = 1 << 10, 2
+    qs, roots = _primes(lib, n, nl, 50)
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, roots)]
+    d = lib.DeviceBuffer(nl * 4 * n)
+    lib.rns_fwd(plans, d.ptr, 0, layout=(n, nl * n))                       # empty batch in a strided layout
+    lib.rns_inv_dot(plans, d.ptr, [d.ptr], [d.ptr], 0, layout=(n, nl * n))
+    lib.rns_fwd_mul(plans, d.ptr, d.ptr, d.ptr, 0, layout=(n, nl * n))
+    plans[0].transform_strided(d.ptr, 2 * n, 0)
+    plans[0].transform_ptrs([])                                            # empty pointer batch
+    lib.rns_transform_ptrs(plans, [], n)
+    plans[0].reserve(0)                                                    # nothing to reserve
+    with pytest.raises(lib.NttError):
+        plans[0].transform_ptrs([0])                                       # null pointer
+    with pytest.raises(lib.NttError):
+        plans[0].transform_ptrs([d.ptr + 4])                               # not 8-byte aligned
+    with pytest.raises(lib.NttError):
+        plans[0].transform_ptrs([d.ptr], flags=1 << 20)                    # unknown flag
+    with pytest.raises(lib.NttError):
+        lib.rns_transform_ptrs(plans, [d.ptr], n - 1)                      # limb stride below N
+    with pytest.raises(lib.NttError):
+        lib.rns_transform_ptrs(plans, [d.ptr], n, flags=lib.FLAG_LAZY_OUT)  # RNS pointer batches take NTT_FLAG_INVERSE only
+    with pytest.raises(lib.NttError):
+        plans[0].get_option(999)
+    with pytest.raises(lib.NttError):
+        plans[0].set_option(lib.OPT_CTL_ALLOCATIONS, 1)                    # read-only
+    assert plans[0].get_option(lib.OPT_BLOCK_OVERSUB) == 0 and plans[0].get_option(lib.OPT_MAX_BATCH_HINT) == 0
+    plans[0].set_option(lib.OPT_BLOCK_OVERSUB, 3)
+    assert plans[0].get_option(lib.OPT_BLOCK_OVERSUB) == 3
+    d.free()
+    for p in plans:
+        p.destroy()
+
+
 @pytest.mark.parametrize("m,bits", [(8, 50), (12, 51), (14, 60), (15, 50)])
 def test_pointer_batch_of_polynomials(lib, oracle, m, bits):
     """ntt_transform_ptrs: one device pointer per polynomial (the reference's fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...) form,
