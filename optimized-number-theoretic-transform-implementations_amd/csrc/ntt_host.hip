@@ -1116,6 +1116,20 @@ static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
   if(g == 0) g = 1;
   return (unsigned)g;
 }
+/* The grid of the pointwise kernels (element-wise, memory-bound, grid-stride loop): about FOUR iterations per workgroup.  Workgroups
+ * that loop over a slab in step produce their traffic in bursts: with the 8192 workgroups of rounds 1-4 (dozens of iterations
+ * each) these kernels reached 0.66-0.68 of the roofline, with four iterations each 0.73-0.75 at 0.25, 1 and 4 GB per operand, and
+ * one-shot workgroups (no loop, what the dispatcher staggers best for a plain copy: 6.3 TB/s, tools/copy_variants.hip) 0.65-0.70
+ * (profiles/r05/pointwise_grid.txt).  max_grid: NTT_OPT_MAX_GRID (0 = this rule). */
+static unsigned grid_pw(uint64_t n, int max_grid)
+{
+  const uint64_t total = (n + 255) / 256;
+  if(max_grid > 0) return (unsigned)(total < (uint64_t)max_grid ? (total ? total : 1) : (uint64_t)max_grid);
+  uint64_t g = (total + 3) / 4;
+  if(g < 2048) g = total < 2048 ? total : 2048;
+  if(g > (1u << 22)) g = 1u << 22;
+  return (unsigned)(g ? g : 1);
+}
 
 /* pstride: words between consecutive polynomials of all three operands (0 = dense: N) */
 static int pointwise_launch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, uint64_t batch,
@@ -1125,7 +1139,7 @@ static int pointwise_launch(const ntt_plan *p, uint64_t *d_c, const uint64_t *d_
   if(batch == 0) return NTT_OK;
   USE_DEVICE(p->device);
   const uint64_t n = batch * p->N;
-  const dim3     g(grid_for(n)), t(256);
+  const dim3     g(grid_pw(n, p->max_grid)), t(256);
   hipStream_t    st = (hipStream_t)stream;
   const PwLayout lay{(uint32_t)p->m, pstride ? pstride : p->N, pstride ? pstride : p->N};
   if(p->arith == NTT_ARITH_F64) {
@@ -1649,7 +1663,7 @@ static int inv_dot(const ntt_plan *p, uint64_t *d_c, int k, const uint64_t *cons
   if(!dot_kernel_applies(p) || (ls.n > 1 && !multi_limb_plan(p))) {
     if(ls.n != 1) return fail(NTT_ERR_UNSUPPORTED, "one launch over several limbs needs the FP64 policies or the wide integer policy");
     const uint64_t n  = batch * p->N;
-    const dim3     g(grid_for(n)), t(256);
+    const dim3     g(grid_pw(n, p->max_grid)), t(256);
     hipStream_t    st = (hipStream_t)stream;
     const PwLayout lay{(uint32_t)p->m, poly_words(p, ls), bcast ? 0 : poly_words(p, ls)};
     for(int i = 0; i < k; i++) {
@@ -1846,7 +1860,7 @@ static int fwd_mul(const ntt_plan *p, uint64_t *d_c, uint64_t *d_a, const uint64
     int rc = run_transform(p, d_a, batch, false, false, stream, false, &ls);
     if(rc) return rc;
     const uint64_t n  = batch * p->N;
-    const dim3     g(grid_for(n)), t(256);
+    const dim3     g(grid_pw(n, p->max_grid)), t(256);
     hipStream_t    st = (hipStream_t)stream;
     const PwLayout lay{(uint32_t)p->m, poly_words(p, ls), bcast ? 0 : poly_words(p, ls)};
 #define NTT_PW_MUL(A, CONSTS)                                                                                              \
@@ -2186,7 +2200,7 @@ extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t 
   if(rc) return rc;
   if(!d_a || q == 0) return fail(NTT_ERR_ARG, "bad argument");
   USE_DEVICE(device);
-  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_a, n, q, seed,
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n, 256 * 32)), dim3(256), 0, (hipStream_t)stream, d_a, n, q, seed,
                      offset);
   HIP_TRY(hipGetLastError());
   return NTT_OK;
@@ -2227,7 +2241,7 @@ extern "C" int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mas
   if(n == 0) return NTT_OK;
   USE_DEVICE(device);
   /* one workgroup per 4 KiB up to 65536 workgroups: the fastest of the grids tried (profiles/r02/skeleton.txt) */
-  hipLaunchKernelGGL(rmw_probe_kernel, dim3(grid_for(n / 2, 65536)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_a, n / 2, mask);
+  hipLaunchKernelGGL(rmw_probe_kernel, dim3(grid_for(n / 2, 65536u)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_a, n / 2, mask);
   HIP_TRY(hipGetLastError());
   return NTT_OK;
 }
@@ -2236,6 +2250,8 @@ extern "C" int ntt_rmw_probe(int device, uint64_t *d_a, uint64_t n, uint64_t mas
  * for (MI355X_MICROARCH.md: about 6.3 TB/s of read + written bytes) */
 __global__ void __launch_bounds__(256) copy_probe_kernel(U64x2 *dst, const U64x2 *src, uint64_t n2)
 {
+  /* (one 16-byte word per thread where the grid allows it, i.e. always in practice: the fastest of eight copy shapes measured,
+   * 6.3 TB/s -- a grid-stride loop over the same slab 4.8-5.5, tools/copy_variants.hip) */
   for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
@@ -2246,7 +2262,7 @@ extern "C" int ntt_copy_probe(int device, uint64_t *d_dst, const uint64_t *d_src
   if(!d_dst || !d_src || (n & 1) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) return fail(NTT_ERR_ARG, "copy probe: null, odd length or unaligned buffer");
   if(n == 0) return NTT_OK;
   USE_DEVICE(device);
-  hipLaunchKernelGGL(copy_probe_kernel, dim3(grid_for(n / 2, 65536)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_dst, (const U64x2 *)d_src, n / 2);
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(grid_for(n / 2, 1u << 24)), dim3(256), 0, (hipStream_t)stream, (U64x2 *)d_dst, (const U64x2 *)d_src, n / 2);
   HIP_TRY(hipGetLastError());
   return NTT_OK;
 }
