@@ -62,6 +62,9 @@ __device__ __forceinline__ bool below(uint64_t a, uint64_t b) { return (int64_t)
 #ifndef NTT_TEAMDOT_NT
 #define NTT_TEAMDOT_NT 0 /* A/B builds: team_dot_kernel's operand loads non-temporal (1: a and a per-polynomial b; 2: a only) */
 #endif
+#ifndef NTT_COLUMN_ITERS
+#define NTT_COLUMN_ITERS 1 /* A/B builds: grid-stride iterations per workgroup of column_kernel (1 = one-shot workgroups: shipped) */
+#endif
 #ifndef NTT_WL12
 #  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
 #endif
@@ -2955,6 +2958,10 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
   const uint64_t nl    = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
   const uint64_t total = pa.batch << (pa.logn - R);
   uint64_t       wgs   = (total + 255) / 256;
+#if NTT_COLUMN_ITERS > 1
+  wgs = (wgs + NTT_COLUMN_ITERS - 1) / NTT_COLUMN_ITERS; /* (A/B builds: grid-stride iterations per workgroup of the column passes) */
+  if(wgs < 2048) wgs = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+#endif
   uint64_t       cap   = pa.max_grid > 0 ? (uint64_t)pa.max_grid : (1ull << 22);
   cap                  = cap / nl > 0 ? cap / nl : 1;
   if(wgs > cap) wgs = cap;
