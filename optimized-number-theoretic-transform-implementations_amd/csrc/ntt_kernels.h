@@ -2807,6 +2807,9 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
      * unchanged (profiles/r05/small_size_grid.txt). */
     constexpr int per_slot = (LOGN == 8 || LOGN == 9) ? 64 : 4;
     cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * per_slot;
+    /* 2^10: about six iterations per workgroup on large batches (32768 workgroups on a 6 GiB slab: slow mode 0.633 -> 0.653; the
+     * 8192 of smaller batches stay, where more workgroups lost 2 %) */
+    if(LOGN == 10 && wgs / 6 > cap) cap = wgs / 6;
   }
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   cap = cap / nl > 0 ? cap / nl : 1; /* the limbs of one launch share the resident workgroups */
