@@ -18,6 +18,7 @@ ap.add_argument("--no-broadcast", action="store_true")
 ap.add_argument("--chunk-mib", type=int, default=0)
 ap.add_argument("--xcd-local", type=int, default=-1, help="N = 2^15..2^17: 1 = both passes as items of one launch (team_dot_kernel), 0 = per-chunk launches, -1 = the library's choice")
 ap.add_argument("--lag", type=int, default=0, help="--xcd-local 1: polynomials between the two passes (0 = default)")
+ap.add_argument("--max-grid", type=int, default=0, help="cap on workgroups per launch (0 = the kernels' own choice)")
 ap.add_argument("--oversub", type=int, default=0, help="persistent block kernels: workgroups per resident slot (0 = the library's choice)")
 a = ap.parse_args()
 AR = {"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "f64": lib.ARITH_F64}
@@ -46,6 +47,8 @@ for bits in a.bits:
             plan.set_option(lib.OPT_CHUNK_MIB, a.chunk_mib)
         if a.oversub:
             plan.set_option(lib.OPT_BLOCK_OVERSUB, a.oversub)
+        if a.max_grid:
+            plan.set_option(lib.OPT_MAX_GRID, a.max_grid)
         plan.set_option(lib.OPT_XCD_LOCAL, a.xcd_local)
         plan.set_option(lib.OPT_XCD_LOCAL_LAG, a.lag)
         if os.environ.get("NTT_INT_WIDE") == "0" and plan.info()["arith"] == lib.ARITH_U64:
