@@ -2523,6 +2523,23 @@ def test_xcd_local_fwd_mul_over_rns_limbs(lib, oracle, m, nl, batch, bits, layou
         for p_ in (0, batch - 1):
             exp = (oracle.pointwise(cx.fwd(a[l, p_].copy()), key[l].copy(), qs[l]) + c0[l, p_]) % np.uint64(qs[l])
             assert np.array_equal(got[l, p_], exp), (l, p_)
+    # a per-polynomial b^ laid out like a (its limb stride is the layout's), lazy words, no accumulator
+    bh = rng.integers(0, min(qs), size=(nl, batch, n), dtype=np.uint64)
+    db = lib.DeviceBuffer(nl * batch * n)
+    res = {}
+    for form in (0, 1):
+        for p in plans:
+            p.set_option(lib.OPT_XCD_LOCAL, form)
+        lib.set_rns_launch(plans, 1 - form)
+        da.upload(place(a)), db.upload(place(bh))
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch, lib.MUL_LAZY_IN, layout=lay)
+        res[form] = dc.download()
+    assert np.array_equal(res[0], res[1])
+    got = res[1].reshape(batch, nl, n).transpose(1, 0, 2) if layout == "bm" else res[1].reshape(nl, batch, n)
+    l, p_ = nl - 1, batch // 2
+    cx = oracle.ctx(n, qs[l], ws[l])
+    assert np.array_equal(got[l, p_], oracle.pointwise(cx.fwd(a[l, p_].copy()), bh[l, p_].copy(), qs[l]))
+    db.free()
     for x in (da, dk, dc):
         x.free()
     for p in plans:
