@@ -2590,6 +2590,8 @@ namespace {
 struct CompatPlan {
   uint64_t  N = 0, q = 0, key = 0, ninv = 0, stride = 0;
   uint64_t  first[2] = {0, 0}, last = 0; /* table entries 0, 1 and the last one: compared besides the hash */
+  const uint64_t *w_ptr = nullptr, *wcon_ptr = nullptr; /* where the caller's tables lay the last time this entry served: a call with
+                                                         * the same pointers starts on this entry while its tables are still being hashed */
   bool      inverse = false;
   int       device = 0, arith = 0;
   ntt_plan *plan = nullptr;
@@ -2724,17 +2726,100 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
   const int      arith   = compat_arith(q, N, kind, inverse);
   const uint64_t entries = kind == kCompatR4 ? 2 * N : N;
   /* the integer policies use the caller's precomputation too: it is part of the key.  (Hashing happens outside any lock.) */
-  const uint64_t key = table_key(w, entries, 1) ^ (arith != NTT_ARITH_F64 && w_con ? table_key(w_con, entries, 1) * 3 : 0);
+  const auto hash_tables = [&]() { return table_key(w, entries, 1) ^ (arith != NTT_ARITH_F64 && w_con ? table_key(w_con, entries, 1) * 3 : 0); };
+  const auto cheap_match = [&](const CompatPlan &c) {
+    return c.N == N && c.q == q && c.stride == (uint64_t)kind && c.inverse == inverse && c.ninv == ninv && c.device == device &&
+           c.arith == arith && c.first[0] == w[0] && c.first[1] == w[1] && c.last == w[entries - 1];
+  };
+  const uint64_t batch = a2 ? 2 : 1;
+  const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
+  /* copies and kernels queue on the entry's stream; ONE synchronisation at the end (the _dbl form's second polynomial rides in
+   * the same queue).  enqueue: staging buffer, H2D, the transform; finish: D2H and the synchronisation.  (The caller holds the
+   * entry's lock and a DeviceGuard.) */
+  const auto enqueue = [&](CompatPlan *ent) {
+    if(!ent->stream && hipStreamCreateWithFlags(&ent->stream, hipStreamNonBlocking) != hipSuccess) {
+      g_err = "hipStreamCreate";
+      die(fn);
+    }
+    if(bytes > ent->stage_bytes) {
+      if(ent->stage) (void)hipFree(ent->stage);
+      ent->stage       = nullptr;
+      ent->stage_bytes = 0;
+      if(hipMalloc((void **)&ent->stage, bytes) != hipSuccess) {
+        g_err = "hipMalloc staging buffer";
+        die(fn);
+      }
+      ent->stage_bytes = bytes;
+    }
+    uint64_t *const   stage = ent->stage;
+    const hipStream_t st    = ent->stream;
+    bool ok = hipMemcpyAsync(stage, a1, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+    if(ok && a2) ok = hipMemcpyAsync(stage + N, a2, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+    if(!ok) {
+      g_err = "hipMemcpy H2D";
+      die(fn);
+    }
+    /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
+    /* (the radix-4x4 formulation has lazy words of its own only when log2 N = 4k+3: see run_r4x4_layers) */
+    const bool layered = r4x4 && !inverse && arith == NTT_ARITH_U64_R4 && (h_log2(N) & 3) == 3;
+    if(layered ? run_r4x4_layers(ent->plan, stage, st) : run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
+  };
+  const auto finish = [&](CompatPlan *ent) {
+    bool ok = hipMemcpyAsync(a1, ent->stage, N * 8, hipMemcpyDeviceToHost, ent->stream) == hipSuccess;
+    if(ok && a2) ok = hipMemcpyAsync(a2, ent->stage + N, N * 8, hipMemcpyDeviceToHost, ent->stream) == hipSuccess;
+    if(ok) ok = hipStreamSynchronize(ent->stream) == hipSuccess;
+    if(!ok) {
+      g_err = std::string("hipMemcpy D2H / kernel execution: ") + hipGetErrorString(hipGetLastError());
+      die(fn);
+    }
+  };
+  DeviceGuard guard(device);
+  if(!guard.ok) {
+    g_err = "hipSetDevice";
+    die(fn);
+  }
+  /* Speculation: a call that hands over the SAME table pointers as an entry served before (and agrees with it in every parameter
+   * and in the three sampled entries) starts on that entry at once -- upload and transform are queued -- and hashes ALL table
+   * entries meanwhile (256-512 KiB at 2^14: as long as the transform itself).  Only when the full hash confirms the entry is the
+   * result copied back; if the caller edited the table in place, the speculative work is drained and dropped (the caller's
+   * polynomial has not been touched) and the call proceeds as a miss.  Nothing is ever served on a sampled digest alone. */
+  uint64_t key      = 0;
+  bool     have_key = false;
+  {
+    std::shared_ptr<CompatPlan> spec;
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      for(const std::shared_ptr<CompatPlan> &c : g_plans) {
+        if(c->w_ptr == w && c->wcon_ptr == w_con && cheap_match(*c)) spec = c;
+      }
+    }
+    if(spec) {
+      std::lock_guard<std::mutex> run_lock(spec->mu);
+      enqueue(spec.get());
+      key      = hash_tables();
+      have_key = true;
+      if(key == spec->key) {
+        finish(spec.get());
+        std::lock_guard<std::mutex> lock(g_mu);
+        spec->last_use = ++g_use_clock;
+        return;
+      }
+      if(hipStreamSynchronize(spec->stream) != hipSuccess) { /* the tables changed under the same pointers: forget the result */
+        g_err = "hipStreamSynchronize";
+        die(fn);
+      }
+    }
+  }
+  if(!have_key) key = hash_tables();
   std::shared_ptr<CompatPlan> ent;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     for(const std::shared_ptr<CompatPlan> &c : g_plans) {
       /* the 64-bit hash AND the parameters AND three entries of the table itself: a hash collision alone cannot hand a
        * caller somebody else's tables */
-      if(c->N == N && c->q == q && c->key == key && c->stride == (uint64_t)kind && c->inverse == inverse && c->ninv == ninv &&
-         c->device == device && c->arith == arith && c->first[0] == w[0] && c->first[1] == w[1] && c->last == w[entries - 1]) {
-        ent           = c;
-        c->last_use   = ++g_use_clock;
+      if(c->key == key && cheap_match(*c)) {
+        ent         = c;
+        c->last_use = ++g_use_clock;
       }
     }
   }
@@ -2786,48 +2871,13 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     g_plans.push_back(ent);
   }
   std::lock_guard<std::mutex> run_lock(ent->mu);
-  const uint64_t batch = a2 ? 2 : 1;
-  const size_t   bytes = (size_t)batch * N * sizeof(uint64_t);
-  DeviceGuard guard(device);
-  if(!guard.ok) {
-    g_err = "hipSetDevice";
-    die(fn);
+  {
+    std::lock_guard<std::mutex> lock(g_mu); /* (read under g_mu by the speculative lookup; lock order entry -> cache everywhere) */
+    ent->w_ptr    = w;                      /* the next call with these pointers speculates on this entry */
+    ent->wcon_ptr = w_con;
   }
-  if(!ent->stream && hipStreamCreateWithFlags(&ent->stream, hipStreamNonBlocking) != hipSuccess) {
-    g_err = "hipStreamCreate";
-    die(fn);
-  }
-  if(bytes > ent->stage_bytes) {
-    if(ent->stage) (void)hipFree(ent->stage);
-    ent->stage       = nullptr;
-    ent->stage_bytes = 0;
-    if(hipMalloc((void **)&ent->stage, bytes) != hipSuccess) {
-      g_err = "hipMalloc staging buffer";
-      die(fn);
-    }
-    ent->stage_bytes = bytes;
-  }
-  /* copies and kernels queue on the entry's stream; ONE synchronisation at the end (the _dbl form's second polynomial
-   * rides in the same queue) */
-  uint64_t *const   stage = ent->stage;
-  const hipStream_t st    = ent->stream;
-  bool ok = hipMemcpyAsync(stage, a1, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-  if(ok && a2) ok = hipMemcpyAsync(stage + N, a2, N * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-  if(!ok) {
-    g_err = "hipMemcpy H2D";
-    die(fn);
-  }
-  /* lazy inputs accepted, lazy outputs returned: the *_lazy contract (include/ntt_reference.h:13-17) */
-  /* (the radix-4x4 formulation has lazy words of its own only when log2 N = 4k+3: see run_r4x4_layers) */
-  const bool layered = r4x4 && !inverse && arith == NTT_ARITH_U64_R4 && (h_log2(N) & 3) == 3;
-  if(layered ? run_r4x4_layers(ent->plan, stage, st) : run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
-  ok = hipMemcpyAsync(a1, stage, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
-  if(ok && a2) ok = hipMemcpyAsync(a2, stage + N, N * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
-  if(ok) ok = hipStreamSynchronize(st) == hipSuccess;
-  if(!ok) {
-    g_err = std::string("hipMemcpy D2H / kernel execution: ") + hipGetErrorString(hipGetLastError());
-    die(fn);
-  }
+  enqueue(ent.get());
+  finish(ent.get());
 }
 
 } // namespace

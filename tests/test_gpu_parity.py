@@ -779,6 +779,28 @@ def test_compat_cache_sees_every_table_entry(lib, oracle, kat):
     y = a.copy()
     lib.fwd_ntt_ref_harvey(y, n, q, tab2, con)
     assert not np.array_equal(y, x)
+    # the same ARRAYS edited in place between two calls (same pointers: the call starts speculatively on the cached entry while it
+    # hashes the tables, round 5): the stale entry must not be served, and restoring the entry restores the result
+    x2 = a.copy()
+    lib.fwd_ntt_ref_harvey(x2, n, q, tab, con)            # second call with these pointers: served speculatively
+    assert np.array_equal(x2, x)
+    saved = int(tab[k])
+    tab[k] = (saved + 1) % q
+    y2 = a.copy()
+    lib.fwd_ntt_ref_harvey(y2, n, q, tab, con)
+    assert np.array_equal(y2, y)                           # = the result of the edited copy above, not the cached plan's
+    tab[k] = saved
+    x3 = a.copy()
+    lib.fwd_ntt_ref_harvey(x3, n, q, tab, con)
+    assert np.array_equal(x3, x)
+    con_saved = int(con[k])
+    con[k] = (con_saved + 1) & ((1 << 64) - 1)            # the precomputed quotients are part of the key too
+    y3 = a.copy()
+    lib.fwd_ntt_ref_harvey(y3, n, q, tab, con)
+    con[k] = con_saved
+    z3 = a.copy()
+    lib.fwd_ntt_ref_harvey(z3, n, q, tab, con)
+    assert np.array_equal(z3, x)
     lib.compat_release()
     assert lib.compat_cached_plans() == 0
     for i in range(40):                                   # 40 distinct tables: the cache stays at <= 32 plans
