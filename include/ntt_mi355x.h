@@ -153,7 +153,8 @@ NTT_API int  ntt_plan_export_table(const ntt_plan *p, int which, void *h_dst, si
 /* force the strided multi-pass path (self-check of the fused kernels) */
 NTT_API int  ntt_plan_set_generic(ntt_plan *p, int on);
 /* tuning / test knobs of one plan (ntt_option).  The batched API reads NO environment variable; the reference-signature entry points
- * (which have no argument to carry a choice) read NTT_DEVICE and NTT_COMPAT_ARITH once, at their first call. */
+ * (which have no argument to carry a choice) read NTT_DEVICE, NTT_COMPAT_ARITH and NTT_COMPAT_ZERO_COPY (0 = stage single-pass
+ * transforms through device memory instead of running them on a pinned, device-mapped host buffer) once, at their first call. */
 NTT_API int  ntt_plan_set_option(ntt_plan *p, int option, int64_t value);
 NTT_API int  ntt_plan_get_option(const ntt_plan *p, int option, int64_t *value); /* the value in force (0 / -1 = the default, as set) */
 /* Allocates the control blocks (queue heads + one counter per polynomial, 4 bytes each; the direct one and the one captured

@@ -2599,11 +2599,14 @@ struct CompatPlan {
   std::mutex  mu;
   uint64_t *  stage       = nullptr;
   size_t      stage_bytes = 0;
+  uint64_t *  hstage      = nullptr; /* pinned, device-mapped host buffer: single-pass transforms run on it in place (zero copy) */
+  size_t      hstage_bytes = 0;
   hipStream_t stream      = nullptr;
   ~CompatPlan()
   {
     if(plan) {
       DeviceGuard guard(device);
+      if(hstage) (void)hipHostFree(hstage);
       if(stage) (void)hipFree(stage);
       if(stream) (void)hipStreamDestroy(stream);
       ntt_plan_destroy(plan);
@@ -2667,12 +2670,13 @@ enum CompatKind { kCompatR2 = 0, kCompatR4 = 1 };
 struct CompatConfig {
   int  device;
   bool f64;
+  bool zero_copy;
 };
 const CompatConfig &compat_config()
 {
   static const CompatConfig cfg = [] {
-    const char *d = getenv("NTT_DEVICE"), *a = getenv("NTT_COMPAT_ARITH");
-    return CompatConfig{d ? atoi(d) : 0, a && !strcmp(a, "f64")};
+    const char *d = getenv("NTT_DEVICE"), *a = getenv("NTT_COMPAT_ARITH"), *z = getenv("NTT_COMPAT_ZERO_COPY");
+    return CompatConfig{d ? atoi(d) : 0, a && !strcmp(a, "f64"), !(z && !strcmp(z, "0"))};
   }();
   return cfg;
 }
@@ -2736,10 +2740,36 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
   /* copies and kernels queue on the entry's stream; ONE synchronisation at the end (the _dbl form's second polynomial rides in
    * the same queue).  enqueue: staging buffer, H2D, the transform; finish: D2H and the synchronisation.  (The caller holds the
    * entry's lock and a DeviceGuard.) */
+  /* One pass over the data (N <= 2^14, block kernels): the kernel reads the polynomial from a pinned, device-mapped host buffer and
+   * writes it back there -- every word crosses PCIe once in each direction inside the kernel, no DMA submissions, no device
+   * staging.  Transforms of several passes keep the device staging buffer (their intermediates must not cross PCIe). */
+  const bool layered_ = r4x4 && !inverse && arith == NTT_ARITH_U64_R4 && (h_log2(N) & 3) == 3;
+  const bool zero_copy = compat_config().zero_copy && !layered_ && h_log2(N) >= kFusedMin && h_log2(N) <= kFusedMax;
   const auto enqueue = [&](CompatPlan *ent) {
     if(!ent->stream && hipStreamCreateWithFlags(&ent->stream, hipStreamNonBlocking) != hipSuccess) {
       g_err = "hipStreamCreate";
       die(fn);
+    }
+    if(zero_copy) {
+      if(bytes > ent->hstage_bytes) {
+        if(ent->hstage) (void)hipHostFree(ent->hstage);
+        ent->hstage       = nullptr;
+        ent->hstage_bytes = 0;
+        if(hipHostMalloc((void **)&ent->hstage, bytes, hipHostMallocMapped) != hipSuccess) {
+          g_err = "hipHostMalloc staging buffer";
+          die(fn);
+        }
+        ent->hstage_bytes = bytes;
+      }
+      memcpy(ent->hstage, a1, N * 8);
+      if(a2) memcpy(ent->hstage + N, a2, N * 8);
+      void *dev = nullptr;
+      if(hipHostGetDevicePointer(&dev, ent->hstage, 0) != hipSuccess) {
+        g_err = "hipHostGetDevicePointer";
+        die(fn);
+      }
+      if(run_transform(ent->plan, (uint64_t *)dev, batch, inverse, true, (void *)ent->stream, !inverse)) die(fn);
+      return;
     }
     if(bytes > ent->stage_bytes) {
       if(ent->stage) (void)hipFree(ent->stage);
@@ -2765,6 +2795,15 @@ void compat_run(const char *fn, uint64_t *a1, uint64_t *a2, uint64_t N, uint64_t
     if(layered ? run_r4x4_layers(ent->plan, stage, st) : run_transform(ent->plan, stage, batch, inverse, true, (void *)st, !inverse)) die(fn);
   };
   const auto finish = [&](CompatPlan *ent) {
+    if(zero_copy) {
+      if(hipStreamSynchronize(ent->stream) != hipSuccess) {
+        g_err = std::string("kernel execution: ") + hipGetErrorString(hipGetLastError());
+        die(fn);
+      }
+      memcpy(a1, ent->hstage, N * 8);
+      if(a2) memcpy(a2, ent->hstage + N, N * 8);
+      return;
+    }
     bool ok = hipMemcpyAsync(a1, ent->stage, N * 8, hipMemcpyDeviceToHost, ent->stream) == hipSuccess;
     if(ok && a2) ok = hipMemcpyAsync(a2, ent->stage + N, N * 8, hipMemcpyDeviceToHost, ent->stream) == hipSuccess;
     if(ok) ok = hipStreamSynchronize(ent->stream) == hipSuccess;
