@@ -994,6 +994,16 @@ def test_reference_test_driver_drop_in_fp64_engine():
     assert out.stdout.count("Test ") == 19 and "Bad results" not in out.stdout
 
 
+def test_reference_test_driver_drop_in_device_staging():
+    """the same driver with NTT_COMPAT_ZERO_COPY=0: single-pass transforms staged through device memory (H2D, kernel, D2H) as in
+    rounds 1-4 instead of running in place on the pinned, device-mapped host buffer (the default since round 5)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ntt-variants-dropin")
+    assert os.path.exists(exe), "oracle/_ref/ntt-variants-dropin did not travel to the GPU box"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, NTT_COMPAT_ZERO_COPY="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("Test ") == 19 and "Bad results" not in out.stdout
+
+
 @pytest.mark.parametrize("i", (14, 15, 16, 17, 18))
 @pytest.mark.parametrize("arith", ("u64", "f64"))
 def test_two_phase_equals_per_pass_path(lib, oracle, kat, i, arith):
@@ -1305,7 +1315,7 @@ def test_wide_integer_policy(lib, oracle, m, k, top):
 
 
 def test_compat_device_selection_env():
-    """NTT_DEVICE (with NTT_COMPAT_ARITH the only environment the library reads): the reference-signature entry points
+    """NTT_DEVICE (with NTT_COMPAT_ARITH and NTT_COMPAT_ZERO_COPY the only environment the library reads): the reference-signature entry points
     run on that device, and a device that does not exist makes them fail loudly (stderr + abort), never silently"""
     import sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
