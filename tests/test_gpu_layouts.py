@@ -270,6 +270,64 @@ def test_layouts_that_overlap_are_refused(lib, oracle):
     d.free()
 
 
+@pytest.mark.parametrize("m,bits", [(15, 50), (16, 52), (15, 57)])
+def test_xcd_local_launches_on_8_byte_aligned_padded_polynomials(lib, oracle, m, bits):
+    """the one-launch kernels (transform, NTT-domain product, forward-side product) on polynomials that start 8 bytes into an
+    allocation and lie N + 1 words apart: every 16-byte access of the row and column items is misaligned by half its width; against
+    the per-pass / per-chunk launches on the same placement, every word, and samples against the oracle; the pad words stay"""
+    n, batch = 1 << m, 72
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    plan = lib.Plan(n, q, w)
+    stride = n + 1
+    words = batch * stride + 8
+    a = oracle.fill_uniform(batch * n, q, 9900 + m).reshape(batch, n)
+    b = oracle.fill_uniform(batch * n, q, 9950 + m).reshape(batch, n)
+
+    def image(x):
+        img = np.full(words, GUARD, dtype=np.uint64)
+        for p_ in range(batch):
+            img[1 + p_ * stride:1 + p_ * stride + n] = x[p_]
+        return img
+
+    def rows(img):
+        return np.stack([img[1 + p_ * stride:1 + p_ * stride + n] for p_ in range(batch)])
+
+    def pads_intact(img):
+        return img[0] == GUARD and all(img[1 + p_ * stride + n] == GUARD for p_ in range(batch))
+
+    da, db, dc = lib.DeviceBuffer(words), lib.DeviceBuffer(words), lib.DeviceBuffer(words)
+    ls = (0, stride)                                       # one limb: only the polynomial stride matters
+    res = {}
+    for form in (0, 1):
+        plan.set_option(lib.OPT_XCD_LOCAL, form)
+        da.upload(image(a))
+        plan.transform_strided(da.ptr + 8, stride, batch)
+        f = da.download()
+        plan.transform_strided(da.ptr + 8, stride, batch, flags=lib.FLAG_INVERSE)
+        back = da.download()
+        da.upload(image(f_rows := rows(f))), db.upload(image(b)), dc.upload(image(np.zeros_like(a)))
+        lib.rns_inv_dot([plan], dc.ptr + 8, [da.ptr + 8], [db.ptr + 8], batch, layout=(batch * stride, stride))
+        dot = dc.download()
+        da.upload(image(a)), dc.upload(image(np.zeros_like(a)))
+        lib.rns_fwd_mul([plan], dc.ptr + 8, da.ptr + 8, db.ptr + 8, batch, layout=(batch * stride, stride))
+        mul = dc.download()
+        res[form] = (f, back, dot, mul)
+        assert all(pads_intact(x) for x in (f, back, dot, mul)), form
+        assert np.array_equal(rows(back), a), form
+    for i in range(4):
+        assert np.array_equal(res[0][i], res[1][i]), i
+    for p_ in (0, batch - 1):
+        fa = cx.fwd(a[p_].copy())
+        assert np.array_equal(rows(res[1][0])[p_], fa)
+        assert np.array_equal(rows(res[1][2])[p_], cx.inv(oracle.pointwise(fa, b[p_], q)))
+        assert np.array_equal(rows(res[1][3])[p_], oracle.pointwise(fa, b[p_], q))
+    for x in (da, db, dc):
+        x.free()
+    plan.destroy()
+
+
 def test_empty_inputs_and_bad_arguments_of_the_round_5_entry_points(lib, oracle):
     """empty batches and counts are no-ops (no launch, NTT_OK); null and misaligned pointers, unknown flags, strides below N and a
     reserve during capture-less misuse are refused with an error, never a crash"""
