@@ -1357,6 +1357,21 @@ def test_c_example_rns_modulus_chain_runs():
     assert "MISMATCH" not in out.stdout
 
 
+def test_c_example_graph_replay_runs():
+    """examples/graph_replay.c: a key-switching step (three forward-side multiply-accumulates with a broadcast key, one NTT-domain
+    product: four XCD-local launches at N = 2^16) captured into a HIP graph from plain C after ntt_plan_reserve, replayed four times
+    on new inputs, each replay equal to the direct calls on every polynomial; the capture and the replays allocate nothing"""
+    exe = os.path.join(ROOT, "build", "graph_replay")
+    libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "graph_replay.c"), "-L" + libdir, "-lntt_mi355x", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("graph == direct calls") == 4 and "MISMATCH" not in out.stdout
+
+
 def test_torch_tensors_and_streams_interoperate():
     """PyTorch is plumbing here (device memory, streams): a CUDA int64 tensor's data_ptr and a torch stream go straight
     into the C ABI; the library leaves torch's current device alone.  Run in a fresh process with torch imported FIRST:
