@@ -56,6 +56,24 @@ TRAFFIC_DIR = os.path.join(ROOT, "profiles", "r05")
 TRAFFIC_JSON = os.path.join(TRAFFIC_DIR, "pmc_traffic.json")      # the headline launch (config 4); pmc_traffic_config{2,3,5}.json beside it
 
 
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def traffic_lib_sha256(path=None):
+    """sha256 of the libntt_mi355x.so the committed counter passes were taken on (written by tools/pmc_traffic_json.py), or None"""
+    try:
+        with open(path or TRAFFIC_JSON) as f:
+            return json.load(f).get("lib_sha256")
+    except Exception:
+        return None
+
+
 # --------------------------------------------------------------------------------------------------------------
 # workloads = BASELINE.json configs 2..5 on one GPU's shard
 # --------------------------------------------------------------------------------------------------------------
@@ -569,7 +587,7 @@ def kernel_chain(w, arith, f64_class, hbm_passes=1, batch=None):
 
 
 def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=None, copy_gbs=None, workload=None,
-                step_ms=None, f64_class=0, shape_gbs=None, oop_gbs=None):
+                step_ms=None, f64_class=0, shape_gbs=None, oop_gbs=None, layout=None, shards_checked=None):
     n = n or N
     w = workload
     bytes_per_unit = w.bytes_per_unit if w else 16 * n
@@ -598,7 +616,7 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     qdesc = ", ".join(hex(q) for q in qs)
     if cfg == 4:
         qdesc += " (51-bit, reference test case 12)"
-    traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else measured_traffic_config(cfg, batch, n)
+    traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else measured_traffic_config(cfg, batch, n, layout)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r05/pmc_traffic*.json), "
@@ -619,6 +637,8 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
             "best_memory_only_skeleton_frac": (shape_gbs / HBM_PEAK_GBS) if shape_gbs else None,
             "best_memory_only_skeleton_source": "ntt_shape_probe, measured in this run after the timed region" if shape_gbs else None,
             "frac_of_best_memory_only_skeleton": (achieved / shape_gbs) if shape_gbs else None}
+    if traffic is not None:
+        roof["traffic_over_algorithmic"] = traffic / (batch * bytes_per_unit)
     if step_ms:
         roof["step_ms_min"] = min(step_ms)
         roof["step_ms_median"] = statistics.median(step_ms)
@@ -629,6 +649,14 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
         "metric": w.metric if w else METRIC, "value": value, "unit": w.unit if w else "NTT/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "f64" if arith == 2 else "u64", "data": "synthetic",
+        # dtype names the unit the arithmetic is CARRIED in, not its precision: every coefficient is an integer below 2^53 held in a
+        # double, every product is formed without rounding (error-free product + exact quotient step), and the outputs
+        # are compared bit for bit with the u64 oracle -- exact modular arithmetic, the same words the reference's uint64_t code writes
+        "arith_exact": True,
+        "dtype_note": "u64 results, bit-exact; carried in f64 (integer-valued doubles below 2^53, no rounding anywhere)" if arith == 2
+                      else "u64 Harvey/Shoup arithmetic, bit-exact",
+        "parity": {"shards_checked": shards_checked, "of": n_gpus,
+                   "what": "first and last polynomial of every shard against the oracle, on the first warm-up step of the benchmarked launches"},
         "config": {"workload": "config%d: %s, N=%d, q=%s, %s" % (cfg, what, n, qdesc, share),
                    "N": n, "q": hex(qs[0]) if len(qs) == 1 else [hex(q) for q in qs], "batch_per_gpu": batch,
                    "global_batch": n_gpus * batch,
@@ -677,14 +705,14 @@ class Parity:
         which = [0, self.batch - 1]
         if w.kind == "fwd":
             cx = orc.ctx(n, w.qs[0], w.roots[0])
-            assert np.array_equal(s.polys(which), cx.fwd(self.before["a"])), "GPU forward NTT differs from the oracle"
+            assert np.array_equal(s.polys(which), cx.fwd(self.before["a"])), "shard %d: GPU forward NTT differs from the oracle" % s.index
         elif w.kind == "roundtrip":
-            assert np.array_equal(s.polys(which), self.before["a"]), "forward+inverse round trip is not the identity"
+            assert np.array_equal(s.polys(which), self.before["a"]), "shard %d: forward+inverse round trip is not the identity" % s.index
         else:
             for l in (0, w.limbs - 1):
                 cx = orc.ctx(n, w.qs[l], w.roots[l])
                 exp = cx.inv(orc.pointwise(cx.fwd(self.before["a%d" % l]), cx.fwd(self.before["b%d" % l]), w.qs[l]))
-                assert np.array_equal(s.polys(which, base=s.out, limb=l), exp), "GPU RNS product differs from the oracle"
+                assert np.array_equal(s.polys(which, base=s.out, limb=l), exp), "shard %d: GPU RNS product differs from the oracle" % s.index
 
     def check_roundtrip_forward(self):
         """config 3: the forward half against the oracle, on a separate small launch after the timed region (the timed
@@ -695,6 +723,13 @@ class Parity:
         a = self.before["a"]
         assert np.array_equal(self.s.plan.fwd_host(a), cx.fwd(a)), "GPU forward NTT differs from the oracle"
         self.mid["fwd_checked"] = True
+
+
+def parity_all(pars):
+    """every shard this process drives, not shard 0 only: a wrong shard anywhere stops the run before a line is printed"""
+    for p in pars:
+        p.check()
+    return len(pars)
 
 
 def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
@@ -729,6 +764,12 @@ def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
            "algorithmic_bytes_per_unit": w.bytes_per_unit, "batch_per_gpu": batch, "N": w.n,
            "q": [hex(q) for q in w.qs], "parity_checked": bool(check), "kernel": kname, "launches_per_step": launches,
            "workload": w.metric}
+    if config == 2:
+        # what this block is NOT: a cold 20-step figure.  The same launch timed over 20 steps behind 3 warm-ups (the shape the
+        # driver asks the headline for) reads 0.57-0.59 -- the clocks are still settling behind the idle gap of the parity check
+        # (profiles/r05/clock_settling_after_idle.txt, bench_warmup_length.txt); `--config 2 --steps 20 --warmup 3` reproduces it
+        out["steady_state"] = True
+        out["cold_20_steps_3_warmups_frac"] = "0.57-0.59 (rounds 1-4, same kernel; one-millisecond steps measured inside the clock-settling window)"
     shard.close()
     return out
 
@@ -742,6 +783,7 @@ def main():
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2, 3, 4 (default, the metric) or 5 (60: N=2^16 with a 60-bit modulus, not a BASELINE configuration)")
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (default: from --config and --scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="seconds of CPU work of the all-core leg of the CPU baseline (tests: less)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side measurements (copy probe, other primes): profiler runs then see the step's kernels only")
     ap.add_argument("--logn", type=int, default=0, help="(experiments, config 4 only) other transform sizes")
@@ -803,17 +845,30 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # parity spot check on the benchmarked launches themselves (class Parity): first and last polynomial of shard 0
-    # against the oracle after the first warm-up step
-    check = rank == 0 and not os.environ.get("NTT_BENCH_NOCHECK")   # (ablation builds compute garbage on purpose)
-    par = Parity(w, shards[0], batch)
+    # parity spot check on the benchmarked launches themselves (class Parity): first and last polynomial of EVERY shard --
+    # every rank checks the shards it drives -- against the oracle after the first warm-up step.  A rank whose shard is wrong
+    # raises: under torch.distributed.run that ends the job non-zero, and no JSON line is printed.
+    check = not os.environ.get("NTT_BENCH_NOCHECK")   # (ablation builds compute garbage on purpose)
+    pars = [Parity(w, s, batch) for s in shards]
+    par = pars[0]
+
+    def check_all():
+        parity_all(pars)
 
     if check:
-        par.capture()
+        for p in pars:
+            p.capture()
     elapsed, kernel_ms = run_steps(shards, args.steps, max(args.warmup, 1 if check else 0), barrier,
-                                   par.check if check else None)
+                                   check_all if check else None)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     elapsed = allreduce_max(dist, elapsed, device="cuda" if on_gpu else None)
+    # shards whose first and last polynomial were compared with the oracle, summed over the ranks (= n_gpus when all did)
+    shards_checked = len(pars) if check else 0
+    if dist is not None:
+        import torch
+        t = torch.tensor([float(shards_checked)], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        shards_checked = int(t.item())
     if dist is not None:
         # per-GPU launch times of the other ranks, for the report only
         import torch
@@ -833,16 +888,27 @@ def main():
         oop_gbs = None if args.headline_only else s0.out_of_place_copy_gbs()   # (last: it overwrites half of the buffer)
         slow = max(range(len(shards)), key=lambda i: kernel_ms[i] if i < len(kernel_ms) else 0) if world == 1 else 0
         out = make_report(args, n_gpus, batch, elapsed, kernel_ms, s0.arith(), s0.hbm_passes(), n=n, copy_gbs=copy_gbs,
-                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class(), shape_gbs=shape_gbs, oop_gbs=oop_gbs)
-        if n_gpus == 1 and not args.headline_only:
+                          workload=w, step_ms=shards[slow].step_ms(), f64_class=s0.f64_class(), shape_gbs=shape_gbs, oop_gbs=oop_gbs,
+                          layout=s0.layout, shards_checked=shards_checked)
+        if s0.layout:
+            out["config"]["layout"] = "[batch][limb][N]"
+        # the binary this line was measured on, and whether the committed counter passes (roofline.traffic) were taken on the same one
+        out["lib_sha256"] = file_sha256(lib.LIB_PATH)
+        out["roofline"]["traffic_lib_sha256"] = traffic_lib_sha256()
+        out["roofline"]["traffic_from_this_binary"] = out["roofline"]["traffic_lib_sha256"] == out["lib_sha256"]
+        if not args.headline_only:
             if w.config == 4 and n == N:
                 out["also_literal_50_bit_q"] = literal_50_bit(lib, s0, args.steps)
             if w.config == 3:
                 out["also_reference_case_17"] = side_forward(lib, s0, Q, max(args.steps // 2, 2),
                                                              "forward only, 51-bit q of reference test case 17")
-            if w.config == 4 and n == N and not args.no_also:
+            if w.config == 4 and n == N and not args.no_also and not args.batch and args.scaling == "weak":
                 # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
-                # above): the driver only runs this default command, so their numbers ride on its line
+                # above): the driver only runs this default command, so their numbers ride on its line.  At N > 1 they run on
+                # rank 0's GPU (shard 0's device) while the other ranks wait at the closing barrier: one GPU's share is what they
+                # time at every N
+                if n_gpus > 1:
+                    out["also_scope"] = "the also_* blocks time ONE GPU's share on rank 0's GPU (device %d), after the timed region" % s0.device
                 for cfg, lay in ((2, None), (3, None), (5, None), (5, "batch_major"), (60, None)):
                     key = "also_config%d" % cfg if cfg != 60 else "also_60_bit_q_n65536"
                     if lay:
@@ -863,8 +929,10 @@ def main():
                         if isinstance(e, AssertionError):
                             out["also_failed"] = True
                             also_failed = True
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, lib)
+        # north_star: the CPU baseline "timed on the host cores of the same box in the same run" -- on every line, N > 1 included
+        # (rank 0, after the timed region; the other ranks wait at the closing barrier)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, lib, budget_s=args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     barrier()
     for s in shards:

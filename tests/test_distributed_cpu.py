@@ -119,6 +119,59 @@ def test_single_process_multi_shard_path():
     assert np.array_equal(np.concatenate([s.a for s in shards]), expect)
 
 
+def test_eight_shards_every_one_parity_checked():
+    """the driver's 8-GPU shape on the CPU: run_steps() over eight shards with the after-first-warm-up hook bench.main() installs
+    (parity_all: every shard, not shard 0), make_report() carrying the count; a corrupted LAST shard must stop the run"""
+    import argparse
+    import bench
+    from oracle_binding import Oracle
+    orc = Oracle()
+    n = 1 << M
+
+    class _Par:
+        def __init__(self, s):
+            self.s, self.checked = s, 0
+
+        def capture(self):
+            self.s.fill()
+            self.before = self.s.a.copy()
+
+        def check(self):
+            exp = orc.ctx(n, Q, self.s.w).fwd(self.before)
+            assert np.array_equal(self.s.a, exp), "shard %d differs from the oracle" % self.s.index
+            self.checked += 1
+
+    shards = [_EmuShard(i, 2) for i in range(8)]
+    pars = [_Par(s) for s in shards]
+    for p in pars:
+        p.capture()
+    for s in shards:               # run_steps() fills again: same generator, same data
+        s.fill = lambda: None
+    elapsed, kms = bench.run_steps(shards, steps=1, warmup=1, barrier=lambda: None, after_first_warmup=lambda: bench.parity_all(pars))
+    assert [p.checked for p in pars] == [1] * 8 and len(kms) == 8
+    args = argparse.Namespace(steps=1, warmup=1, scaling="weak")
+    rep = bench.make_report(args, 8, 2, elapsed, kms, 2, 1, n=n, shards_checked=8)
+    assert rep["parity"]["shards_checked"] == 8 and rep["parity"]["of"] == 8 and rep["arith_exact"] is True and rep["dtype"] == "f64"
+    # distinct shards: the generator offsets differ, so do the inputs
+    assert len({p.before.tobytes() for p in pars}) == 8
+    # a wrong word in the last shard is caught
+    shards[7].a[5] ^= np.uint64(1)
+    pars[7].before = shards[7].a.copy()
+    shards[7].a[9] ^= np.uint64(1)
+    with pytest.raises(AssertionError, match="shard 7"):
+        bench.parity_all([_Par7(pars[7])])
+
+
+class _Par7:
+    """parity of an already transformed shard against a tampered input: must fail"""
+
+    def __init__(self, p):
+        self.p = p
+
+    def check(self):
+        self.p.check()
+
+
 def test_scaling_modes():
     import bench
     assert bench.per_gpu_batch("weak", 1) == bench.per_gpu_batch("weak", 8) == 131072

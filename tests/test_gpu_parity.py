@@ -681,13 +681,15 @@ def test_bench_two_ranks_folded_on_one_gpu():
     env = dict(os.environ, NTT_BENCH_DEVICE_MOD="1", NTT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192", "--cpu-budget-s", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2 * 8192
-    assert d["value"] > 1e5 and "cpu_baseline" not in d
+    # every rank checked its own shard against the oracle; the CPU baseline rides on every line, N > 1 included (north_star: "in the same run")
+    assert d["value"] > 1e5 and d["parity"] == dict(d["parity"], shards_checked=2, of=2)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port")
 
 
 def test_bench_single_process_two_shards_folded_on_one_gpu():
@@ -711,6 +713,38 @@ def test_bench_single_process_two_shards_folded_on_one_gpu():
         assert d["n_gpus"] == 2 and d["scaling"] == scaling
         assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"]
         assert len(d["roofline"]["kernel_ms_per_gpu"]) == 2 and d["value"] > 1e5
+
+
+def test_bench_eight_shards_folded_on_one_gpu():
+    """the shape of the driver's 8-GPU run, folded onto the one GPU of the test box: `bench.py --gpus 8` in one process (eight
+    streams, eight chains of events, one host clock) for config 4 and for config 2 (0.8 ms steps: sixteen host calls per step),
+    every shard parity-checked, the CPU baseline on the line; then the same eight shards as eight ranks under
+    torch.distributed.run (gloo for the control plane).  The aggregate rate against one shard of the same total batch is a
+    measurement, kept in profiles/r06/folded_8_shards.txt; here only a loose bound guards against a serialising host loop."""
+    import json
+    import sys
+    env = dict(os.environ, NTT_BENCH_DEVICE_MOD="1")
+    env.pop("WORLD_SIZE", None)
+
+    def run(extra, launcher=False, e=env):
+        cmd = [sys.executable]
+        if launcher:
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29547"]
+        cmd += [os.path.join(ROOT, "bench.py")] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for cfg, batch in ((4, 8192), (2, 16384)):
+        one = run(["--gpus", "1", "--config", str(cfg), "--batch", str(8 * batch), "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--headline-only"])
+        d = run(["--gpus", "8", "--config", str(cfg), "--batch", str(batch), "--steps", "10", "--warmup", "4", "--cpu-budget-s", "1", "--headline-only"])
+        assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * batch and len(d["roofline"]["kernel_ms_per_gpu"]) == 8
+        assert d["parity"]["shards_checked"] == 8 and d["parity"]["of"] == 8
+        assert d["cpu_baseline"]["value"] > 0
+        assert d["value"] > 0.8 * one["value"], (cfg, d["value"], one["value"])
+    d = run(["--gpus", "8", "--batch", "8192", "--steps", "5", "--warmup", "2", "--cpu-budget-s", "1", "--headline-only"], launcher=True,
+            e=dict(env, NTT_BENCH_BACKEND="gloo"))
+    assert d["n_gpus"] == 8 and d["parity"]["shards_checked"] == 8 and d["cpu_baseline"]["value"] > 0
+    assert len(d["roofline"]["kernel_ms_per_gpu"]) == 8
 
 
 def test_bench_refuses_more_gpus_than_devices():
