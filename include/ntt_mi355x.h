@@ -110,6 +110,12 @@ typedef enum ntt_option {
   NTT_OPT_BLOCK_OVERSUB = 11, /* persistent block kernels: workgroups launched per resident slot (0 = default: 8 for the 2^12-point
                           * block kernels, whose four workgroups per CU otherwise run in phase -- measured +5 % forward, +4 % inverse,
                           * profiles/r05/grid_sweep.txt --, 1 elsewhere: 2^13 and 2^14 measured no gain) */
+  NTT_OPT_ONE_PASS = 16, /* N = 2^15, FP64 policies (q < 2^52): 1 = the transform in ONE pass over the data -- a 1024-thread workgroup holds
+                          * the whole polynomial (32 words per thread) in its registers, the stage on pairs 2^14 apart runs thread-locally
+                          * and the two halves go through the 2^14-point block stages one after the other: 16N bytes cross HBM, where the
+                          * two-pass forms move 24N..32N across the fabric (measured forward 0.43 -> see profiles/r06/onepass_2p15.txt);
+                          * 0 = the two-pass forms (XCD-local launch / per-pass launches); -1 (default) = one pass when the batch gives
+                          * every CU a polynomial.  Calls that ask for lazy outputs keep the two-pass forms.  Results are identical. */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
                           * operands through the forward stages, multiplies in registers and runs the inverse: 24N bytes up to
                           * 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise one launch (all limbs of an RNS set
@@ -301,19 +307,31 @@ NTT_API int ntt_rns_fwd_mul_batch_strided(int nlimbs, ntt_plan *const *plans, ui
 NTT_API int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uint64_t poly_stride, uint64_t batch, unsigned flags,
                                         void *stream);
 
-/* ---- pointer batches: one DEVICE pointer per polynomial, in a HOST array.  The reference's own batch form is one array per
- * polynomial -- fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...) (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91) --; this is
- * that form for `count` polynomials resident on the device.  The polynomials are independent and transformed in place, so the
- * call is free to reorder them: the pointers are sorted and cut into maximal arithmetic progressions, each of which is ONE strided
- * launch chain (separately allocated ciphertexts out of a pool, the rows of a matrix of polynomials, two arrays a fixed distance
- * apart: one launch; no regularity at all: one launch chain per polynomial -- prefer ntt_transform_batch_strided when the placement is
- * known).  Pointers must be 8-byte aligned; overlapping polynomials (or a pointer listed twice) are refused.  flags = NTT_FLAG_*.
- * ntt_rns_transform_ptrs: h_polys[i] points at limb 0 of RNS polynomial i, whose limbs are limb_stride words apart ([limb][N] per
- * polynomial: limb_stride = N; pointers INTO a [limb][batch][N] slab: limb_stride = batch * N -- the polynomials then interleave
- * without overlapping, which the check, made limb image by limb image, accepts); flags: NTT_FLAG_INVERSE only. ---- */
+/* ---- pointer batches: one DEVICE pointer per polynomial.  The reference's own batch form is one array per polynomial --
+ * fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...) (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91) --; this is that form for
+ * `count` polynomials resident on the device and placed ANYWHERE: ONE launch chain serves the whole batch, the kernels read each
+ * polynomial's address from a device table (separately allocated ciphertexts, a shuffled pool, rows of several matrices: 4096
+ * separately held 2^14-point polynomials run at the rate of one contiguous slab; rounds 1-5 launched every arithmetic progression
+ * of the sorted pointers by itself).  Pointers must be 8-byte aligned.  flags = NTT_FLAG_*.
+ *   ntt_transform_ptrs      h_polys is a HOST array.  The polynomials are independent and transformed in place, so the call is free
+ *                           to reorder them: the pointers are sorted (address order), checked -- overlapping polynomials or a pointer
+ *                           listed twice are refused, NTT_ERR_ARG -- and uploaded through a pinned staging buffer the plan keeps per
+ *                           stream (asynchronous; its first use on a stream allocates).  A batch that is one arithmetic progression
+ *                           takes the strided launch, no table.  While `stream` is being captured into a HIP graph nothing can be
+ *                           uploaded: the call then launches progression by progression (no regularity: one launch chain per
+ *                           polynomial) -- in graphs use
+ *   ntt_transform_dev_ptrs  d_polys is a DEVICE array of `count` device pointers, used as it is: no copy, no allocation, no check
+ *                           (overlapping polynomials are the caller's responsibility), capturable; it must stay valid and unchanged
+ *                           until the call's kernels have run.
+ * ntt_rns_transform_ptrs / _dev_ptrs: entry i points at limb 0 of RNS polynomial i, whose limbs are limb_stride words apart ([limb][N]
+ * per polynomial: limb_stride = N; pointers INTO a [limb][batch][N] slab: limb_stride = batch * N -- the polynomials then interleave
+ * without overlapping, which the host form's check, made limb image by limb image, accepts); flags: NTT_FLAG_INVERSE only. ---- */
 NTT_API int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, uint64_t count, unsigned flags, void *stream);
+NTT_API int ntt_transform_dev_ptrs(const ntt_plan *p, const uint64_t *const *d_polys, uint64_t count, unsigned flags, void *stream);
 NTT_API int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64_t *const *h_polys, uint64_t count, uint64_t limb_stride,
                                    unsigned flags, void *stream);
+NTT_API int ntt_rns_transform_dev_ptrs(int nlimbs, ntt_plan *const *plans, const uint64_t *const *d_polys, uint64_t count,
+                                       uint64_t limb_stride, unsigned flags, void *stream);
 
 /* ---- device memory / streams / timing (thin HIP wrappers for C callers) ---- */
 NTT_API int ntt_dev_malloc(int device, void **d_ptr, size_t bytes);

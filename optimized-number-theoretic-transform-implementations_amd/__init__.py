@@ -42,7 +42,7 @@ FLAG_INVERSE, FLAG_WIDE_IN, FLAG_LAZY_OUT = 1, 2, 4
 MUL_LAZY_IN, MUL_B_BROADCAST, MUL_ACCUMULATE = 1, 2, 4
 OPT_MAX_GRID, OPT_CHUNK_MIB, OPT_F64_CLASS, OPT_TWO_PHASE, OPT_FUSED_PRODUCT, OPT_BLOCK_LOG = 1, 2, 3, 4, 5, 6
 OPT_XCD_LOCAL, OPT_XCD_LOCAL_LAG, OPT_XCD_LOCAL_WGS_PER_CU, OPT_INT_WIDE, OPT_BLOCK_OVERSUB = 7, 8, 9, 10, 11
-OPT_RNS_LAUNCH, OPT_DOT_FUSED, OPT_MAX_BATCH_HINT, OPT_CTL_ALLOCATIONS = 12, 13, 14, 15
+OPT_RNS_LAUNCH, OPT_DOT_FUSED, OPT_MAX_BATCH_HINT, OPT_CTL_ALLOCATIONS, OPT_ONE_PASS = 12, 13, 14, 15, 16
 
 #: every symbol include/ntt_mi355x.h and the reference-named headers declare
 EXPORTED_SYMBOLS = [
@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch",
     "ntt_rns_fwd_batch_strided", "ntt_rns_inv_batch_strided", "ntt_rns_negacyclic_mul_batch_strided", "ntt_rns_inv_dot_batch_strided",
-    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_dev_malloc", "ntt_dev_free", "ntt_dev_mem_info",
+    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_transform_dev_ptrs", "ntt_rns_transform_dev_ptrs", "ntt_dev_malloc", "ntt_dev_free", "ntt_dev_mem_info",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_copy_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
@@ -130,6 +130,8 @@ _sig("ntt_rns_fwd_mul_batch_strided", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP,
 _sig("ntt_transform_batch_strided", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_transform_ptrs", C.c_int, VOIDP, C.POINTER(VOIDP), C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_rns_transform_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_transform_dev_ptrs", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_transform_dev_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_mem_info", C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
@@ -352,6 +354,10 @@ class Plan:
         k = len(ptrs)
         _check(_lib.ntt_transform_ptrs(self.h, (VOIDP * k)(*ptrs), k, flags, stream))
 
+    def transform_dev_ptrs(self, d_table, count, flags=0, stream=None):
+        """the same with the pointers already in DEVICE memory (ntt_transform_dev_ptrs): d_table = device address of `count` pointers"""
+        _check(_lib.ntt_transform_dev_ptrs(self.h, d_table, count, flags, stream))
+
     def pointwise_mul(self, dc, da, db, batch, stream=None, lazy_in=False):
         f = _lib.ntt_pointwise_mul_batch_lazy if lazy_in else _lib.ntt_pointwise_mul_batch
         _check(f(self.h, dc, da, db, batch, stream))
@@ -422,6 +428,11 @@ def rns_transform_ptrs(plans, ptrs, limb_stride, flags=0, stream=None):
     """one device pointer per RNS polynomial (its limbs limb_stride words apart): ntt_rns_transform_ptrs"""
     k = len(ptrs)
     _check(_lib.ntt_rns_transform_ptrs(len(plans), _plan_array(plans), (VOIDP * k)(*ptrs), k, limb_stride, flags, stream))
+
+
+def rns_transform_dev_ptrs(plans, d_table, count, limb_stride, flags=0, stream=None):
+    """ntt_rns_transform_dev_ptrs: the pointers (limb 0 of every RNS polynomial) in a DEVICE array"""
+    _check(_lib.ntt_rns_transform_dev_ptrs(len(plans), _plan_array(plans), d_table, count, limb_stride, flags, stream))
 
 
 def batch_major(plans):

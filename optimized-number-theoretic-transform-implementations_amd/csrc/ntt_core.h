@@ -33,6 +33,7 @@
 #include <utility>
 
 #include "ntt_arith.h"
+#include "ntt_passplan.h" /* kFusedLarge: the block size the one-pass 2^15 schedule is written for */
 
 namespace ntt {
 
@@ -257,6 +258,9 @@ template <class A> struct Params {
   uint64_t               nblocks; /* batch * 2^s0 blocks of 2^LOGN                */
   uint64_t               pstride; /* words between consecutive polynomials of this limb: N for the dense [batch][N] slab, more
                                    * for a caller-native layout ([polynomial][limb][N]: limbs * N) -- see block_offset */
+  const uint64_t *       ptab;    /* pointer batches (ntt_transform_ptrs, ntt_transform_dev_ptrs): device table, one entry per polynomial =
+                                   * the ADDRESS of its limb 0 (a plain array of device pointers; the launch passes a = the limb's offset
+                                   * alone); null = the arithmetic progression above -- see poly_offset */
 };
 
 /* Where block b of a pass starts, in words from the limb's first coefficient.  A pass over `batch` polynomials of 2^logn points
@@ -268,6 +272,32 @@ template <class A> struct Params {
 template <int LOGN> NTT_HD uint64_t block_offset(uint64_t b, uint32_t s0, uint64_t pstride)
 {
   return (b >> s0) * pstride + ((b & ((1ull << s0) - 1ull)) << LOGN);
+}
+
+/* Where polynomial `poly` of the limb starts, in words from Params::a: the progression poly * pstride, or -- a batch of separately
+ * held arrays, the reference's own batch form (fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...), include/ntt_reference.h:44-49,
+ * src/ntt_reference.c:71-91) for any number of polynomials placed anywhere -- entry `poly` of a device table.  UNIFORM: `poly` is the
+ * same for the whole wave (derived from the workgroup id and loop counters): the entry is read through the constant address space,
+ * one s_load_dwordx2 into scalar registers like a wave-uniform twiddle, and everything derived from it (the block's buffer
+ * descriptor) stays scalar.  The table is written before the launch and never by it. */
+template <bool UNIFORM = true> NTT_HD uint64_t poly_offset(uint64_t poly, uint64_t pstride, const uint64_t *ptab)
+{
+  if(ptab) {
+    /* entries are byte addresses of 8-byte aligned polynomials; Params::a is the limb's offset from a null base: words */
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr(UNIFORM) {
+      typedef const uint64_t __attribute__((address_space(4))) * ctab_t;
+      return ((ctab_t)(uintptr_t)ptab)[poly] >> 3;
+    }
+#endif
+    return ptab[poly] >> 3;
+  }
+  return poly * pstride;
+}
+/* block_offset for the kernels that serve pointer batches (the transform kernels): block b mod 2^s0 of polynomial b >> s0 */
+template <int LOGN> NTT_HD uint64_t block_offset(uint64_t b, uint32_t s0, uint64_t pstride, const uint64_t *ptab)
+{
+  return poly_offset<true>(b >> s0, pstride, ptab) + ((b & ((1ull << s0) - 1ull)) << LOGN);
 }
 
 NTT_HD uint32_t uniform_u32(uint32_t v)
@@ -712,7 +742,9 @@ NTT_HD void run_group_r4(typename A::val (&x)[kE], uint32_t t, uint32_t blk, con
   }
 }
 
-template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false, bool MIRROR = false>
+/* LSTAGES (with LTW): which local stages the LDS table holds (Geom::TBL_STAGES: a prefix); the others fetch per lane from global
+ * memory, requested one stage ahead like every per-lane stage of a group without a table */
+template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false, bool MIRROR = false, uint32_t LSTAGES = 0xFu>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
 {
@@ -735,7 +767,8 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
   }
   StageTw<A> wcur, wnxt;
   constexpr int JFIRST = INV ? R - 1 : 0;
-  if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !LTW) {
+  constexpr auto in_lds = [](int j) constexpr { return LTW && ((LSTAGES >> j) & 1u) != 0; };
+  if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !in_lds(JFIRST)) {
     load_stage_tw<A, LOGN, G, JFIRST, INV, false>(wcur, ib, blk, p, nullptr);
   }
   static_for<0, R>([&](auto jj) {
@@ -744,9 +777,11 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int SL = SG + J;                 /* local stage              */
     constexpr int AB = P::ABIT(G, J);
     constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
-    constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
-    constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
-    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW, MIRROR>(wcur, ib, blk, p, ltw);
+    constexpr int  JNC  = JN < 0 ? 0 : (JN < R ? JN : 0);
+    constexpr bool LJ   = LTW && ((LSTAGES >> J) & 1u) != 0;
+    constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LJ;
+    constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JNC) && !(LTW && ((LSTAGES >> JNC) & 1u) != 0);
+    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LJ, MIRROR && LJ>(wcur, ib, blk, p, ltw);
     if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
     constexpr bool FOLDED = INV && SL == 0 && (MASK & kLastInvFlag) != 0;
     if constexpr(FOLDED) {
@@ -1327,6 +1362,38 @@ template <class A, int R, bool INV, int KSH> constexpr uint32_t column_mask()
   } else {
     return f64_schedule(INV, R, KSH, 1.0).mask;
   }
+}
+
+/* ------------------------------------------------------------------ */
+/* N = 2^15 in one pass (onepass_kernel): the stage on pairs 2^14 apart  */
+/* ------------------------------------------------------------------ */
+/* The reduction schedule of the FP64 policies over all FIFTEEN forward stages: bit 0 = the pair stage (global stage 0, a full twiddle
+ * record), bits 1..14 = the block stages (local stage s of either half = global stage s + 1, compact twiddles where the 2^14 block
+ * has them).  One schedule instead of "column pass + block pass with canonical words between": nothing is reduced just because a
+ * pass ends. */
+template <class A, int KSH> constexpr uint32_t onepass_fwd_mask()
+{
+  if constexpr(A::kWide52) {
+    return f64w_fwd_schedule(kFusedLarge + 1, 1.0, 0u).mask;
+  } else {
+    return f64_schedule(false, kFusedLarge + 1, KSH, 1.0, fused_cmask<A, kFusedLarge>() << 1).mask;
+  }
+}
+/* forward: x[i] +- w x[i + 2^14] for the thread's sixteen pairs (slot e of half 0 with slot e of half 1), the single twiddle of
+ * slot 1 -- the reference's first stage, src/ntt_reference.c:17-30 with m = 1 */
+template <class A, bool RED0> NTT_HD void onepass_pairs_fwd(typename A::val (&xa)[kE], typename A::val (&xb)[kE], const Params<A> &p)
+{
+  const typename A::tw w = load_tw<A, true>(p.tw, 1u);
+  static_for<0, kE>([&](auto ee) { A::template fwd_bfly<RED0>(xa[decltype(ee)::value], xb[decltype(ee)::value], w, p.c); });
+}
+/* inverse: the last Gentleman-Sande stage with N^-1 folded in (src/ntt_reference.c:55-65) on one pair.  Its inputs are what the
+ * halves' block stages left in registers -- unreduced, bounded by the per-slot plan's `bout`, which the last butterfly's exactness
+ * argument (sum and difference of CANONICAL words) does not cover: both are reduced first, three exact instructions each. */
+template <class A> NTT_HD void onepass_pair_inv(typename A::val &va, typename A::val &vb, const typename A::consts &c)
+{
+  va = A::reduce(va, c);
+  vb = A::reduce(vb, c);
+  A::inv_bfly_last(va, vb, c);
 }
 
 /* ------------------------------------------------------------------ */

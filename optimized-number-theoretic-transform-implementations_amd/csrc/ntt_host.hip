@@ -265,6 +265,18 @@ struct ntt_plan {
   mutable std::mutex           team_mu;
   uint64_t                     batch_hint = 0; /* NTT_OPT_MAX_BATCH_HINT: polynomials x limbs of the largest call; blocks of new streams start at this size */
   mutable uint64_t             ctl_allocs = 0; /* hipMalloc calls team_buffer has made for this plan (NTT_OPT_CTL_ALLOCATIONS, read-only) */
+  /* pointer batches handed over as HOST arrays (ntt_transform_ptrs): the sorted addresses travel to the device through a pinned
+   * staging buffer and live in a device table, one pair per stream the plan is used on (stream order makes the reuse safe: the next
+   * call's copy queues behind the previous call's kernels); grown by retiring, like the control blocks; under team_mu */
+  struct PtrBuf {
+    void *     stream;
+    uint64_t * d;      /* device table */
+    uint64_t * h;      /* pinned host staging */
+    size_t     words;
+    hipEvent_t copied; /* the last upload from h has completed (h may be rewritten) */
+  };
+  mutable std::vector<PtrBuf> ptr_bufs;
+  mutable std::vector<std::pair<void *, void *>> ptr_retired; /* {device, pinned host} */
   hipStream_t      own_stream = nullptr; /* used by ntt_batch_multi */
   int              max_grid   = 0;
   int              rns_launch = -1; /* ntt_rns_*: 0 = one launch over a run of limbs wherever it is built, 1 = one launch chain per limb,
@@ -276,6 +288,8 @@ struct ntt_plan {
   int              block_log  = 0;     /* multi-pass transforms: block size below the column passes (0 = multi_pass_block's choice) */
   int              fused_product = 1; /* N = 2^8..2^17, FP64: ntt_negacyclic_mul_batch through the fused product kernels (0: four-launch
                                        * chain; 2: as 1, but a's forward transform always as a launch of its own) */
+  int              one_pass   = -1;    /* 2^15, FP64 policies: the transform in ONE pass, the polynomial in the registers of one workgroup
+                                        * (onepass_kernel): 1 on, 0 off, -1 = batches that give every CU a polynomial */
   int              two_phase  = -1;    /* 2^16, 2^17: both passes of a polynomial inside one workgroup (twophase_kernel):
                                         * 1 on, 0 off, -1 where it measured faster (forward 2^16, scheduled FP64 policy: +3 %) */
 };
@@ -579,6 +593,15 @@ extern "C" void ntt_plan_destroy(ntt_plan *p)
     if(tb.g) (void)hipFree(tb.g);
   }
   for(void *d : p->team_retired) (void)hipFree(d);
+  for(const ntt_plan::PtrBuf &pb : p->ptr_bufs) {
+    if(pb.d) (void)hipFree(pb.d);
+    if(pb.h) (void)hipHostFree(pb.h);
+    if(pb.copied) (void)hipEventDestroy(pb.copied);
+  }
+  for(const std::pair<void *, void *> &r : p->ptr_retired) {
+    (void)hipFree(r.first);
+    (void)hipHostFree(r.second);
+  }
   if(p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
@@ -601,7 +624,8 @@ extern "C" int ntt_plan_info(const ntt_plan *p, uint64_t info[8])
                       p->m <= kTeamBlock + 5 && p->xcd_local != 0;
     const bool tp     = f64big && p->m >= kFusedMax + 2 && p->m <= kFusedMax + 3 &&
                     (p->two_phase == 1 || (p->two_phase < 0 && p->m == kFusedMax + 2 && p->kcls != kWideClass));
-    info[5] = (team || tp) ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
+    const bool op     = f64big && p->m == kFusedMax + 1 && p->one_pass != 0; /* 2^15: one pass, the polynomial in registers */
+    info[5] = (team || tp || op) ? 1u : (uint64_t)make_passes(p->m, p->generic).n;
   }
   info[6] = (uint64_t)p->device;
   info[7] = p->root;
@@ -646,7 +670,10 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       return NTT_OK;
     case NTT_OPT_MAX_BATCH_HINT:
       if(value < 0) return fail(NTT_ERR_ARG, "batch hint must be >= 0");
-      p->batch_hint = (uint64_t)value;
+      {
+        std::lock_guard<std::mutex> lock(p->team_mu); /* team_buffer reads it under this mutex */
+        p->batch_hint = (uint64_t)value;
+      }
       return value ? ntt_plan_reserve(p, nullptr, (uint64_t)value) : NTT_OK;
     case NTT_OPT_BLOCK_OVERSUB:
       if(value < 0 || value > 256) return fail(NTT_ERR_ARG, "workgroups per resident slot: 0 (default) .. 256");
@@ -658,6 +685,9 @@ extern "C" int ntt_plan_set_option(ntt_plan *p, int option, int64_t value)
       return NTT_OK;
     case NTT_OPT_TWO_PHASE:
       p->two_phase = value < 0 ? -1 : (value != 0);
+      return NTT_OK;
+    case NTT_OPT_ONE_PASS:
+      p->one_pass = value < 0 ? -1 : (value != 0);
       return NTT_OK;
     case NTT_OPT_FUSED_PRODUCT:
       if(value < 0 || value > 2) return fail(NTT_ERR_ARG, "fused product: 0, 1 or 2");
@@ -721,6 +751,7 @@ extern "C" int ntt_plan_get_option(const ntt_plan *p, int option, int64_t *value
     case NTT_OPT_CHUNK_MIB: *value = p->chunk_mib; return NTT_OK;
     case NTT_OPT_F64_CLASS: *value = p->arith == NTT_ARITH_F64 ? p->kcls : -1; return NTT_OK;
     case NTT_OPT_TWO_PHASE: *value = p->two_phase; return NTT_OK;
+    case NTT_OPT_ONE_PASS: *value = p->one_pass; return NTT_OK;
     case NTT_OPT_FUSED_PRODUCT: *value = p->fused_product; return NTT_OK;
     case NTT_OPT_BLOCK_LOG: *value = p->block_log; return NTT_OK;
     case NTT_OPT_XCD_LOCAL: *value = p->xcd_local; return NTT_OK;
@@ -811,10 +842,12 @@ static bool team_applies(const ntt_plan *p, uint64_t batch, bool inverse, bool w
  * sufficient size *out stays null and the caller takes the per-pass launches. */
 static int team_buffer(const ntt_plan *p, void *stream, uint64_t batch, void **out)
 {
-  const size_t need = sizeof(TeamCtl) + (size_t)(batch > 2 * p->batch_hint ? batch : 2 * p->batch_hint) * sizeof(unsigned);
   std::lock_guard<std::mutex> lock(p->team_mu);
+  /* (batch_hint is written by ntt_plan_set_option under the same mutex) */
+  const size_t need = sizeof(TeamCtl) + (size_t)(batch > 2 * p->batch_hint ? batch : 2 * p->batch_hint) * sizeof(unsigned);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  /* a query that fails (the legacy stream asked during a global-mode capture) counts as capturing: allocating would invalidate it */
+  const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
   *out = nullptr;
   ntt_plan::TeamBuf *tb = nullptr;
   for(ntt_plan::TeamBuf &t : p->team_bufs) {
@@ -838,10 +871,16 @@ static int team_buffer(const ntt_plan *p, void *stream, uint64_t batch, void **o
     tb->d     = d;
     tb->bytes = grow;
   }
-  if(!tb->g) {
-    /* the graph block is sized once, by the first direct call (run the largest batch once before capturing) */
-    HIP_TRY(hipMalloc(&tb->g, tb->bytes));
+  if(tb->gbytes < tb->bytes) {
+    /* the graph block follows the direct block's size (first direct call, a larger direct call, ntt_plan_reserve): graphs
+     * captured so far keep the address baked into their nodes -- the old block is retired, not freed -- and captures from now on
+     * get the larger one.  (Rounds 3-5 sized it once: a larger ntt_plan_reserve before a capture silently left the captured call on
+     * the per-pass launches.) */
+    void *g = nullptr;
+    HIP_TRY(hipMalloc(&g, tb->bytes));
     p->ctl_allocs++;
+    if(tb->g) p->team_retired.push_back(tb->g);
+    tb->g      = g;
     tb->gbytes = tb->bytes;
   }
   *out = tb->d;
@@ -857,7 +896,7 @@ extern "C" int ntt_plan_reserve(const ntt_plan *p, void *stream, uint64_t polys)
   if(polys == 0) return NTT_OK;
   USE_DEVICE(p->device);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if(hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+  if(hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
     return fail(NTT_ERR_ARG, "reserve before the capture begins");
   void *ctl = nullptr;
   return team_buffer(p, stream, 2 * polys, &ctl);
@@ -870,14 +909,19 @@ struct LimbSet {
   int         n;
   uint64_t    stride;  /* words between consecutive limbs of one polynomial */
   uint64_t    pstride; /* words between consecutive polynomials of one limb; 0 = dense (N) */
+  const uint64_t *ptab = nullptr; /* pointer batch: DEVICE table, entry i = address of polynomial i's limb 0 (the data pointer of the call is
+                                   * then the limb offset alone: null + limb * stride words); pstride is then only a hint of the typical
+                                   * spacing (queue numbering of the XCD-local launches) */
 };
+/* (pointer + words) that is also defined for the null base of a pointer batch */
+static uint64_t *advance(uint64_t *base, uint64_t words) { return reinterpret_cast<uint64_t *>(reinterpret_cast<uintptr_t>(base) + 8u * (uintptr_t)words); }
 /* the words between consecutive polynomials of a limb */
 static uint64_t poly_words(const ntt_plan *p, const LimbSet &ls) { return ls.pstride ? ls.pstride : p->N; }
 
 static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool inverse, bool wide, void *stream,
                          bool lazy = false, const LimbSet *set = nullptr)
 {
-  if(!p || (!d_a && batch)) return fail(NTT_ERR_ARG, "null argument");
+  if(!p || (!d_a && batch && !(set && set->ptab))) return fail(NTT_ERR_ARG, "null argument");
   if(batch == 0) return NTT_OK;
   if(inverse ? !p->has_inv : !p->has_fwd) return fail(NTT_ERR_ARG, "plan lacks the table for this direction");
   USE_DEVICE(p->device);
@@ -885,6 +929,36 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
   const PassList L = p->arith == NTT_ARITH_U64_R4
                          ? make_passes_r4(p->m)
                          : make_passes(p->m, p->generic, p->block_log ? p->block_log : multi_pass_block(p->m, inverse, p->arith == NTT_ARITH_F64));
+  /* N = 2^15, FP64 policies: ONE pass -- a workgroup holds the whole polynomial in its registers, every coefficient crosses HBM
+   * twice (ntt_kernels.h: onepass_kernel; measured against the two-pass forms in profiles/r06/onepass_2p15.txt).  One workgroup
+   * per CU and polynomial: the automatic choice wants a polynomial for every CU; smaller batches spread over the chip as 2^12-point
+   * blocks through the per-pass launches.  Lazy outputs keep the two-pass forms (the FP64 lazy store is a kernel variant of the
+   * block kernels). */
+  if(p->m == kFusedMax + 1 && p->arith == NTT_ARITH_F64 && !p->generic && !lazy && ls.n <= kMaxLimbs &&
+     (p->one_pass == 1 || (p->one_pass < 0 && batch * (uint64_t)ls.n >= (uint64_t)p->num_cus))) {
+    PassArgs pa{};
+    pa.a           = d_a;
+    pa.limbs       = ls.d;
+    pa.nlimbs      = ls.n;
+    pa.limb_stride = ls.stride;
+    pa.poly_stride = ls.pstride;
+    pa.ptab        = ls.ptab;
+    pa.batch       = batch;
+    pa.logn        = (uint32_t)p->m;
+    pa.fused       = 4;
+    pa.r           = 1;
+    pa.s           = 0;
+    pa.inverse     = inverse;
+    pa.wide        = wide;
+    pa.lastinv     = inverse;
+    pa.ends        = 1;
+    pa.max_grid    = p->max_grid;
+    pa.num_cus     = p->num_cus;
+    pa.stream      = (hipStream_t)stream;
+    hipError_t e   = dispatch_pass(p, pa);
+    if(e != hipSuccess) return fail(NTT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTT_OK;
+  }
   /* both passes as items of ONE launch with the intermediate kept in each XCD's L2 (ntt_kernels.h: team_kernel) */
   void *ctl = nullptr;
   if(team_applies(p, batch, inverse, wide, lazy, ls.n)) {
@@ -901,6 +975,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.nlimbs      = ls.n;
     pa.limb_stride = ls.stride;
     pa.poly_stride = ls.pstride;
+    pa.ptab        = ls.ptab;
     pa.batch       = batch;
     pa.logn        = (uint32_t)p->m;
     pa.fused       = 3;
@@ -939,6 +1014,7 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     pa.nlimbs   = ls.n;
     pa.limb_stride = ls.stride;
     pa.poly_stride = ls.pstride;
+    pa.ptab     = ls.ptab;
     pa.batch    = batch;
     pa.logn     = (uint32_t)p->m;
     pa.fused    = 2;
@@ -972,7 +1048,9 @@ static int run_transform(const ntt_plan *p, uint64_t *d_a, uint64_t batch, bool 
     for(int k = 0; k < L.n; k++) {
       const Pass &ps = L.p[inverse ? L.n - 1 - k : k];
       PassArgs    pa{};
-      pa.a        = d_a + first * poly_words(p, ls);
+      /* a chunk starts `first` polynomials in: that many strides -- or table entries -- further */
+      pa.a        = ls.ptab ? d_a : d_a + first * poly_words(p, ls);
+      pa.ptab     = ls.ptab ? ls.ptab + first : nullptr;
       /* (radix-4 inverse: a pass that does not end the transform multiplies by 1, not by N^-1) */
       pa.limbs    = p->arith == NTT_ARITH_U64_R4 && inverse && ps.s != 0 ? (const void *)p->limbrec_mid.data() : ls.d;
       pa.nlimbs   = ls.n;
@@ -1113,6 +1191,10 @@ static unsigned grid_for(uint64_t n, unsigned cap = 256 * 32)
 {
   uint64_t g = (n + 255) / 256;
   if(g > cap) g = cap;
+  /* a launch's threads per dimension must stay below 2^32 (hipErrorInvalidConfiguration otherwise: the 128 GiB slab of
+   * `bench.py --scaling strong --gpus 1` asked the one-word-per-thread copy probe for exactly 2^32); the kernels that use this are
+   * grid-stride loops, so a smaller grid only means a second iteration */
+  if(g > (1u << 24) - 1u) g = (1u << 24) - 1u;
   if(g == 0) g = 1;
   return (unsigned)g;
 }
@@ -1394,7 +1476,7 @@ static bool rns_compatible(const ntt_plan *a, const ntt_plan *b)
          (b->int_cls >= 0) == (a->int_cls >= 0) && b->m == a->m &&
          b->generic == a->generic && b->block_log == a->block_log && b->chunk_mib == a->chunk_mib && b->two_phase == a->two_phase &&
          b->fused_product == a->fused_product && b->max_grid == a->max_grid && b->block_oversub == a->block_oversub && b->rns_launch == a->rns_launch && b->dot_fused == a->dot_fused && b->has_fwd == a->has_fwd && b->has_inv == a->has_inv &&
-         b->xcd_local == a->xcd_local && b->team_lag == a->team_lag && b->team_wpc == a->team_wpc;
+         b->xcd_local == a->xcd_local && b->team_lag == a->team_lag && b->team_wpc == a->team_wpc && b->one_pass == a->one_pass;
 }
 
 /* Where the limbs and polynomials of an RNS operand live (words): polynomial p of limb l starts l * limb + p * poly words in.
@@ -1402,6 +1484,7 @@ static bool rns_compatible(const ntt_plan *a, const ntt_plan *b)
  * FHE library holds: a ciphertext polynomial = its limbs side by side --: {N, limbs * N}.  Padded forms of either are fine. */
 struct Layout {
   uint64_t limb, poly;
+  const uint64_t *ptab = nullptr; /* pointer batch: device table of the polynomials' limb-0 addresses (poly = typical spacing, a hint) */
 };
 /* the strides must keep the (limb, polynomial) ranges apart: limb-major (a limb's polynomials inside its slab) or
  * polynomial-major (a polynomial's limbs inside its record) */
@@ -1440,7 +1523,7 @@ static int rns_for_runs(int nlimbs, ntt_plan *const *plans, const Layout &lay, P
     const int first = run.first, n = run.second;
     if(n > 1 && pays(plans[first], n)) {
       const std::vector<unsigned char> recs = rns_records(plans, first, n);
-      const LimbSet                    ls{recs.data(), n, lay.limb, lay.poly};
+      const LimbSet                    ls{recs.data(), n, lay.limb, lay.poly, lay.ptab};
       int kc = plans[first]->kcls, ic = plans[first]->int_cls;
       for(int l = first + 1; l < first + n; l++) {
         kc = plans[l]->kcls < kc ? plans[l]->kcls : kc;
@@ -1488,22 +1571,23 @@ static std::vector<unsigned char> rns_records(ntt_plan *const *plans, int first,
 }
 
 /* the plan's own record as a one-limb set whose polynomials are lay.poly words apart */
-static LimbSet own_set(const ntt_plan *p, const Layout &lay) { return LimbSet{p->limbrec.data(), 1, 0, lay.poly}; }
+static LimbSet own_set(const ntt_plan *p, const Layout &lay) { return LimbSet{p->limbrec.data(), 1, 0, lay.poly, lay.ptab}; }
 
 static int rns_transform(int nlimbs, ntt_plan *const *plans, uint64_t *d_a, uint64_t batch, bool inverse, void *stream, const Layout &lay)
 {
   int rc = rns_check(nlimbs, plans);
   if(rc || batch == 0) return rc;
-  if(!d_a) return fail(NTT_ERR_ARG, "null argument");
-  rc = layout_check(plans[0]->N, nlimbs, batch, lay);
+  if(!d_a && !lay.ptab) return fail(NTT_ERR_ARG, "null argument");
+  /* (a pointer batch: the images were checked one by one where the pointers were visible -- ptr_runs) */
+  rc = lay.ptab ? NTT_OK : layout_check(plans[0]->N, nlimbs, batch, lay);
   if(rc) return rc;
   return rns_for_runs(
     nlimbs, plans, lay,
     [&](const ntt_plan *p, int n) { return rns_one_launch_pays(p, batch) || rns_team_launch(p, n, batch, inverse, false); },
-    [&](int first, const LimbSet &ls) { return run_transform(plans[first], d_a + (uint64_t)first * lay.limb, batch, inverse, false, stream, false, &ls); },
+    [&](int first, const LimbSet &ls) { return run_transform(plans[first], advance(d_a, (uint64_t)first * lay.limb), batch, inverse, false, stream, false, &ls); },
     [&](int l) {
       const LimbSet own = own_set(plans[l], lay);
-      return run_transform(plans[l], d_a + (uint64_t)l * lay.limb, batch, inverse, false, stream, false, &own);
+      return run_transform(plans[l], advance(d_a, (uint64_t)l * lay.limb), batch, inverse, false, stream, false, &own);
     });
 }
 
@@ -2099,18 +2183,25 @@ extern "C" int ntt_transform_batch_strided(const ntt_plan *p, uint64_t *d_a, uin
   return run_transform(p, d_a, batch, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream, (flags & NTT_FLAG_LAZY_OUT) != 0, &own);
 }
 
-/* ---- pointer batches: one device pointer per polynomial (host array) ----
+/* ---- pointer batches: one device pointer per polynomial ----
  * The reference's batching precedent hands over one array per polynomial: fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...)
- * (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91).  Generalised to `count` pointers: the polynomials are independent
- * and transformed in place, so their order is free -- the pointers are sorted and cut into maximal arithmetic progressions,
- * and every progression is ONE strided launch chain (a pool of equally spaced ciphertexts, the rows of a caller's matrix, two
- * arrays a fixed distance apart: one launch; pointers with no regularity: one launch chain each).  Overlapping polynomials are
- * refused. */
-static int ptr_runs(uint64_t N, int nlimbs, uint64_t limb_stride, uint64_t *const *h_polys, uint64_t count,
-                    std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> &runs)
+ * (include/ntt_reference.h:44-49, src/ntt_reference.c:71-91).  Generalised to `count` pointers placed anywhere: ONE launch chain
+ * for the whole batch -- the kernels read a polynomial's address from a device table where they would multiply its index by the
+ * stride (ntt_core.h poly_offset; round 6: rounds 1-5 cut the sorted pointers into arithmetic progressions and launched every
+ * progression by itself, i.e. 4096 separately allocated polynomials = 4096 launches).
+ *   host array  (ntt_transform_ptrs):     sorted (the polynomials are independent and transformed in place: their order is free, and
+ *                address order is what the memory system likes), checked for overlap, uploaded through the plan's staging buffer of
+ *                the stream.  A batch that IS one arithmetic progression keeps the strided launch (no table).  While the stream is
+ *                being captured nothing can be uploaded: progression by progression then -- use the device-array form in graphs.
+ *   device array (ntt_transform_dev_ptrs): taken as it is -- no copy, no check (overlaps are the caller's business), capturable. */
+struct PtrRun {
+  uint64_t *first;
+  uint64_t  stride, count; /* words between consecutive polynomials (0: a single one), polynomials */
+};
+static int ptr_sorted(uint64_t N, int nlimbs, uint64_t limb_stride, uint64_t *const *h_polys, uint64_t count, std::vector<uintptr_t> &v)
 {
   if(!h_polys) return fail(NTT_ERR_ARG, "null argument");
-  std::vector<uintptr_t> v(count);
+  v.resize(count);
   for(uint64_t i = 0; i < count; i++) {
     if(!h_polys[i] || ((uintptr_t)h_polys[i] & 7)) return fail(NTT_ERR_ARG, "pointer batch: null or misaligned polynomial pointer");
     v[i] = (uintptr_t)h_polys[i];
@@ -2119,33 +2210,81 @@ static int ptr_runs(uint64_t N, int nlimbs, uint64_t limb_stride, uint64_t *cons
   /* overlap: every limb image [pointer + l * limb_stride, + N) of every polynomial is an interval of N words; sorted by start,
    * two of them intersect iff two neighbours do.  (Exact also for pointers INTO a [limb][batch][N] slab, whose polynomials
    * interleave without overlapping.) */
-  {
-    std::vector<uintptr_t> img;
-    const std::vector<uintptr_t> *starts = &v;
-    if(nlimbs > 1) {
-      img.reserve((size_t)count * (size_t)nlimbs);
-      for(uint64_t i = 0; i < count; i++) {
-        for(int l = 0; l < nlimbs; l++) img.push_back(v[i] + (uintptr_t)l * (uintptr_t)limb_stride * 8u);
-      }
-      std::sort(img.begin(), img.end());
-      starts = &img;
+  std::vector<uintptr_t> img;
+  const std::vector<uintptr_t> *starts = &v;
+  if(nlimbs > 1) {
+    img.reserve((size_t)count * (size_t)nlimbs);
+    for(uint64_t i = 0; i < count; i++) {
+      for(int l = 0; l < nlimbs; l++) img.push_back(v[i] + (uintptr_t)l * (uintptr_t)limb_stride * 8u);
     }
-    for(size_t i = 0; i + 1 < starts->size(); i++) {
-      if((*starts)[i + 1] - (*starts)[i] < N * 8) return fail(NTT_ERR_ARG, "pointer batch: polynomials overlap (or a pointer is listed twice)");
-    }
+    std::sort(img.begin(), img.end());
+    starts = &img;
   }
-  for(uint64_t i = 0; i < count;) {
-    uint64_t j = i, d = 0;
-    if(i + 1 < count) {
-      d = (uint64_t)(v[i + 1] - v[i]);
-      j = i + 1;
-      while(j + 1 < count && (uint64_t)(v[j + 1] - v[j]) == d) j++;
-    }
-    /* {first polynomial, {word stride (0: a single polynomial), polynomials}} */
-    runs.push_back({reinterpret_cast<uint64_t *>(v[i]), {d / 8, j - i + 1}});
-    i = j + 1;
+  for(size_t i = 0; i + 1 < starts->size(); i++) {
+    if((*starts)[i + 1] - (*starts)[i] < N * 8) return fail(NTT_ERR_ARG, "pointer batch: polynomials overlap (or a pointer is listed twice)");
   }
   return NTT_OK;
+}
+/* the sorted addresses as maximal arithmetic progressions (the fallback while capturing, and the test for "one progression").  A
+ * run of two is not taken greedily: {0, 100N, 101N, 102N} is 1 + 3, not 2 + 2 -- when the pair's successor starts a longer
+ * progression of another step, the first pointer goes by itself.  Steps beyond the strided entry points' bound (2^40 words)
+ * never join a run. */
+static void ptr_runs(const std::vector<uintptr_t> &v, std::vector<PtrRun> &runs)
+{
+  const uint64_t count = v.size();
+  const auto     step  = [&](uint64_t i) { return (uint64_t)(v[i + 1] - v[i]); };
+  const auto     ok    = [&](uint64_t d) { return d / 8 <= (1ull << 40); };
+  for(uint64_t i = 0; i < count;) {
+    uint64_t j = i, d = 0;
+    if(i + 1 < count && ok(step(i))) {
+      d = step(i);
+      j = i + 1;
+      while(j + 1 < count && step(j) == d) j++;
+      if(j == i + 1 && j + 2 < count && step(j) != d && step(j) == step(j + 1)) j = i, d = 0; /* the pair's second member starts a longer run */
+    }
+    runs.push_back(PtrRun{reinterpret_cast<uint64_t *>(v[i]), d / 8, j - i + 1});
+    i = j + 1;
+  }
+}
+/* uploads the sorted addresses into the (plan, stream) device table; *out = the table, or null while the stream is being captured */
+static int ptr_table(const ntt_plan *p, void *stream, const std::vector<uintptr_t> &v, const uint64_t **out)
+{
+  *out = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if(hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return NTT_OK;
+  std::lock_guard<std::mutex> lock(p->team_mu);
+  ntt_plan::PtrBuf *pb = nullptr;
+  for(ntt_plan::PtrBuf &b : p->ptr_bufs) {
+    if(b.stream == stream) pb = &b;
+  }
+  if(!pb) {
+    p->ptr_bufs.push_back(ntt_plan::PtrBuf{stream, nullptr, nullptr, 0, nullptr});
+    pb = &p->ptr_bufs.back();
+    HIP_TRY(hipEventCreateWithFlags(&pb->copied, hipEventDisableTiming));
+  }
+  if(pb->words < v.size()) {
+    const size_t words = v.size() * 2;
+    uint64_t *   d = nullptr, *h = nullptr;
+    HIP_TRY(hipMalloc(&d, words * 8));
+    if(hipHostMalloc(&h, words * 8, hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(d);
+      return fail(NTT_ERR_NOMEM, "pointer batch: pinned staging buffer");
+    }
+    if(pb->d) p->ptr_retired.push_back({pb->d, pb->h}); /* launches and copies still queued may be using them */
+    pb->d = d, pb->h = h, pb->words = words;
+  } else {
+    HIP_TRY(hipEventSynchronize(pb->copied)); /* the previous upload has left the staging buffer (an event never recorded is complete) */
+  }
+  for(size_t i = 0; i < v.size(); i++) pb->h[i] = (uint64_t)v[i];
+  HIP_TRY(hipMemcpyAsync(pb->d, pb->h, v.size() * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipEventRecord(pb->copied, (hipStream_t)stream));
+  *out = pb->d;
+  return NTT_OK;
+}
+/* typical distance between neighbours of a sorted batch, in words: the hint the XCD-local launches number their queues by */
+static uint64_t ptr_spacing(const std::vector<uintptr_t> &v, uint64_t fallback)
+{
+  return v.size() > 1 ? (uint64_t)(v[v.size() / 2] - v[v.size() / 2 - 1]) / 8 : fallback;
 }
 
 extern "C" int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, uint64_t count, unsigned flags, void *stream)
@@ -2153,14 +2292,36 @@ extern "C" int ntt_transform_ptrs(const ntt_plan *p, uint64_t *const *h_polys, u
   if(flags & ~(unsigned)(NTT_FLAG_INVERSE | NTT_FLAG_WIDE_IN | NTT_FLAG_LAZY_OUT)) return fail(NTT_ERR_ARG, "unknown flag");
   if(!p) return fail(NTT_ERR_ARG, "null argument");
   if(count == 0) return NTT_OK;
-  std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
-  int rc = ptr_runs(p->N, 1, 0, h_polys, count, runs);
+  USE_DEVICE(p->device);
+  std::vector<uintptr_t> v;
+  int rc = ptr_sorted(p->N, 1, 0, h_polys, count, v);
+  if(rc) return rc;
+  std::vector<PtrRun> runs;
+  ptr_runs(v, runs);
+  const bool inverse = (flags & NTT_FLAG_INVERSE) != 0, wide = (flags & NTT_FLAG_WIDE_IN) != 0, lazy = (flags & NTT_FLAG_LAZY_OUT) != 0;
+  const uint64_t *tab = nullptr;
+  if(runs.size() > 1) {
+    rc = ptr_table(p, stream, v, &tab);
+    if(rc) return rc;
+  }
+  if(tab) {
+    const LimbSet set{p->limbrec.data(), 1, 0, 0, tab};
+    return run_transform(p, nullptr, count, inverse, wide, stream, lazy, &set);
+  }
   for(size_t r = 0; !rc && r < runs.size(); r++) {
-    const LimbSet own{p->limbrec.data(), 1, 0, runs[r].second.first};
-    rc = run_transform(p, runs[r].first, runs[r].second.second, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream,
-                       (flags & NTT_FLAG_LAZY_OUT) != 0, &own);
+    const LimbSet own{p->limbrec.data(), 1, 0, runs[r].stride};
+    rc = run_transform(p, runs[r].first, runs[r].count, inverse, wide, stream, lazy, &own);
   }
   return rc;
+}
+
+extern "C" int ntt_transform_dev_ptrs(const ntt_plan *p, const uint64_t *const *d_polys, uint64_t count, unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)(NTT_FLAG_INVERSE | NTT_FLAG_WIDE_IN | NTT_FLAG_LAZY_OUT)) return fail(NTT_ERR_ARG, "unknown flag");
+  if(!p || (!d_polys && count)) return fail(NTT_ERR_ARG, "null argument");
+  if(count == 0) return NTT_OK;
+  const LimbSet set{p->limbrec.data(), 1, 0, 0, reinterpret_cast<const uint64_t *>(d_polys)};
+  return run_transform(p, nullptr, count, (flags & NTT_FLAG_INVERSE) != 0, (flags & NTT_FLAG_WIDE_IN) != 0, stream, (flags & NTT_FLAG_LAZY_OUT) != 0, &set);
 }
 
 /* the same for RNS polynomials: h_polys[i] points at limb 0 of polynomial i, its limbs limb_stride words apart */
@@ -2172,25 +2333,48 @@ extern "C" int ntt_rns_transform_ptrs(int nlimbs, ntt_plan *const *plans, uint64
   if(rc || count == 0) return rc;
   const uint64_t N = plans[0]->N;
   if(limb_stride < N || limb_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the limb stride must be at least N words");
+  USE_DEVICE(plans[0]->device);
   const uint64_t span = (uint64_t)(nlimbs - 1) * limb_stride + N; /* words one RNS polynomial covers */
-  std::vector<std::pair<uint64_t *, std::pair<uint64_t, uint64_t>>> runs;
-  rc = ptr_runs(N, nlimbs, limb_stride, h_polys, count, runs);
+  const bool inverse  = (flags & NTT_FLAG_INVERSE) != 0;
+  std::vector<uintptr_t> v;
+  rc = ptr_sorted(N, nlimbs, limb_stride, h_polys, count, v);
+  if(rc) return rc;
+  std::vector<PtrRun> runs;
+  ptr_runs(v, runs);
+  /* a progression the strided entry point takes whole is limb-major (the limbs' slabs apart: pointers into a [limb][batch][N]
+   * slab) or polynomial-major (every polynomial's limbs inside its own record); any other spacing is legal here -- the
+   * images were checked one by one above -- but not expressible as ONE layout */
+  const auto whole = [&](const PtrRun &r) { return r.count <= 1 || limb_stride >= (r.count - 1) * r.stride + N || r.stride >= span; };
+  const uint64_t *tab = nullptr;
+  if(runs.size() > 1 || !whole(runs[0])) {
+    rc = ptr_table(plans[0], stream, v, &tab);
+    if(rc) return rc;
+  }
+  if(tab) return rns_transform(nlimbs, plans, nullptr, count, inverse, stream, Layout{limb_stride, ptr_spacing(v, span), tab});
   for(size_t r = 0; !rc && r < runs.size(); r++) {
-    uint64_t *first = runs[r].first;
-    uint64_t  d = runs[r].second.first ? runs[r].second.first : span, cnt = runs[r].second.second;
-    /* a progression the strided entry point takes whole is limb-major (the limbs' slabs apart: pointers into a [limb][batch][N]
-     * slab) or polynomial-major (every polynomial's limbs inside its own record); any other spacing is legal here -- the
-     * images were checked one by one above -- but not expressible as ONE layout: polynomial by polynomial then */
-    const bool whole = cnt <= 1 || limb_stride >= (cnt - 1) * d + N || d >= span;
-    if(whole) {
-      rc = rns_transform(nlimbs, plans, first, cnt, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, cnt > 1 ? d : span});
+    const uint64_t d = runs[r].stride ? runs[r].stride : span;
+    if(whole(runs[r])) {
+      rc = rns_transform(nlimbs, plans, runs[r].first, runs[r].count, inverse, stream, Layout{limb_stride, runs[r].count > 1 ? d : span});
     } else {
-      for(uint64_t i = 0; !rc && i < cnt; i++) {
-        rc = rns_transform(nlimbs, plans, first + i * d, 1, (flags & NTT_FLAG_INVERSE) != 0, stream, Layout{limb_stride, span});
-      }
+      for(uint64_t i = 0; !rc && i < runs[r].count; i++) rc = rns_transform(nlimbs, plans, runs[r].first + i * d, 1, inverse, stream, Layout{limb_stride, span});
     }
   }
   return rc;
+}
+
+extern "C" int ntt_rns_transform_dev_ptrs(int nlimbs, ntt_plan *const *plans, const uint64_t *const *d_polys, uint64_t count, uint64_t limb_stride,
+                                          unsigned flags, void *stream)
+{
+  if(flags & ~(unsigned)NTT_FLAG_INVERSE) return fail(NTT_ERR_ARG, "unknown flag (RNS transforms take NTT_FLAG_INVERSE only)");
+  int rc = rns_check(nlimbs, plans);
+  if(rc || count == 0) return rc;
+  if(!d_polys) return fail(NTT_ERR_ARG, "null argument");
+  const uint64_t N = plans[0]->N;
+  if(limb_stride < N || limb_stride > (1ull << 40)) return fail(NTT_ERR_ARG, "layout: the limb stride must be at least N words");
+  /* (spacing hint: a polynomial's limbs side by side unless the limb stride says they are slabs apart) */
+  const uint64_t span = (uint64_t)(nlimbs - 1) * limb_stride + N;
+  return rns_transform(nlimbs, plans, nullptr, count, (flags & NTT_FLAG_INVERSE) != 0, stream,
+                       Layout{limb_stride, limb_stride >= count * N ? N : span, reinterpret_cast<const uint64_t *>(d_polys)});
 }
 
 extern "C" int ntt_fill_uniform(int device, uint64_t *d_a, uint64_t n, uint64_t q, uint64_t seed, uint64_t offset,

@@ -84,10 +84,17 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
    * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
    * and L2 latencies better.) */
-  /* 2^13 (FP64 policies): TWO blocks per 1024-thread workgroup, each half running the persistent loop on its own
-   * exchange buffer and sharing the twiddle table -- the resource shape of the 2^14 kernel (16 waves per CU,
-   * 158 KB of LDS).  One 512-thread workgroup per CU with every table in LDS (round 1) left two waves per SIMD. */
-  static constexpr bool PERSIST2 = FLAVOR == 1 && LOGN == 13 && !INV;
+  /* 2^13 forward (FP64 policies), round 6: TWO INDEPENDENT 512-thread workgroups per CU, one block each -- own exchange buffer, own
+   * barriers, own (partial, see TBL_STAGES) twiddle table, 8 workgroups launched per resident slot like the 2^12 kernels, so that the
+   * two residents of a CU drift apart.  Rounds 2-5 ran ONE 1024-thread workgroup whose halves owned a block each and shared the
+   * table (PERSIST2): the resource shape of the 2^14 kernel, but the halves met at every workgroup barrier -- in step by
+   * construction, which is what round 5 measured as 4-9 % at 2^12 (profiles/r05/NOTES_blk12.md) -- and their block index lived in
+   * vector registers (it depends on the wave), with it every block address.  PERSIST2 is kept as a compile-time switch for A/B
+   * builds (-DNTT_PERSIST2_13=1). */
+#ifndef NTT_PERSIST2_13
+#  define NTT_PERSIST2_13 0
+#endif
+  static constexpr bool PERSIST2 = NTT_PERSIST2_13 != 0 && FLAVOR == 1 && LOGN == 13 && !INV;
   /* (inverse: measured 0.584 -> 0.48 in round 2 and again in round 3 (profiles/r03/ablations.txt) -- with the stage-12
    * twiddles register-resident the kernel needs 133 VGPRs (5 spilled); requested per block it fits in 122 without a
    * spill and is still 18 % slower: the two exchange buffers leave 1.8 KB of LDS, 128 bytes short of even the 1.9 KB
@@ -115,6 +122,17 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
       if(P::TW_UNIFORM(g, j)) return false;
     return true;
   }
+  /* which stages of group g the LDS table holds (bit j = local stage j; always a prefix: the table is laid out stage by stage).
+   * 2^13 forward with two independent workgroups per CU: the second-to-last group's stages 8..10 (1792 entries, 14 KB) -- with
+   * stage 11 (2048 entries, 16 KB) two workgroups of 64.1 KB + 30 KB would not fit the CU's 160 KB; its eight twiddles per thread
+   * come from global memory, requested a stage ahead (run_group's pipelining) */
+  static constexpr uint32_t TBL_STAGES(int g)
+  {
+    if(g < 0 || g >= P::NG) return 0u;
+    const uint32_t all = (1u << P::R(g)) - 1u;
+    if(FLAVOR == 1 && LOGN == 13 && !INV && !PERSIST2 && g == P::NG - 2) return all >> 1;
+    return all;
+  }
   static constexpr int TBL(int g)
   {
     if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
@@ -122,7 +140,7 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
     if(LOGN == 14 || LOGN == 12 || (LOGN == 13 && !INV)) on = (g == P::NG - 2);
     if(LOGN >= 8 && LOGN <= 11) on = true; /* several blocks per workgroup share the tables (2^6, 2^7: measured no gain) */
     if(LOGN == 13 && INV) on = true;
-    return on ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
+    return on ? (int)(TBL_STAGES(g) << P::S(g)) : 0;
   }
   /* first entry of group g's table behind the exchange buffer(s) */
   static constexpr int TBL_OFF(int g)
@@ -172,6 +190,8 @@ template <class A> struct KArgs {
   uint32_t          wgs_per_limb; /* grid = wgs_per_limb * limbs                                  */
   uint32_t          logn, s0, wide, lastinv, lazy;
   uint64_t          nblocks;      /* per limb                                                     */
+  const uint64_t *  ptab;         /* transform launches over a pointer batch: device table of per-polynomial word offsets from `a`
+                                   * (ntt_core.h poly_offset; a = null, so an entry is address / 8); null otherwise */
   /* one record per limb, IN the kernel-argument segment: its loads are kernarg-relative scalar loads like those of a
    * single set of tables (the compiler re-loads them at will instead of holding or spilling them -- a table in global
    * memory cost the 2^14 inverse kernel 3-4 spilled VGPRs) */
@@ -215,6 +235,7 @@ __device__ __forceinline__ Params<A> limb_params(const KArgs<A> &k, uint32_t &bi
   p.lazy    = k.lazy;
   p.nblocks = k.nblocks;
   p.pstride = k.poly_stride;
+  p.ptab    = k.ptab;
   return p;
 }
 
@@ -222,6 +243,11 @@ __device__ __forceinline__ Params<A> limb_params(const KArgs<A> &k, uint32_t &bi
 template <int LOGN, class A> __device__ __forceinline__ uint64_t blk_off(const Params<A> &p, uint64_t b)
 {
   return block_offset<LOGN>(b, p.s0, p.pstride);
+}
+/* the same for the transform kernels, which also serve pointer batches (Params::ptab: the polynomial's start comes from a table) */
+template <int LOGN, class A> __device__ __forceinline__ uint64_t blk_off_t(const Params<A> &p, uint64_t b)
+{
+  return block_offset<LOGN>(b, p.s0, p.pstride, p.ptab);
 }
 
 #ifdef NTT_STAMPS
@@ -450,6 +476,7 @@ __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Par
       typename A::ctw *tg = tabl + G::TBL_OFF(GI);
       static_for<0, P::R(GI)>([&](auto jj) {
         constexpr int JJ  = decltype(jj)::value;
+        if constexpr(((G::TBL_STAGES(GI) >> JJ) & 1u) == 0) return;
         constexpr int SG  = P::S(GI);
         constexpr int SLJ = SG + JJ;
         const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
@@ -479,7 +506,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
   __shared__ typename A::val lds_all[G::BPW * P::LDS_ELEMS + LDS_TW];
 
   const uint32_t     tid = threadIdx.x;
-  const uint32_t     sub = tid >> P::LT;
+  /* (two blocks per 1024-thread workgroup, the A/B shape PERSIST2: the half is a property of the wave -- said so, the block index and
+   * every address derived from it stay in scalar registers) */
+  const uint32_t     sub = G::PERSIST2 ? uniform_u32(tid >> P::LT) : (tid >> P::LT);
   const uint32_t     t   = tid & (P::T - 1);
   typename A::val *  lds = lds_all + sub * P::LDS_ELEMS;
   const uint32_t     bmask = (1u << p.s0) - 1u;
@@ -515,8 +544,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       fill_lds_tables<A, LOGN, INV>(tabl, p, (uint32_t)b & bmask, tid);
       __syncthreads();
     }
+    /* Block offsets run one block ahead of the loads: off_cur = the block being transformed, off_nxt = the block whose words are
+     * requested during this iteration -- computed (a pointer batch: read from the table, Params::ptab, one scalar load) a whole
+     * iteration before the prefetch that uses it, so no table latency ever sits in front of the coefficient loads */
+    const auto next_blk = [&](uint64_t at) -> uint64_t {
+      const uint64_t n0 = below(at + stride, p.nblocks) ? at + stride : at;
+      return G::BPW == 1 ? n0 : (n0 + sub < p.nblocks ? n0 + sub : lastb);
+    };
+    uint64_t off_cur = blk_off_t<LOGN>(p, b), off_nxt = blk_off_t<LOGN>(p, next_blk(b0));
     uint64_t raw[kE];
-    prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
+    prefetch_first<LOGN>(raw, tt, p.a + off_cur);
     pin_raw(raw);
 #ifdef NTT_STAMPS
     unsigned long long last_ = stamp_now();
@@ -539,7 +576,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
-      uint64_t *     base = p.a + blk_off<LOGN>(p, b);
+      uint64_t *     base = p.a + off_cur;
       typename A::val x[kE];
       convert_inputs<A, false>(x, raw, p.wide != 0, p.c);
       {
@@ -548,9 +585,9 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
          * four placements: after the first exchange -4 %, inside the last group -3 %,
          * a quarter after every exchange -7 %; profiles/r01/ablations.txt) */
         const bool     more = b0 + stride < p.nblocks;
-        const uint64_t nb0  = more ? b0 + stride : b0;
-        const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, nb), more);
+        prefetch_first<LOGN>(raw, tt, p.a + off_nxt, more);
+        off_cur = off_nxt;
+        off_nxt = blk_off_t<LOGN>(p, next_blk(more ? b0 + stride : b0)); /* the block after the next: used one iteration from now */
       }
       STAMP(0); /* wait for prefetched coefficients + convert */
       run_group<A, LOGN, 0, false, MASK>(x, tt, blk, p);
@@ -562,7 +599,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
-          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tt, blk, p, ltw + G::TBL_OFF(GI + 1));
+          run_group<A, LOGN, GI + 1, false, MASK, true, false, G::TBL_STAGES(GI + 1)>(x, tt, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
           run_group<A, LOGN, GI + 1, false, MASK>(x, tt, blk, p);
         }
@@ -611,8 +648,14 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
                           !(LOGN == 12 && KSH == 1);
     typename A::ctw pre[4][kE / 2];
     if constexpr(IPRE) preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
+    /* (block offsets one block ahead of the loads, as in the forward loop) */
+    const auto next_blk = [&](uint64_t at) -> uint64_t {
+      const uint64_t n0 = below(at + stride, p.nblocks) ? at + stride : at;
+      return G::BPW == 1 ? n0 : (n0 + sub < p.nblocks ? n0 + sub : lastb);
+    };
+    uint64_t off_cur = blk_off_t<LOGN>(p, b), off_nxt = blk_off_t<LOGN>(p, next_blk(b0));
     uint64_t raw[kE];
-    prefetch_last<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
+    prefetch_last<LOGN>(raw, tt, p.a + off_cur);
     pin_raw(raw);
     if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
 #if NTT_STAGGER
@@ -622,15 +665,15 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t blk  = (uint32_t)b & bmask;
-      uint64_t *     base = p.a + blk_off<LOGN>(p, b);
+      uint64_t *     base = p.a + off_cur;
       typename A::val x[kE];
       convert_inputs<A, true>(x, raw, p.wide != 0, p.c);
       {
         /* (whole-line loads through the same lane swap as the forward stores: measured 17.74 vs 17.75 M, not kept) */
         const bool     more = b0 + stride < p.nblocks;
-        const uint64_t nb0  = more ? b0 + stride : b0;
-        const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_last<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, nb), more);
+        prefetch_last<LOGN>(raw, tt, p.a + off_nxt, more);
+        off_cur = off_nxt;
+        off_nxt = blk_off_t<LOGN>(p, next_blk(more ? b0 + stride : b0));
       }
       if constexpr(IPRE) {
         run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
@@ -677,15 +720,16 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     const bool live = b < p.nblocks;
     if(!live) b = p.nblocks - 1; /* idle lanes shadow a real block, never store */
     const uint32_t blk  = (uint32_t)b & bmask;
-    uint64_t *     base = p.a + blk_off<LOGN>(p, b);
+    /* (several blocks per workgroup: `sub` is per wave at most, the table entry of a pointer batch a per-lane load) */
+    uint64_t *     base = p.a + (poly_offset<false>(b >> p.s0, p.pstride, p.ptab) + ((b & bmask) << LOGN));
     typename A::val x[kE];
     if constexpr(!INV) {
       global_load_first<A, LOGN, false>(x, t, base, p.wide != 0, p.c);
-      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, t, blk, p, gtw);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0), false, G::TBL_STAGES(0)>(x, t, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, t, lds);
-        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0), false, G::TBL_STAGES(GI + 1)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
       if(live) global_store_last<A, LOGN, false, LAZY>(x, t, base, p.c, p.lazy != 0);
     } else {
@@ -875,7 +919,7 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
   constexpr bool MID_LAZY = !A::kTracksBounds;
 
   for(uint64_t poly = bid; poly < p.nblocks; poly += gdim) {
-    uint64_t *const base = p.a + poly * p.pstride;
+    uint64_t *const base = p.a + poly_offset<true>(poly, p.pstride, p.ptab);
     if constexpr(!INV) {
       twophase_columns<A, LEAD, false, KSH>(base, tid, p, p.wide != 0, MID_LAZY);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -976,6 +1020,229 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       twophase_columns<A, LEAD, true, KSH>(base, tid, p, false, p.lazy != 0);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* N = 2^15 in ONE pass: the whole polynomial in the registers of one workgroup */
+/* ------------------------------------------------------------------ */
+/*
+ * Round 6 (review r05 item 5; tools/skel15.hip, profiles/r06/skel15.txt).  A 2^15-point transform is one stage on pairs 2^14
+ * apart and two independent 2^14-point transforms with the twiddles of block positions 0 and 1 -- the shape the 2^14 block
+ * kernel already runs below a column pass.  A 1024-thread workgroup that owns BOTH halves of a polynomial (32 words per thread,
+ * 256 KiB of registers per CU) runs that first stage thread-locally -- slot e of half 0 and slot e of half 1 are index (e << 10) + t
+ * and 2^14 + (e << 10) + t -- so every coefficient crosses HBM exactly twice: 16N bytes, where the two-pass forms move 24N..32N across
+ * the fabric (team_kernel 0.43 of the roofline forward, per-pass launches 0.38 inverse; the skeleton with this kernel's VALU count
+ * and exchanges: 0.60).  Registers decide the schedule: the polynomial is 64 VGPRs, so the NEXT polynomial cannot be prefetched
+ * whole.  Forward: half A's 16 words are requested when half A has been stored, half B's when half B has been stored (the first
+ * stage of the next polynomial needs both: half B's latency is exposed once per polynomial -- the skeleton prices that at 3 %).
+ * Inverse (blocks first, the pair stage last, N^-1 folded): half B of the SAME polynomial arrives while half A runs its fourteen
+ * stages; the next polynomial's half A is requested behind the final stores.  The blocks are the body of twophase_kernel's block
+ * loops: second-to-last group's twiddles from an LDS table REFRESHED per half between the two barriers of the cross-wave exchange,
+ * last group's twiddles requested per half (two halves = two sets: they cannot stay resident as in the 2^14 kernel).
+ * Reduction schedule (FP64): ONE schedule over all fifteen forward stages (onepass_fwd_mask) -- the pair stage is its bit 0, the
+ * blocks take the rest; inverse: the blocks' per-slot plan, then both inputs of the pair stage reduced (3 exact instructions each;
+ * the plan's bound at a block's end is not an input the last butterfly's 2B <= LIM argument covers).
+ * Reference precedent: src/ntt_radix4x4.c:54-78 (several stages on values held close), third_party/hexl/fwd-ntt-avx512.c:311-329.
+ */
+/* one half (block position blk of a 2^15-point polynomial, s0 = 1) through the forward block stages and out to memory */
+template <class A, uint32_t MASK>
+__device__ __forceinline__ void onepass_block_fwd(typename A::val (&x)[kE], uint32_t blk, uint32_t tid, uint64_t *bb, const Params<A> &p,
+                                                  typename A::val *lds_all, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, flavor_of<A>()>;
+  constexpr int  GL  = P::NG - 1;
+  constexpr bool LTW = G::LDS_TW > 0;
+  constexpr bool PRE = A::kCompact && stage_is_compact<A, LOGN, false>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  TableRegs<A, LOGN, false> tr;
+  run_group<A, LOGN, 0, false, MASK>(x, tid, blk, p);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr(LTW) tr.load(p, blk, tid);
+  __builtin_amdgcn_sched_barrier(0);
+  typename A::ctw pre[4][kE / 2];
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = decltype(gg)::value;
+    if constexpr(GI == 0 && LTW) {
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all, [&]() { tr.store(tabl, tid); });
+    } else {
+      exchange<A, LOGN, GI, GI + 1>(x, tid, lds_all);
+    }
+    if constexpr(GI == kTpPreAt && PRE) preload_group_tw<A, LOGN, GL>(pre, tid, blk, p);
+    if constexpr(PRE && GI + 1 == GL) {
+      run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
+    } else if constexpr(G::TBL(GI + 1) > 0) {
+      run_group<A, LOGN, GI + 1, false, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI + 1));
+    } else {
+      run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
+    }
+  });
+  store_last_whole_lines<A, LOGN, false>(x, tid, bb, p.c, false);
+}
+
+/* one half through the inverse block stages (not the transform's last pass): x holds the block's results, unreduced, in the
+ * first-kind layout.  pre: this half's first-group twiddles (requested by the caller ahead of time); nblk: the half whose table
+ * and twiddles are fetched for the NEXT call (the table refresh sits between this call's cross-wave barriers) */
+#ifndef NTT_ONEPASS_INV_PRE
+#  define NTT_ONEPASS_INV_PRE 0 /* 1 (A/B builds) = the inverse halves request their first group's twiddles a half ahead, as twophase_kernel does: 20 spilled VGPRs here */
+#endif
+template <class A, uint32_t MASK>
+__device__ __forceinline__ void onepass_block_inv(typename A::val (&x)[kE], typename A::ctw (&pre)[4][kE / 2], uint32_t blk, uint32_t nblk, uint32_t tid,
+                                                  const Params<A> &p, typename A::val *lds_all, typename A::ctw *tabl)
+{
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, true, flavor_of<A>()>;
+  constexpr int  GL  = P::NG - 1;
+  constexpr bool LTW = G::LDS_TW > 0;
+  constexpr bool PRE = NTT_ONEPASS_INV_PRE != 0 && A::kCompact && stage_is_compact<A, LOGN, true>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
+  const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
+  if constexpr(PRE) {
+    run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
+  } else {
+    run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
+  }
+  TableRegs<A, LOGN, true> tr;
+  if constexpr(LTW) tr.load(p, nblk, tid);
+  static_for<0, P::NG - 1>([&](auto gg) {
+    constexpr int GI = P::NG - 1 - decltype(gg)::value;
+    if constexpr(GI == 1 && LTW) {
+      exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all, [&]() { tr.store(tabl, tid); });
+      if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tid, nblk, p); /* the next half's first-group twiddles: their registers are free from here on */
+    } else {
+      exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
+    }
+    if constexpr(G::TBL(GI - 1) > 0) {
+      run_group<A, LOGN, GI - 1, true, MASK, true>(x, tid, blk, p, ltw + G::TBL_OFF(GI - 1));
+    } else {
+      run_group<A, LOGN, GI - 1, true, MASK>(x, tid, blk, p);
+    }
+  });
+}
+
+template <class A, bool INV, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
+{
+  uint32_t  bid, gdim, limb_;
+  Params<A> p = limb_params<A, INV, MULTI>(k, bid, gdim, limb_);
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, INV, flavor_of<A>()>;
+  static_assert(A::kCompact && A::kTracksBounds && G::BPW == 1 && P::T == 1024, "built for the FP64 policies on the 2^14 block");
+  __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+  const uint32_t         tid  = threadIdx.x;
+  p.s0                        = 1;
+  constexpr uint64_t HALF     = 1ull << LOGN;
+  uint64_t poly = bid;
+  if(!below(poly, p.nblocks)) return;
+  /* polynomial offsets one polynomial ahead of the loads, as in fused_kernel's loops (a pointer batch reads them from a table) */
+  const auto next_poly = [&](uint64_t at) -> uint64_t { return below(at + gdim, p.nblocks) ? at + gdim : at; };
+  uint64_t off_cur = poly_offset<true>(poly, p.pstride, p.ptab), off_nxt = poly_offset<true>(next_poly(poly), p.pstride, p.ptab);
+  /* ONE copy of the block body per direction: the two halves are the iterations of a loop that is not unrolled, the half that waits
+   * (forward: half B's values; inverse: half B's raw words, then half A's results) parked as bit patterns in `hold` -- two inlined
+   * copies let the compiler hoist either copy's lane offsets and LDS addresses out of the polynomial loop, into registers the
+   * halves need (79 spilled VGPRs in the first version of this kernel) */
+  uint64_t hold[kE], rb[kE];
+  const auto bits = [](typename A::val v) -> uint64_t { return __builtin_bit_cast(uint64_t, v); };
+  const auto vals = [](uint64_t u) -> typename A::val { return __builtin_bit_cast(typename A::val, u); };
+  if constexpr(!INV) {
+    constexpr uint32_t M15  = onepass_fwd_mask<A, KSH>();
+    constexpr uint32_t MASK = M15 >> 1;
+    constexpr bool     RED0 = (M15 & 1u) != 0;
+    prefetch_first<LOGN>(hold, tid, p.a + off_cur);
+    prefetch_first<LOGN>(rb, tid, p.a + off_cur + HALF);
+    for(; below(poly, p.nblocks); poly += gdim) {
+      uint64_t *const base = p.a + off_cur;
+      const bool      more = below(poly + gdim, p.nblocks);
+      uint64_t *const nxt  = p.a + off_nxt;
+      off_cur              = off_nxt;
+      off_nxt              = poly_offset<true>(next_poly(more ? poly + gdim : poly), p.pstride, p.ptab);
+      typename A::val x[kE];
+      {
+        typename A::val xb[kE];
+        convert_inputs<A, false>(x, hold, p.wide != 0, p.c);
+        convert_inputs<A, false>(xb, rb, p.wide != 0, p.c);
+        onepass_pairs_fwd<A, RED0>(x, xb, p); /* global stage 0, thread-local (ntt_core.h) */
+        static_for<0, kE>([&](auto ee) { hold[decltype(ee)::value] = bits(xb[decltype(ee)::value]); });
+      }
+#pragma unroll 1
+      for(uint32_t h = 0; h < 2u; h++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl)); /* per-half lane offsets: recomputed, not carried in registers through the launch */
+        onepass_block_fwd<A, MASK>(x, h, tl, base + (h ? HALF : 0), p, lds_all, tabl);
+        if(h == 0) {
+          static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = vals(hold[decltype(ee)::value]); });
+          prefetch_first<LOGN>(hold, tl, nxt, more); /* half A has been stored: the next polynomial's first half */
+        }
+      }
+      prefetch_first<LOGN>(rb, tid, nxt + HALF, more); /* ... and its second half, behind half B's stores */
+    }
+  } else {
+    constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (A::kWide52 ? kCanonInFlag : 0u); /* the blocks do not end the transform; canonical inputs */
+    constexpr int      GL   = P::NG - 1;
+    constexpr bool     PRE  = NTT_ONEPASS_INV_PRE != 0 && A::kCompact && stage_is_compact<A, LOGN, true>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
+    constexpr bool     LTW  = G::LDS_TW > 0;
+    typename A::ctw pre[4][kE / 2];
+    prefetch_last<LOGN>(rb, tid, p.a + off_cur);
+    if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tid, 0u, p);
+    if constexpr(LTW) {
+      fill_lds_tables<A, LOGN, true>(tabl, p, 0u, tid);
+      __syncthreads();
+    }
+    for(; below(poly, p.nblocks); poly += gdim) {
+      uint64_t *const base = p.a + off_cur;
+      const bool      more = below(poly + gdim, p.nblocks);
+      uint64_t *const nxt  = p.a + off_nxt;
+      off_cur              = off_nxt;
+      off_nxt              = poly_offset<true>(next_poly(more ? poly + gdim : poly), p.pstride, p.ptab);
+      typename A::val x[kE];
+      convert_inputs<A, true>(x, rb, p.wide != 0, p.c);
+      prefetch_last<LOGN>(hold, tid, base + HALF); /* this polynomial's second half arrives during the first half's stages */
+#pragma unroll 1
+      for(uint32_t h = 0; h < 2u; h++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        onepass_block_inv<A, MASK>(x, pre, h, h ^ 1u, tl, p, lds_all, tabl);
+        if(h == 0) {
+          /* half A's results wait as bit patterns where half B's raw words were; half B's words become the values */
+          /* (slot by slot: a second array of sixteen values between the two would not fit) */
+          const auto swap_in = [&](auto wide_c) {
+            static_for<0, kE>([&](auto ee) {
+              constexpr int         E = decltype(ee)::value;
+              const typename A::val v = A::template load<true, decltype(wide_c)::value>(hold[E], p.c);
+              hold[E]                 = bits(x[E]);
+              x[E]                    = v;
+            });
+          };
+          if(p.wide != 0) swap_in(std::true_type{});
+          else swap_in(std::false_type{});
+        }
+      }
+      /* global stage 0 with N^-1 folded in: both inputs reduced first (see the header comment), then the pair's two products,
+       * stored pair by pair (slot e <-> index (e << 10) + t of either half: coalesced 8-byte rows) so that no second copy of the
+       * polynomial is ever live */
+      {
+        const __amdgpu_buffer_rsrc_t r0 = block_rsrc<LOGN>(base), r1 = block_rsrc<LOGN>(base + HALF);
+        typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+        static_for<0, kE>([&](auto ee) {
+          constexpr int   E  = decltype(ee)::value;
+          typename A::val va = vals(hold[E]), vb = x[E];
+          onepass_pair_inv<A>(va, vb, p.c); /* ntt_core.h */
+          const uint64_t ua = A::store_inv(va, p.c), ub = A::store_inv(vb, p.c);
+          v2u32          wa, wb;
+          wa.x = (unsigned)ua, wa.y = (unsigned)(ua >> 32);
+          wb.x = (unsigned)ub, wb.y = (unsigned)(ub >> 32);
+          __builtin_amdgcn_raw_buffer_store_b64(wa, r0, (int)(tid * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
+          __builtin_amdgcn_raw_buffer_store_b64(wb, r1, (int)(tid * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
+          /* (two pairs at a time: sixteen interleaved pairs would need their temporaries next to the waiting twiddles) */
+          if constexpr(E % 2 == 1) sched_fence();
+        });
+      }
+      prefetch_last<LOGN>(rb, tid, nxt, more);
     }
   }
 }
@@ -1312,7 +1579,7 @@ __global__ void __launch_bounds__(256, 4) team_kernel(const KTeam<A> kt)
         team_split(pidx, batch, kt.nlimbs, kt.poly_major, kt.split_rcp, limb, pl);
         team_limb<A, INV>(p, kt.k, limb);
       }
-      uint64_t *poly = p.a + (uint64_t)pl * p.pstride;
+      uint64_t *poly = p.a + poly_offset<true>((uint64_t)pl, p.pstride, p.ptab);
       if(second) {
         if(tid == 0) {
 #ifdef NTT_TEAM_WATCHDOG
@@ -2385,7 +2652,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
-          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tl, blk, p, ltw + G::TBL_OFF(GI + 1));
+          run_group<A, LOGN, GI + 1, false, MASK, true, false, G::TBL_STAGES(GI + 1)>(x, tl, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
           run_group<A, LOGN, GI + 1, false, MASK>(x, tl, blk, p);
         }
@@ -2434,11 +2701,11 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       asm volatile("" : "+v"(tg));
       typename A::val x[kE];
       global_load_first<A, LOGN, false>(x, tg, p.a + blk_off<LOGN>(p, b), false, p.c);
-      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tg, blk, p, gtw);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0), false, G::TBL_STAGES(0)>(x, tg, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, tg, lds);
-        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, tg, blk, p, gtw + G::TBL_OFF(GI + 1));
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0), false, G::TBL_STAGES(GI + 1)>(x, tg, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
       static_for<0, 4>([&](auto qq) {
         constexpr int Q = decltype(qq)::value;
@@ -2628,9 +2895,9 @@ __global__ void __launch_bounds__(256) column_kernel(const KArgs<A> k)
     const uint32_t col  = (uint32_t)(g & ((1ull << lcols) - 1));
     if constexpr(A::kRadix4) {
       /* (even stage count: launch_pass refuses anything else for this policy) */
-      if constexpr(R % 2 == 0) column_pass_thread_r4<A, R, INV>(p.a + poly * p.pstride, col, p.logn, p.s0, p.tw, p.c, p.lazy != 0);
+      if constexpr(R % 2 == 0) column_pass_thread_r4<A, R, INV>(p.a + poly_offset<false>(poly, p.pstride, p.ptab), col, p.logn, p.s0, p.tw, p.c, p.lazy != 0);
     } else {
-      column_pass_thread<A, R, INV, MASK>(p.a + poly * p.pstride, col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
+      column_pass_thread<A, R, INV, MASK>(p.a + poly_offset<false>(poly, p.pstride, p.ptab), col, p.logn, p.s0, p.wide != 0, p.lastinv != 0, p.tw, p.c, p.lazy != 0);
     }
   }
 }
@@ -2644,10 +2911,13 @@ struct PassArgs {
   int         nlimbs;      /* >= 1 */
   uint64_t    limb_stride; /* words between consecutive limbs' slabs   */
   uint64_t    poly_stride; /* words between consecutive polynomials of a limb (0 = dense: N) */
+  const uint64_t *ptab;    /* pointer batch: DEVICE table of per-polynomial word offsets (a = null: entries are addresses / 8), `batch` entries;
+                            * null = the progression above */
   uint64_t    batch;       /* polynomials per limb                     */
   uint32_t    logn;   /* whole transform                   */
   int         fused;  /* Pass::fused; 2 = both passes of a 2^16 / 2^17 transform in one workgroup (r = m - 14); 3 = both passes as
-                       * items of one launch with the intermediate kept in the XCD's L2 (team_kernel, r = m - 12) */
+                       * items of one launch with the intermediate kept in the XCD's L2 (team_kernel, r = m - 12); 4 = a 2^15-point
+                       * transform in one pass, the polynomial in the registers of one workgroup (onepass_kernel) */
   int         r;      /* Pass::r                           */
   int         s;      /* Pass::s                           */
   int         inverse;
@@ -2752,7 +3022,8 @@ template <class A> constexpr bool multi_limb_built() { return A::kCompact || A::
  * measured no gain (0.591 at 1, 2, 4 per slot, 0.586 at 8) and keep one.  requested > 0 (NTT_OPT_BLOCK_OVERSUB) overrides. */
 template <int LOGN, int WG> constexpr int block_oversub_default(bool whole_polynomials)
 {
-  return (LOGN == 12 && WG == 256 && whole_polynomials) ? 8 : 1;
+  /* (round 6: the 2^13 forward kernels are two independent 512-thread workgroups per CU now and get the same treatment) */
+  return ((LOGN == 12 && WG == 256) || (LOGN == 13 && WG == 512)) && whole_polynomials ? 8 : 1;
 }
 template <int LOGN, int WG> inline uint64_t block_oversub(int requested, bool whole_polynomials)
 {
@@ -2774,6 +3045,7 @@ template <class A> KArgs<A> make_kargs(const PassArgs &pa)
   k.lastinv      = (uint32_t)pa.lastinv;
   k.lazy         = (uint32_t)pa.lazy;
   k.nblocks      = pa.batch;
+  k.ptab         = pa.ptab;
   return k;
 }
 
@@ -2805,11 +3077,11 @@ template <class A, int LOGN, bool INV, int KSH> hipError_t launch_fused(const Pa
      * workgroups (one or two iterations each on a 6 GiB slab) lift the slow mode by 5-7 % (0.633 -> 0.678, 0.636 -> 0.667;
      * inverse +4.5 %) and leave the fast one where it was; 2^10 and 2^11 lose what the larger tables cost, 2^6 and 2^7 are mixed:
      * unchanged (profiles/r05/small_size_grid.txt). */
-    constexpr int per_slot = (LOGN == 8 || LOGN == 9) ? 64 : 4;
-    cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * per_slot;
+    const int per_slot = pa.oversub > 0 ? pa.oversub : ((LOGN == 8 || LOGN == 9) ? 64 : 4); /* (NTT_OPT_BLOCK_OVERSUB: sweeps) */
+    cap                  = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256) * (per_cu > 0 ? per_cu : 1) * (uint64_t)per_slot;
     /* 2^10: about six iterations per workgroup on large batches (32768 workgroups on a 6 GiB slab: slow mode 0.633 -> 0.653; the
      * 8192 of smaller batches stay, where more workgroups lost 2 %) */
-    if(LOGN == 10 && wgs / 6 > cap) cap = wgs / 6;
+    if(LOGN == 10 && pa.oversub <= 0 && wgs / 6 > cap) cap = wgs / 6;
   }
   if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
   cap = cap / nl > 0 ? cap / nl : 1; /* the limbs of one launch share the resident workgroups */
@@ -2898,6 +3170,35 @@ template <class A, int LEAD, bool INV, int KSH> hipError_t launch_twophase(const
   p.wgs_per_limb = (uint32_t)wgs;
   hipLaunchKernelGGL((twophase_kernel<A, LEAD, INV, KSH>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, p);
   return hipGetLastError();
+  }
+}
+
+/* N = 2^15 in one pass (onepass_kernel): one persistent 1024-thread workgroup per CU, pa.batch polynomials per limb */
+template <class A> constexpr bool onepass_built() { return A::kCompact && A::kTracksBounds; }
+template <class A, bool INV, int KSH> hipError_t launch_onepass(const PassArgs &pa)
+{
+  if constexpr(!onepass_built<A>()) {
+    return hipErrorNotSupported;
+  } else {
+    if(pa.logn != (uint32_t)kFusedLarge + 1 || pa.lazy) return hipErrorNotSupported;
+    const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
+    if(nl > (uint64_t)kMaxLimbs) return hipErrorNotSupported;
+    KArgs<A> p = make_kargs<A>(pa);
+    p.s0       = 1;
+    p.lastinv  = (uint32_t)pa.inverse;
+    p.lazy     = 0;
+    p.nblocks  = pa.batch;
+    uint64_t wgs = pa.batch;
+    uint64_t cap = (uint64_t)(pa.num_cus > 0 ? pa.num_cus : 256);
+    if(pa.max_grid > 0) cap = (uint64_t)pa.max_grid;
+    cap = cap / nl > 0 ? cap / nl : 1;
+    if(wgs > cap) wgs = cap;
+    if(wgs == 0) return hipSuccess;
+    p.wgs_per_limb = (uint32_t)wgs;
+    const dim3 grid((unsigned)wgs, (unsigned)nl);
+    if(nl > 1) hipLaunchKernelGGL((onepass_kernel<A, INV, KSH, true>), grid, dim3(1024), 0, pa.stream, p);
+    else hipLaunchKernelGGL((onepass_kernel<A, INV, KSH, false>), grid, dim3(1024), 0, pa.stream, p);
+    return hipGetLastError();
   }
 }
 
@@ -3452,6 +3753,7 @@ template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 #define NTT_DEFINE_LAUNCH_PASS(A, KSH)                                                   \
   template <> hipError_t launch_pass<A, KSH>(const PassArgs &pa)                         \
   {                                                                                      \
+    if(pa.fused == 4) return pa.inverse ? launch_onepass<A, true, KSH>(pa) : launch_onepass<A, false, KSH>(pa); \
     if(pa.fused == 3) {                                                                  \
       switch(pa.r) {                                                                     \
         case 3: return pa.inverse ? launch_team<A, 3, true, KSH>(pa) : launch_team<A, 3, false, KSH>(pa); \

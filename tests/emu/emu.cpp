@@ -35,6 +35,9 @@ using namespace ntt;
  * the library's *_strided entry points, through the same block_offset the kernels use */
 inline uint64_t g_pstride = 0;
 static inline uint64_t emu_pstride(int m) { return g_pstride ? g_pstride : (1ull << m); }
+/* pointer batches (emu_set_poly_table): host table of the polynomials' ADDRESSES for the next emu_transform -- the kernels' own
+ * poly_offset / block_offset (csrc/ntt_core.h) then take every polynomial's start from it, with a null data pointer */
+inline const uint64_t *g_ptab = nullptr;
 inline uint64_t g_opstride = 0; /* emu_inv_dot: words between consecutive operands of the a / b arrays (0 = batch * N: dense) */
 
 inline uint64_t g_chk_fail  = 0;   /* number of violated claims          (inline: one copy for all parts) */
@@ -391,7 +394,7 @@ template <class A, int LOGN, bool INV, int KSH, bool LASTINV, bool LAZY = false>
   std::vector<Regs<A>>         regs(P::T);
   for(uint64_t b = 0; b < p.nblocks; b++) {
     const uint32_t blk  = (uint32_t)(b & ((1ull << p.s0) - 1));
-    uint64_t *     base = p.a + block_offset<LOGN>(b, p.s0, p.pstride); /* as the kernels: csrc/ntt_kernels.h blk_off */
+    uint64_t *     base = p.a + block_offset<LOGN>(b, p.s0, p.pstride, p.ptab); /* as the transform kernels: csrc/ntt_kernels.h blk_off_t */
     if constexpr(!INV) {
       for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
         global_load_first<A, LOGN, false>(regs[t].x, t, base, p.wide, p.c);
@@ -805,7 +808,8 @@ static void emu_column(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S, b
   const uint64_t     cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
     for(uint64_t col = 0; col < cols; col++) {
-      column_pass_thread<A, R, INV, MASK>(a + pidx * emu_pstride((int)logn), (uint32_t)col, logn, S, wide, lastinv, tab, c, lazy_out);
+      column_pass_thread<A, R, INV, MASK>((g_ptab ? (uint64_t *)nullptr : a) + poly_offset<false>(pidx, emu_pstride((int)logn), g_ptab), (uint32_t)col, logn, S,
+                                          wide, lastinv, tab, c, lazy_out); /* as column_kernel */
     }
   }
 }
@@ -816,7 +820,82 @@ static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S
 {
   const uint64_t cols = (1ull << logn) >> R;
   for(uint64_t pidx = 0; pidx < batch; pidx++) {
-    for(uint64_t col = 0; col < cols; col++) column_pass_thread_r4<A, R, INV>(a + pidx * emu_pstride((int)logn), (uint32_t)col, logn, S, tab, c, lazy_out);
+    for(uint64_t col = 0; col < cols; col++)
+      column_pass_thread_r4<A, R, INV>((g_ptab ? (uint64_t *)nullptr : a) + poly_offset<false>(pidx, emu_pstride((int)logn), g_ptab), (uint32_t)col, logn, S, tab, c,
+                                       lazy_out);
+  }
+}
+
+/* N = 2^15 in one pass (csrc/ntt_kernels.h onepass_kernel), thread by thread: both halves of a polynomial in "registers", the pair
+ * stage thread-local (ntt_core.h onepass_pairs_fwd / onepass_pair_inv), each half through the 2^14-point block stages at block
+ * position 0 / 1 -- forward with the fifteen-stage reduction schedule (onepass_fwd_mask), which the checked policies verify */
+inline int g_one_pass = -1; /* emu_set_one_pass: 1 = 2^15 transforms of the FP64 policies take this route, 0 = the two-pass route, -1 = as the library (on) */
+template <class A, bool INV, int KSH> static void emu_onepass(const Params<A> &pin)
+{
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  constexpr uint64_t HALF = 1ull << LOGN;
+  Params<A> p = pin;
+  p.s0        = 1;
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         half[2] = {std::vector<Regs<A>>(P::T), std::vector<Regs<A>>(P::T)};
+  for(uint64_t poly = 0; poly < p.nblocks; poly++) {
+    uint64_t *base = p.a + poly_offset<true>(poly, p.pstride, p.ptab);
+    if constexpr(!INV) {
+      constexpr uint32_t M15  = onepass_fwd_mask<A, KSH>();
+      constexpr uint32_t MASK = M15 >> 1;
+      constexpr bool     RED0 = (M15 & 1u) != 0;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        global_load_first<A, LOGN, false>(half[0][t].x, t, base, p.wide, p.c);
+        global_load_first<A, LOGN, false>(half[1][t].x, t, base + HALF, p.wide, p.c);
+        onepass_pairs_fwd<A, RED0>(half[0][t].x, half[1][t].x, p);
+      }
+      for(uint32_t h = 0; h < 2; h++) {
+        std::vector<Regs<A>> &regs = half[h];
+        for(uint32_t t = 0; t < (uint32_t)P::T; t++) run_group<A, LOGN, 0, false, MASK>(regs[t].x, t, h, p);
+        static_for<0, P::NG - 1>([&](auto gg) {
+          constexpr int G = decltype(gg)::value;
+          for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+          for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+            lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+            if constexpr(A::kCompact && G + 1 == P::NG - 1) {
+              typename A::ctw pre[4][kE / 2];
+              preload_group_tw<A, LOGN, G + 1>(pre, t, h, p);
+              run_group_preloaded<A, LOGN, G + 1, MASK>(regs[t].x, pre, p);
+            } else {
+              run_group<A, LOGN, G + 1, false, MASK>(regs[t].x, t, h, p);
+            }
+          }
+        });
+        for(uint32_t t = 0; t < (uint32_t)P::T; t++) global_store_last<A, LOGN, false, false>(regs[t].x, t, base + h * HALF, p.c, false);
+      }
+    } else {
+      constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (A::kWide52 ? kCanonInFlag : 0u); /* as onepass_kernel: not the last pass */
+      for(uint32_t h = 0; h < 2; h++) {
+        std::vector<Regs<A>> &regs = half[h];
+        for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+          global_load_last<A, LOGN, true>(regs[t].x, t, base + h * HALF, p.wide, p.c);
+          run_group<A, LOGN, P::NG - 1, true, MASK>(regs[t].x, t, h, p);
+        }
+        static_for<0, P::NG - 1>([&](auto gg) {
+          constexpr int G = P::NG - 1 - decltype(gg)::value;
+          for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+          for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+            lds_gather<A, LOGN, G, G - 1>(regs[t].x, t, lds.data());
+            run_group<A, LOGN, G - 1, true, MASK>(regs[t].x, t, h, p);
+          }
+        });
+      }
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        static_for<0, kE>([&](auto ee) {
+          constexpr int   E  = decltype(ee)::value;
+          typename A::val va = half[0][t].x[E], vb = half[1][t].x[E];
+          onepass_pair_inv<A>(va, vb, p.c);
+          base[((uint32_t)E << P::LT) + t]        = A::store_inv(va, p.c);
+          base[HALF + ((uint32_t)E << P::LT) + t] = A::store_inv(vb, p.c);
+        });
+      }
+    }
   }
 }
 
@@ -830,6 +909,26 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
   const PassList L = A::kRadix4 ? make_passes_r4(m) : make_passes(m, generic, multi_pass_block(m, INV, A::kTracksBounds));
   if(A::kRadix4 && (generic || m > kRadix4Max)) return -4; /* the library refuses these too */
   const bool lazy  = g_lazy;
+  if constexpr(A::kCompact && A::kTracksBounds) {
+    /* as the library's run_transform: N = 2^15, FP64 policies, no lazy outputs -> one pass */
+#ifndef EMU_SAN_BUILD /* (the sanitizer build keeps its instrumented compile short: two-pass route only) */
+    if(m == kFusedMax + 1 && !generic && !lazy && g_one_pass != 0) {
+      Params<A> p{};
+      p.a       = g_ptab ? nullptr : a;
+      p.ptab    = g_ptab;
+      p.tw      = tab;
+      p.tw8     = tab8;
+      p.c       = c;
+      p.logn    = (uint32_t)m;
+      p.pstride = emu_pstride(m);
+      p.wide    = wide;
+      p.lastinv = INV;
+      p.nblocks = batch;
+      emu_onepass<A, INV, KSH>(p);
+      return 0;
+    }
+#endif
+  }
   for(int k = 0; k < L.n; k++) {
     const Pass &ps      = L.p[INV ? L.n - 1 - k : k];
     const bool  lastinv = INV && ps.s == 0;
@@ -840,7 +939,8 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
     const bool plazy = ends ? lazy : true;
     if(ps.fused) {
       Params<A> p{};
-      p.a       = a;
+      p.a       = g_ptab ? nullptr : a;
+      p.ptab    = g_ptab;
       p.tw      = tab;
       p.tw8     = tab8;
       p.c       = c;
@@ -1091,7 +1191,9 @@ int emu_transform(uint64_t *a, uint64_t batch, int m, uint64_t q, uint64_t root,
 }
 
 void emu_set_lazy(int on) { g_lazy = on != 0; }
+void emu_set_one_pass(int mode) { g_one_pass = mode; }
 void emu_set_poly_stride(uint64_t words) { g_pstride = words; }
+void emu_set_poly_table(const uint64_t *addresses) { g_ptab = addresses; }
 void emu_set_operand_stride(uint64_t words) { g_opstride = words; }
 void emu_set_u64x_worst(int on) { g_u64x_worst = on != 0; }
 void emu_set_product_both(int on) { g_prod_both = on != 0; }

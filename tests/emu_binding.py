@@ -24,6 +24,8 @@ class Emu:
         L.emu_pointwise_lazy.argtypes = [U64P, U64P, U64P, C.c_uint64, C.c_uint64, C.c_int]
         L.emu_set_lazy.argtypes = [C.c_int]
         L.emu_set_poly_stride.argtypes = [C.c_uint64]
+        L.emu_set_poly_table.argtypes = [C.c_void_p]
+        L.emu_set_one_pass.argtypes = [C.c_int]
         L.emu_set_operand_stride.argtypes = [C.c_uint64]
         L.emu_set_u64x_worst.argtypes = [C.c_int]
         L.emu_u64x_schedule.restype = C.c_uint32
@@ -46,6 +48,21 @@ class Emu:
                                     int(generic), int(wide), ksh)
         self.lib.emu_set_lazy(0)
         return rc, a
+
+    def set_one_pass(self, mode):
+        """N = 2^15, FP64 policies: 1 / -1 = the one-pass route of onepass_kernel (the library's default), 0 = the two-pass route"""
+        self.lib.emu_set_one_pass(int(mode))
+
+    def transform_ptrs(self, buf, offsets, m, q, root, arith, inverse=False, generic=False, ksh=-1):
+        """a pointer batch: the polynomials of `buf` that start at the given word offsets (any order, any spacing), in place, through
+        the table addressing of the transform kernels (csrc/ntt_core.h poly_offset: entries are the polynomials' addresses, the data
+        pointer is null); returns the status"""
+        assert buf.dtype == np.uint64 and buf.flags["C_CONTIGUOUS"]
+        table = np.array([buf.ctypes.data + 8 * int(o) for o in offsets], dtype=np.uint64)
+        self.lib.emu_set_poly_table(table.ctypes.data)
+        rc = self.lib.emu_transform(C.cast(0, U64P), len(offsets), m, q, root, arith, int(inverse), int(generic), 0, ksh)
+        self.lib.emu_set_poly_table(None)
+        return rc
 
     def transform_limb(self, buf, limb, nlimbs, batch, m, q, root, arith, inverse=False, ksh=-1):
         """limb `limb` of a [batch][nlimbs][N] buffer (SURVEY 8(d)'s layout: polynomials nlimbs * N words apart), in place, through

@@ -708,3 +708,75 @@ def test_caller_native_layout_block_offsets(oracle, emu, m, q):
     for p in range(batch):
         assert np.array_equal(out2[p, limb], oracle.pointwise(fwd[p, limb].copy(), b[0, p, limb].copy(), q)), p
         assert (out2[p, 0] == 9).all()
+
+
+@pytest.mark.parametrize("m,q,arith", [(6, 0x7ffe0001, 1), (10, 0x7ffe0001, 1), (12, 0x7fffffffe0001, 1), (13, 0x7fffffffe0001, 1),
+                                       (15, 0x7fffffffe0001, 1), (12, 0x7fffffffe0001, 0), (3, 0x7ffe0001, 0)])
+def test_pointer_batch_table_addressing(oracle, emu, m, q, arith):
+    """round 6: a batch of separately held polynomials (the reference's own batch form, fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...),
+    include/ntt_reference.h:44-49) through the table addressing of the transform kernels -- csrc/ntt_core.h poly_offset /
+    block_offset with Params::ptab, the functions fused_kernel, column_kernel and team_kernel call -- executed on the CPU: polynomials
+    at irregular, unsorted places of one buffer (odd word offsets included), every one against the oracle, every other word
+    untouched; forward and inverse, block passes and column passes (m = 15: both; m = 3: columns only)"""
+    n = 1 << m
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    guard = np.uint64(0xA5A5A5A5A5A5A5A5)
+    offs = [5 * n + 3, 0, 2 * n + 1, 9 * n + 8, 7 * n + 2]          # no progression, not sorted
+    buf = np.full(11 * n, guard, dtype=np.uint64)
+    polys = [oracle.fill_uniform(n, q, 700 + i) for i in range(len(offs))]
+    for o, a in zip(offs, polys):
+        buf[o:o + n] = a
+    mask = np.ones(buf.size, dtype=bool)
+    for o in offs:
+        mask[o:o + n] = False
+    assert emu.transform_ptrs(buf, offs, m, q, w, arith) == 0
+    for o, a in zip(offs, polys):
+        assert np.array_equal(buf[o:o + n], cx.fwd(a.copy())), o
+    assert (buf[mask] == guard).all()
+    assert emu.transform_ptrs(buf, offs[::-1], m, q, w, arith, inverse=True) == 0
+    for o, a in zip(offs, polys):
+        assert np.array_equal(buf[o:o + n], a), o
+    assert (buf[mask] == guard).all()
+
+
+@pytest.mark.parametrize("arith,bits,ksh", [(2, 51, -1), (2, 50, -1), (2, 33, -1), (2, 33, 0), (5, 52, -1), (1, 51, -1), (4, 52, -1)])
+def test_one_pass_2p15_against_the_oracle_and_the_two_pass_route(oracle, emu, arith, bits, ksh):
+    """round 6: N = 2^15 in ONE pass (csrc/ntt_kernels.h onepass_kernel) executed on the CPU -- the pair stage thread-local, both
+    halves through the 2^14-point block stages at block positions 0 and 1, forward with ONE reduction schedule over all fifteen stages
+    (ntt_core.h onepass_fwd_mask), inverse with both inputs of the folded last stage reduced first.  The CHECKED policies (arith 2, 5)
+    assert every exactness bound of DESIGN 4 with 128-bit integers, on random and on extreme inputs, for every headroom class (51, 50
+    and 33-bit moduli: classes 0, 1 and 18; a 33-bit modulus forced through class 0); results against the oracle and bit for bit
+    against the two-pass route."""
+    m, n = 15, 1 << 15
+    q = oracle.find_prime(bits, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    rnd = oracle.fill_uniform(2 * n, q, 4242)
+    edge = np.full(2 * n, q - 1, dtype=np.uint64)                      # first polynomial: every coefficient maximal
+    edge[n + 1::2] = 1                                                 # second: the +-1 pattern
+    half = np.full(2 * n, q // 2, dtype=np.uint64)                     # largest balanced magnitude
+    emu.chk_stats(reset=True)
+    for data in (rnd, edge, half):
+        emu.set_one_pass(1)
+        rc, f1 = emu.transform(data, m, q, w, arith, ksh=ksh)
+        assert rc == 0 and np.array_equal(f1, cx.fwd(data.copy()))
+        emu.set_one_pass(0)
+        rc, f0 = emu.transform(data, m, q, w, arith, ksh=ksh)
+        assert rc == 0 and np.array_equal(f0, f1)
+        emu.set_one_pass(1)
+        rc, b1 = emu.transform(f1, m, q, w, arith, inverse=True, ksh=ksh)
+        assert rc == 0 and np.array_equal(b1, data)
+        rc, inv = emu.transform(data, m, q, w, arith, inverse=True, ksh=ksh)       # inputs the inverse does not get from a forward transform
+        assert rc == 0 and np.array_equal(inv, cx.inv(data.copy()))
+        if q < (1 << 51):
+            # lazy (wide) inputs through the one-pass route: the words the reference's *_lazy entry points emit
+            rc, b2 = emu.transform(f1 + np.uint64(3 * q), m, q, w, arith, inverse=True, wide=True, ksh=ksh)
+            assert rc == 0 and np.array_equal(b2, data)
+            rc, f2 = emu.transform(data + np.uint64(7 * q), m, q, w, arith, wide=True, ksh=ksh)
+            assert rc == 0 and np.array_equal(f2, f1)
+    emu.set_one_pass(-1)
+    fails, maxb, maxr = emu.chk_stats()
+    assert fails == 0
+    if arith == 2:
+        assert maxb < 2.0 ** 53 / q * (1 - 1 / 64), (maxb, q)

@@ -1,0 +1,269 @@
+"""Pointer batches placed ANYWHERE, in one launch (round 6; review r05 item 2): the reference's own batch form is one array per
+polynomial -- fwd_ntt_ref_harvey_lazy_dbl(a1[], a2[], ...), include/ntt_reference.h:44-49, src/ntt_reference.c:71-91 --; here `count`
+device-resident polynomials at irregular, shuffled places go through ntt_transform_ptrs (host array: sorted, overlap-checked,
+uploaded) and ntt_transform_dev_ptrs (device array: as given, capturable), the kernels reading every polynomial's address from a
+device table (csrc/ntt_core.h poly_offset).  Every polynomial against the oracle, every word between them untouched."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GUARD = np.uint64(0xA5A5A5A5A5A5A5A5)
+
+
+def _scatter(rng, count, n, slack):
+    """`count` non-overlapping polynomial starts (word offsets, 8-byte granularity, odd offsets included) in random order, with
+    random gaps of 1..slack words between neighbours: no two differences alike, so the sorted pointers hold no progression"""
+    gaps = rng.integers(1, slack, size=count)
+    gaps = gaps + np.arange(count) % 7          # (make equal neighbours unlikely even for small slack)
+    starts = np.cumsum(gaps + n) - n
+    order = rng.permutation(count)
+    return [int(starts[i]) for i in order], int(starts[-1] + n + 8)
+
+
+def _place(lib, oracle, n, q, offs, words, seed):
+    polys = oracle.fill_uniform(len(offs) * n, q, seed).reshape(len(offs), n)
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    for o, a in zip(offs, polys):
+        img[o:o + n] = a
+        mask[o:o + n] = False
+    return polys, img, mask, lib.DeviceBuffer(words).upload(img)
+
+
+def _check(d, offs, n, expect, mask, what):
+    got = d.download()
+    assert (got[mask] == GUARD).all(), "%s: words outside the listed polynomials were written" % what
+    for i, o in enumerate(offs):
+        assert np.array_equal(got[o:o + n], expect(i)), (what, i)
+
+
+CASES = [  # (m, bits, arith, count): every block size, the column-only sizes, multi-pass sizes, every policy
+    (3, 30, "auto", 40), (6, 30, "auto", 300), (8, 50, "auto", 300), (10, 50, "auto", 200), (11, 50, "auto", 130), (12, 50, "auto", 100),
+    (13, 50, "auto", 70), (14, 51, "auto", 40), (15, 50, "auto", 24), (16, 50, "auto", 12), (17, 50, "auto", 6),
+    (12, 52, "auto", 50), (14, 52, "auto", 20), (16, 52, "auto", 10),        # FP64, 2^51 < q < 2^52
+    (12, 60, "auto", 50), (14, 58, "auto", 20), (16, 60, "auto", 10),        # the wide integer policy
+    (12, 50, "u64", 50), (14, 60, "u64", 20), (15, 50, "u64", 10),           # the reference's butterflies
+    (12, 50, "r4", 50), (14, 50, "r4", 20), (15, 50, "r4", 10),              # its radix-4 formulation
+]
+
+
+@pytest.mark.parametrize("m,bits,arith,count", CASES)
+def test_shuffled_pointer_batch_in_one_launch(lib, oracle, m, bits, arith, count):
+    n = 1 << m
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w, arith={"auto": lib.ARITH_AUTO, "u64": lib.ARITH_U64, "r4": lib.ARITH_U64_R4}[arith])
+    cx = oracle.ctx(n, q, w)
+    rng = np.random.default_rng(1000 * m + bits)
+    offs, words = _scatter(rng, count, n, 40)
+    polys, img, mask, d = _place(lib, oracle, n, q, offs, words, 31 * m + bits)
+    ptrs = [d.ptr + 8 * o for o in offs]
+    fwd = [cx.fwd(a.copy()) for a in polys]
+    # host array: sorted, checked, uploaded, ONE launch chain
+    plan.transform_ptrs(ptrs)
+    _check(d, offs, n, lambda i: fwd[i], mask, "forward")
+    plan.transform_ptrs(ptrs, lib.FLAG_INVERSE)
+    _check(d, offs, n, lambda i: polys[i], mask, "inverse")
+    # device array, in the caller's (shuffled) order, no copy
+    tab = lib.DeviceBuffer(count).upload(np.array(ptrs, dtype=np.uint64))
+    plan.transform_dev_ptrs(tab.ptr, count)
+    _check(d, offs, n, lambda i: fwd[i], mask, "forward, device table")
+    plan.transform_dev_ptrs(tab.ptr, count, lib.FLAG_INVERSE)
+    _check(d, offs, n, lambda i: polys[i], mask, "inverse, device table")
+    # lazy outputs and lazy inputs through the same table
+    plan.transform_dev_ptrs(tab.ptr, count, lib.FLAG_LAZY_OUT)
+    got = d.download()
+    bound = (8 if arith == "r4" else 4) * q
+    for i, o in enumerate(offs):
+        assert int(got[o:o + n].max()) < bound and np.array_equal(got[o:o + n] % np.uint64(q), fwd[i]), i
+    plan.transform_dev_ptrs(tab.ptr, count, lib.FLAG_INVERSE | lib.FLAG_WIDE_IN)
+    _check(d, offs, n, lambda i: polys[i], mask, "inverse of lazy words")
+    tab.free(), d.free(), plan.destroy()
+
+
+@pytest.mark.parametrize("m,bits,count", [(15, 50, 96), (16, 50, 80), (17, 50, 64), (16, 52, 72), (16, 60, 72)])
+def test_pointer_batch_through_the_xcd_local_launch(lib, oracle, m, bits, count):
+    """N = 2^15..2^17 with the one-launch XCD-local kernels forced (team_kernel: the queues hand out polynomials by INDEX, the item
+    reads the address from the table), forward and inverse, against the per-pass launches over the same table (chunked: the table
+    pointer advances with the chunk) and the oracle on sampled polynomials"""
+    n = 1 << m
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w)
+    cx = oracle.ctx(n, q, w)
+    rng = np.random.default_rng(7 * m + bits)
+    offs, words = _scatter(rng, count, n, 300)
+    polys, img, mask, d = _place(lib, oracle, n, q, offs, words, 5 * m)
+    ptrs = [d.ptr + 8 * o for o in offs]
+    tab = lib.DeviceBuffer(count).upload(np.array(ptrs, dtype=np.uint64))
+    results = {}
+    for mode in (1, 0):
+        plan.set_option(lib.OPT_XCD_LOCAL, mode)
+        plan.set_option(lib.OPT_CHUNK_MIB, 8 if mode == 0 else 256)       # several chunks per call on the per-pass route
+        d.upload(img)
+        plan.transform_dev_ptrs(tab.ptr, count)
+        results[mode] = d.download()
+        assert (results[mode][mask] == GUARD).all()
+        plan.transform_ptrs(ptrs, lib.FLAG_INVERSE)
+        _check(d, offs, n, lambda i: polys[i], mask, "round trip, xcd_local=%d" % mode)
+    assert np.array_equal(results[0], results[1])
+    for i in (0, count // 2, count - 1):
+        assert np.array_equal(results[1][offs[i]:offs[i] + n], cx.fwd(polys[i].copy())), i
+    tab.free(), d.free(), plan.destroy()
+
+
+@pytest.mark.parametrize("m,nl,bits,count,launch", [(12, 3, 50, 40, None), (12, 3, 50, 40, "1"), (14, 4, 50, 9, "0"), (14, 4, 57, 30, None),
+                                                   (16, 2, 50, 70, None), (16, 3, 50, 5, "0"), (13, 5, 50, 12, "0")])
+def test_shuffled_rns_pointer_batch(lib, oracle, m, nl, bits, count, launch):
+    """RNS polynomials held one by one ([limb][N] each: what an FHE library allocates) at shuffled places: ntt_rns_transform_ptrs and
+    ntt_rns_transform_dev_ptrs -- one launch over the limbs (the MULTI kernels: the limb's offset is added to the table's address),
+    one launch chain per limb, or the XCD-local launch with the limb in the queue entry, whichever the library takes"""
+    n = 1 << m
+    qs = [lib.find_prime(bits, n, k) for k in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    lib.set_rns_launch(plans, launch)
+    ctx = [oracle.ctx(n, q, w) for q, w in zip(qs, ws)]
+    rng = np.random.default_rng(11 * m + nl)
+    offs, words = _scatter(rng, count, nl * n, 50)
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    polys = []
+    for i, o in enumerate(offs):
+        limbs = [oracle.fill_uniform(n, q, 900 + 17 * i + l) for l, q in enumerate(qs)]
+        polys.append(limbs)
+        for l, a in enumerate(limbs):
+            img[o + l * n:o + (l + 1) * n] = a
+        mask[o:o + nl * n] = False
+    d = lib.DeviceBuffer(words).upload(img)
+    ptrs = [d.ptr + 8 * o for o in offs]
+
+    def check(expect, what):
+        got = d.download()
+        assert (got[mask] == GUARD).all(), what
+        for i, o in enumerate(offs):
+            for l in range(nl):
+                assert np.array_equal(got[o + l * n:o + (l + 1) * n], expect(i, l)), (what, i, l)
+    lib.rns_transform_ptrs(plans, ptrs, n)
+    check(lambda i, l: ctx[l].fwd(polys[i][l].copy()), "forward")
+    tab = lib.DeviceBuffer(count).upload(np.array(ptrs, dtype=np.uint64))
+    lib.rns_transform_dev_ptrs(plans, tab.ptr, count, n, lib.FLAG_INVERSE)
+    check(lambda i, l: polys[i][l], "inverse, device table")
+    tab.free(), d.free()
+    for p in plans:
+        p.destroy()
+
+
+def test_device_pointer_table_captured_in_a_hip_graph():
+    """ntt_transform_dev_ptrs allocates nothing and copies nothing: a forward transform over a shuffled pointer batch captured into
+    a HIP graph (torch.cuda.CUDAGraph; a process of its own: torch has to be imported before the library), replayed on fresh data"""
+    import subprocess
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, count = 1 << 14, 24
+q = lib.find_prime(51, n, 0)
+w = lib.min_root(q, n)
+plan, cx = lib.Plan(n, q, w), orc.ctx(n, q, w)
+rng = np.random.default_rng(5)
+gaps = rng.integers(1, 64, size=count) + np.arange(count) %% 7
+starts = np.cumsum(gaps + n) - n
+offs = [int(starts[i]) for i in rng.permutation(count)]
+words = int(starts[-1] + n + 8)
+GUARD = np.uint64(0xA5A5A5A5A5A5A5A5)
+buf = torch.zeros(words, dtype=torch.int64, device="cuda:0")
+ptrs = np.array([buf.data_ptr() + 8 * o for o in offs], dtype=np.uint64)
+tab = torch.from_numpy(ptrs.view(np.int64)).to("cuda:0")
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    plan.transform_dev_ptrs(tab.data_ptr(), count, 0, stream=st)
+for seed in (1, 2, 3):
+    polys = orc.fill_uniform(count * n, q, seed).reshape(count, n)
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    for o, a in zip(offs, polys):
+        img[o:o + n] = a
+        mask[o:o + n] = False
+    buf.copy_(torch.from_numpy(img.view(np.int64)))
+    g.replay()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().view(np.uint64)
+    assert (got[mask] == GUARD).all()
+    for i in range(count):
+        assert np.array_equal(got[offs[i]:offs[i] + n], cx.fwd(polys[i].copy())), (seed, i)
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "graph ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_pointer_batch_arguments(lib, oracle):
+    n = 1 << 12
+    q = lib.find_prime(50, n, 0)
+    plan = lib.Plan(n, q, lib.min_root(q, n))
+    d = lib.DeviceBuffer(8 * n)
+    ptrs = [d.ptr + 8 * o for o in (0, 3 * n + 1, 5 * n)]
+    # irregular AND overlapping: refused before anything is launched
+    with pytest.raises(lib.NttError):
+        plan.transform_ptrs(ptrs + [d.ptr + 8 * (3 * n + 100)])
+    with pytest.raises(lib.NttError):
+        plan.transform_ptrs(ptrs + [ptrs[1]])
+    with pytest.raises(lib.NttError):
+        plan.transform_dev_ptrs(0, 3)                                  # null table
+    with pytest.raises(lib.NttError):
+        plan.transform_dev_ptrs(d.ptr, 3, 1 << 20)                     # unknown flag
+    plan.transform_dev_ptrs(0, 0)                                      # empty batch
+    # the staging buffer of a stream is reused and regrown: batches of growing and shrinking size, back to back, one stream
+    rng = np.random.default_rng(3)
+    cx = oracle.ctx(n, q, lib.min_root(q, n))
+    for count in (3, 50, 7, 200, 1):
+        offs, words = _scatter(rng, count, n, 30)
+        polys, img, mask, dd = _place(lib, oracle, n, q, offs, words, count)
+        plan.transform_ptrs([dd.ptr + 8 * o for o in offs])
+        _check(dd, offs, n, lambda i: cx.fwd(polys[i].copy()), mask, "count %d" % count)
+        dd.free()
+    d.free(), plan.destroy()
+
+
+def test_randomly_placed_polynomials_run_at_the_rate_of_a_slab(lib):
+    """review r05 item 2, the measured bar: 4096 randomly placed 2^14-point polynomials through ntt_transform_ptrs / _dev_ptrs against
+    the same 4096 polynomials as one contiguous slab (profiles/r06/pointer_batches.txt holds the measured figures: within 3 %); here
+    a loose bound that separates one launch from 4096"""
+    n, count = 1 << 14, 4096
+    q = lib.find_prime(51, n, 0)
+    plan = lib.Plan(n, q, lib.min_root(q, n))
+    rng = np.random.default_rng(1)
+    offs, words = _scatter(rng, count, n, 4096)
+    d = lib.DeviceBuffer(words)
+    lib.fill_uniform(d.ptr, words, q, 1, 0)
+    ptrs = [d.ptr + 8 * o for o in offs]
+    tab = lib.DeviceBuffer(count).upload(np.array(ptrs, dtype=np.uint64))
+    ev0, ev1 = lib.Event(0), lib.Event(0)
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        ev0.record(None)
+        for _ in range(reps):
+            fn()
+        ev1.record(None)
+        return ev1.elapsed_ms_since(ev0) / reps
+    slab = timed(lambda: plan.fwd(d.ptr, count))
+    dev = timed(lambda: plan.transform_dev_ptrs(tab.ptr, count))
+    host = timed(lambda: plan.transform_ptrs(ptrs))
+    assert dev < 1.25 * slab and host < 2.0 * slab, (slab, dev, host)
+    tab.free(), d.free(), plan.destroy()

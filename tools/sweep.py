@@ -20,6 +20,7 @@ ap.add_argument("--lag", type=int, default=0, help="--xcd-local 1: polynomials b
 ap.add_argument("--wpc", type=int, default=0, help="--xcd-local 1: workgroups per CU (0 = default)")
 ap.add_argument("--max-grid", type=int, default=0, help="cap on workgroups per launch (0 = the kernels' own choice)")
 ap.add_argument("--oversub", type=int, default=0, help="persistent block kernels: workgroups per resident slot (0 = the library's choice)")
+ap.add_argument("--one-pass", type=int, default=-1, help="N=2^15, FP64: 1 = the one-pass kernel, 0 = the two-pass forms, -1 = the library's choice")
 ap.add_argument("--block-log", type=int, default=0, help="N=2^15, 2^16: block size below the column pass (12, 14, 0 = library's choice)")
 a = ap.parse_args()
 ap2 = None
@@ -42,6 +43,9 @@ for qs in a.qs:
             plan.set_option(lib.OPT_XCD_LOCAL, a.xcd_local)
             plan.set_option(lib.OPT_XCD_LOCAL_LAG, a.lag)
             plan.set_option(lib.OPT_XCD_LOCAL_WGS_PER_CU, a.wpc)
+            if a.one_pass >= 0 and hasattr(lib, "OPT_ONE_PASS"):
+                try: plan.set_option(lib.OPT_ONE_PASS, a.one_pass)
+                except lib.NttError: pass
             if a.max_grid: plan.set_option(lib.OPT_MAX_GRID, a.max_grid)
             if os.environ.get("NTT_DOT_UNFUSED") == "1": plan.set_option(lib.OPT_DOT_FUSED, 0)   # (tools/ab_product_tail.sh)
             if a.oversub and hasattr(lib, "OPT_BLOCK_OVERSUB"):
