@@ -742,9 +742,7 @@ NTT_HD void run_group_r4(typename A::val (&x)[kE], uint32_t t, uint32_t blk, con
   }
 }
 
-/* LSTAGES (with LTW): which local stages the LDS table holds (Geom::TBL_STAGES: a prefix); the others fetch per lane from global
- * memory, requested one stage ahead like every per-lane stage of a group without a table */
-template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false, bool MIRROR = false, uint32_t LSTAGES = 0xFu>
+template <class A, int LOGN, int G, bool INV, uint32_t MASK, bool LTW = false, bool MIRROR = false>
 NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
                       const Params<A> &p, lds_ctw_ptr<A> ltw = nullptr)
 {
@@ -767,8 +765,7 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
   }
   StageTw<A> wcur, wnxt;
   constexpr int JFIRST = INV ? R - 1 : 0;
-  constexpr auto in_lds = [](int j) constexpr { return LTW && ((LSTAGES >> j) & 1u) != 0; };
-  if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !in_lds(JFIRST)) {
+  if constexpr(stage_is_compact<A, LOGN, INV>(G, JFIRST) && !LTW) {
     load_stage_tw<A, LOGN, G, JFIRST, INV, false>(wcur, ib, blk, p, nullptr);
   }
   static_for<0, R>([&](auto jj) {
@@ -777,11 +774,9 @@ NTT_HD void run_group(typename A::val (&x)[kE], uint32_t t, uint32_t blk,
     constexpr int SL = SG + J;                 /* local stage              */
     constexpr int AB = P::ABIT(G, J);
     constexpr int  JN   = INV ? J - 1 : J + 1;   /* stage processed next     */
-    constexpr int  JNC  = JN < 0 ? 0 : (JN < R ? JN : 0);
-    constexpr bool LJ   = LTW && ((LSTAGES >> J) & 1u) != 0;
-    constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LJ;
-    constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JNC) && !(LTW && ((LSTAGES >> JNC) & 1u) != 0);
-    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LJ, MIRROR && LJ>(wcur, ib, blk, p, ltw);
+    constexpr bool PIPE = stage_is_compact<A, LOGN, INV>(G, J) && !LTW;
+    constexpr bool PIPN = JN >= 0 && JN < R && stage_is_compact<A, LOGN, INV>(G, JN < 0 ? 0 : (JN < R ? JN : 0)) && !LTW;
+    if constexpr(!PIPE) load_stage_tw<A, LOGN, G, J, INV, LTW, MIRROR>(wcur, ib, blk, p, ltw);
     if constexpr(PIPN) load_stage_tw<A, LOGN, G, (PIPN ? JN : J), INV, false>(wnxt, ib, blk, p, nullptr);
     constexpr bool FOLDED = INV && SL == 0 && (MASK & kLastInvFlag) != 0;
     if constexpr(FOLDED) {

@@ -41,33 +41,10 @@
 
 namespace ntt {
 
-#ifndef NTT_BLOCK_PERM
-#  define NTT_BLOCK_PERM 0 /* A/B builds: 1 = the small-block loop walks the blocks in a permuted order */
-#endif
-#ifndef NTT_STAGGER
-#define NTT_STAGGER 0 /* A/B builds: the 2^12 persistent loops start (slot & 3) * NTT_STAGGER * 1024 clocks apart, slot = the workgroup's TG_ID on its CU */
-#endif
-#if NTT_STAGGER
-__device__ __forceinline__ void stagger_start()
-{
-  uint32_t v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 16, 4)" : "=s"(v));
-  for(uint32_t i = 0; i < (v & 3u) * (uint32_t)NTT_STAGGER; i++) __builtin_amdgcn_s_sleep(16);
-}
-#endif
 /* a < b for block counts (both far below 2^63) as a subtraction and a sign test: the 64-bit unsigned comparison has no scalar
  * instruction, so the compiler copies b into two VGPRs for the whole kernel (v_cmp_lt_u64) -- in the 52-bit class's one-launch
  * product at 2^14 those were the two registers that spilled */
 __device__ __forceinline__ bool below(uint64_t a, uint64_t b) { return (int64_t)(a - b) < 0; }
-#ifndef NTT_TEAMDOT_NT
-#define NTT_TEAMDOT_NT 0 /* A/B builds: team_dot_kernel's operand loads non-temporal (1: a and a per-polynomial b; 2: a only) */
-#endif
-#ifndef NTT_COLUMN_ITERS
-#define NTT_COLUMN_ITERS 1 /* A/B builds: grid-stride iterations per workgroup of column_kernel (1 = one-shot workgroups: shipped) */
-#endif
-#ifndef NTT_WL12
-#  define NTT_WL12 0 /* A/B builds: 1 = the 2^12 forward loop stores whole lines like the 2^14 one */
-#endif
 constexpr int kPreAlso = 12; /* forward: last group's twiddles register-resident at this size too (2^14 always) */
 constexpr int kIpreMin = 12; /* inverse: first executed group's twiddles register-resident from this size up */
 
@@ -84,17 +61,15 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
   /* one plan thread per hardware thread.  (Two per lane -- 512-thread workgroups with 256
    * VGPRs -- was measured at 14.5 vs 16.0 M NTT/s and removed: four waves per SIMD hide LDS
    * and L2 latencies better.) */
-  /* 2^13 forward (FP64 policies), round 6: TWO INDEPENDENT 512-thread workgroups per CU, one block each -- own exchange buffer, own
-   * barriers, own (partial, see TBL_STAGES) twiddle table, 8 workgroups launched per resident slot like the 2^12 kernels, so that the
-   * two residents of a CU drift apart.  Rounds 2-5 ran ONE 1024-thread workgroup whose halves owned a block each and shared the
-   * table (PERSIST2): the resource shape of the 2^14 kernel, but the halves met at every workgroup barrier -- in step by
-   * construction, which is what round 5 measured as 4-9 % at 2^12 (profiles/r05/NOTES_blk12.md) -- and their block index lived in
-   * vector registers (it depends on the wave), with it every block address.  PERSIST2 is kept as a compile-time switch for A/B
-   * builds (-DNTT_PERSIST2_13=1). */
-#ifndef NTT_PERSIST2_13
-#  define NTT_PERSIST2_13 0
-#endif
-  static constexpr bool PERSIST2 = NTT_PERSIST2_13 != 0 && FLAVOR == 1 && LOGN == 13 && !INV;
+  /* 2^13 (FP64 policies): TWO blocks per 1024-thread workgroup, each half running the persistent loop on its own
+   * exchange buffer and sharing the twiddle table -- the resource shape of the 2^14 kernel (16 waves per CU,
+   * 158 KB of LDS).  One 512-thread workgroup per CU with every table in LDS (round 1) left two waves per SIMD.
+   * Round 6 measured the alternative the review of round 5 proposed -- two INDEPENDENT 512-thread workgroups per CU (own barriers,
+   * a table of stages 8..10 each, stage 11's twiddles from the L2 because two full tables do not fit, 1..16 workgroups per
+   * resident slot) -- against this shape on one box, alternating: 0.570 (1 per slot) .. 0.590 (8 per slot) against 0.599-0.600 for
+   * the lock-stepped halves: the halves' common barriers are not what holds 2^13 back (profiles/r06/ab_2p13_shapes.txt; the code was
+   * removed again).  The half is a property of the wave: `sub` is made uniform, so block indices and addresses stay scalar. */
+  static constexpr bool PERSIST2 = FLAVOR == 1 && LOGN == 13 && !INV;
   /* (inverse: measured 0.584 -> 0.48 in round 2 and again in round 3 (profiles/r03/ablations.txt) -- with the stage-12
    * twiddles register-resident the kernel needs 133 VGPRs (5 spilled); requested per block it fits in 122 without a
    * spill and is still 18 % slower: the two exchange buffers leave 1.8 KB of LDS, 128 bytes short of even the 1.9 KB
@@ -122,17 +97,6 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
       if(P::TW_UNIFORM(g, j)) return false;
     return true;
   }
-  /* which stages of group g the LDS table holds (bit j = local stage j; always a prefix: the table is laid out stage by stage).
-   * 2^13 forward with two independent workgroups per CU: the second-to-last group's stages 8..10 (1792 entries, 14 KB) -- with
-   * stage 11 (2048 entries, 16 KB) two workgroups of 64.1 KB + 30 KB would not fit the CU's 160 KB; its eight twiddles per thread
-   * come from global memory, requested a stage ahead (run_group's pipelining) */
-  static constexpr uint32_t TBL_STAGES(int g)
-  {
-    if(g < 0 || g >= P::NG) return 0u;
-    const uint32_t all = (1u << P::R(g)) - 1u;
-    if(FLAVOR == 1 && LOGN == 13 && !INV && !PERSIST2 && g == P::NG - 2) return all >> 1;
-    return all;
-  }
   static constexpr int TBL(int g)
   {
     if(!COMPACT || g < 0 || g >= P::NG || !group_is_per_lane(g)) return 0;
@@ -140,7 +104,7 @@ template <int LOGN, bool INV, int FLAVOR> struct Geom {
     if(LOGN == 14 || LOGN == 12 || (LOGN == 13 && !INV)) on = (g == P::NG - 2);
     if(LOGN >= 8 && LOGN <= 11) on = true; /* several blocks per workgroup share the tables (2^6, 2^7: measured no gain) */
     if(LOGN == 13 && INV) on = true;
-    return on ? (int)(TBL_STAGES(g) << P::S(g)) : 0;
+    return on ? (((1 << P::R(g)) - 1) << P::S(g)) : 0;
   }
   /* first entry of group g's table behind the exchange buffer(s) */
   static constexpr int TBL_OFF(int g)
@@ -250,35 +214,6 @@ template <int LOGN, class A> __device__ __forceinline__ uint64_t blk_off_t(const
   return block_offset<LOGN>(b, p.s0, p.pstride, p.ptab);
 }
 
-#ifdef NTT_STAMPS
-/* diagnostic build only: per-phase s_memtime stamps of every wave of the first
- * 256 workgroups (never compiled into the shipped library) */
-__device__ unsigned long long g_stamps[256][16][12];
-__device__ __forceinline__ unsigned long long stamp_now()
-{
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-template <class T> __device__ __forceinline__ void pin_all(T (&x)[kE])
-{
-#pragma unroll
-  for(int e = 0; e < kE; e++) asm volatile("" ::"v"(x[e]));
-}
-#  define STAMP(ph)                                                                                   \
-    do {                                                                                              \
-      pin_all(x);                                                                                     \
-      const unsigned long long now_ = stamp_now();                                                    \
-      if((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][threadIdx.x >> 6][ph] += now_ - last_; \
-      last_ = now_;                                                                                   \
-    } while(0)
-#else
-#  define STAMP(ph) \
-    do {            \
-    } while(0)
-#endif
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -476,7 +411,6 @@ __device__ __forceinline__ void fill_lds_tables(typename A::ctw *tabl, const Par
       typename A::ctw *tg = tabl + G::TBL_OFF(GI);
       static_for<0, P::R(GI)>([&](auto jj) {
         constexpr int JJ  = decltype(jj)::value;
-        if constexpr(((G::TBL_STAGES(GI) >> JJ) & 1u) == 0) return;
         constexpr int SG  = P::S(GI);
         constexpr int SLJ = SG + JJ;
         const typename A::ctw *src = p.tw8 + ((size_t)1 << (p.s0 + SLJ)) + ((size_t)blk0 << SLJ);
@@ -555,9 +489,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     uint64_t raw[kE];
     prefetch_first<LOGN>(raw, tt, p.a + off_cur);
     pin_raw(raw);
-#ifdef NTT_STAMPS
-    unsigned long long last_ = stamp_now();
-#endif
     /* The last group's per-lane twiddles (8-byte form, 24 VGPRs) stay in registers for the whole
      * launch: a workgroup always sees the same block position (its stride over the blocks is a
      * multiple of the blocks per polynomial, as for the LDS tables), so they never change.  This
@@ -569,9 +500,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
       preload_group_tw<A, LOGN, GL>(pre, tt, (uint32_t)b & bmask, p);
       pin_preloaded<A, LOGN, GL>(pre);
     }
-#if NTT_STAGGER
-    if constexpr(LOGN == 12 && G::WG == 256) stagger_start();
-#endif
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
@@ -589,29 +517,24 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
         off_cur = off_nxt;
         off_nxt = blk_off_t<LOGN>(p, next_blk(more ? b0 + stride : b0)); /* the block after the next: used one iteration from now */
       }
-      STAMP(0); /* wait for prefetched coefficients + convert */
       run_group<A, LOGN, 0, false, MASK>(x, tt, blk, p);
-      STAMP(1); /* group 0 */
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, tt, ll);
-        STAMP(2 + 2 * GI); /* exchange GI -> GI+1 */
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
-          run_group<A, LOGN, GI + 1, false, MASK, true, false, G::TBL_STAGES(GI + 1)>(x, tt, blk, p, ltw + G::TBL_OFF(GI + 1));
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tt, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
           run_group<A, LOGN, GI + 1, false, MASK>(x, tt, blk, p);
         }
-        STAMP(3 + 2 * GI); /* twiddle request (GI==0) + group GI+1 */
       });
       /* whole-line stores: measured +0.6..0.9 % at 2^14, -0.5 % at 2^12 (profiles/r02/ablations.txt) */
-      if constexpr(LOGN == 14 || (LOGN == 12 && NTT_WL12 != 0 && G::BPW == 1)) {
+      if constexpr(LOGN == 14) {
         store_last_whole_lines<A, LOGN, LAZY>(x, tid, base, p.c, p.lazy != 0);
       } else {
         if(live) global_store_last<A, LOGN, false, LAZY>(x, tt, base, p.c, p.lazy != 0);
       }
-      STAMP(10); /* final reduction + stores */
     }
     return;
   }
@@ -658,9 +581,6 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     prefetch_last<LOGN>(raw, tt, p.a + off_cur);
     pin_raw(raw);
     if constexpr(IPRE) pin_preloaded<A, LOGN, GL>(pre);
-#if NTT_STAGGER
-    if constexpr(LOGN == 12 && G::WG == 256) stagger_start();
-#endif
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
@@ -707,16 +627,7 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     __syncthreads();
   }
   for(uint64_t b0 = (uint64_t)bid * G::BPW; b0 < p.nblocks; b0 += (uint64_t)gdim * G::BPW) {
-#if NTT_BLOCK_PERM
-    /* experiment (profiles/r05/small_size_modes.txt): the workgroups in flight touch blocks spread over the whole buffer
-     * instead of one contiguous window -- a multiplicative permutation of the workgroup-sized groups of blocks */
-    const uint64_t groups = (p.nblocks + G::BPW - 1) / G::BPW;
-    const uint64_t gidx   = b0 / G::BPW;
-    const uint64_t pidx   = groups % 1000003ull ? (gidx * 1000003ull) % groups : gidx;
-    uint64_t       b      = pidx * G::BPW + sub;
-#else
     uint64_t   b    = b0 + sub;
-#endif
     const bool live = b < p.nblocks;
     if(!live) b = p.nblocks - 1; /* idle lanes shadow a real block, never store */
     const uint32_t blk  = (uint32_t)b & bmask;
@@ -725,11 +636,11 @@ __global__ void __launch_bounds__((Geom<LOGN, INV, flavor_of<A>()>::WG), (Geom<L
     typename A::val x[kE];
     if constexpr(!INV) {
       global_load_first<A, LOGN, false>(x, t, base, p.wide != 0, p.c);
-      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0), false, G::TBL_STAGES(0)>(x, t, blk, p, gtw);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, t, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, t, lds);
-        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0), false, G::TBL_STAGES(GI + 1)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, t, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
       if(live) global_store_last<A, LOGN, false, LAZY>(x, t, base, p.c, p.lazy != 0);
     } else {
@@ -1084,34 +995,27 @@ __device__ __forceinline__ void onepass_block_fwd(typename A::val (&x)[kE], uint
 }
 
 /* one half through the inverse block stages (not the transform's last pass): x holds the block's results, unreduced, in the
- * first-kind layout.  pre: this half's first-group twiddles (requested by the caller ahead of time); nblk: the half whose table
- * and twiddles are fetched for the NEXT call (the table refresh sits between this call's cross-wave barriers) */
-#ifndef NTT_ONEPASS_INV_PRE
-#  define NTT_ONEPASS_INV_PRE 0 /* 1 (A/B builds) = the inverse halves request their first group's twiddles a half ahead, as twophase_kernel does: 20 spilled VGPRs here */
-#endif
+ * first-kind layout.  nblk: the half whose LDS table is fetched for the NEXT call (the refresh sits between this call's cross-wave
+ * barriers).  The first group's per-lane twiddles are fetched stage by stage, a stage ahead (run_group's pipelining): requested a
+ * half ahead, as twophase_kernel does, their 24 registers next to the waiting half cost 20-44 spilled VGPRs and 3 % (measured:
+ * profiles/r06/onepass_2p15.txt). */
 template <class A, uint32_t MASK>
-__device__ __forceinline__ void onepass_block_inv(typename A::val (&x)[kE], typename A::ctw (&pre)[4][kE / 2], uint32_t blk, uint32_t nblk, uint32_t tid,
-                                                  const Params<A> &p, typename A::val *lds_all, typename A::ctw *tabl)
+__device__ __forceinline__ void onepass_block_inv(typename A::val (&x)[kE], uint32_t blk, uint32_t nblk, uint32_t tid, const Params<A> &p,
+                                                  typename A::val *lds_all, typename A::ctw *tabl)
 {
   constexpr int LOGN = kFusedLarge;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, true, flavor_of<A>()>;
   constexpr int  GL  = P::NG - 1;
   constexpr bool LTW = G::LDS_TW > 0;
-  constexpr bool PRE = NTT_ONEPASS_INV_PRE != 0 && A::kCompact && stage_is_compact<A, LOGN, true>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
   const lds_ctw_ptr<A> ltw = (lds_ctw_ptr<A>)tabl;
-  if constexpr(PRE) {
-    run_group_preloaded<A, LOGN, GL, MASK, true>(x, pre, p);
-  } else {
-    run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
-  }
+  run_group<A, LOGN, GL, true, MASK>(x, tid, blk, p);
   TableRegs<A, LOGN, true> tr;
   if constexpr(LTW) tr.load(p, nblk, tid);
   static_for<0, P::NG - 1>([&](auto gg) {
     constexpr int GI = P::NG - 1 - decltype(gg)::value;
     if constexpr(GI == 1 && LTW) {
       exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all, [&]() { tr.store(tabl, tid); });
-      if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tid, nblk, p); /* the next half's first-group twiddles: their registers are free from here on */
     } else {
       exchange<A, LOGN, GI, GI - 1>(x, tid, lds_all);
     }
@@ -1183,12 +1087,8 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
     }
   } else {
     constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (A::kWide52 ? kCanonInFlag : 0u); /* the blocks do not end the transform; canonical inputs */
-    constexpr int      GL   = P::NG - 1;
-    constexpr bool     PRE  = NTT_ONEPASS_INV_PRE != 0 && A::kCompact && stage_is_compact<A, LOGN, true>(GL, 0) && G::TBL(GL) == 0 && P::R(GL) < 4;
     constexpr bool     LTW  = G::LDS_TW > 0;
-    typename A::ctw pre[4][kE / 2];
     prefetch_last<LOGN>(rb, tid, p.a + off_cur);
-    if constexpr(PRE) preload_group_tw<A, LOGN, GL>(pre, tid, 0u, p);
     if constexpr(LTW) {
       fill_lds_tables<A, LOGN, true>(tabl, p, 0u, tid);
       __syncthreads();
@@ -1206,7 +1106,7 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
       for(uint32_t h = 0; h < 2u; h++) {
         uint32_t tl = tid;
         asm volatile("" : "+v"(tl));
-        onepass_block_inv<A, MASK>(x, pre, h, h ^ 1u, tl, p, lds_all, tabl);
+        onepass_block_inv<A, MASK>(x, h, h ^ 1u, tl, p, lds_all, tabl);
         if(h == 0) {
           /* half A's results wait as bit patterns where half B's raw words were; half B's words become the values */
           /* (slot by slot: a second array of sixteen values between the two would not fit) */
@@ -1224,12 +1124,20 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
       }
       /* global stage 0 with N^-1 folded in: both inputs reduced first (see the header comment), then the pair's two products,
        * stored pair by pair (slot e <-> index (e << 10) + t of either half: coalesced 8-byte rows) so that no second copy of the
-       * polynomial is ever live */
+       * polynomial is ever live.  The next polynomial's first half is requested IN FRONT of the stage, whose arithmetic and stores hide
+       * part of its way from HBM (96 VGPRs of data for the length of the stage; measured on one box, alternating: requested behind the
+       * stage 0.396 of the roofline, in front of pair 8 0.417, in front of the stage 0.438 -- profiles/r06/onepass_inverse_prefetch_position.txt) */
       {
         const __amdgpu_buffer_rsrc_t r0 = block_rsrc<LOGN>(base), r1 = block_rsrc<LOGN>(base + HALF);
         typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
         static_for<0, kE>([&](auto ee) {
-          constexpr int   E  = decltype(ee)::value;
+          constexpr int E = decltype(ee)::value;
+          if constexpr(E == 0) {
+            /* (inside the unrolled sequence on purpose: issued in front of it, as a statement of its own, the same request made the
+             * register allocator spill 12-16 VGPRs) */
+            prefetch_last<LOGN>(rb, tid, nxt, more);
+            sched_fence();
+          }
           typename A::val va = vals(hold[E]), vb = x[E];
           onepass_pair_inv<A>(va, vb, p.c); /* ntt_core.h */
           const uint64_t ua = A::store_inv(va, p.c), ub = A::store_inv(vb, p.c);
@@ -1238,11 +1146,10 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
           wb.x = (unsigned)ub, wb.y = (unsigned)(ub >> 32);
           __builtin_amdgcn_raw_buffer_store_b64(wa, r0, (int)(tid * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
           __builtin_amdgcn_raw_buffer_store_b64(wb, r1, (int)(tid * 8u), (int)(((uint32_t)E << P::LT) * 8u), 0);
-          /* (two pairs at a time: sixteen interleaved pairs would need their temporaries next to the waiting twiddles) */
+          /* (two pairs at a time: sixteen interleaved pairs would need their temporaries all at once) */
           if constexpr(E % 2 == 1) sched_fence();
         });
       }
-      prefetch_last<LOGN>(rb, tid, nxt, more);
     }
   }
 }
@@ -2036,13 +1943,28 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       uint64_t *      bpoly = pf.a + poff;
       const uint64_t *apoly = pp.ahat + poff;
       uint64_t *      cpoly = pp.out + poff;
+      /* NTT_TEAMPROD_ONLY (diagnostic builds, like NTT_STAMPS; never in the shipped library): which item types do their work -- bit 0
+       * b's column items, 3 a's column items, 1 the block products, 2 c's inverse column items; the others only run the queue protocol.
+       * Wrong results; one --pmc pass per build gives an item type's FETCH / WRITE bytes by themselves (profiles/r06/config5_bytes_by_item.txt) */
+#ifndef NTT_TEAMPROD_ONLY
+#  define NTT_TEAMPROD_ONLY 15
+#endif
+      constexpr uint32_t kOnly = NTT_TEAMPROD_ONLY;
       if(pass == 0) {
         uint64_t *const src = FOUR && item >= NCOL ? const_cast<uint64_t *>(apoly) : bpoly; /* (a is an operand buffer of the caller's: written here) */
-        team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(src, (item & (NCOL - 1u)) * kTeamCols + tid, logn, pf, MID_LAZY);
+        if((kOnly & 9u) == 9u || (kOnly & (FOUR && item >= NCOL ? 8u : 1u)) != 0)
+          team_column_item<A, LEAD, false, CMASKF, kAuxSc0Sc1, 0>(src, (item & (NCOL - 1u)) * kTeamCols + tid, logn, pf, MID_LAZY);
+      } else if((kOnly & (pass == 1 ? 2u : 4u)) == 0) {
+        /* (switched off in this diagnostic build) */
       } else if(pass == 1) {
         if constexpr(FOUR) {
+          /* (NTT_TEAMPROD_FAKEBLK, diagnostic builds: every block product reads block 0's twiddles -- wrong results, the same loads,
+           * all of them L2-hot: what the twiddle reads of the product items cost at the fabric) */
+#ifndef NTT_TEAMPROD_FAKEBLK
+#  define NTT_TEAMPROD_FAKEBLK 0
+#endif
           team_product_item2<A, KSH, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
-                                                cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
+                                                cpoly + ((uint64_t)item << LOGN), NTT_TEAMPROD_FAKEBLK ? 0u : item, tid, pf, pi, lds, tabl);
         } else {
           team_product_item<A, KSH, kAuxNt, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
                                                          cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
@@ -2399,9 +2321,8 @@ __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa,
       constexpr int H = decltype(hh)::value;
       uint64_t      ra[kE], rb[kE];
       sched_fence();
-      load_last_raw<LOGN, 8 * H, 8 * H + 8, (NTT_TEAMDOT_NT != 0)>(ra, tid, kd.a[i] + aoff + offa);
-      if(NTT_TEAMDOT_NT == 1 && !kd.b_bcast) load_last_raw<LOGN, 8 * H, 8 * H + 8, true>(rb, tid, kd.b[i] + boff + offb);
-      else load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
+      load_last_raw<LOGN, 8 * H, 8 * H + 8, false>(ra, tid, kd.a[i] + aoff + offa);
+      load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
       dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
     });
   }
@@ -2523,9 +2444,6 @@ __global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
  * the last group, the second one while the first half's products run -- and the accumulator words right where each half is
  * finished.
  */
-#ifndef NTT_MUL_B0_EARLY
-#  define NTT_MUL_B0_EARLY 0 /* tuning (A/B builds): 1 = the first quarter of b^ is requested in front of the last group */
-#endif
 template <class A> struct KMul {
   KArgs<A>        k;             /* k.a = a (coefficients, limb 0); nblocks / s0 / logn as for a forward block pass */
   const uint64_t *b;             /* b^ (limb 0) */
@@ -2642,17 +2560,10 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
           sched_fence();
         }
         exchange<A, LOGN, GI, GI + 1>(x, tl, ll);
-#if NTT_MUL_B0_EARLY
-        if constexpr(GI + 1 == GL) {
-          sched_fence();
-          prefetch_last_range<LOGN, 0, 4>(rb, tl, bblk); /* the first quarter of b^ lands during the last group */
-          sched_fence();
-        }
-#endif
         if constexpr(PRE && GI + 1 == GL) {
           run_group_preloaded<A, LOGN, GL, MASK>(x, pre, p);
         } else if constexpr(G::TBL(GI + 1) > 0) {
-          run_group<A, LOGN, GI + 1, false, MASK, true, false, G::TBL_STAGES(GI + 1)>(x, tl, blk, p, ltw + G::TBL_OFF(GI + 1));
+          run_group<A, LOGN, GI + 1, false, MASK, true>(x, tl, blk, p, ltw + G::TBL_OFF(GI + 1));
         } else {
           run_group<A, LOGN, GI + 1, false, MASK>(x, tl, blk, p);
         }
@@ -2663,9 +2574,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       uint32_t t2 = tt; /* (a fresh opaque copy: the lane offsets of this phase are computed here, not carried through the groups) */
       asm volatile("" : "+v"(t2));
       sched_fence();
-#if !NTT_MUL_B0_EARLY
       prefetch_last_range<LOGN, 0, 4>(rb, t2, bblk);
-#endif
       static_for<0, 4>([&](auto qq) {
         constexpr int Q = decltype(qq)::value;
         sched_fence();
@@ -2701,11 +2610,11 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       asm volatile("" : "+v"(tg));
       typename A::val x[kE];
       global_load_first<A, LOGN, false>(x, tg, p.a + blk_off<LOGN>(p, b), false, p.c);
-      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0), false, G::TBL_STAGES(0)>(x, tg, blk, p, gtw);
+      run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tg, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
         exchange<A, LOGN, GI, GI + 1>(x, tg, lds);
-        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0), false, G::TBL_STAGES(GI + 1)>(x, tg, blk, p, gtw + G::TBL_OFF(GI + 1));
+        run_group<A, LOGN, GI + 1, false, MASK, (G::TBL(GI + 1) > 0)>(x, tg, blk, p, gtw + G::TBL_OFF(GI + 1));
       });
       static_for<0, 4>([&](auto qq) {
         constexpr int Q = decltype(qq)::value;
@@ -3022,8 +2931,7 @@ template <class A> constexpr bool multi_limb_built() { return A::kCompact || A::
  * measured no gain (0.591 at 1, 2, 4 per slot, 0.586 at 8) and keep one.  requested > 0 (NTT_OPT_BLOCK_OVERSUB) overrides. */
 template <int LOGN, int WG> constexpr int block_oversub_default(bool whole_polynomials)
 {
-  /* (round 6: the 2^13 forward kernels are two independent 512-thread workgroups per CU now and get the same treatment) */
-  return ((LOGN == 12 && WG == 256) || (LOGN == 13 && WG == 512)) && whole_polynomials ? 8 : 1;
+  return (LOGN == 12 && WG == 256 && whole_polynomials) ? 8 : 1;
 }
 template <int LOGN, int WG> inline uint64_t block_oversub(int requested, bool whole_polynomials)
 {
@@ -3262,10 +3170,6 @@ template <class A, int R, bool INV, int KSH> hipError_t launch_column(const Pass
   const uint64_t nl    = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
   const uint64_t total = pa.batch << (pa.logn - R);
   uint64_t       wgs   = (total + 255) / 256;
-#if NTT_COLUMN_ITERS > 1
-  wgs = (wgs + NTT_COLUMN_ITERS - 1) / NTT_COLUMN_ITERS; /* (A/B builds: grid-stride iterations per workgroup of the column passes) */
-  if(wgs < 2048) wgs = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
-#endif
   uint64_t       cap   = pa.max_grid > 0 ? (uint64_t)pa.max_grid : (1ull << 22);
   cap                  = cap / nl > 0 ? cap / nl : 1;
   if(wgs > cap) wgs = cap;
