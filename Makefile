@@ -19,7 +19,7 @@ OBJS     = $(CSRC)/inst_f64k0.o $(CSRC)/inst_f64k1.o $(CSRC)/inst_f64k18.o $(CSR
            $(CSRC)/inst_team_f64k0.o $(CSRC)/inst_team_f64k1.o $(CSRC)/inst_team_f64k18.o $(CSRC)/inst_team_f64w.o $(CSRC)/ntt_host.o
 # the kernel translation units see the kernel headers only; the host layer also the public headers
 KHDRS    = $(wildcard $(CSRC)/*.h)
-HDRS     = $(KHDRS) $(wildcard include/*.h) $(wildcard include/internal/*.h)
+HDRS     = $(KHDRS) $(wildcard $(CSRC)/host/*.inc) $(wildcard include/*.h) $(wildcard include/internal/*.h)
 
 lib: $(LIB)
 

@@ -5,7 +5,7 @@ Every round draws a transform size 2^1..2^18, a prime of 20..60 bits with 2N | q
 library offers for it, a ragged batch (with a bias to the persistent grids' edges: 255, 256, 257, 511, ...), plan
 options (chunk size, grid cap, two-phase, XCD-local launch with random lag and residency, column-only engine, fused
 product on/off, workgroups per resident slot), now and then an RNS set (one launch over all limbs or the per-prime loop, in
-[limb][batch][N] or [batch][limb][N] layout) or a shuffled pointer batch and checks, bit for bit against
+[limb][batch][N] or [batch][limb][N] layout) or a shuffled pointer batch (host array or device table), the one-pass 2^15 kernel forced on / off, and checks, bit for bit against
 the oracle: forward, inverse, lazy-input and lazy-output forms, the product chain in all aliasing forms, the products of
 operands given in the NTT domain (inner products of k pairs, canonical / lazy / broadcast; one operand transformed beforehand).
 usage: python3 tools/soak.py [--seconds 300] [--seed 1] [--max-coeffs 2^22]"""
@@ -85,6 +85,12 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         opts["fused_product"] = int(rng.choice([0, 0, 2]))      # 2: a's forward transform as a launch of its own
         plan.set_option(lib.OPT_FUSED_PRODUCT, opts["fused_product"])
+    if m == 15 and rng.random() < 0.7:
+        # round 6: N = 2^15 in one pass (FP64 policies): forced on / off; the automatic choice wants a polynomial per CU
+        opts["one_pass"] = int(rng.choice([1, 1, 0]))
+        plan.set_option(lib.OPT_ONE_PASS, opts["one_pass"])
+        if rng.random() < 0.3:
+            batch = max(1, min(int(rng.choice([255, 256, 257, 300, 513])), cap))
     if m in (15, 16, 17) and rng.random() < 0.6:
         # both passes as items of one launch (needs batch >= 64; forced on for both directions, random lag / residency)
         opts["xcd_local"] = int(rng.choice([1, 1, 0]))
@@ -140,8 +146,26 @@ while time.time() < t_end:
         for i, slot in enumerate(order):
             host[slot * (n + gap): slot * (n + gap) + n] = a[i * n:(i + 1) * n]
         pool.upload(host)
-        plan.transform_ptrs([pool.ptr + 8 * int(slot) * (n + gap) for slot in order])
+        # irregular gaps every other time (no progression: the device table), and the device-array form (as given, no upload)
+        ptrs = [pool.ptr + 8 * int(slot) * (n + gap) for slot in order]
+        if rng.random() < 0.5:
+            tab = lib.DeviceBuffer(batch).upload(np.array(ptrs, dtype=np.uint64))
+            plan.transform_dev_ptrs(tab.ptr, batch)
+            tab.free()
+        else:
+            plan.transform_ptrs(ptrs)
         res = pool.download()
+        if batch >= 4 and rng.random() < 0.5:
+            # ... and back, leaving one polynomial of the pool out: the sorted pointers are then no single progression (table path of
+            # the host-array form); the polynomial left out must come back transformed, all others as they went in
+            skip = batch // 3
+            plan.transform_ptrs([p_ for i_, p_ in enumerate(ptrs) if i_ != skip], lib.FLAG_INVERSE)
+            back = pool.download()
+            for i in (0, skip, batch - 1):
+                slot = int(order[i])
+                exp = want[i * n:(i + 1) * n] if i == skip else a[i * n:(i + 1) * n]
+                if not np.array_equal(back[slot * (n + gap): slot * (n + gap) + n], exp):
+                    fail("transform_ptrs, irregular subset", gap=gap, poly=i, **ctxt)
         for i in (0, batch // 2, batch - 1):
             slot = int(order[i])
             if not np.array_equal(res[slot * (n + gap): slot * (n + gap) + n], want[i * n:(i + 1) * n]):
