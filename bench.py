@@ -52,7 +52,7 @@ SEED = 0x5EED5EED
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NTT = 16 * N       # one 8-byte read + one 8-byte write per coefficient
 METRIC = "batched forward NTTs/sec at N=2^14, 50-bit q; achieved HBM GB/s vs peak"
-TRAFFIC_DIR = os.path.join(ROOT, "profiles", "r05")
+TRAFFIC_DIR = os.path.join(ROOT, "profiles", "r06")
 TRAFFIC_JSON = os.path.join(TRAFFIC_DIR, "pmc_traffic.json")      # the headline launch (config 4); pmc_traffic_config{2,3,5}.json beside it
 
 
@@ -619,7 +619,7 @@ def make_report(args, n_gpus, batch, elapsed, kernel_ms, arith, hbm_passes, n=No
     traffic = measured_traffic(batch, kname) if (cfg == 4 and n == N) else measured_traffic_config(cfg, batch, n, layout)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r05/pmc_traffic*.json), "
+            "traffic_source": "committed rocprofv3 --pmc passes of the same launch (profiles/r06/pmc_traffic*.json), "
                               "not collected in this run" if traffic is not None else None,
             "kernel": kname, "launches_per_step": launches, "kernel_ms": slowest, "kernel_ms_per_gpu": kernel_ms,
             "algorithmic_bytes_per_step": batch * bytes_per_unit,
@@ -753,7 +753,7 @@ def also_config(lib, config, steps=8, warmup=3, check=True, layout=None):
     traffic = measured_traffic_config(config, batch, w.n, layout)
     out = {"value": batch / (elapsed / steps), "unit": w.unit, "frac": gbs / HBM_PEAK_GBS, "achieved_GBs": gbs,
            # HBM-side bytes of one step from the committed counter passes (FETCH_SIZE x2 + WRITE_SIZE over the step's launches;
-           # profiles/r05/pmc_traffic_config*.json), and their ratio to the algorithmic bytes: > 1 = bytes moved twice
+           # profiles/r06/pmc_traffic_config*.json), and their ratio to the algorithmic bytes: > 1 = bytes moved twice
            "traffic": traffic, "traffic_over_algorithmic": (traffic / (batch * w.bytes_per_unit)) if traffic else None,
            "layout": "[batch][limb][N]" if layout else ("[limb][batch][N]" if w.kind == "rns_product" else "[batch][N]"),
            "kernel_ms": kernel_ms[0], "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": max(warmup, 1 if check else 0),

@@ -169,7 +169,12 @@ NTT_API int  ntt_plan_get_option(const ntt_plan *p, int option, int64_t *value);
  * after this call they do not.  Call it outside stream capture. */
 NTT_API int  ntt_plan_reserve(const ntt_plan *p, void *stream, uint64_t polys);
 
-/* ---- batched transforms: d_a is device memory laid out [batch][N], in place ---- */
+/* ---- batched transforms: d_a is device memory laid out [batch][N], in place ----
+ * Input contract: ntt_fwd_batch / ntt_inv_batch (and every entry point that does not say otherwise) take CANONICAL words, 0 <= a < q.
+ * The library does not check it, and plans for 2^51 < q < 2^52 (info[4] == 52) rely on it: the first inverse stage multiplies the
+ * unreduced difference of two inputs, exact only while that difference is below q in magnitude -- words in [q, 2q) handed to
+ * ntt_inv_batch give wrong results there (rounds 3-4 happened to tolerate them).  Lazy words of any range this header names go
+ * through the *_wide entry points (NTT_FLAG_WIDE_IN), which fold them first. */
 NTT_API int ntt_fwd_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
 NTT_API int ntt_inv_batch(const ntt_plan *p, uint64_t *d_a, uint64_t batch, void *stream);
 /* lazy outputs: the reference's *_lazy contract (include/ntt_reference.h:13-17, tests/bench.c:123-137) --

@@ -83,6 +83,25 @@ def test_traffic_json_matches_bench():
     assert bench.measured_traffic(t["batch"] // 2, t["kernel"]) is None
     # no more than 2 % above the algorithmic bytes: anything else means re-reads crept in
     assert 1.0 <= t["hbm_bytes_per_launch"] / (t["batch"] * 16 * t["N"]) < 1.02
+    # The evidence is tied to the BINARY (review r05 item 3): every committed counter summary names the sha256 of the library it was
+    # taken on, all of them the same one, and that is the library this tree builds (`make lib` is reproducible: the shipped .so is
+    # rebuilt byte for byte from a `git archive`).  A kernel change after the collection fails here until tools/collect_r06.sh has
+    # run again on the new library.
+    import glob
+    import hashlib
+    shas = set()
+    for f in glob.glob(os.path.join(bench.TRAFFIC_DIR, "pmc_traffic*.json")):
+        with open(f) as fh:
+            shas.add(json.load(fh).get("lib_sha256"))
+    with open(os.path.join(bench.TRAFFIC_DIR, "LIBRARY_SHA256")) as fh:
+        shas.add(fh.read().split()[0])
+    assert len(shas) == 1 and None not in shas, shas
+    lib = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd", "libntt_mi355x.so")
+    assert os.path.exists(lib), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    with open(lib, "rb") as fh:
+        built = hashlib.sha256(fh.read()).hexdigest()
+    assert built in shas, "profiles/r06 was collected on library %s, this tree builds %s: run tools/collect_r06.sh again" % (shas, built)
+    assert bench.traffic_lib_sha256() == built
 
 
 def test_headers_compile_as_c_and_cxx():

@@ -780,3 +780,25 @@ def test_one_pass_2p15_against_the_oracle_and_the_two_pass_route(oracle, emu, ar
     assert fails == 0
     if arith == 2:
         assert maxb < 2.0 ** 53 / q * (1 - 1 / 64), (maxb, q)
+
+
+def test_52_bit_inverse_input_contract(oracle, emu):
+    """advisor r05: plans for 2^51 < q < 2^52 multiply the unreduced difference of two INPUTS in their first inverse stage (round 5's
+    per-slot plan, kCanonInFlag) -- exact for canonical words only.  include/ntt_mi355x.h states the contract; this pins both sides of
+    it on the CPU with the checked policy: words in [q, 2q) through the strict inverse trip the exactness checks (or give wrong
+    words), the same words through the wide form -- where callers with lazy words belong -- are exact and right."""
+    m, n = 12, 1 << 12
+    q = oracle.find_prime(52, n)
+    w = oracle.min_root(q, n)
+    cx = oracle.ctx(n, q, w)
+    a = oracle.fill_uniform(2 * n, q, 77)
+    fa = cx.fwd(a.copy())
+    lazy = fa.copy()
+    lazy[::3] += np.uint64(q)                 # every third word in [q, 2q)
+    emu.chk_stats(reset=True)
+    rc, back = emu.transform(lazy, m, q, w, 5, inverse=True, wide=True)
+    assert rc == 0 and np.array_equal(back, a) and emu.chk_stats()[0] == 0
+    emu.chk_stats(reset=True)
+    rc, strict = emu.transform(lazy, m, q, w, 5, inverse=True)
+    assert rc == 0 and (emu.chk_stats()[0] > 0 or not np.array_equal(strict, a)), "the strict inverse is documented NOT to take lazy words"
+    emu.chk_stats(reset=True)

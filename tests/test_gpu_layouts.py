@@ -482,3 +482,52 @@ def test_pointer_batch_of_rns_polynomials(lib, oracle, m, nl, bits):
             assert np.array_equal(got[(2 * i + 3 * l) * n:(2 * i + 3 * l + 1) * n], ctxs[l].fwd(polys[i][l].copy())), (i, l)
     assert (got[n:2 * n] == GUARD).all() and (got[6 * n:7 * n] == GUARD).all()
     d.free()
+
+
+@pytest.mark.parametrize("oversub", [1, 3, 64])
+def test_block_oversub_settings_are_bit_exact(lib, oracle, oversub):
+    """NTT_OPT_BLOCK_OVERSUB (workgroups launched per resident slot of the persistent block kernels; round 6 also the table-sharing
+    small-block kernels) changes which workgroup takes which block, never a result: forward, inverse, the product and the NTT-domain
+    product at the sizes whose kernels read the option, with batches that are not multiples of any grid (review r05: the option was
+    only set and read back by a test, and soaked)"""
+    for m, batch in ((10, 1000), (11, 777), (12, 1029), (13, 515), (14, 301)):
+        n = 1 << m
+        q = lib.find_prime(50, n, 0)
+        w = lib.min_root(q, n)
+        plan, cx = lib.Plan(n, q, w), oracle.ctx(n, q, w)
+        plan.set_option(lib.OPT_BLOCK_OVERSUB, oversub)
+        a = oracle.fill_uniform(batch * n, q, 31 + m)
+        b = oracle.fill_uniform(batch * n, q, 32 + m)
+        da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size).upload(b), lib.DeviceBuffer(a.size)
+        plan.fwd(da.ptr, batch)
+        fa = da.download()
+        for p in (0, batch // 2, batch - 1):
+            assert np.array_equal(fa[p * n:(p + 1) * n], cx.fwd(a[p * n:(p + 1) * n].copy())), (m, p)
+        plan.inv(da.ptr, batch)
+        assert np.array_equal(da.download(), a), m
+        plan.negacyclic_mul(dc.ptr, da.ptr, db.ptr, batch)
+        got = dc.download()
+        for p in (0, batch - 1):
+            sl = slice(p * n, (p + 1) * n)
+            assert np.array_equal(got[sl], cx.inv(oracle.pointwise(cx.fwd(a[sl].copy()), cx.fwd(b[sl].copy()), q))), (m, p)
+        da.upload(fa)
+        plan.fwd(db.upload(b).ptr, batch)
+        plan.inv_product(dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), got), m
+        for x in (da, db, dc):
+            x.free()
+        plan.destroy()
+
+
+def test_layout_check_does_not_wrap(lib):
+    """(batch - 1) * stride is formed in 128 bits: an absurd batch with a legal stride is an overlap, not a wrapped 'fits'"""
+    n = 1 << 10
+    qs = [lib.find_prime(50, n, k) for k in range(2)]
+    plans = [lib.Plan(n, q, lib.min_root(q, n)) for q in qs]
+    d = lib.DeviceBuffer(4 * n)
+    with pytest.raises(lib.NttError):
+        # limb stride 2^40 words, polynomial stride 2^40 / 2: (batch - 1) * poly wraps 64 bits for batch = 2^25 + 1
+        lib.rns_fwd(plans, d.ptr, (1 << 25) + 1, layout=(1 << 40, 1 << 39))
+    d.free()
+    for p in plans:
+        p.destroy()

@@ -2,6 +2,7 @@
 the oracle and the golden vectors on every reference parameter set; the
 reference-signature entry points behave like the reference's; full-size runs
 are checked through round trips, linearity and per-polynomial checksums."""
+import ctypes as C
 import os
 import subprocess
 
@@ -2666,3 +2667,45 @@ def test_xcd_local_ntt_domain_products_over_rns_limbs(lib, oracle, m, nl, batch,
         x.free()
     for p in plans:
         p.destroy()
+
+
+def test_graph_control_block_follows_a_larger_reserve(lib, oracle):
+    """advisor r05 (medium): the control block that CAPTURED XCD-local launches use was sized once, by the first direct call or
+    reserve on a (plan, stream) pair; a later, larger ntt_plan_reserve grew only the direct block, and a capture of the larger batch
+    silently took the per-pass launches.  Now: reserve(small), reserve(big), capture -- the graph holds the TWO kernel nodes of the
+    one-launch form (control-block clear + team_kernel), not the twelve of the per-pass launches over six 8 MiB chunks; the counter of
+    control-block allocations moves with the second reserve and not with the capture; replays are bit-exact."""
+    hip = C.CDLL("libamdhip64.so.7")
+    n, batch = 1 << 16, 96
+    q = lib.find_prime(50, n, 0)
+    w = lib.min_root(q, n)
+    plan, cx = lib.Plan(n, q, w), oracle.ctx(n, q, w)
+    plan.set_option(lib.OPT_XCD_LOCAL, 1)
+    plan.set_option(lib.OPT_CHUNK_MIB, 8)
+    st = C.c_void_p()
+    lib._check(lib._lib.ntt_stream_create(0, C.byref(st)))
+    plan.reserve(8, stream=st.value)
+    a0 = plan.get_option(lib.OPT_CTL_ALLOCATIONS)
+    plan.reserve(batch, stream=st.value)
+    a1 = plan.get_option(lib.OPT_CTL_ALLOCATIONS)
+    assert a1 > a0
+    a = oracle.fill_uniform(batch * n, q, 4)
+    d = lib.DeviceBuffer(a.size).upload(a)
+    graph, exe, count = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    assert hip.hipStreamBeginCapture(st, 2) == 0          # hipStreamCaptureModeRelaxed
+    plan.fwd(d.ptr, batch, stream=st.value)
+    assert hip.hipStreamEndCapture(st, C.byref(graph)) == 0
+    assert plan.get_option(lib.OPT_CTL_ALLOCATIONS) == a1          # nothing allocated while capturing
+    assert hip.hipGraphGetNodes(graph, None, C.byref(count)) == 0
+    assert count.value == 2, "captured %d nodes: the per-pass launches, not the one-launch form" % count.value
+    assert hip.hipGraphInstantiate(C.byref(exe), graph, None, None, C.c_size_t(0)) == 0
+    for rep in range(3):
+        d.upload(a)
+        assert hip.hipGraphLaunch(exe, st) == 0
+        lib.stream_sync(0, st.value)
+        got = d.download()
+        for p in (0, 41, batch - 1):
+            assert np.array_equal(got[p * n:(p + 1) * n], cx.fwd(a[p * n:(p + 1) * n].copy())), (rep, p)
+    hip.hipGraphExecDestroy(exe), hip.hipGraphDestroy(graph)
+    d.free(), plan.destroy()
+    lib._lib.ntt_stream_destroy(0, st)

@@ -65,7 +65,7 @@ timeout 600 python3 tools/sweep.py --logn 10 12 13 14 15 16 17 --ops fwd inv mul
 timeout 600 python3 tools/pointer_batch_bench.py > $out/pointer_batches.txt 2>&1
 timeout 1500 bash tools/folded_8_shards.sh $out/folded_8_shards.txt > /dev/null 2>&1
 if [ -x oracle/_ref/ntt-variants-bench-dropin ]; then timeout 600 oracle/_ref/ntt-variants-bench-dropin > $out/reference_bench_driver_dropin.txt 2>&1; fi
-timeout 900 python3 tools/soak.py --minutes 5 > $out/soak.txt 2>&1
+timeout 900 python3 tools/soak.py --seconds 300 > $out/soak.txt 2>&1
 # kernel-stats CSVs: the sha256 of the library as a first comment line
 for c in 4 2 3 5 5_bm onepass; do
   f=$(ls $out/kt$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(ls $out/kt_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -z "$f" ] && continue
