@@ -54,7 +54,8 @@ EXPORTED_SYMBOLS = [
     "ntt_rns_negacyclic_mul_batch", "ntt_inv_product_batch", "ntt_inv_dot_batch", "ntt_mul_transformed_batch",
     "ntt_rns_inv_dot_batch", "ntt_rns_mul_transformed_batch", "ntt_fwd_mul_batch", "ntt_rns_fwd_mul_batch",
     "ntt_rns_fwd_batch_strided", "ntt_rns_inv_batch_strided", "ntt_rns_negacyclic_mul_batch_strided", "ntt_rns_inv_dot_batch_strided",
-    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_transform_dev_ptrs", "ntt_rns_transform_dev_ptrs", "ntt_dev_malloc", "ntt_dev_free", "ntt_dev_mem_info",
+    "ntt_rns_mul_transformed_batch_strided", "ntt_rns_fwd_mul_batch_strided", "ntt_transform_batch_strided", "ntt_transform_ptrs", "ntt_rns_transform_ptrs", "ntt_transform_dev_ptrs", "ntt_rns_transform_dev_ptrs", "ntt_inv_dot_dev_ptrs", "ntt_fwd_mul_dev_ptrs", "ntt_negacyclic_mul_dev_ptrs",
+    "ntt_rns_inv_dot_dev_ptrs", "ntt_rns_fwd_mul_dev_ptrs", "ntt_rns_negacyclic_mul_dev_ptrs", "ntt_dev_malloc", "ntt_dev_free", "ntt_dev_mem_info",
     "ntt_h2d", "ntt_d2h", "ntt_stream_create", "ntt_stream_destroy", "ntt_stream_sync",
     "ntt_event_create", "ntt_event_destroy", "ntt_event_record", "ntt_event_elapsed_ms",
     "ntt_fill_uniform", "ntt_poly_checksum", "ntt_rmw_probe", "ntt_shape_probe", "ntt_copy_probe", "ntt_batch_multi", "ntt_rns_mul_multi", "ntt_min_root", "ntt_find_prime",
@@ -132,6 +133,12 @@ _sig("ntt_transform_ptrs", C.c_int, VOIDP, C.POINTER(VOIDP), C.c_uint64, C.c_uin
 _sig("ntt_rns_transform_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_transform_dev_ptrs", C.c_int, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
 _sig("ntt_rns_transform_dev_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_inv_dot_dev_ptrs", C.c_int, VOIDP, VOIDP, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_fwd_mul_dev_ptrs", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_negacyclic_mul_dev_ptrs", C.c_int, VOIDP, VOIDP, VOIDP, VOIDP, C.c_uint64, VOIDP)
+_sig("ntt_rns_inv_dot_dev_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, C.c_int, C.POINTER(VOIDP), C.POINTER(VOIDP), C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_fwd_mul_dev_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, C.c_uint, VOIDP)
+_sig("ntt_rns_negacyclic_mul_dev_ptrs", C.c_int, C.c_int, C.POINTER(VOIDP), VOIDP, VOIDP, VOIDP, C.c_uint64, C.c_uint64, VOIDP)
 _sig("ntt_dev_malloc", C.c_int, C.c_int, C.POINTER(VOIDP), C.c_size_t)
 _sig("ntt_dev_mem_info", C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig("ntt_dev_free", C.c_int, C.c_int, VOIDP)
@@ -358,6 +365,17 @@ class Plan:
         """the same with the pointers already in DEVICE memory (ntt_transform_dev_ptrs): d_table = device address of `count` pointers"""
         _check(_lib.ntt_transform_dev_ptrs(self.h, d_table, count, flags, stream))
 
+    def inv_dot_dev_ptrs(self, c_tab, a_tabs, b_tabs, count, flags=0, stream=None):
+        """ntt_inv_dot_dev_ptrs: c_tab = device table of `count` pointers; a_tabs / b_tabs = lists of k device tables (a broadcast b: device pointers to ONE polynomial each)"""
+        k = len(a_tabs)
+        _check(_lib.ntt_inv_dot_dev_ptrs(self.h, c_tab, k, (VOIDP * k)(*a_tabs), (VOIDP * k)(*b_tabs), count, flags, stream))
+
+    def fwd_mul_dev_ptrs(self, c_tab, a_tab, b_tab, count, flags=0, stream=None):
+        _check(_lib.ntt_fwd_mul_dev_ptrs(self.h, c_tab, a_tab, b_tab, count, flags, stream))
+
+    def negacyclic_mul_dev_ptrs(self, c_tab, a_tab, b_tab, count, stream=None):
+        _check(_lib.ntt_negacyclic_mul_dev_ptrs(self.h, c_tab, a_tab, b_tab, count, stream))
+
     def pointwise_mul(self, dc, da, db, batch, stream=None, lazy_in=False):
         f = _lib.ntt_pointwise_mul_batch_lazy if lazy_in else _lib.ntt_pointwise_mul_batch
         _check(f(self.h, dc, da, db, batch, stream))
@@ -433,6 +451,19 @@ def rns_transform_ptrs(plans, ptrs, limb_stride, flags=0, stream=None):
 def rns_transform_dev_ptrs(plans, d_table, count, limb_stride, flags=0, stream=None):
     """ntt_rns_transform_dev_ptrs: the pointers (limb 0 of every RNS polynomial) in a DEVICE array"""
     _check(_lib.ntt_rns_transform_dev_ptrs(len(plans), _plan_array(plans), d_table, count, limb_stride, flags, stream))
+
+
+def rns_inv_dot_dev_ptrs(plans, c_tab, a_tabs, b_tabs, count, limb_stride, flags=0, stream=None):
+    k = len(a_tabs)
+    _check(_lib.ntt_rns_inv_dot_dev_ptrs(len(plans), _plan_array(plans), c_tab, k, (VOIDP * k)(*a_tabs), (VOIDP * k)(*b_tabs), count, limb_stride, flags, stream))
+
+
+def rns_fwd_mul_dev_ptrs(plans, c_tab, a_tab, b_tab, count, limb_stride, flags=0, stream=None):
+    _check(_lib.ntt_rns_fwd_mul_dev_ptrs(len(plans), _plan_array(plans), c_tab, a_tab, b_tab, count, limb_stride, flags, stream))
+
+
+def rns_negacyclic_mul_dev_ptrs(plans, c_tab, a_tab, b_tab, count, limb_stride, stream=None):
+    _check(_lib.ntt_rns_negacyclic_mul_dev_ptrs(len(plans), _plan_array(plans), c_tab, a_tab, b_tab, count, limb_stride, stream))
 
 
 def batch_major(plans):

@@ -2673,10 +2673,10 @@ def test_graph_control_block_follows_a_larger_reserve(lib, oracle):
     """advisor r05 (medium): the control block that CAPTURED XCD-local launches use was sized once, by the first direct call or
     reserve on a (plan, stream) pair; a later, larger ntt_plan_reserve grew only the direct block, and a capture of the larger batch
     silently took the per-pass launches.  Now: reserve(small), reserve(big), capture -- the graph holds the TWO kernel nodes of the
-    one-launch form (control-block clear + team_kernel), not the twelve of the per-pass launches over six 8 MiB chunks; the counter of
+    one-launch form (control-block clear + team_kernel), not the 76 of the per-pass launches over 38 chunks of 8 MiB; the counter of
     control-block allocations moves with the second reserve and not with the capture; replays are bit-exact."""
     hip = C.CDLL("libamdhip64.so.7")
-    n, batch = 1 << 16, 96
+    n, batch = 1 << 16, 600        # (the first reserve's block -- doubled on first allocation -- holds 545 entries: 600 outgrows it)
     q = lib.find_prime(50, n, 0)
     w = lib.min_root(q, n)
     plan, cx = lib.Plan(n, q, w), oracle.ctx(n, q, w)
@@ -2704,7 +2704,7 @@ def test_graph_control_block_follows_a_larger_reserve(lib, oracle):
         assert hip.hipGraphLaunch(exe, st) == 0
         lib.stream_sync(0, st.value)
         got = d.download()
-        for p in (0, 41, batch - 1):
+        for p in (0, 341, batch - 1):
             assert np.array_equal(got[p * n:(p + 1) * n], cx.fwd(a[p * n:(p + 1) * n].copy())), (rep, p)
     hip.hipGraphExecDestroy(exe), hip.hipGraphDestroy(graph)
     d.free(), plan.destroy()

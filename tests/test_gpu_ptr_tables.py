@@ -267,3 +267,145 @@ def test_randomly_placed_polynomials_run_at_the_rate_of_a_slab(lib):
     host = timed(lambda: plan.transform_ptrs(ptrs))
     assert dev < 1.25 * slab and host < 2.0 * slab, (slab, dev, host)
     tab.free(), d.free(), plan.destroy()
+
+
+def _tables(lib, oracle, rng, n, q, count, operands, seed, unit=None):
+    """`operands` sets of `count` polynomials, every polynomial at its own random place of ONE pool buffer (shuffled, irregular gaps,
+    all operands interleaved): returns the pool, the host images, per operand the word offsets and the device table"""
+    unit = unit or n
+    offs_all, words = _scatter(rng, operands * count, unit, 40)
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    polys, offs = [], []
+    for o in range(operands):
+        offs.append(offs_all[o * count:(o + 1) * count])
+        polys.append(oracle.fill_uniform(count * n, q, seed + o).reshape(count, n))
+    return offs, polys, img, mask, words
+
+
+@pytest.mark.parametrize("m,bits,arith", [(8, 50, "auto"), (12, 50, "auto"), (14, 52, "auto"), (14, 58, "auto"), (12, 50, "r4"), (16, 50, "auto"), (4, 30, "auto")])
+def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
+    """round 6: the NTT-domain products and the product chain over SEPARATELY HELD operands -- every operand a device table of
+    pointers into a pool where all polynomials of all operands lie shuffled: c = inv(sum_i a_i^ . b_i^) for k = 1, 3 (canonical, lazy,
+    broadcast key), c^ = fwd(a) . b^ and c^ += fwd(a) . key^, c = a * b (c on a table of its own, on a's, squaring); every polynomial
+    against the oracle, every word between the polynomials untouched"""
+    n, count = 1 << m, 24
+    q = lib.find_prime(bits, n, 0)
+    w = lib.min_root(q, n)
+    plan = lib.Plan(n, q, w, arith={"auto": lib.ARITH_AUTO, "r4": lib.ARITH_U64_R4}[arith])
+    cx = oracle.ctx(n, q, w)
+    rng = np.random.default_rng(m * 100 + bits)
+    K = 3
+    offs, polys, img, mask, words = _tables(lib, oracle, rng, n, q, count, 2 * K + 1, 500 + m)
+    # operands 0..K-1: a_i, K..2K-1: b_i, 2K: c
+    A = [polys[i] for i in range(K)]
+    B = [polys[K + i] for i in range(K)]
+    Ah = [np.stack([cx.fwd(x.copy()) for x in a]) for a in A]
+    Bh = [np.stack([cx.fwd(x.copy()) for x in b]) for b in B]
+
+    def place(sets):
+        im = img.copy()
+        mk = mask.copy()
+        for o, data in sets.items():
+            for off, x in zip(offs[o], data):
+                im[off:off + n] = x
+                mk[off:off + n] = False
+        return im, mk
+    d = lib.DeviceBuffer(words)
+    tabs = [lib.DeviceBuffer(count).upload(np.array([d.ptr + 8 * o for o in offs[i]], dtype=np.uint64)) for i in range(2 * K + 1)]
+    key = lib.DeviceBuffer(n).upload(Bh[0][0])
+    for k in (1, K):
+        for lazy in (False, True):
+            mult = np.uint64(q) * np.uint64(3 if (lazy and q < (1 << 60)) else 0)
+            im, mk = place({**{i: Ah[i] + mult for i in range(k)}, **{K + i: Bh[i] + mult for i in range(k)}})
+            d.upload(im)
+            plan.inv_dot_dev_ptrs(tabs[2 * K].ptr, [tabs[i].ptr for i in range(k)], [tabs[K + i].ptr for i in range(k)], count, lib.MUL_LAZY_IN if lazy else 0)
+            got = d.download()
+            for p in range(count):
+                acc = np.zeros(n, dtype=np.uint64)
+                for i in range(k):
+                    acc = (acc + oracle.pointwise(Ah[i][p].copy(), Bh[i][p].copy(), q)) % np.uint64(q)
+                assert np.array_equal(got[offs[2 * K][p]:offs[2 * K][p] + n], cx.inv(acc)), (k, lazy, p)
+            mk2 = mk.copy()
+            for off in offs[2 * K]:
+                mk2[off:off + n] = False
+            assert (got[mk2] == GUARD).all(), (k, lazy)
+    # broadcast key, k = 1, c on a's own table
+    im, mk = place({0: Ah[0]})
+    d.upload(im)
+    plan.inv_dot_dev_ptrs(tabs[0].ptr, [tabs[0].ptr], [key.ptr], count, lib.MUL_B_BROADCAST)
+    got = d.download()
+    for p in range(count):
+        assert np.array_equal(got[offs[0][p]:offs[0][p] + n], cx.inv(oracle.pointwise(Ah[0][p].copy(), Bh[0][0].copy(), q))), p
+    assert (got[mk] == GUARD).all()
+    # c^ = fwd(a) . b^, then c^ += fwd(a') . key^
+    im, mk = place({0: A[0], 1: A[1], K: Bh[0]})
+    d.upload(im)
+    plan.fwd_mul_dev_ptrs(tabs[2 * K].ptr, tabs[0].ptr, tabs[K].ptr, count)
+    plan.fwd_mul_dev_ptrs(tabs[2 * K].ptr, tabs[1].ptr, key.ptr, count, lib.MUL_ACCUMULATE | lib.MUL_B_BROADCAST)
+    got = d.download()
+    for p in range(count):
+        exp = (oracle.pointwise(Ah[0][p].copy(), Bh[0][p].copy(), q) + oracle.pointwise(Ah[1][p].copy(), Bh[0][0].copy(), q)) % np.uint64(q)
+        assert np.array_equal(got[offs[2 * K][p]:offs[2 * K][p] + n], exp), p
+    # c = a * b: own table, a's table, squaring
+    for form in ("own", "on_a", "square"):
+        im, mk = place({0: A[0], K: B[0]})
+        d.upload(im)
+        ct = tabs[2 * K] if form == "own" else tabs[0]
+        bt = tabs[0] if form == "square" else tabs[K]
+        plan.negacyclic_mul_dev_ptrs(ct.ptr, tabs[0].ptr, bt.ptr, count)
+        got = d.download()
+        co = offs[2 * K] if form == "own" else offs[0]
+        for p in range(count):
+            other = Ah[0][p] if form == "square" else Bh[0][p]
+            assert np.array_equal(got[co[p]:co[p] + n], cx.inv(oracle.pointwise(Ah[0][p].copy(), other.copy(), q))), (form, p)
+    for t in tabs:
+        t.free()
+    key.free(), d.free(), plan.destroy()
+
+
+def test_rns_products_over_pointer_tables(lib, oracle):
+    """the RNS twins: every table entry points at limb 0 of an RNS polynomial ([limb][N] each), the limbs one after the other"""
+    m, nl, count = 13, 3, 10
+    n = 1 << m
+    qs = [lib.find_prime(50, n, i) for i in range(nl)]
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    ctx = [oracle.ctx(n, q, w) for q, w in zip(qs, ws)]
+    rng = np.random.default_rng(9)
+    offs_all, words = _scatter(rng, 3 * count, nl * n, 40)
+    offs = [offs_all[o * count:(o + 1) * count] for o in range(3)]
+    img = np.full(words, GUARD, dtype=np.uint64)
+    a = [[oracle.fill_uniform(n, q, 10 * p + l) for l, q in enumerate(qs)] for p in range(count)]
+    b = [[oracle.fill_uniform(n, q, 1000 + 10 * p + l) for l, q in enumerate(qs)] for p in range(count)]
+    for p in range(count):
+        for l in range(nl):
+            img[offs[0][p] + l * n:offs[0][p] + (l + 1) * n] = a[p][l]
+            img[offs[1][p] + l * n:offs[1][p] + (l + 1) * n] = b[p][l]
+    d = lib.DeviceBuffer(words).upload(img)
+    tabs = [lib.DeviceBuffer(count).upload(np.array([d.ptr + 8 * o for o in offs[i]], dtype=np.uint64)) for i in range(3)]
+    lib.rns_negacyclic_mul_dev_ptrs(plans, tabs[2].ptr, tabs[0].ptr, tabs[1].ptr, count, n)
+    got = d.download()
+    for p in range(count):
+        for l in range(nl):
+            fa, fb = ctx[l].fwd(a[p][l].copy()), ctx[l].fwd(b[p][l].copy())
+            assert np.array_equal(got[offs[2][p] + l * n:offs[2][p] + (l + 1) * n], ctx[l].inv(oracle.pointwise(fa, fb, qs[l]))), (p, l)
+            assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], fa), "a is left in the NTT domain"
+    # the operands are transformed now: c = inv(a^ . b^) again through the inner-product form, and c^ += fwd(c) . b^ on top of a^
+    lib.rns_inv_dot_dev_ptrs(plans, tabs[2].ptr, [tabs[0].ptr], [tabs[1].ptr], count, n)
+    again = d.download()
+    for p in range(count):
+        assert np.array_equal(again[offs[2][p]:offs[2][p] + nl * n], got[offs[2][p]:offs[2][p] + nl * n]), p
+    lib.rns_fwd_mul_dev_ptrs(plans, tabs[0].ptr, tabs[2].ptr, tabs[1].ptr, count, n, lib.MUL_ACCUMULATE)
+    acc = d.download()
+    for p in (0, count - 1):
+        for l in range(nl):
+            fa, fb = ctx[l].fwd(a[p][l].copy()), ctx[l].fwd(b[p][l].copy())
+            c = ctx[l].inv(oracle.pointwise(fa, fb, qs[l]))
+            exp = (fa + oracle.pointwise(ctx[l].fwd(c.copy()), fb, qs[l])) % np.uint64(qs[l])
+            assert np.array_equal(acc[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], exp), (p, l)
+    for t in tabs:
+        t.free()
+    d.free()
+    for p in plans:
+        p.destroy()
