@@ -248,8 +248,9 @@ NTT_API int ntt_mul_transformed_batch(const ntt_plan *p, uint64_t *d_c, uint64_t
  * (canonical words, bit-reversed order as ntt_fwd_batch leaves them): a plaintext or key-switching key kept transformed is
  * multiplied in where the forward transform would reduce and store its outputs -- the multiply-accumulate of a key-switching
  * inner product, digit by digit.  ONE launch up to N = 2^14: 24N bytes (16N with NTT_MUL_B_BROADCAST) instead of 40N for
- * ntt_fwd_batch + ntt_pointwise_mul_batch; accumulating 32N (24N) instead of 48N.  Above 2^14 the product rides in the block pass of
- * the forward transform: one launch over both passes from 2^26 coefficients per operand on (NTT_OPT_XCD_LOCAL), else a column and a
+ * ntt_fwd_batch + ntt_pointwise_mul_batch; accumulating 32N (24N) instead of 48N.  N = 2^15 (FP64 policies, NTT_OPT_ONE_PASS): the
+ * one-pass transform with the product at its output, 24N bytes, d_a left as it was (round 6).  Else above 2^14 the product rides in
+ * the block pass of the forward transform: one launch over both passes from 2^26 coefficients per operand on (NTT_OPT_XCD_LOCAL), else a column and a
  * block launch per 256 MiB chunk.  d_a is left as it was up to 2^14 and
  * OVERWRITTEN (scratch) above -- and at every size by plans without the fused kernel (radix-4 policy, column-only plans, N <
  * 2^6: forward transform in place, then a pointwise launch); d_c may alias d_a (not when accumulating) or d_bhat. */

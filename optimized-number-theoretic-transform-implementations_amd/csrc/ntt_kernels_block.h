@@ -923,10 +923,10 @@ __global__ void __launch_bounds__(1024, 4) twophase_kernel(const KArgs<A> k)
  * the plan's bound at a block's end is not an input the last butterfly's 2B <= LIM argument covers).
  * Reference precedent: src/ntt_radix4x4.c:54-78 (several stages on values held close), third_party/hexl/fwd-ntt-avx512.c:311-329.
  */
-/* one half (block position blk of a 2^15-point polynomial, s0 = 1) through the forward block stages and out to memory */
-template <class A, uint32_t MASK>
-__device__ __forceinline__ void onepass_block_fwd(typename A::val (&x)[kE], uint32_t blk, uint32_t tid, uint64_t *bb, const Params<A> &p,
-                                                  typename A::val *lds_all, typename A::ctw *tabl)
+/* one half (block position blk of a 2^15-point polynomial, s0 = 1) through the forward block stages and out to memory (`out`) */
+template <class A, uint32_t MASK, class OUT>
+__device__ __forceinline__ void onepass_block_fwd(typename A::val (&x)[kE], uint32_t blk, uint32_t tid, const Params<A> &p, typename A::val *lds_all,
+                                                  typename A::ctw *tabl, OUT out)
 {
   constexpr int LOGN = kFusedLarge;
   using P            = Plan<LOGN>;
@@ -957,7 +957,7 @@ __device__ __forceinline__ void onepass_block_fwd(typename A::val (&x)[kE], uint
       run_group<A, LOGN, GI + 1, false, MASK>(x, tid, blk, p);
     }
   });
-  store_last_whole_lines<A, LOGN, false>(x, tid, bb, p.c, false);
+  out(x, tid); /* the half's outputs: whole-line stores (transforms), or the product by b^ where they would be reduced and stored */
 }
 
 /* one half through the inverse block stages (not the transform's last pass): x holds the block's results, unreduced, in the
@@ -993,6 +993,59 @@ __device__ __forceinline__ void onepass_block_inv(typename A::val (&x)[kE], uint
   });
 }
 
+/* the forward polynomial loop of the one-pass kernels: p.a = the coefficients; out(x, tl, h, off) disposes of half h of the polynomial
+ * whose word offset (from every operand's base) is off */
+template <class A, int KSH, class OUT>
+__device__ __forceinline__ void onepass_forward(Params<A> &p, uint32_t bid, uint32_t gdim, uint32_t tid, typename A::val *lds_all, typename A::ctw *tabl,
+                                                OUT out)
+{
+  constexpr int      LOGN = kFusedLarge;
+  constexpr uint64_t HALF = 1ull << LOGN;
+  constexpr uint32_t M15  = onepass_fwd_mask<A, KSH>();
+  constexpr uint32_t MASK = M15 >> 1;
+  constexpr bool     RED0 = (M15 & 1u) != 0;
+  p.s0          = 1;
+  uint64_t poly = bid;
+  if(!below(poly, p.nblocks)) return;
+  /* polynomial offsets one polynomial ahead of the loads, as in fused_kernel's loops (a pointer batch reads them from a table) */
+  const auto next_poly = [&](uint64_t at) -> uint64_t { return below(at + gdim, p.nblocks) ? at + gdim : at; };
+  uint64_t off_cur = poly_offset<true>(poly, p.pstride, p.ptab), off_nxt = poly_offset<true>(next_poly(poly), p.pstride, p.ptab);
+  /* ONE copy of the block body: the two halves are the iterations of a loop that is not unrolled, the half that waits parked as bit
+   * patterns in `hold` -- two inlined copies let the compiler hoist either copy's lane offsets and LDS addresses out of the
+   * polynomial loop, into registers the halves need (79 spilled VGPRs in the first version of this kernel) */
+  uint64_t hold[kE], rb[kE];
+  const auto bits = [](typename A::val v) -> uint64_t { return __builtin_bit_cast(uint64_t, v); };
+  const auto vals = [](uint64_t u) -> typename A::val { return __builtin_bit_cast(typename A::val, u); };
+  prefetch_first<LOGN>(hold, tid, p.a + off_cur);
+  prefetch_first<LOGN>(rb, tid, p.a + off_cur + HALF);
+  for(; below(poly, p.nblocks); poly += gdim) {
+    const uint64_t  off  = off_cur;
+    const bool      more = below(poly + gdim, p.nblocks);
+    uint64_t *const nxt  = p.a + off_nxt;
+    off_cur              = off_nxt;
+    off_nxt              = poly_offset<true>(next_poly(more ? poly + gdim : poly), p.pstride, p.ptab);
+    typename A::val x[kE];
+    {
+      typename A::val xb[kE];
+      convert_inputs<A, false>(x, hold, p.wide != 0, p.c);
+      convert_inputs<A, false>(xb, rb, p.wide != 0, p.c);
+      onepass_pairs_fwd<A, RED0>(x, xb, p); /* global stage 0, thread-local (ntt_core.h) */
+      static_for<0, kE>([&](auto ee) { hold[decltype(ee)::value] = bits(xb[decltype(ee)::value]); });
+    }
+#pragma unroll 1
+    for(uint32_t h = 0; h < 2u; h++) {
+      uint32_t tl = tid;
+      asm volatile("" : "+v"(tl)); /* per-half lane offsets: recomputed, not carried in registers through the launch */
+      onepass_block_fwd<A, MASK>(x, h, tl, p, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t t2) { out(y, t2, h, off); });
+      if(h == 0) {
+        static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = vals(hold[decltype(ee)::value]); });
+        prefetch_first<LOGN>(hold, tl, nxt, more); /* half A has been stored: the next polynomial's first half */
+      }
+    }
+    prefetch_first<LOGN>(rb, tid, nxt + HALF, more); /* ... and its second half, behind half B's stores */
+  }
+}
+
 template <class A, bool INV, int KSH, bool MULTI = false>
 __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
 {
@@ -1005,55 +1058,24 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
   __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
   typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
   const uint32_t         tid  = threadIdx.x;
-  p.s0                        = 1;
   constexpr uint64_t HALF     = 1ull << LOGN;
-  uint64_t poly = bid;
-  if(!below(poly, p.nblocks)) return;
-  /* polynomial offsets one polynomial ahead of the loads, as in fused_kernel's loops (a pointer batch reads them from a table) */
-  const auto next_poly = [&](uint64_t at) -> uint64_t { return below(at + gdim, p.nblocks) ? at + gdim : at; };
-  uint64_t off_cur = poly_offset<true>(poly, p.pstride, p.ptab), off_nxt = poly_offset<true>(next_poly(poly), p.pstride, p.ptab);
-  /* ONE copy of the block body per direction: the two halves are the iterations of a loop that is not unrolled, the half that waits
-   * (forward: half B's values; inverse: half B's raw words, then half A's results) parked as bit patterns in `hold` -- two inlined
-   * copies let the compiler hoist either copy's lane offsets and LDS addresses out of the polynomial loop, into registers the
-   * halves need (79 spilled VGPRs in the first version of this kernel) */
-  uint64_t hold[kE], rb[kE];
-  const auto bits = [](typename A::val v) -> uint64_t { return __builtin_bit_cast(uint64_t, v); };
-  const auto vals = [](uint64_t u) -> typename A::val { return __builtin_bit_cast(typename A::val, u); };
   if constexpr(!INV) {
-    constexpr uint32_t M15  = onepass_fwd_mask<A, KSH>();
-    constexpr uint32_t MASK = M15 >> 1;
-    constexpr bool     RED0 = (M15 & 1u) != 0;
-    prefetch_first<LOGN>(hold, tid, p.a + off_cur);
-    prefetch_first<LOGN>(rb, tid, p.a + off_cur + HALF);
-    for(; below(poly, p.nblocks); poly += gdim) {
-      uint64_t *const base = p.a + off_cur;
-      const bool      more = below(poly + gdim, p.nblocks);
-      uint64_t *const nxt  = p.a + off_nxt;
-      off_cur              = off_nxt;
-      off_nxt              = poly_offset<true>(next_poly(more ? poly + gdim : poly), p.pstride, p.ptab);
-      typename A::val x[kE];
-      {
-        typename A::val xb[kE];
-        convert_inputs<A, false>(x, hold, p.wide != 0, p.c);
-        convert_inputs<A, false>(xb, rb, p.wide != 0, p.c);
-        onepass_pairs_fwd<A, RED0>(x, xb, p); /* global stage 0, thread-local (ntt_core.h) */
-        static_for<0, kE>([&](auto ee) { hold[decltype(ee)::value] = bits(xb[decltype(ee)::value]); });
-      }
-#pragma unroll 1
-      for(uint32_t h = 0; h < 2u; h++) {
-        uint32_t tl = tid;
-        asm volatile("" : "+v"(tl)); /* per-half lane offsets: recomputed, not carried in registers through the launch */
-        onepass_block_fwd<A, MASK>(x, h, tl, base + (h ? HALF : 0), p, lds_all, tabl);
-        if(h == 0) {
-          static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = vals(hold[decltype(ee)::value]); });
-          prefetch_first<LOGN>(hold, tl, nxt, more); /* half A has been stored: the next polynomial's first half */
-        }
-      }
-      prefetch_first<LOGN>(rb, tid, nxt + HALF, more); /* ... and its second half, behind half B's stores */
-    }
+    onepass_forward<A, KSH>(p, bid, gdim, tid, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t tl, uint32_t h, uint64_t off) {
+      store_last_whole_lines<A, LOGN, false>(y, tl, p.a + off + (h ? HALF : 0), p.c, false);
+    });
   } else {
     constexpr uint32_t MASK = fused_mask<A, LOGN, true, KSH>() | (A::kWide52 ? kCanonInFlag : 0u); /* the blocks do not end the transform; canonical inputs */
     constexpr bool     LTW  = G::LDS_TW > 0;
+    p.s0          = 1;
+    uint64_t poly = bid;
+    if(!below(poly, p.nblocks)) return;
+    const auto next_poly = [&](uint64_t at) -> uint64_t { return below(at + gdim, p.nblocks) ? at + gdim : at; };
+    uint64_t off_cur = poly_offset<true>(poly, p.pstride, p.ptab), off_nxt = poly_offset<true>(next_poly(poly), p.pstride, p.ptab);
+    /* (the halves as the iterations of a loop that is not unrolled, as in onepass_forward: half B's raw words, then half A's results,
+     * wait as bit patterns in `hold`) */
+    uint64_t hold[kE], rb[kE];
+    const auto bits = [](typename A::val v) -> uint64_t { return __builtin_bit_cast(uint64_t, v); };
+    const auto vals = [](uint64_t u) -> typename A::val { return __builtin_bit_cast(typename A::val, u); };
     prefetch_last<LOGN>(rb, tid, p.a + off_cur);
     if constexpr(LTW) {
       fill_lds_tables<A, LOGN, true>(tabl, p, 0u, tid);

@@ -124,6 +124,7 @@ struct MulArgs {
   int             oversub; /* as PassArgs::oversub */
   void *          team_ctl; /* N = 2^15..2^17: non-null = column items and row items with the product as ONE launch (team_mul_kernel); a = the caller's coefficients */
   int             team_lag, team_wpc;
+  int             one_pass; /* N = 2^15, FP64 policies: the transform in one pass with the product at its output (onepass_mul_kernel) */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
@@ -839,9 +840,47 @@ template <class A, int KSH> hipError_t launch_team_mul(const MulArgs &ma)
   }
 }
 
+/* N = 2^15 in one pass with the product at the output (onepass_mul_kernel): one persistent 1024-thread workgroup per CU */
+template <class A, int KSH> hipError_t launch_onepass_mul(const MulArgs &ma)
+{
+  if constexpr(!onepass_built<A>()) {
+    return hipErrorNotSupported;
+  } else {
+    if(ma.logn != (uint32_t)kFusedLarge + 1) return hipErrorNotSupported;
+    const uint64_t nl = (uint64_t)(ma.nlimbs > 0 ? ma.nlimbs : 1);
+    KMul<A> km{};
+    km.k.a = ma.a;
+    const LimbRec<A> *recs = static_cast<const LimbRec<A> *>(ma.limbs);
+    for(uint64_t i = 0; i < nl; i++) km.k.limbs[i] = recs[i];
+    km.k.limb_stride = ma.limb_stride;
+    km.k.poly_stride = ma.poly_stride ? ma.poly_stride : (1ull << ma.logn);
+    km.k.logn        = ma.logn;
+    km.k.s0          = 1;
+    km.k.nblocks     = ma.batch;
+    km.b             = ma.b;
+    km.out           = ma.out;
+    km.b_limb_stride = ma.b_limb_stride;
+    km.lazy_in       = (uint32_t)ma.lazy_in;
+    km.b_bcast       = (uint32_t)ma.b_bcast;
+    km.accumulate    = (uint32_t)ma.accumulate;
+    uint64_t wgs = ma.batch;
+    uint64_t cap = (uint64_t)(ma.num_cus > 0 ? ma.num_cus : 256);
+    if(ma.max_grid > 0) cap = (uint64_t)ma.max_grid;
+    cap = cap / nl > 0 ? cap / nl : 1;
+    if(wgs > cap) wgs = cap;
+    if(wgs == 0) return hipSuccess;
+    km.k.wgs_per_limb = (uint32_t)wgs;
+    const dim3 grid((unsigned)wgs, (unsigned)nl);
+    if(nl > 1) hipLaunchKernelGGL((onepass_mul_kernel<A, KSH, true>), grid, dim3(1024), 0, ma.stream, km);
+    else hipLaunchKernelGGL((onepass_mul_kernel<A, KSH, false>), grid, dim3(1024), 0, ma.stream, km);
+    return hipGetLastError();
+  }
+}
+
 template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 {
   if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(ma.one_pass) return launch_onepass_mul<A, KSH>(ma);
   if(ma.team_ctl) return launch_team_mul<A, KSH>(ma);
   if(ma.logn > (uint32_t)kFusedMax) {
     if(ma.block_log == (uint32_t)kFusedSmallBlock) return launch_fwd_mul_blocks<A, kFusedSmallBlock, KSH>(ma);

@@ -1103,6 +1103,48 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
   }
 }
 
+/* c^ = fwd(a) (.) b^ (+ c^) at N = 2^15 in ONE pass (round 6): onepass_forward (ntt_kernels_block.h) with fwd_mul_kernel's epilogue where a
+ * half would be reduced and stored -- b^ and the accumulator read in the last group's layout by the lane that owns the words, a
+ * quarter of the tile at a time, c^ written; a itself is left as it was.  The one-pass transform is bound by its arithmetic and the
+ * half of its loads it cannot prefetch, not by bytes: the 8N (16N accumulating) more that the product reads ride almost free --
+ * measured 0.475 -> see profiles/r06/onepass_products_2p15.txt of the 24N roofline. */
+template <class A, int KSH, bool MULTI = false>
+__global__ void __launch_bounds__(1024, 4) onepass_mul_kernel(const KMul<A> km)
+{
+  uint32_t  bid, gdim, limb;
+  Params<A> p = limb_params<A, false, MULTI>(km.k, bid, gdim, limb);
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  using G            = Geom<LOGN, false, flavor_of<A>()>;
+  static_assert(A::kCompact && A::kTracksBounds && G::BPW == 1 && P::T == 1024, "built for the FP64 policies on the 2^14 block");
+  __shared__ typename A::val lds_all[P::LDS_ELEMS + G::LDS_TW];
+  typename A::ctw *const tabl = reinterpret_cast<typename A::ctw *>(lds_all + P::LDS_ELEMS);
+  constexpr uint64_t HALF     = 1ull << LOGN;
+  const bool       lazy = km.lazy_in != 0, bc = km.b_bcast != 0, acc = km.accumulate != 0;
+  const uint64_t * bptr = km.b + (uint64_t)limb * km.b_limb_stride; /* (MULTI off: limb == 0) */
+  uint64_t *       cptr = km.out + (uint64_t)limb * km.k.limb_stride;
+  onepass_forward<A, KSH>(p, bid, gdim, threadIdx.x, lds_all, tabl, [&](typename A::val(&x)[kE], uint32_t tl, uint32_t h, uint64_t off) {
+    const uint64_t *bblk = bptr + (bc ? 0 : off) + (h ? HALF : 0);
+    uint64_t *      cblk = cptr + off + (h ? HALF : 0);
+    /* the products, a quarter of the tile at a time, the next quarter's words in flight meanwhile (as fwd_mul_kernel) */
+    uint64_t u[kE], rb[kE], rc[kE];
+    uint32_t t2 = tl;
+    asm volatile("" : "+v"(t2));
+    sched_fence();
+    prefetch_last_range<LOGN, 0, 4>(rb, t2, bblk);
+    static_for<0, 4>([&](auto qq) {
+      constexpr int Q = decltype(qq)::value;
+      sched_fence();
+      prefetch_last_range<LOGN, 4 * Q, 4 * Q + 4>(rc, t2, cblk, acc);
+      if constexpr(Q < 3) prefetch_last_range<LOGN, 4 * Q + 4, 4 * Q + 8>(rb, t2, bblk);
+      sched_fence();
+      mul_out_tile<A, 4 * Q, 4 * Q + 4, 1>(u, x, rb, rc, lazy, p.c);
+      buffer_store_last_range<LOGN, 4 * Q, 4 * Q + 4>(u, t2, cblk);
+      sched_fence();
+    });
+  });
+}
+
 /* ------------------------------------------------------------------ */
 /* c^ = fwd(a) (.) b^ (+ c^) at N = 2^15 .. 2^17 as ONE launch            */
 /* ------------------------------------------------------------------ */

@@ -38,6 +38,7 @@ static inline uint64_t emu_pstride(int m) { return g_pstride ? g_pstride : (1ull
 /* pointer batches (emu_set_poly_table): host table of the polynomials' ADDRESSES for the next emu_transform -- the kernels' own
  * poly_offset / block_offset (csrc/ntt_core.h) then take every polynomial's start from it, with a null data pointer */
 inline const uint64_t *g_ptab = nullptr;
+inline int g_one_pass = -1; /* emu_set_one_pass: 1 = 2^15 transforms of the FP64 policies take the one-pass route, 0 = the two-pass route, -1 = as the library (on) */
 inline uint64_t g_opstride = 0; /* emu_inv_dot: words between consecutive operands of the a / b arrays (0 = batch * N: dense) */
 
 inline uint64_t g_chk_fail  = 0;   /* number of violated claims          (inline: one copy for all parts) */
@@ -706,7 +707,60 @@ void emu_fwd_mul_blocks(const Params<A> &p, const uint64_t *bhat, uint64_t *out,
   }
 }
 
-/* the library's fwd_mul (ntt_host.hip): one block launch up to 2^14; above, the forward column passes on a, then the blocks */
+/* onepass_mul_kernel (N = 2^15): the one-pass forward transform -- pair stage, both halves through the block stages with the
+ * fifteen-stage schedule -- with fwd_mul_kernel's product where a half would be reduced and stored */
+template <class A, int KSH>
+void emu_onepass_mul(const Params<A> &pin, const uint64_t *bhat, uint64_t *out, bool lazy, bool bcast, bool acc)
+{
+  constexpr int LOGN = kFusedLarge;
+  using P            = Plan<LOGN>;
+  constexpr uint64_t HALF = 1ull << LOGN;
+  constexpr uint32_t M15  = onepass_fwd_mask<A, KSH>();
+  constexpr uint32_t MASK = M15 >> 1;
+  constexpr bool     RED0 = (M15 & 1u) != 0;
+  Params<A> p = pin;
+  p.s0        = 1;
+  std::vector<typename A::val> lds(P::LDS_ELEMS);
+  std::vector<Regs<A>>         half[2] = {std::vector<Regs<A>>(P::T), std::vector<Regs<A>>(P::T)};
+  for(uint64_t poly = 0; poly < p.nblocks; poly++) {
+    const uint64_t off = poly * p.pstride;
+    for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+      global_load_first<A, LOGN, false>(half[0][t].x, t, p.a + off, false, p.c);
+      global_load_first<A, LOGN, false>(half[1][t].x, t, p.a + off + HALF, false, p.c);
+      onepass_pairs_fwd<A, RED0>(half[0][t].x, half[1][t].x, p);
+    }
+    for(uint32_t h = 0; h < 2; h++) {
+      std::vector<Regs<A>> &regs = half[h];
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) run_group<A, LOGN, 0, false, MASK>(regs[t].x, t, h, p);
+      static_for<0, P::NG - 1>([&](auto gg) {
+        constexpr int G = decltype(gg)::value;
+        for(uint32_t t = 0; t < (uint32_t)P::T; t++) lds_scatter<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+        for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+          lds_gather<A, LOGN, G, G + 1>(regs[t].x, t, lds.data());
+          if constexpr(A::kCompact && G + 1 == P::NG - 1) {
+            typename A::ctw pre[4][kE / 2];
+            preload_group_tw<A, LOGN, G + 1>(pre, t, h, p);
+            run_group_preloaded<A, LOGN, G + 1, MASK>(regs[t].x, pre, p);
+          } else {
+            run_group<A, LOGN, G + 1, false, MASK>(regs[t].x, t, h, p);
+          }
+        }
+      });
+      const uint64_t *bblk = bhat + (bcast ? 0 : off) + h * HALF;
+      uint64_t *      cblk = out + off + h * HALF;
+      for(uint32_t t = 0; t < (uint32_t)P::T; t++) {
+        uint64_t rb[kE], rc[kE], u[kE];
+        load_last_raw<LOGN>(rb, t, bblk);
+        if(acc) load_last_raw<LOGN>(rc, t, cblk);
+        else for(int e = 0; e < kE; e++) rc[e] = 0;
+        mul_out_tile<A, 0, kE, 1>(u, regs[t].x, rb, rc, lazy, p.c);
+        store_last_raw<LOGN>(u, t, cblk);
+      }
+    }
+  }
+}
+
+/* the library's fwd_mul (ntt_host.hip): one block launch up to 2^14; 2^15 (FP64 policies): one pass; above, the forward column passes on a, then the blocks */
 template <class A, int KSH>
 int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t batch, int m, const typename A::tw *tab,
                     const typename A::ctw *tab8, const typename A::consts &c, bool lazy, bool bcast, bool acc)
@@ -714,6 +768,21 @@ int emu_fwd_mul_run(uint64_t *out, uint64_t *a, const uint64_t *bhat, uint64_t b
   if(m < kFusedMin) return -1;
 #ifdef EMU_SAN_BUILD
   if(m > kFusedMax) return -1;
+#else
+  if constexpr(A::kCompact && A::kTracksBounds) {
+    if(m == kFusedMax + 1 && g_one_pass != 0) {
+      Params<A> p{};
+      p.a       = a;
+      p.tw      = tab;
+      p.tw8     = tab8;
+      p.c       = c;
+      p.logn    = (uint32_t)m;
+      p.pstride = emu_pstride(m);
+      p.nblocks = batch;
+      emu_onepass_mul<A, KSH>(p, bhat, out, lazy, bcast, acc);
+      return 0;
+    }
+  }
 #endif
   const int      pblk = m > kFusedMax ? multi_pass_block(m, false, A::kTracksBounds) : m;
   const PassList L    = make_passes(m, false, pblk);
@@ -829,7 +898,6 @@ static void emu_column_r4(uint64_t *a, uint64_t batch, uint32_t logn, uint32_t S
 /* N = 2^15 in one pass (csrc/ntt_kernels.h onepass_kernel), thread by thread: both halves of a polynomial in "registers", the pair
  * stage thread-local (ntt_core.h onepass_pairs_fwd / onepass_pair_inv), each half through the 2^14-point block stages at block
  * position 0 / 1 -- forward with the fifteen-stage reduction schedule (onepass_fwd_mask), which the checked policies verify */
-inline int g_one_pass = -1; /* emu_set_one_pass: 1 = 2^15 transforms of the FP64 policies take this route, 0 = the two-pass route, -1 = as the library (on) */
 template <class A, bool INV, int KSH> static void emu_onepass(const Params<A> &pin)
 {
   constexpr int LOGN = kFusedLarge;

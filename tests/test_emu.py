@@ -497,7 +497,7 @@ def test_dot_kernel_logic_integer_policy(oracle, emu, m, q):
 
 # ---- forward transform with the product at its output: fwd_mul_kernel's logic and arithmetic on the CPU ------------------
 @pytest.mark.parametrize("m,q,arith", [(12, 0x7fffffffe0001, 1), (14, 0x7fffffffe0001, 1), (14, 0x3ffffffdf0001, 1), (8, 0x7ffe0001, 1),
-                                       (13, 0xffffffff00001, 1), (14, 0xffffffff00001, 1), (15, 0x7fffffffe0001, 1), (16, 0xffffffff00001, 1),
+                                       (13, 0xffffffff00001, 1), (14, 0xffffffff00001, 1), (15, 0x7fffffffe0001, 1), (15, 0xffffffff00001, 1), (16, 0xffffffff00001, 1),
                                        (10, 0x10001, 0), (14, 0xffffffffffc0001, 0), (15, 0xffffffffffc0001, 0)])
 def test_fwd_mul_kernel_logic(oracle, emu, m, q, arith):
     """c^ = fwd(a) (.) b^ and c^ += fwd(a) (.) b^ as fwd_mul_kernel forms them -- the product where the forward transform would
@@ -522,10 +522,14 @@ def test_fwd_mul_kernel_logic(oracle, emu, m, q, arith):
         exp = oracle.pointwise(fa, np.tile(b, batch) if bcast else b, q)
         if acc:
             exp = (exp + c0) % np.uint64(q)
-        emu.chk_stats(reset=True)
-        rc, got = emu.fwd_mul(a, bw, m, q, w, arith=arith, lazy=lazy, bcast=bcast, acc=c0 if acc else None)
-        assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc)
-        assert emu.chk_stats()[0] == 0
+        # N = 2^15, FP64 policies: the one-pass kernel with the product at its output (round 6: onepass_mul_kernel) AND the two-pass route
+        for route in ((1, 0) if m == 15 and arith == 1 else (-1,)):
+            emu.set_one_pass(route)
+            emu.chk_stats(reset=True)
+            rc, got = emu.fwd_mul(a, bw, m, q, w, arith=arith, lazy=lazy, bcast=bcast, acc=c0 if acc else None)
+            assert rc == 0 and np.array_equal(got, exp), (m, hex(q), lazy, bcast, acc, route)
+            assert emu.chk_stats()[0] == 0
+        emu.set_one_pass(-1)
 
 
 @pytest.mark.parametrize("m", [3, 7, 11, 15])

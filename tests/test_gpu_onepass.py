@@ -156,3 +156,84 @@ def test_one_pass_layouts_pointer_tables_and_rns_sets(lib, oracle):
         d.free()
     for p in plans:
         p.destroy()
+
+
+@pytest.mark.parametrize("bits", [51, 50, 33, 52])
+def test_one_pass_forward_with_the_product_at_its_output(lib, oracle, bits):
+    """onepass_mul_kernel: c^ = fwd(a) . b^ and c^ += fwd(a) . key^ at N = 2^15 in one pass (the one-pass forward transform with
+    fwd_mul_kernel's epilogue where a half would be reduced and stored): canonical / lazy b^, per-polynomial / broadcast, accumulating
+    or not, against the oracle on sampled polynomials and bit for bit against the two-pass forms over the whole slab; a is left as it
+    was; c^ may alias a or b^"""
+    plan, q, w = _plan(lib, bits)
+    cx = oracle.ctx(N, q, w)
+    batch = 261
+    a = oracle.fill_uniform(batch * N, q, 11)
+    b = oracle.fill_uniform(batch * N, q, 12)
+    c0 = oracle.fill_uniform(batch * N, q, 13)
+    fb = np.concatenate([cx.fwd(b[p * N:(p + 1) * N].copy()) for p in (0, 1, batch - 1)])
+    da, db, dc = lib.DeviceBuffer(a.size).upload(a), lib.DeviceBuffer(b.size), lib.DeviceBuffer(a.size)
+    plan.fwd(db.upload(b).ptr, batch)
+    bhat = db.download()
+    assert np.array_equal(np.concatenate([bhat[p * N:(p + 1) * N] for p in (0, 1, batch - 1)]), fb)
+    rng = np.random.default_rng(bits)
+    for lazy, bcast, acc in ((False, False, False), (True, False, True), (False, True, True), (True, True, False)):
+        bw = bhat + (rng.integers(0, 4, bhat.size).astype(np.uint64) * np.uint64(q) if (lazy and bits < 52) else np.uint64(0))
+        flags = (lib.MUL_LAZY_IN if lazy else 0) | (lib.MUL_B_BROADCAST if bcast else 0) | (lib.MUL_ACCUMULATE if acc else 0)
+        res = {}
+        for mode in (1, 0):
+            plan.set_option(lib.OPT_ONE_PASS, mode)
+            da.upload(a), db.upload(bw), dc.upload(c0)
+            plan.fwd_mul(dc.ptr, da.ptr, db.ptr, batch, flags)
+            res[mode] = dc.download()
+            if mode == 1:
+                assert np.array_equal(da.download(), a), "one pass: a is left as it was"
+        assert np.array_equal(res[0], res[1]), (lazy, bcast, acc)
+        for p in (0, 1, batch - 1):
+            sl = slice(p * N, (p + 1) * N)
+            exp = oracle.pointwise(cx.fwd(a[sl].copy()), bhat[:N].copy() if bcast else bhat[sl].copy(), q)
+            if acc:
+                exp = (exp + c0[sl]) % np.uint64(q)
+            assert np.array_equal(res[1][sl], exp), (lazy, bcast, acc, p)
+    # aliasing: c^ on a, c^ on b^
+    plan.set_option(lib.OPT_ONE_PASS, 1)
+    da.upload(a), db.upload(bhat)
+    plan.fwd_mul(da.ptr, da.ptr, db.ptr, batch)
+    got = da.download()
+    da.upload(a)
+    plan.fwd_mul(db.ptr, da.ptr, db.ptr, batch)
+    assert np.array_equal(db.download(), got)
+    sl = slice((batch - 1) * N, batch * N)
+    assert np.array_equal(got[sl], oracle.pointwise(cx.fwd(a[sl].copy()), bhat[sl].copy(), q))
+    for x in (da, db, dc):
+        x.free()
+    plan.destroy()
+
+
+def test_one_pass_forward_product_over_rns_limbs(lib, oracle):
+    """the MULTI variant (blockIdx.y = limb) behind ntt_rns_fwd_mul_batch, both layouts, small per-limb batches in one launch"""
+    nl, batch = 3, 7
+    qs = [lib.find_prime(50, N, k) for k in range(nl)]
+    ws = [lib.min_root(x, N) for x in qs]
+    plans = [lib.Plan(N, x, y) for x, y in zip(qs, ws)]
+    ctx = [oracle.ctx(N, x, y) for x, y in zip(qs, ws)]
+    for p in plans:
+        p.set_option(lib.OPT_ONE_PASS, 1)
+    a = np.concatenate([oracle.fill_uniform(batch * N, x, 70 + l) for l, x in enumerate(qs)])
+    b = np.concatenate([oracle.fill_uniform(batch * N, x, 80 + l) for l, x in enumerate(qs)])
+    bh = np.concatenate([ctx[l].fwd(b[(l * batch + p) * N:(l * batch + p + 1) * N].copy()) for l in range(nl) for p in range(batch)])
+    exp = np.concatenate([oracle.pointwise(ctx[l].fwd(a[(l * batch + p) * N:(l * batch + p + 1) * N].copy()),
+                                           bh[(l * batch + p) * N:(l * batch + p + 1) * N].copy(), qs[l]) for l in range(nl) for p in range(batch)])
+    da, db, dc = lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size), lib.DeviceBuffer(a.size)
+    for launch in ("0", "1"):
+        lib.set_rns_launch(plans, launch)
+        da.upload(a), db.upload(bh)
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch)
+        assert np.array_equal(dc.download(), exp), launch
+        tr = lambda v: v.reshape(nl, batch, N).transpose(1, 0, 2).copy().reshape(-1)
+        da.upload(tr(a)), db.upload(tr(bh))
+        lib.rns_fwd_mul(plans, dc.ptr, da.ptr, db.ptr, batch, layout=lib.batch_major(plans))
+        assert np.array_equal(dc.download(), tr(exp)), (launch, "batch-major")
+    for x in (da, db, dc):
+        x.free()
+    for p in plans:
+        p.destroy()
