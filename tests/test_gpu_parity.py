@@ -1367,6 +1367,7 @@ def test_compat_device_selection_env():
 def test_c_example_runs():
     """the plain-C caller of the batched API (examples/batched_product.c): built here if it did not travel, run on the
     GPU, exit code 0 = its product coefficient equals the schoolbook value"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     exe = os.path.join(ROOT, "build", "batched_product")
     libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-I" + os.path.join(ROOT, "include"),
@@ -1380,6 +1381,7 @@ def test_c_example_runs():
 def test_c_example_rns_modulus_chain_runs():
     """examples/rns_chain_product.c: the RNS entry points from plain C over a chain of a 60-bit, three 50-bit and two 57-bit
     primes (runs of compatible limbs), every limb's product coefficient against the schoolbook value"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     exe = os.path.join(ROOT, "build", "rns_chain_product")
     libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
@@ -1396,6 +1398,7 @@ def test_c_example_graph_replay_runs():
     """examples/graph_replay.c: a key-switching step (three forward-side multiply-accumulates with a broadcast key, one NTT-domain
     product: four XCD-local launches at N = 2^16) captured into a HIP graph from plain C after ntt_plan_reserve, replayed four times
     on new inputs, each replay equal to the direct calls on every polynomial; the capture and the replays allocate nothing"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     exe = os.path.join(ROOT, "build", "graph_replay")
     libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
