@@ -115,7 +115,8 @@ typedef enum ntt_option {
                           * and the two halves go through the 2^14-point block stages one after the other: 16N bytes cross HBM, where the
                           * two-pass forms move 24N..32N across the fabric (measured forward 0.43 -> see profiles/r06/onepass_2p15.txt);
                           * 0 = the two-pass forms (XCD-local launch / per-pass launches); -1 (default) = one pass when the batch gives
-                          * every CU a polynomial.  Calls that ask for lazy outputs keep the two-pass forms.  Results are identical. */
+                          * every second CU a polynomial (measured crossover: 64..96 polynomials).  Calls that ask for lazy outputs get canonical words from it
+                          * (inside the lazy ranges).  Results are identical. */
   NTT_OPT_FUSED_PRODUCT = 5 /* N = 2^8..2^17, FP64: 1 (default) = ntt_negacyclic_mul_batch as ONE launch that takes both
                           * operands through the forward stages, multiplies in registers and runs the inverse: 24N bytes up to
                           * 2^14; from 2^23 coefficients per operand of N >= 2^15 on likewise one launch (all limbs of an RNS set

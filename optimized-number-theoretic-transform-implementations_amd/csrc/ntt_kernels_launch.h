@@ -306,7 +306,7 @@ template <class A, bool INV, int KSH> hipError_t launch_onepass(const PassArgs &
   if constexpr(!onepass_built<A>()) {
     return hipErrorNotSupported;
   } else {
-    if(pa.logn != (uint32_t)kFusedLarge + 1 || pa.lazy) return hipErrorNotSupported;
+    if(pa.logn != (uint32_t)kFusedLarge + 1) return hipErrorNotSupported; /* (a lazy call gets canonical words: inside the lazy ranges) */
     const uint64_t nl = (uint64_t)(pa.nlimbs > 0 ? pa.nlimbs : 1);
     if(nl > (uint64_t)kMaxLimbs) return hipErrorNotSupported;
     KArgs<A> p = make_kargs<A>(pa);

@@ -978,9 +978,9 @@ int emu_run(uint64_t *a, uint64_t batch, int m, const typename A::tw *tab,
   if(A::kRadix4 && (generic || m > kRadix4Max)) return -4; /* the library refuses these too */
   const bool lazy  = g_lazy;
   if constexpr(A::kCompact && A::kTracksBounds) {
-    /* as the library's run_transform: N = 2^15, FP64 policies, no lazy outputs -> one pass */
+    /* as the library's run_transform: N = 2^15, FP64 policies -> one pass */
 #ifndef EMU_SAN_BUILD /* (the sanitizer build keeps its instrumented compile short: two-pass route only) */
-    if(m == kFusedMax + 1 && !generic && !lazy && g_one_pass != 0) {
+    if(m == kFusedMax + 1 && !generic && g_one_pass != 0) { /* (lazy calls too: canonical words satisfy the lazy contract) */
       Params<A> p{};
       p.a       = g_ptab ? nullptr : a;
       p.ptab    = g_ptab;

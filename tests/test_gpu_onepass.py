@@ -59,7 +59,7 @@ def test_one_pass_transforms_against_oracle_and_two_pass_routes(lib, oracle, bit
         d.upload(one + np.uint64(3 * q))
         plan.inv(d.ptr, batch, wide=True)
         assert np.array_equal(d.download(), a)
-    # lazy OUTPUTS keep the two-pass forms, same residues
+    # lazy OUTPUTS: the one-pass kernel's canonical words satisfy the lazy contract
     d.upload(a)
     plan.fwd(d.ptr, batch, lazy=True)
     lz = d.download()

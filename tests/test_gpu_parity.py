@@ -1378,6 +1378,20 @@ def test_c_example_runs():
     assert "schoolbook" in out.stdout
 
 
+def test_c_example_pointer_batch_runs():
+    """examples/pointer_batch.c: 96 polynomials allocated ONE BY ONE (ntt_dev_malloc each), transformed in one launch through
+    ntt_transform_ptrs and ntt_transform_dev_ptrs, multiplied through ntt_negacyclic_mul_dev_ptrs -- from plain C; exit code 0 =
+    equal to the contiguous slab word for word, product coefficient equal to the schoolbook value"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    exe = os.path.join(ROOT, "build", "pointer_batch")
+    libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "pointer_batch.c"), "-L" + libdir, "-lntt_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("equal to the slab") == 2 and "schoolbook" in out.stdout
+
+
 def test_c_example_rns_modulus_chain_runs():
     """examples/rns_chain_product.c: the RNS entry points from plain C over a chain of a 60-bit, three 50-bit and two 57-bit
     primes (runs of compatible limbs), every limb's product coefficient against the schoolbook value"""
