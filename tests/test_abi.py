@@ -209,7 +209,7 @@ def test_headline_kernels_do_not_spill():
     # the MULTI variants (several RNS limbs in one launch: the limb's tables are picked at run time from an array in the
     # kernel arguments) spilled 2-6 VGPRs in rounds 3 and 4 -- not because of the run-time index but because the limb came out
     # of a VALU division and dragged every address after it into vector registers; since round 5 (the limb is blockIdx.y, the
-    # queue kernels split with a scalar multiply-high: csrc/ntt_kernels.h limb_params, team_split) they are held to the same rule
+    # queue kernels split with a scalar multiply-high: csrc/ntt_kernels_block.h limb_params, ntt_kernels_team.h team_split) they are held to the same rule
     multi = [k for k in every if _last_template_bool_is_multi(k["name"])]
     ks = [k for k in every if k not in multi]
     assert len(ks) >= 80 and len(multi) >= 40
@@ -223,7 +223,7 @@ def test_headline_kernels_do_not_spill():
     for k in big:
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
     # (rounds 2-4 had one exception, the one-launch product at 2^14 for 52-bit moduli: its two spilled VGPRs were the block count,
-    # copied into vector registers for a 64-bit unsigned comparison that has no scalar form -- csrc/ntt_kernels.h `below`)
+    # copied into vector registers for a 64-bit unsigned comparison that has no scalar form -- csrc/ntt_kernels_block.h `below`)
     for k in ks:
         assert k["group_segment_fixed_size"] <= 160 * 1024, k
         assert k["vgpr_spill_count"] == 0, k   # no kernel of the library spills vector registers

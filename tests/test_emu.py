@@ -746,7 +746,7 @@ def test_pointer_batch_table_addressing(oracle, emu, m, q, arith):
 
 @pytest.mark.parametrize("arith,bits,ksh", [(2, 51, -1), (2, 50, -1), (2, 33, -1), (2, 33, 0), (5, 52, -1), (1, 51, -1), (4, 52, -1)])
 def test_one_pass_2p15_against_the_oracle_and_the_two_pass_route(oracle, emu, arith, bits, ksh):
-    """round 6: N = 2^15 in ONE pass (csrc/ntt_kernels.h onepass_kernel) executed on the CPU -- the pair stage thread-local, both
+    """round 6: N = 2^15 in ONE pass (csrc/ntt_kernels_block.h onepass_kernel) executed on the CPU -- the pair stage thread-local, both
     halves through the 2^14-point block stages at block positions 0 and 1, forward with ONE reduction schedule over all fifteen stages
     (ntt_core.h onepass_fwd_mask), inverse with both inputs of the folded last stage reduced first.  The CHECKED policies (arith 2, 5)
     assert every exactness bound of DESIGN 4 with 128-bit integers, on random and on extreme inputs, for every headroom class (51, 50

@@ -1,4 +1,4 @@
-"""CPU model of the in-launch queue protocol of the XCD-local kernels (team_kernel, team_product_kernel; csrc/ntt_kernels.h).
+"""CPU model of the in-launch queue protocol of the XCD-local kernels (team_kernel, team_product_kernel; csrc/ntt_kernels_team.h, ntt_kernels_products.h).
 
 The device code that turns a queue entry into an item -- csrc/ntt_core.h team_decode -- is compiled for the host
 (tests/emu) and driven here by a simulation of what the kernels do around it: workgroups resident on 1..8 XCDs claim queues
