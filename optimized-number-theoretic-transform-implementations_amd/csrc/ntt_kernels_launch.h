@@ -80,6 +80,8 @@ struct ProdArgs {
   int             team_lag, team_wpc;
   int             four; /* launch_team_product: ahat holds a's COEFFICIENTS; the launch transforms both operands */
   int             both; /* launch_product, N <= 2^14: the same for the fused product kernels */
+  int             ptrs; /* launch_product, N <= 2^14, both, one limb: b, ahat and out are DEVICE TABLES of polynomial addresses (the PTRS kernels) */
+  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
@@ -103,6 +105,8 @@ struct DotArgs {
   int                    oversub; /* as PassArgs::oversub */
   void *                 team_ctl; /* N = 2^15..2^17: non-null = both passes as items of ONE launch (team_dot_kernel); TeamCtl + nlimbs * batch counters */
   int                    team_lag, team_wpc;
+  int                    ptrs; /* N <= 2^14, one limb: out, every a[i] and every b[i] that is not broadcast are DEVICE TABLES of polynomial addresses */
+  uint64_t               ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
   hipStream_t            stream;
 };
 template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
@@ -125,6 +129,8 @@ struct MulArgs {
   void *          team_ctl; /* N = 2^15..2^17: non-null = column items and row items with the product as ONE launch (team_mul_kernel); a = the caller's coefficients */
   int             team_lag, team_wpc;
   int             one_pass; /* N = 2^15, FP64 policies: the transform in one pass with the product at its output (onepass_mul_kernel) */
+  int             ptrs; /* N <= 2^14, one limb: a, out and b (unless broadcast) are DEVICE TABLES of polynomial addresses */
+  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
@@ -441,6 +447,12 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
      * at all: pa.both, whole polynomials, a's coefficients in pa.ahat */
     if(!pa.a_lazy && !pa.both) return hipErrorNotSupported;
     if(pa.both && s0 != 0 && blog != 12 && blog != 14) return hipErrorInvalidValue;
+    if(pa.ptrs) {
+      /* separately held polynomials: the three operand pointers are tables (fused_product_kernel's PTRS form) */
+      if(!pa.both || s0 != 0 || nl != 1) return hipErrorNotSupported;
+      pp.f.ptab = reinterpret_cast<const uint64_t *>(pa.b);
+      pp.f.a    = reinterpret_cast<uint64_t *>((uintptr_t)pa.ptr_limb_off * 8u);
+    }
     if(blog < 12) {
       switch(pa.logn) {
 #define NTT_SMALL_PRODUCT(LN)                                                                                       \
@@ -453,6 +465,10 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     gcap = gcap / nl > 0 ? gcap / nl : 1;                                                                           \
     if(g > gcap) g = gcap;                                                                                          \
     pp.f.wgs_per_limb = (unsigned)g;                                                                                \
+    if(pa.ptrs) {                                                                                                   \
+      hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
+      return hipGetLastError();                                                                                     \
+    }                                                                                                               \
     if(pa.both) {                                                                                                   \
       if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true, true>), dim3((unsigned)g, (unsigned)nl), dim3(GS::WG), 0, pa.stream, pp); \
       else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
@@ -482,6 +498,10 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       cap12 &= ~((1ull << s0) - 1);
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
       pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(pa.ptrs) {
+        hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        return hipGetLastError();
+      }
       if(pa.both) {
         if(s0 == 0) {
           if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
@@ -506,6 +526,10 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       /* one 512-thread workgroup per CU by LDS (64 KB exchange buffer + 30 KB table); a second one does not fit */
       if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
       pp.f.wgs_per_limb = (uint32_t)wgs;
+      if(pa.ptrs) {
+        hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
+        return hipGetLastError();
+      }
       if(pa.both) {
         if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G13::WG), 0, pa.stream, pp);
         else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
@@ -516,6 +540,10 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       return hipGetLastError();
     }
     pp.f.wgs_per_limb = (uint32_t)wgs;
+    if(pa.ptrs) {
+      hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      return hipGetLastError();
+    }
     if(pa.both) {
       if(s0 == 0) {
         if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
@@ -644,6 +672,17 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   kd.k.wgs_per_limb = (uint32_t)wgs;
+  if(da.ptrs) {
+    if constexpr(LASTINV) {
+      if(nl > 1) return hipErrorNotSupported;
+      kd.k.ptab = reinterpret_cast<const uint64_t *>(da.out);
+      kd.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)da.ptr_limb_off * 8u);
+      hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, true, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, da.stream, kd);
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   if(nl > 1) {
     if constexpr(multi_limb_built<A>()) {
       hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, LASTINV, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, da.stream, kd);
@@ -716,8 +755,9 @@ template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
 template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
 {
   if(da.npairs < 1 || da.npairs > kMaxDot || da.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
-  if(da.team_ctl) return launch_team_dot<A, KSH>(da);
+  if(da.team_ctl) return da.ptrs ? hipErrorNotSupported : launch_team_dot<A, KSH>(da);
   if(da.logn > (uint32_t)kFusedMax) {
+    if(da.ptrs) return hipErrorNotSupported;
     if(da.block_log == (uint32_t)kFusedSmallBlock) return launch_dot_blocks<A, kFusedSmallBlock, KSH, false>(da);
     if(da.block_log == (uint32_t)kFusedLarge) return launch_dot_blocks<A, kFusedLarge, KSH, false>(da);
     return hipErrorInvalidValue;
@@ -775,6 +815,13 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
   if(wgs > cap) wgs = cap;
   if(wgs == 0) return hipSuccess;
   km.k.wgs_per_limb = (uint32_t)wgs;
+  if(ma.ptrs) {
+    if(nl > 1 || km.k.s0 != 0) return hipErrorNotSupported;
+    km.k.ptab = reinterpret_cast<const uint64_t *>(ma.a);
+    km.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)ma.ptr_limb_off * 8u);
+    hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, ma.stream, km);
+    return hipGetLastError();
+  }
   if(nl > 1) {
     if constexpr(multi_limb_built<A>()) {
       hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, ma.stream, km);
@@ -880,6 +927,7 @@ template <class A, int KSH> hipError_t launch_onepass_mul(const MulArgs &ma)
 template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 {
   if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
+  if(ma.ptrs && (ma.one_pass || ma.team_ctl || ma.logn > (uint32_t)kFusedMax)) return hipErrorNotSupported;
   if(ma.one_pass) return launch_onepass_mul<A, KSH>(ma);
   if(ma.team_ctl) return launch_team_mul<A, KSH>(ma);
   if(ma.logn > (uint32_t)kFusedMax) {

@@ -53,6 +53,15 @@ template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_pro
   return pp;
 }
 
+/* PTRS forms of the product kernels (round 6): whole polynomials held SEPARATELY -- every operand pointer of the kernel arguments
+ * is a DEVICE TABLE of polynomial addresses (a plain array of device pointers, as for the transforms: poly_offset), one limb per
+ * launch; `limb` carries the words from every table entry to that limb as an offset from a null base, where the slab forms carry
+ * an operand's base.  UNIFORM as in poly_offset: the polynomial's index is the same for the whole wave (one s_load_dwordx2). */
+template <bool UNIFORM> __device__ __forceinline__ uint64_t *tab_poly(const void *tab, uint64_t poly, const uint64_t *limb)
+{
+  return const_cast<uint64_t *>(limb) + poly_offset<UNIFORM>(poly, 0, reinterpret_cast<const uint64_t *>(tab));
+}
+
 /* WHOLE: the block is the whole polynomial (N = 2^14).  !WHOLE: the blocks of a larger transform (N = 2^15..2^17,
  * pp.f.s0 = log2 N - 14 leading stages done by column passes before and after this launch): the product is
  * element-wise, so it fuses block by block just the same -- per limb col(a), blocks(a), col(b), THIS, col^-1(c):
@@ -62,10 +71,12 @@ template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_pro
 /* BOTH: pp.ahat holds a's COEFFICIENTS (blocks of a larger product: a after its column passes) and the kernel takes them through the forward stages too -- a^
  * waits, as doubles, in the 32 VGPRs that hold the prefetched a^ words otherwise, so the register budget is the same; a^
  * never exists in memory (24N instead of 40N bytes per product, one launch instead of two) and a is left untouched. */
-template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false, bool BOTH = false>
+/* PTRS (whole polynomials, BOTH, one limb): kp.ahat / kp.f.ptab / kp.out are the tables of a, b and c, kp.f.a = the limb's offset. */
+template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false, bool BOTH = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_kernel(const KProd<A> kp)
 {
+  static_assert(!PTRS || (WHOLE && BOTH && !MULTI), "pointer tables: coefficient-domain products of whole polynomials, one limb per launch");
   /* (!WHOLE && BOTH: the blocks of a larger product; pp.ahat then holds what a's column passes left, as pf.a does for b) */
   uint32_t            bid, gdim;
   const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
@@ -102,8 +113,21 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
   const uint32_t blk = WHOLE ? 0u : ((uint32_t)b & ((1u << pf.s0) - 1u)); /* the same for every block of this workgroup */
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid);
   __syncthreads();
+  /* where block bb of the three operands starts */
+  const auto at_a = [&](uint64_t bb) -> const uint64_t * {
+    if constexpr(PTRS) return tab_poly<true>(pp.ahat, bb, pf.a);
+    else return pp.ahat + blk_off<LOGN>(pf, bb);
+  };
+  const auto at_b = [&](uint64_t bb) -> const uint64_t * {
+    if constexpr(PTRS) return tab_poly<true>(pf.ptab, bb, pf.a);
+    else return pf.a + blk_off<LOGN>(pf, bb);
+  };
+  const auto at_c = [&](uint64_t bb) -> uint64_t * {
+    if constexpr(PTRS) return tab_poly<true>(pp.out, bb, pf.a);
+    else return pp.out + blk_off<LOGN>(pf, bb);
+  };
   uint64_t raw[kE];
-  prefetch_first<LOGN>(raw, tid, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, b));
+  prefetch_first<LOGN>(raw, tid, BOTH ? at_a(b) : at_b(b));
   pin_raw(raw);
   for(; SCMP ? below(b, pf.nblocks) : b < pf.nblocks; b += stride) {
     /* The two sets of 12 per-lane twiddles (forward half's last group, inverse half's first group) share one set
@@ -114,6 +138,18 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
      * to the iteration. */
     uint32_t tl = tid;
     asm volatile("" : "+v"(tl));
+    /* (PTRS: the table entries this iteration needs -- b and c of this block, a of the next one -- are read here, scalar loads a
+     * whole half ahead of their use.  a's entry read where the next block is requested, between the two halves, cost 31 spilled
+     * VGPRs: the inverse half's per-lane twiddles went to scratch) */
+    const uint64_t *pb_cur = nullptr;
+    uint64_t *      pc_cur = nullptr;
+    const uint64_t *pa_nxt = nullptr;
+    if constexpr(PTRS) {
+      pb_cur = at_b(b);
+      pc_cur = at_c(b);
+      const bool more0 = SCMP ? below(b + stride, pf.nblocks) : b + stride < pf.nblocks;
+      pa_nxt           = at_a(more0 ? b + stride : b);
+    }
     typename A::ctw pre[4][kE / 2];
     preload_group_tw<A, LOGN, GL>(pre, tl, blk, pf);
     /* (52-bit class, BOTH at 2^14: b's words are requested behind a's first stage group instead of in front of it -- the
@@ -123,7 +159,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
       run_group<A, LOGN, 0, false, MASKF>(v, tl, blk, pf);
       if constexpr(decltype(late)::value) {
         __builtin_amdgcn_sched_barrier(0);
-        prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b));
+        prefetch_first<LOGN>(raw, tl, PTRS ? pb_cur : at_b(b));
       }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
@@ -141,7 +177,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     typename A::val xa[BOTH ? kE : 1];
     if constexpr(BOTH) {
       convert_inputs<A, false>(xa, raw, false, pf.c);
-      if constexpr(!LATE_B) prefetch_first<LOGN>(raw, tl, pf.a + blk_off<LOGN>(pf, b)); /* b's words travel during a's forward stages */
+      if constexpr(!LATE_B) prefetch_first<LOGN>(raw, tl, PTRS ? pb_cur : at_b(b)); /* b's words travel during a's forward stages */
       forward(xa, std::integral_constant<bool, LATE_B>{});
       /* (b's words are converted after a's last stage, not before: interleaved by the scheduler, x, xa and the raw words
        * lived side by side and spilled) */
@@ -150,7 +186,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     } else {
       convert_inputs<A, false>(x, raw, false, pf.c);
       /* a^ in the last group's layout: requested now, used after the 14 forward stages */
-      prefetch_last<LOGN>(raw, tl, pp.ahat + blk_off<LOGN>(pf, b));
+      prefetch_last<LOGN>(raw, tl, at_a(b));
     }
     forward(x, std::false_type{});
     /* the inverse's first group: its twiddles land while the product is computed */
@@ -167,7 +203,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     {
       const bool     more = SCMP ? below(b + stride, pf.nblocks) : b + stride < pf.nblocks;
       const uint64_t nb   = more ? b + stride : b;
-      prefetch_first<LOGN>(raw, tl, (BOTH ? pp.ahat : pf.a) + blk_off<LOGN>(pf, nb), more);
+      prefetch_first<LOGN>(raw, tl, PTRS ? pa_nxt : (BOTH ? at_a(nb) : at_b(nb)), more);
     }
     run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -184,7 +220,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     });
     uint64_t out[kE];
     static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
-    buffer_store_first_raw<LOGN>(out, tl, pp.out + blk_off<LOGN>(pf, b));
+    buffer_store_first_raw<LOGN>(out, tl, PTRS ? pc_cur : at_c(b));
   }
 }
 
@@ -457,10 +493,11 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
  * the product and the inverse half appended.  Every per-lane group has its forward table in LDS at these sizes, and the
  * inverse half reads all of them mirrored, so the kernel issues no per-lane global twiddle load at all; a^ arrives in
  * the last group's layout as 16-byte loads.  40N bytes per product instead of 72N. */
-template <class A, int LOGN, int KSH, bool MULTI = false, bool BOTH = false>
+template <class A, int LOGN, int KSH, bool MULTI = false, bool BOTH = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_small_kernel(const KProd<A> kp)
 {
+  static_assert(!PTRS || (BOTH && !MULTI), "pointer tables: coefficient-domain products, one limb per launch (see fused_product_kernel)");
   uint32_t            bid, gdim;
   const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
   using P = Plan<LOGN>;
@@ -490,6 +527,10 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     uint64_t   b    = b0 + sub;
     const bool live = b < pf.nblocks;
     if(!live) b = pf.nblocks - 1; /* idle sub-blocks shadow a real polynomial (barriers are workgroup-wide), never store */
+    /* (PTRS: the sub-block's polynomial differs between the waves of the workgroup -- a per-lane table read) */
+    const uint64_t *ablk = PTRS ? tab_poly<false>(pp.ahat, b, pf.a) : pp.ahat + blk_off<LOGN>(pf, b);
+    uint64_t *      bblk = PTRS ? tab_poly<false>(pf.ptab, b, pf.a) : pf.a + blk_off<LOGN>(pf, b);
+    uint64_t *      cblk = PTRS ? tab_poly<false>(pp.out, b, pf.a) : pp.out + blk_off<LOGN>(pf, b);
     const auto forward = [&](typename A::val(&v)[kE]) {
       run_group<A, LOGN, 0, false, MASKF, (G::TBL(0) > 0)>(v, t, 0u, pf, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
@@ -503,15 +544,20 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     if constexpr(BOTH) {
       /* a's coefficients through the same forward stages first; a^ waits in registers (the ones a^'s words occupy otherwise) */
       typename A::val xa[kE];
-      global_load_first<A, LOGN, false>(xa, t, pp.ahat + blk_off<LOGN>(pf, b), false, pf.c);
-      prefetch_first<LOGN>(raw, t, pf.a + blk_off<LOGN>(pf, b));
+      global_load_first<A, LOGN, false>(xa, t, ablk, false, pf.c);
+      if constexpr(PTRS) {
+        /* (per-lane addresses: plain loads -- a buffer descriptor must be wave-uniform) */
+        static_for<0, kE>([&](auto ee) { raw[decltype(ee)::value] = stream_load(coef_at(bblk + ((uint32_t) decltype(ee)::value << P::LT), t)); });
+      } else {
+        prefetch_first<LOGN>(raw, t, bblk);
+      }
       forward(xa);
       convert_inputs<A, false>(x, raw, false, pf.c);
       forward(x);
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::product_rr(x[decltype(ee)::value], xa[decltype(ee)::value], pf.c); });
     } else {
-      global_load_first<A, LOGN, false>(x, t, pf.a + blk_off<LOGN>(pf, b), false, pf.c);
-      prefetch_last<LOGN>(raw, t, pp.ahat + blk_off<LOGN>(pf, b));
+      global_load_first<A, LOGN, false>(x, t, bblk, false, pf.c);
+      prefetch_last<LOGN>(raw, t, ablk);
       forward(x);
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = A::template product_in_domain<true>(x[decltype(ee)::value], raw[decltype(ee)::value], pf.c); });
     }
@@ -522,7 +568,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
       exchange<A, LOGN, GI, GI - 1>(x, t, lds);
       run_group<A, LOGN, GI - 1, true, MASKI, (G::TBL(GI - 1) > 0), (G::TBL(GI - 1) > 0)>(x, t, 0u, pi, gtw + G::TBL_OFF(GI - 1));
     });
-    if(live) global_store_first<A, LOGN, true>(x, t, pp.out + blk_off<LOGN>(pf, b), pf.c, false);
+    if(live) global_store_first<A, LOGN, true>(x, t, cblk, pf.c, false);
   }
 }
 
@@ -575,9 +621,12 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last_b(uint64_t (&r
   prefetch_last<LOGN, kDotAuxB>(raw, t, blk, live);
 }
 
-template <class A, int LOGN, int KSH, bool LASTINV, bool MULTI = false>
+/* PTRS (whole polynomials, one limb per launch): kd.a[i], kd.b[i] (unless broadcast: then the polynomial itself, as ever) and
+ * kd.k.ptab are the tables of a_i^, b_i^ and c; kd.k.a = the limb's offset (tab_poly). */
+template <class A, int LOGN, int KSH, bool LASTINV, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<LOGN, true, flavor_of<A>()>::WPS)) dot_inv_kernel(const KDot<A> kd)
 {
+  static_assert(!PTRS || (LASTINV && !MULTI), "pointer tables: whole polynomials, one limb per launch");
   uint32_t        bid, gdim, limb;
   const Params<A> p = limb_params<A, true, MULTI>(kd.k, bid, gdim, limb);
   using P = Plan<LOGN>;
@@ -595,6 +644,22 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
   const bool       bc    = kd.b_bcast != 0;
   const uint64_t   aoff  = (uint64_t)limb * kd.k.limb_stride; /* (MULTI off: limb == 0, both offsets fold away) */
   const uint64_t   boff  = (uint64_t)limb * kd.b_limb_stride;
+  /* where block bb of operand pair i and of c starts (UNI: bb is the same for the whole wave) */
+  const auto a_at = [&](uint32_t i, uint64_t bb, auto uni) -> const uint64_t * {
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(kd.a[i], bb, p.a);
+    else return kd.a[i] + aoff + blk_off<LOGN>(p, bb);
+  };
+  const auto b_at = [&](uint32_t i, uint64_t bb, auto uni) -> const uint64_t * {
+    if(bc) return kd.b[i] + boff + ((bb & bmask) << LOGN); /* a broadcast b_i^ is one dense polynomial */
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(kd.b[i], bb, p.a);
+    else return kd.b[i] + boff + blk_off<LOGN>(p, bb);
+  };
+  const auto c_at = [&](uint64_t bb, auto uni) -> uint64_t * {
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(p.ptab, bb, p.a);
+    else return p.a + blk_off<LOGN>(p, bb);
+  };
+  constexpr std::true_type  kUni{};
+  constexpr std::false_type kLane{};
 
   /* (MULTI -- several limbs in one launch -- exists for batches that cannot fill the chip: a workgroup sees one or two blocks,
    * there is nothing to prefetch across, and the plain loop below needs fewer registers next to the run-time limb's constants) */
@@ -619,15 +684,13 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
      * twiddle request to arrive. */
     constexpr bool IPRE = stage_is_compact<A, LOGN, true>(GL, 0) && P::R(GL) < 4 && G::TBL(GL) == 0;
     uint64_t ra[kE], rb[kE];
-    prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tid, kd.a[0] + aoff + blk_off<LOGN>(p, b));
-    prefetch_last_b<LOGN>(rb, tid, kd.b[0] + boff + (bc ? ((b & bmask) << LOGN) : blk_off<LOGN>(p, b)));
+    prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tid, a_at(0, b, kUni));
+    prefetch_last_b<LOGN>(rb, tid, b_at(0, b, kUni));
     pin_raw(ra);
     pin_raw(rb);
     for(; b < p.nblocks; b += stride) {
       const uint32_t blk  = (uint32_t)b & bmask;
-      const uint64_t offa = blk_off<LOGN>(p, b);                    /* operands a_i^ and c: the launch's layout */
-      const uint64_t offb = bc ? ((uint64_t)blk << LOGN) : offa;    /* a broadcast b_i^ is one dense polynomial */
-      uint64_t *     base = p.a + offa;
+      uint64_t *     base = c_at(b, kUni);
       /* (an opaque copy of the thread id ties the per-block twiddle request and every lane-dependent address to the
        * iteration: hoisted, they would stay in registers -- or scratch -- for the whole launch; see fused_product_kernel) */
       uint32_t tl = tid;
@@ -639,8 +702,8 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
       for(uint32_t i = 0; i + 1 < np; i++) {
         if(i != 0 && i % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
         dot_tile<A, 0, kE, NTT_DOT_LOOP_CHUNK>(x, ra, rb, lazy, p.c);
-        prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tl, kd.a[i + 1] + aoff + offa);
-        prefetch_last_b<LOGN>(rb, tl, kd.b[i + 1] + boff + offb);
+        prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, tl, a_at(i + 1, b, kUni));
+        prefetch_last_b<LOGN>(rb, tl, b_at(i + 1, b, kUni));
         sched_fence();
       }
       if(np > 1 && (np - 1) % (uint32_t)A::kDotEvery == 0) dot_fold_tile<A>(x, p.c);
@@ -669,7 +732,7 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
           uint32_t t2 = tid;
           asm volatile("" : "+v"(t2));
           sched_fence();
-          prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, t2, kd.a[0] + aoff + blk_off<LOGN>(p, nb), more);
+          prefetch_last<LOGN, NTT_DOT_AUX_A>(ra, t2, a_at(0, nb, kUni), more);
           sched_fence();
         }
         if constexpr(G::TBL(GI - 1) > 0) {
@@ -683,7 +746,7 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
         uint32_t t3 = tid;
         asm volatile("" : "+v"(t3));
         sched_fence();
-        prefetch_last_b<LOGN>(rb, t3, kd.b[0] + boff + (bc ? ((nb & bmask) << LOGN) : blk_off<LOGN>(p, nb)), more);
+        prefetch_last_b<LOGN>(rb, t3, b_at(0, nb, kUni), more);
         sched_fence();
       }
       uint64_t out[kE];
@@ -706,9 +769,9 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
       const bool live = b < p.nblocks;
       if(!live) b = p.nblocks - 1; /* idle sub-blocks shadow a real block (barriers are workgroup-wide), never store */
       const uint32_t blk  = (uint32_t)b & bmask;
-      const uint64_t offa = blk_off<LOGN>(p, b);
+      const uint64_t offa = PTRS ? 0 : blk_off<LOGN>(p, b);
       const uint64_t offb = bc ? ((uint64_t)blk << LOGN) : offa;
-      uint64_t *     base = p.a + offa;
+      uint64_t *     base = PTRS ? c_at(b, kLane) : p.a + offa;
       typename A::val x[kE];
       static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = typename A::val{}; });
 #pragma unroll 1
@@ -719,8 +782,8 @@ __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<
           constexpr int H = decltype(hh)::value;
           uint64_t      ra[kE], rb[kE];
           sched_fence();
-          load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, t, kd.a[i] + aoff + offa);
-          load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, t, kd.b[i] + boff + offb);
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(ra, t, PTRS ? a_at(i, b, kLane) : kd.a[i] + aoff + offa);
+          load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, t, PTRS ? b_at(i, b, kLane) : kd.b[i] + boff + offb);
           dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
         });
       }
@@ -960,9 +1023,12 @@ __device__ __forceinline__ void buffer_store_last_range(const uint64_t (&u)[kE],
   });
 }
 
-template <class A, int LOGN, int KSH, bool MULTI = false>
+/* PTRS (whole polynomials, one limb per launch): km.k.ptab, km.b (unless broadcast) and km.out are the tables of a, b^ and c^;
+ * km.k.a = the limb's offset (tab_poly). */
+template <class A, int LOGN, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS)) fwd_mul_kernel(const KMul<A> km)
 {
+  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   uint32_t        bid, gdim, limb;
   const Params<A> p = limb_params<A, false, MULTI>(km.k, bid, gdim, limb);
   using P = Plan<LOGN>;
@@ -980,6 +1046,28 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
   const bool       acc   = km.accumulate != 0;
   const uint64_t * bptr  = km.b + (uint64_t)limb * km.b_limb_stride; /* (MULTI off: limb == 0) */
   uint64_t *       cptr  = km.out + (uint64_t)limb * km.k.limb_stride;
+  /* where block bb of the three operands starts (UNI: bb is the same for the whole wave) */
+  /* (the persistent loop's blocks hold at least one wave each: uniform -- with two blocks per workgroup the block index is derived
+   * from the thread id and has to be said to be; the plain loop's blocks may be smaller than a wave) */
+  const auto wave = [&](uint64_t bb, auto uni) {
+    if constexpr(decltype(uni)::value && G::BPW != 1) return ((uint64_t)uniform_u32((uint32_t)(bb >> 32)) << 32) | uniform_u32((uint32_t)bb);
+    else return bb;
+  };
+  const auto a_at = [&](uint64_t bb, auto uni) -> const uint64_t * {
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(p.ptab, wave(bb, uni), p.a);
+    else return p.a + blk_off<LOGN>(p, bb);
+  };
+  const auto b_at = [&](uint64_t bb, auto uni) -> const uint64_t * {
+    if(bc) return bptr + ((bb & bmask) << LOGN); /* a broadcast b^ is one dense polynomial */
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(km.b, wave(bb, uni), p.a);
+    else return bptr + blk_off<LOGN>(p, bb);
+  };
+  const auto c_at = [&](uint64_t bb, auto uni) -> uint64_t * {
+    if constexpr(PTRS) return tab_poly<decltype(uni)::value>(km.out, wave(bb, uni), p.a);
+    else return cptr + blk_off<LOGN>(p, bb);
+  };
+  constexpr std::true_type  kUni{};
+  constexpr std::false_type kLane{};
 
   if constexpr(G::PERSISTENT && A::kCompact && !MULTI) {
     constexpr int  GL  = P::NG - 1;
@@ -1000,14 +1088,14 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       __syncthreads();
     }
     uint64_t raw[kE];
-    prefetch_first<LOGN>(raw, tt, p.a + blk_off<LOGN>(p, b));
+    prefetch_first<LOGN>(raw, tt, a_at(b, kUni));
     pin_raw(raw);
     for(; b0 < p.nblocks; b0 += stride) {
       const bool live = G::BPW == 1 || b0 + sub < p.nblocks;
       b               = live ? b0 + (G::BPW == 1 ? 0u : sub) : lastb;
       const uint32_t  blk   = (uint32_t)b & bmask;
-      const uint64_t *bblk  = bptr + (bc ? ((uint64_t)blk << LOGN) : blk_off<LOGN>(p, b));
-      uint64_t *      cblk  = cptr + blk_off<LOGN>(p, b);
+      const uint64_t *bblk  = b_at(b, kUni);
+      uint64_t *      cblk  = c_at(b, kUni);
       uint32_t        tl    = tt;
       asm volatile("" : "+v"(tl)); /* ties the per-block requests to the iteration (see dot_inv_kernel) */
       typename A::val x[kE];
@@ -1016,7 +1104,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
         const bool     more = b0 + stride < p.nblocks;
         const uint64_t nb0  = more ? b0 + stride : b0;
         const uint64_t nb   = G::BPW == 1 ? nb0 : (nb0 + sub < p.nblocks ? nb0 + sub : lastb);
-        prefetch_first<LOGN>(raw, tl, p.a + blk_off<LOGN>(p, nb), more);
+        prefetch_first<LOGN>(raw, tl, a_at(nb, kUni), more);
       }
       run_group<A, LOGN, 0, false, MASK>(x, tl, blk, p);
       typename A::ctw pre[4][kE / 2];
@@ -1073,14 +1161,14 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
       const bool live = b < p.nblocks;
       if(!live) b = p.nblocks - 1;
       const uint32_t  blk  = (uint32_t)b & bmask;
-      const uint64_t *bblk = bptr + (bc ? ((uint64_t)blk << LOGN) : blk_off<LOGN>(p, b));
-      uint64_t *      cblk = cptr + blk_off<LOGN>(p, b);
+      const uint64_t *bblk = b_at(b, kLane);
+      uint64_t *      cblk = c_at(b, kLane);
       /* (an opaque copy of the thread id per block: the integer policy's per-lane twiddle addresses would otherwise be
        * computed once for the launch and sit in registers -- or scratch -- throughout) */
       uint32_t tg = t;
       asm volatile("" : "+v"(tg));
       typename A::val x[kE];
-      global_load_first<A, LOGN, false>(x, tg, p.a + blk_off<LOGN>(p, b), false, p.c);
+      global_load_first<A, LOGN, false>(x, tg, a_at(b, kLane), false, p.c);
       run_group<A, LOGN, 0, false, MASK, (G::TBL(0) > 0)>(x, tg, blk, p, gtw);
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;

@@ -283,25 +283,49 @@ def _tables(lib, oracle, rng, n, q, count, operands, seed, unit=None):
     return offs, polys, img, mask, words
 
 
-@pytest.mark.parametrize("m,bits,arith", [(8, 50, "auto"), (12, 50, "auto"), (14, 52, "auto"), (14, 58, "auto"), (12, 50, "r4"), (16, 50, "auto"), (4, 30, "auto")])
-def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
+@pytest.mark.parametrize("m,bits,arith,count", [(8, 50, "auto", 24), (12, 50, "auto", 24), (14, 52, "auto", 24), (14, 58, "auto", 24), (12, 50, "r4", 24),
+                                                 (16, 50, "auto", 24), (4, 30, "auto", 24),
+                                                 # the fused kernels' table-reading forms, size by size (up to 2^14: ONE launch per call and limb)
+                                                 (6, 40, "auto", 37), (9, 50, "auto", 301), (10, 50, "auto", 77), (11, 50, "auto", 41), (11, 52, "auto", 41),
+                                                 (12, 52, "auto", 1100), (13, 50, "auto", 23), (13, 52, "auto", 600), (14, 50, "auto", 300), (13, 57, "auto", 23),
+                                                 (12, 59, "auto", 33), (14, 61, "auto", 9), (11, 60, "auto", 19), (15, 50, "auto", 12)])
+def test_products_over_pointer_tables(lib, oracle, m, bits, arith, count):
     """round 6: the NTT-domain products and the product chain over SEPARATELY HELD operands -- every operand a device table of
     pointers into a pool where all polynomials of all operands lie shuffled: c = inv(sum_i a_i^ . b_i^) for k = 1, 3 (canonical, lazy,
     broadcast key), c^ = fwd(a) . b^ and c^ += fwd(a) . key^, c = a * b (c on a table of its own, on a's, squaring); every polynomial
-    against the oracle, every word between the polynomials untouched"""
-    n, count = 1 << m, 24
+    against the oracle, every word between the polynomials untouched.  Counts above the resident workgroups make the persistent
+    loops take several blocks each (the table entries of the NEXT block are read ahead); odd counts leave a workgroup's second
+    block idle where two share one."""
+    n = 1 << m
     q = lib.find_prime(bits, n, 0)
     w = lib.min_root(q, n)
     plan = lib.Plan(n, q, w, arith={"auto": lib.ARITH_AUTO, "r4": lib.ARITH_U64_R4}[arith])
     cx = oracle.ctx(n, q, w)
     rng = np.random.default_rng(m * 100 + bits)
     K = 3
+    if count % 2 == 1:      # a handful of workgroups: every one walks through many blocks
+        plan.set_option(lib.OPT_MAX_GRID, 5)
     offs, polys, img, mask, words = _tables(lib, oracle, rng, n, q, count, 2 * K + 1, 500 + m)
     # operands 0..K-1: a_i, K..2K-1: b_i, 2K: c
     A = [polys[i] for i in range(K)]
     B = [polys[K + i] for i in range(K)]
-    Ah = [np.stack([cx.fwd(x.copy()) for x in a]) for a in A]
-    Bh = [np.stack([cx.fwd(x.copy()) for x in b]) for b in B]
+    # (large counts: every polynomial goes through the GPU, a sample of them -- the first and last ones, a workgroup's second and
+    # later blocks among them -- through the oracle)
+    sample = list(range(count)) if count <= 48 else sorted(set(list(range(6)) + list(range(count - 6, count)) + [int(x) for x in rng.integers(0, count, 12)]))
+    if count <= 48:
+        Ah = [np.stack([cx.fwd(x.copy()) for x in a]) for a in A]
+        Bh = [np.stack([cx.fwd(x.copy()) for x in b]) for b in B]
+    else:       # the GPU's own forward transform of the slabs (itself checked against the oracle on the sample)
+        def gpu_fwd(x):
+            t = lib.DeviceBuffer(count * n).upload(x.reshape(-1))
+            plan.fwd(t.ptr, count)
+            r = t.download().reshape(count, n)
+            t.free()
+            for p in sample[:4]:
+                assert np.array_equal(r[p], cx.fwd(x[p].copy()))
+            return r
+        Ah, Bh = [gpu_fwd(a) for a in A], [gpu_fwd(b) for b in B]
+    fused = 6 <= m <= 14 and arith == "auto"
 
     def place(sets):
         im = img.copy()
@@ -321,7 +345,7 @@ def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
             d.upload(im)
             plan.inv_dot_dev_ptrs(tabs[2 * K].ptr, [tabs[i].ptr for i in range(k)], [tabs[K + i].ptr for i in range(k)], count, lib.MUL_LAZY_IN if lazy else 0)
             got = d.download()
-            for p in range(count):
+            for p in sample:
                 acc = np.zeros(n, dtype=np.uint64)
                 for i in range(k):
                     acc = (acc + oracle.pointwise(Ah[i][p].copy(), Bh[i][p].copy(), q)) % np.uint64(q)
@@ -335,7 +359,7 @@ def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
     d.upload(im)
     plan.inv_dot_dev_ptrs(tabs[0].ptr, [tabs[0].ptr], [key.ptr], count, lib.MUL_B_BROADCAST)
     got = d.download()
-    for p in range(count):
+    for p in sample:
         assert np.array_equal(got[offs[0][p]:offs[0][p] + n], cx.inv(oracle.pointwise(Ah[0][p].copy(), Bh[0][0].copy(), q))), p
     assert (got[mk] == GUARD).all()
     # c^ = fwd(a) . b^, then c^ += fwd(a') . key^
@@ -344,9 +368,16 @@ def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
     plan.fwd_mul_dev_ptrs(tabs[2 * K].ptr, tabs[0].ptr, tabs[K].ptr, count)
     plan.fwd_mul_dev_ptrs(tabs[2 * K].ptr, tabs[1].ptr, key.ptr, count, lib.MUL_ACCUMULATE | lib.MUL_B_BROADCAST)
     got = d.download()
-    for p in range(count):
+    for p in sample:
         exp = (oracle.pointwise(Ah[0][p].copy(), Bh[0][p].copy(), q) + oracle.pointwise(Ah[1][p].copy(), Bh[0][0].copy(), q)) % np.uint64(q)
         assert np.array_equal(got[offs[2 * K][p]:offs[2 * K][p] + n], exp), p
+    mk2 = mk.copy()
+    for off in offs[2 * K]:
+        mk2[off:off + n] = False
+    assert (got[mk2] == GUARD).all()
+    if fused:   # the fused kernel leaves a as it was
+        for p in sample:
+            assert np.array_equal(got[offs[0][p]:offs[0][p] + n], A[0][p]) and np.array_equal(got[offs[1][p]:offs[1][p] + n], A[1][p]), p
     # c = a * b: own table, a's table, squaring
     for form in ("own", "on_a", "square"):
         im, mk = place({0: A[0], K: B[0]})
@@ -356,9 +387,16 @@ def test_products_over_pointer_tables(lib, oracle, m, bits, arith):
         plan.negacyclic_mul_dev_ptrs(ct.ptr, tabs[0].ptr, bt.ptr, count)
         got = d.download()
         co = offs[2 * K] if form == "own" else offs[0]
-        for p in range(count):
+        for p in sample:
             other = Ah[0][p] if form == "square" else Bh[0][p]
             assert np.array_equal(got[co[p]:co[p] + n], cx.inv(oracle.pointwise(Ah[0][p].copy(), other.copy(), q))), (form, p)
+        mk2 = mk.copy()
+        for off in co:
+            mk2[off:off + n] = False
+        assert (got[mk2] == GUARD).all(), form
+        if form == "own" and fused and m >= 8 and plan.info()["arith"] == lib.ARITH_F64:   # one launch, both operands left as they were
+            for p in sample:
+                assert np.array_equal(got[offs[0][p]:offs[0][p] + n], A[0][p]) and np.array_equal(got[offs[K][p]:offs[K][p] + n], B[0][p]), p
     for t in tabs:
         t.free()
     key.free(), d.free(), plan.destroy()
@@ -390,8 +428,11 @@ def test_rns_products_over_pointer_tables(lib, oracle):
         for l in range(nl):
             fa, fb = ctx[l].fwd(a[p][l].copy()), ctx[l].fwd(b[p][l].copy())
             assert np.array_equal(got[offs[2][p] + l * n:offs[2][p] + (l + 1) * n], ctx[l].inv(oracle.pointwise(fa, fb, qs[l]))), (p, l)
-            assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], fa), "a is left in the NTT domain"
-    # the operands are transformed now: c = inv(a^ . b^) again through the inner-product form, and c^ += fwd(c) . b^ on top of a^
+            assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], a[p][l]), "the fused kernel leaves a as it was"
+            assert np.array_equal(got[offs[1][p] + l * n:offs[1][p] + (l + 1) * n], b[p][l]), "... and b"
+    # the operands into the NTT domain: c = inv(a^ . b^) again through the inner-product form, and c^ += fwd(c) . b^ on top of a^
+    lib.rns_transform_dev_ptrs(plans, tabs[0].ptr, count, n)
+    lib.rns_transform_dev_ptrs(plans, tabs[1].ptr, count, n)
     lib.rns_inv_dot_dev_ptrs(plans, tabs[2].ptr, [tabs[0].ptr], [tabs[1].ptr], count, n)
     again = d.download()
     for p in range(count):
