@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void onepass_forward(Params<A> &p, uint32_t bid, uint
     for(uint32_t h = 0; h < 2u; h++) {
       uint32_t tl = tid;
       asm volatile("" : "+v"(tl)); /* per-half lane offsets: recomputed, not carried in registers through the launch */
-      onepass_block_fwd<A, MASK>(x, h, tl, p, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t t2) { out(y, t2, h, off); });
+      onepass_block_fwd<A, MASK>(x, h, tl, p, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t t2) { out(y, t2, h, off, poly); });
       if(h == 0) {
         static_for<0, kE>([&](auto ee) { x[decltype(ee)::value] = vals(hold[decltype(ee)::value]); });
         prefetch_first<LOGN>(hold, tl, nxt, more); /* half A has been stored: the next polynomial's first half */
@@ -1060,7 +1060,7 @@ __global__ void __launch_bounds__(1024, 4) onepass_kernel(const KArgs<A> k)
   const uint32_t         tid  = threadIdx.x;
   constexpr uint64_t HALF     = 1ull << LOGN;
   if constexpr(!INV) {
-    onepass_forward<A, KSH>(p, bid, gdim, tid, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t tl, uint32_t h, uint64_t off) {
+    onepass_forward<A, KSH>(p, bid, gdim, tid, lds_all, tabl, [&](typename A::val(&y)[kE], uint32_t tl, uint32_t h, uint64_t off, uint64_t) {
       store_last_whole_lines<A, LOGN, false>(y, tl, p.a + off + (h ? HALF : 0), p.c, false);
     });
   } else {

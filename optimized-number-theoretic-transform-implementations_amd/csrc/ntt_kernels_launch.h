@@ -918,6 +918,13 @@ template <class A, int KSH> hipError_t launch_onepass_mul(const MulArgs &ma)
     if(wgs == 0) return hipSuccess;
     km.k.wgs_per_limb = (uint32_t)wgs;
     const dim3 grid((unsigned)wgs, (unsigned)nl);
+    if(ma.ptrs) {
+      if(nl > 1) return hipErrorNotSupported;
+      km.k.ptab = reinterpret_cast<const uint64_t *>(ma.a);
+      km.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)ma.ptr_limb_off * 8u);
+      hipLaunchKernelGGL((onepass_mul_kernel<A, KSH, false, true>), grid, dim3(1024), 0, ma.stream, km);
+      return hipGetLastError();
+    }
     if(nl > 1) hipLaunchKernelGGL((onepass_mul_kernel<A, KSH, true>), grid, dim3(1024), 0, ma.stream, km);
     else hipLaunchKernelGGL((onepass_mul_kernel<A, KSH, false>), grid, dim3(1024), 0, ma.stream, km);
     return hipGetLastError();
@@ -927,7 +934,7 @@ template <class A, int KSH> hipError_t launch_onepass_mul(const MulArgs &ma)
 template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 {
   if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
-  if(ma.ptrs && (ma.one_pass || ma.team_ctl || ma.logn > (uint32_t)kFusedMax)) return hipErrorNotSupported;
+  if(ma.ptrs && !ma.one_pass && (ma.team_ctl || ma.logn > (uint32_t)kFusedMax)) return hipErrorNotSupported;
   if(ma.one_pass) return launch_onepass_mul<A, KSH>(ma);
   if(ma.team_ctl) return launch_team_mul<A, KSH>(ma);
   if(ma.logn > (uint32_t)kFusedMax) {

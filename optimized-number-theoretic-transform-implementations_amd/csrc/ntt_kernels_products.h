@@ -144,7 +144,9 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     const uint64_t *pb_cur = nullptr;
     uint64_t *      pc_cur = nullptr;
     const uint64_t *pa_nxt = nullptr;
-    if constexpr(PTRS) {
+    /* (the slab forms gain nothing from the same hoist: 120 instead of 128 VGPRs, 1-2 % slower -- profiles/r06/ab_product_hoist.txt) */
+    constexpr bool HOIST = PTRS;
+    if constexpr(HOIST) {
       pb_cur = at_b(b);
       pc_cur = at_c(b);
       const bool more0 = SCMP ? below(b + stride, pf.nblocks) : b + stride < pf.nblocks;
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
       run_group<A, LOGN, 0, false, MASKF>(v, tl, blk, pf);
       if constexpr(decltype(late)::value) {
         __builtin_amdgcn_sched_barrier(0);
-        prefetch_first<LOGN>(raw, tl, PTRS ? pb_cur : at_b(b));
+        prefetch_first<LOGN>(raw, tl, HOIST ? pb_cur : at_b(b));
       }
       static_for<0, P::NG - 1>([&](auto gg) {
         constexpr int GI = decltype(gg)::value;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     typename A::val xa[BOTH ? kE : 1];
     if constexpr(BOTH) {
       convert_inputs<A, false>(xa, raw, false, pf.c);
-      if constexpr(!LATE_B) prefetch_first<LOGN>(raw, tl, PTRS ? pb_cur : at_b(b)); /* b's words travel during a's forward stages */
+      if constexpr(!LATE_B) prefetch_first<LOGN>(raw, tl, HOIST ? pb_cur : at_b(b)); /* b's words travel during a's forward stages */
       forward(xa, std::integral_constant<bool, LATE_B>{});
       /* (b's words are converted after a's last stage, not before: interleaved by the scheduler, x, xa and the raw words
        * lived side by side and spilled) */
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     {
       const bool     more = SCMP ? below(b + stride, pf.nblocks) : b + stride < pf.nblocks;
       const uint64_t nb   = more ? b + stride : b;
-      prefetch_first<LOGN>(raw, tl, PTRS ? pa_nxt : (BOTH ? at_a(nb) : at_b(nb)), more);
+      prefetch_first<LOGN>(raw, tl, HOIST ? pa_nxt : (BOTH ? at_a(nb) : at_b(nb)), more);
     }
     run_group_preloaded<A, LOGN, GL, MASKI, true>(x, pre, pi);
     static_for<0, P::NG - 1>([&](auto gg) {
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false,
     });
     uint64_t out[kE];
     static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
-    buffer_store_first_raw<LOGN>(out, tl, PTRS ? pc_cur : at_c(b));
+    buffer_store_first_raw<LOGN>(out, tl, HOIST ? pc_cur : at_c(b));
   }
 }
 
@@ -1196,9 +1198,12 @@ __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom
  * quarter of the tile at a time, c^ written; a itself is left as it was.  The one-pass transform is bound by its arithmetic and the
  * half of its loads it cannot prefetch, not by bytes: the 8N (16N accumulating) more that the product reads ride almost free --
  * measured 0.475 -> see profiles/r06/onepass_products_2p15.txt of the 24N roofline. */
-template <class A, int KSH, bool MULTI = false>
+/* PTRS (one limb per launch): km.k.ptab, km.b (unless broadcast) and km.out are the tables of a, b^ and c^, km.k.a = the limb's offset --
+ * as fwd_mul_kernel's PTRS form. */
+template <class A, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(1024, 4) onepass_mul_kernel(const KMul<A> km)
 {
+  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   uint32_t  bid, gdim, limb;
   Params<A> p = limb_params<A, false, MULTI>(km.k, bid, gdim, limb);
   constexpr int LOGN = kFusedLarge;
@@ -1211,9 +1216,9 @@ __global__ void __launch_bounds__(1024, 4) onepass_mul_kernel(const KMul<A> km)
   const bool       lazy = km.lazy_in != 0, bc = km.b_bcast != 0, acc = km.accumulate != 0;
   const uint64_t * bptr = km.b + (uint64_t)limb * km.b_limb_stride; /* (MULTI off: limb == 0) */
   uint64_t *       cptr = km.out + (uint64_t)limb * km.k.limb_stride;
-  onepass_forward<A, KSH>(p, bid, gdim, threadIdx.x, lds_all, tabl, [&](typename A::val(&x)[kE], uint32_t tl, uint32_t h, uint64_t off) {
-    const uint64_t *bblk = bptr + (bc ? 0 : off) + (h ? HALF : 0);
-    uint64_t *      cblk = cptr + off + (h ? HALF : 0);
+  onepass_forward<A, KSH>(p, bid, gdim, threadIdx.x, lds_all, tabl, [&](typename A::val(&x)[kE], uint32_t tl, uint32_t h, uint64_t off, uint64_t poly) {
+    const uint64_t *bblk = (PTRS && !bc ? tab_poly<true>(km.b, poly, p.a) : bptr + (bc ? 0 : off)) + (h ? HALF : 0);
+    uint64_t *      cblk = (PTRS ? tab_poly<true>(km.out, poly, p.a) : cptr + off) + (h ? HALF : 0);
     /* the products, a quarter of the tile at a time, the next quarter's words in flight meanwhile (as fwd_mul_kernel) */
     uint64_t u[kE], rb[kE], rc[kE];
     uint32_t t2 = tl;

@@ -15,7 +15,7 @@ Q = 0x7fffffffe0001
 print("# lib sha256 %s%s" % (__import__("hashlib").sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()[:16], "  (--chain: fused table forms off)" if chain else ""))
 print("%-5s %-6s %-44s %9s %9s %7s %7s" % ("logn", "count", "product", "slab ms", "tables ms", "frac", "vs slab"))
 K = 3
-for logn, count in ((14, 4096), (13, 8192), (12, 16384), (14, 512), (10, 65536)):
+for logn, count in ((14, 4096), (13, 8192), (12, 16384), (14, 512), (10, 65536), (15, 2048)):   # (2^15: only fwd(a) . b^ has a one-launch table form)
     n = 1 << logn
     q = Q if (Q - 1) % (2 * n) == 0 else lib.find_prime(50, n, 0)
     plan = lib.Plan(n, q, lib.min_root(q, n))
