@@ -28,6 +28,30 @@ t_end, rounds, checks = time.time() + args.seconds, 0, 0
 stats = {}
 
 
+def scatter(rng, n, operands):
+    """the polynomials of several operands (count * n words each) shuffled over ONE pool with irregular gaps: the pool, one device
+    table of polynomial addresses per operand, and per operand the word offsets (products over separately held operands)"""
+    count = operands[0].size // n
+    total = len(operands) * count
+    gaps = rng.integers(0, 3, size=total) * int(rng.choice([0, 1, 8, n // 2 + 9]))      # (odd word offsets among them)
+    starts = np.cumsum(gaps + n) - n
+    order = rng.permutation(total)
+    img = np.zeros(int(starts[-1]) + n, dtype=np.uint64)
+    offs = []
+    for o, x in enumerate(operands):
+        st = starts[order[o * count:(o + 1) * count]]
+        offs.append(st)
+        for i, s0 in enumerate(st):
+            img[int(s0):int(s0) + n] = x[i * n:(i + 1) * n]
+    pool = lib.DeviceBuffer(img.size).upload(img)
+    tabs = [lib.DeviceBuffer(count).upload(np.array([pool.ptr + 8 * int(s0) for s0 in st], dtype=np.uint64)) for st in offs]
+    return pool, tabs, offs
+
+
+def gathered(img, st, n):
+    return np.concatenate([img[int(s0):int(s0) + n] for s0 in st])
+
+
 def fail(what, **kw):
     print("SOAK FAILURE:", what, kw, flush=True)
     sys.exit(1)
@@ -192,6 +216,16 @@ while time.time() < t_end:
         for d in (da, db, dc):
             d.free()
         checks += 1
+        if rng.random() < 0.35:
+            # the same product over SEPARATELY HELD operands (device tables; up to 2^14 inside the fused product kernels)
+            pool, tabs, offs = scatter(rng, n, [a, b, np.zeros_like(a)])
+            ci = {0: 2, 1: 0, 2: 1, 3: 2}[form]
+            plan.negacyclic_mul_dev_ptrs(tabs[ci].ptr, tabs[0].ptr, tabs[0 if form == 3 else 1].ptr, batch)
+            if not np.array_equal(gathered(pool.download(), offs[ci], n), prod):
+                fail("product over tables, form %d" % form, **ctxt)
+            for d in tabs + [pool]:
+                d.free()
+            checks += 1
     # operands in the NTT domain: c = inv(sum_i a_i^ (.) b_i^) with k pairs, canonical or lazy words, per-polynomial or
     # broadcast b, c aliasing an operand (k = 1); c = inv(fwd(a) (.) b^) in a random aliasing form
     if rng.random() < 0.6:
@@ -219,6 +253,19 @@ while time.time() < t_end:
         for d in dah + dbh + ([dst] if alias == 0 else []):
             d.free()
         checks += 1
+        if rng.random() < 0.4:
+            # ... over device tables: every a_i^ (and every b_i^ that is not a shared key) a table of its own, c on a table of its own
+            # or (k = 1) on an operand's
+            ops = list(ah) + ([] if bc else list(bh)) + [np.zeros(batch * n, dtype=np.uint64)]
+            pool, tabs, offs = scatter(rng, n, ops)
+            keys = [lib.DeviceBuffer(x.size).upload(x) for x in bh] if bc else []
+            ci = len(ops) - 1 if alias == 0 else (0 if alias == 1 else kk)
+            plan.inv_dot_dev_ptrs(tabs[ci].ptr, [t.ptr for t in tabs[:kk]], [x.ptr for x in keys] if bc else [t.ptr for t in tabs[kk:2 * kk]], batch, flags)
+            if not np.array_equal(gathered(pool.download(), offs[ci], n), expd):
+                fail("inv_dot over tables", k=kk, lazy=lz_in, bcast=bc, alias=alias, **ctxt)
+            for d in tabs + keys + [pool]:
+                d.free()
+            checks += 1
         # (lazy words for the product kernels must stay below 2^53; the radix-4 policy takes canonical words)
         bw = want if (4 * q > (1 << 53) or info["arith"] == lib.ARITH_U64_R4 or rng.random() < 0.5) else \
             want + np.uint64(q) * rng.integers(0, 3, size=want.shape, dtype=np.uint64)
@@ -253,6 +300,18 @@ while time.time() < t_end:
         for d in (dco, dbw, dcc):
             d.free()
         checks += 1
+        if rng.random() < 0.4:
+            ops = [a, c0] + ([] if bc else [bwv])
+            pool, tabs, offs = scatter(rng, n, ops)
+            keyd = lib.DeviceBuffer(bwv.size).upload(bwv) if bc else None
+            ci = 1 if alias == 0 else (0 if alias == 1 else 2)
+            plan.fwd_mul_dev_ptrs(tabs[ci].ptr, tabs[0].ptr, keyd.ptr if bc else tabs[2].ptr, batch,
+                                  (lib.MUL_LAZY_IN if lz_in else 0) | (lib.MUL_B_BROADCAST if bc else 0) | (lib.MUL_ACCUMULATE if ac else 0))
+            if not np.array_equal(gathered(pool.download(), offs[ci], n), expf):
+                fail("fwd_mul over tables", lazy=lz_in, bcast=bc, acc=ac, alias=alias, **ctxt)
+            for d in tabs + ([keyd] if bc else []) + [pool]:
+                d.free()
+            checks += 1
     plan.destroy()
     # reference-signature entry points on the caller's own tables (one polynomial, host pointers): bit-exact lazy values
     if rng.random() < 0.15 and m >= 2 and q < (1 << 60):
