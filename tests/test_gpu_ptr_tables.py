@@ -211,6 +211,74 @@ print("graph ok")
     assert out.returncode == 0 and "graph ok" in out.stdout, out.stderr[-3000:]
 
 
+def test_products_over_device_tables_captured_in_a_hip_graph():
+    """the fused kernels' table forms allocate nothing and copy nothing either: c = a * b, d^ = fwd(c) . key^ and e = inv(a^' . k0^ + b^' . k1^)
+    over shuffled device tables, three launches captured into ONE HIP graph and replayed on fresh data (a process of its own: torch
+    has to be imported before the library)"""
+    import subprocess
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+n, count, ops = 1 << 13, 20, 5          # operands: a, b, c, d, e
+q = lib.find_prime(50, n, 0)
+w = lib.min_root(q, n)
+plan, cx = lib.Plan(n, q, w), orc.ctx(n, q, w)
+rng = np.random.default_rng(11)
+total = ops * count
+gaps = rng.integers(1, 64, size=total) + np.arange(total) %% 7
+starts = np.cumsum(gaps + n) - n
+order = rng.permutation(total)
+offs = [[int(starts[i]) for i in order[o * count:(o + 1) * count]] for o in range(ops)]
+words = int(starts[-1] + n + 8)
+GUARD = np.uint64(0xA5A5A5A5A5A5A5A5)
+buf = torch.zeros(words, dtype=torch.int64, device="cuda:0")
+tabs = [torch.from_numpy(np.array([buf.data_ptr() + 8 * o for o in offs[k]], dtype=np.uint64).view(np.int64)).to("cuda:0") for k in range(ops)]
+keys_h = orc.fill_uniform(2 * n, q, 77).reshape(2, n)
+keys = torch.from_numpy(keys_h.view(np.int64).copy()).to("cuda:0")
+kp = [keys.data_ptr(), keys.data_ptr() + 8 * n]
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+ta, tb, tc, td, te = (t.data_ptr() for t in tabs)
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    plan.negacyclic_mul_dev_ptrs(tc, ta, tb, count, stream=st)                                   # c = a * b   (a, b left as they were)
+    plan.fwd_mul_dev_ptrs(td, tc, kp[0], count, lib.MUL_B_BROADCAST, stream=st)                   # d^ = fwd(c) . key0^
+    plan.inv_dot_dev_ptrs(te, [ta, tb], [kp[0], kp[1]], count, lib.MUL_B_BROADCAST, stream=st)    # e = inv(a . key0^ + b . key1^), a and b read as NTT-domain words
+for seed in (1, 2):
+    A = orc.fill_uniform(count * n, q, seed).reshape(count, n)
+    B = orc.fill_uniform(count * n, q, 100 + seed).reshape(count, n)
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    for k in range(ops):
+        for o in offs[k]:
+            mask[o:o + n] = False
+    for i in range(count):
+        img[offs[0][i]:offs[0][i] + n] = A[i]
+        img[offs[1][i]:offs[1][i] + n] = B[i]
+    buf.copy_(torch.from_numpy(img.view(np.int64)))
+    g.replay()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().view(np.uint64)
+    assert (got[mask] == GUARD).all()
+    for i in range(count):
+        c = cx.inv(orc.pointwise(cx.fwd(A[i].copy()), cx.fwd(B[i].copy()), q))
+        assert np.array_equal(got[offs[2][i]:offs[2][i] + n], c), (seed, i, "c")
+        assert np.array_equal(got[offs[3][i]:offs[3][i] + n], orc.pointwise(cx.fwd(c.copy()), keys_h[0].copy(), q)), (seed, i, "d")
+        e = (orc.pointwise(A[i].copy(), keys_h[0].copy(), q) + orc.pointwise(B[i].copy(), keys_h[1].copy(), q)) %% np.uint64(q)
+        assert np.array_equal(got[offs[4][i]:offs[4][i] + n], cx.inv(e)), (seed, i, "e")
+        assert np.array_equal(got[offs[0][i]:offs[0][i] + n], A[i]) and np.array_equal(got[offs[1][i]:offs[1][i] + n], B[i]), (seed, i, "operands")
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "graph ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_pointer_batch_arguments(lib, oracle):
     n = 1 << 12
     q = lib.find_prime(50, n, 0)
