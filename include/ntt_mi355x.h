@@ -345,16 +345,18 @@ NTT_API int ntt_rns_transform_dev_ptrs(int nlimbs, ntt_plan *const *plans, const
  * Up to N = 2^14 the fused product kernels read every operand through its own table: ONE launch per call and limb at the slab forms'
  * bytes (24N for c = a * b, (2k + 1) 8N for an inner product of k pairs, 24N / 32N for fwd(a) (.) b^ (+ c^)) -- measured 0.84-1.14 x the
  * rate of the same product over contiguous slabs (profiles/r06/pointer_products.txt).  fwd(a) (.) b^ at 2^15 takes the one-pass kernel
- * the same way.  Larger sizes, and plans the fused kernels are not built for, run the element-wise products as a table-reading kernel of
- * their own and the transforms over the tables: k + 1 launch chains per call whatever the batch.  Semantics, flags and operand ranges
+ * the same way, and at 2^15..2^17 the XCD-local one-launch kernels read the tables from 64 polynomials on (they need the plan's control
+ * block: ntt_plan_reserve before capturing such a call into a graph).  Smaller batches of those sizes, and plans the fused kernels are
+ * not built for, run the element-wise products as a table-reading kernel of their own and the transforms over the tables: k + 1 launch
+ * chains per call whatever the batch.  Semantics, flags and operand ranges
  * are those of the slab forms:
  *   ntt_inv_dot_dev_ptrs         c_p = inv( sum_{i<k} a_{i,p}^ (.) b_{i,p}^ ); h_ahat / h_bhat: HOST arrays of k device tables;
  *                                NTT_MUL_B_BROADCAST: h_bhat[i] is a device pointer to ONE polynomial (RNS: [limb][N]); k = 1: c's table
  *                                may be an operand's
  *   ntt_fwd_mul_dev_ptrs         c_p^ = fwd(a_p) (.) b_p^ (NTT_MUL_ACCUMULATE: += ...); a is SCRATCH: left as it was where a fused kernel
- *                                serves (up to 2^14; 2^15 in one pass), transformed in place otherwise
- *   ntt_negacyclic_mul_dev_ptrs  c_p = a_p * b_p; a and b are SCRATCH: left as they were by the one-launch form (FP64 plans up to 2^14),
- *                                in the NTT domain otherwise; c's table may be a's or b's (the table itself, entry for entry -- not a
+ *                                serves (up to 2^14; 2^15 in one pass), overwritten otherwise
+ *   ntt_negacyclic_mul_dev_ptrs  c_p = a_p * b_p; a and b are SCRATCH: left as they were by the one-launch form up to 2^14 (FP64 plans),
+ *                                overwritten otherwise; c's table may be a's or b's (the table itself, entry for entry -- not a
  *                                permutation of it); d_a == d_b squares ---- */
 NTT_API int ntt_inv_dot_dev_ptrs(const ntt_plan *p, const uint64_t *const *d_c, int k, const uint64_t *const *const *h_ahat,
                                  const uint64_t *const *const *h_bhat, uint64_t count, unsigned flags, void *stream);

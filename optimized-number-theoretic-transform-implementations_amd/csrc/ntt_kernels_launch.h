@@ -607,6 +607,18 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
     if(nl > 1) hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, FOURV, true>), g, t, 0, pa.stream, kt);      \
     else hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, FOURV, false>), g, t, 0, pa.stream, kt);           \
   } while(0)
+    if(pa.ptrs) {
+      /* separately held polynomials: b, ahat (a's coefficients) and out are device tables (team_product_kernel's PTRS form) */
+      if(!pa.four || nl != 1) return hipErrorNotSupported;
+      kt.k.f.ptab = reinterpret_cast<const uint64_t *>(pa.b);
+      kt.k.f.a    = reinterpret_cast<uint64_t *>((uintptr_t)pa.ptr_limb_off * 8u);
+      switch(pa.logn - kTeamBlock) {
+        case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
+        case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
+        default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
+      }
+      return hipGetLastError();
+    }
     if(pa.four) {
       /* ahat = a itself (coefficients): both forward transforms happen inside the launch */
       switch(pa.logn - kTeamBlock) {
@@ -737,6 +749,17 @@ template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
     if(da.max_grid > 0) wgs = (uint64_t)da.max_grid;
     kt.d.k.wgs_per_limb = (uint32_t)wgs;
     const dim3 g((unsigned)wgs), t(256);
+    if(da.ptrs) {
+      if(nl != 1) return hipErrorNotSupported;
+      kt.d.k.ptab = reinterpret_cast<const uint64_t *>(da.out);
+      kt.d.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)da.ptr_limb_off * 8u);
+      switch(da.logn - kTeamBlock) {
+        case 3: hipLaunchKernelGGL((team_dot_kernel<A, 3, KSH, false, true>), g, t, 0, da.stream, kt); break;
+        case 4: hipLaunchKernelGGL((team_dot_kernel<A, 4, KSH, false, true>), g, t, 0, da.stream, kt); break;
+        default: hipLaunchKernelGGL((team_dot_kernel<A, 5, KSH, false, true>), g, t, 0, da.stream, kt); break;
+      }
+      return hipGetLastError();
+    }
 #define NTT_TEAM_DOT(LEADV)                                                                                  \
   do {                                                                                                       \
     if(nl > 1) hipLaunchKernelGGL((team_dot_kernel<A, LEADV, KSH, true>), g, t, 0, da.stream, kt);           \
@@ -755,7 +778,7 @@ template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
 template <class A, int KSH> hipError_t launch_dot_impl(const DotArgs &da)
 {
   if(da.npairs < 1 || da.npairs > kMaxDot || da.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
-  if(da.team_ctl) return da.ptrs ? hipErrorNotSupported : launch_team_dot<A, KSH>(da);
+  if(da.team_ctl) return launch_team_dot<A, KSH>(da);
   if(da.logn > (uint32_t)kFusedMax) {
     if(da.ptrs) return hipErrorNotSupported;
     if(da.block_log == (uint32_t)kFusedSmallBlock) return launch_dot_blocks<A, kFusedSmallBlock, KSH, false>(da);
@@ -872,6 +895,17 @@ template <class A, int KSH> hipError_t launch_team_mul(const MulArgs &ma)
     if(ma.max_grid > 0) wgs = (uint64_t)ma.max_grid;
     kt.m.k.wgs_per_limb = (uint32_t)wgs;
     const dim3 g((unsigned)wgs), t(256);
+    if(ma.ptrs) {
+      if(nl != 1) return hipErrorNotSupported;
+      kt.m.k.ptab = reinterpret_cast<const uint64_t *>(ma.a);
+      kt.m.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)ma.ptr_limb_off * 8u);
+      switch(ma.logn - kTeamBlock) {
+        case 3: hipLaunchKernelGGL((team_mul_kernel<A, 3, KSH, false, true>), g, t, 0, ma.stream, kt); break;
+        case 4: hipLaunchKernelGGL((team_mul_kernel<A, 4, KSH, false, true>), g, t, 0, ma.stream, kt); break;
+        default: hipLaunchKernelGGL((team_mul_kernel<A, 5, KSH, false, true>), g, t, 0, ma.stream, kt); break;
+      }
+      return hipGetLastError();
+    }
 #define NTT_TEAM_MUL(LEADV)                                                                                  \
   do {                                                                                                       \
     if(nl > 1) hipLaunchKernelGGL((team_mul_kernel<A, LEADV, KSH, true>), g, t, 0, ma.stream, kt);           \
@@ -934,7 +968,7 @@ template <class A, int KSH> hipError_t launch_onepass_mul(const MulArgs &ma)
 template <class A, int KSH> hipError_t launch_fwd_mul_impl(const MulArgs &ma)
 {
   if(ma.nlimbs > kMaxLimbs) return hipErrorInvalidValue;
-  if(ma.ptrs && !ma.one_pass && (ma.team_ctl || ma.logn > (uint32_t)kFusedMax)) return hipErrorNotSupported;
+  if(ma.ptrs && !ma.one_pass && !ma.team_ctl && ma.logn > (uint32_t)kFusedMax) return hipErrorNotSupported;
   if(ma.one_pass) return launch_onepass_mul<A, KSH>(ma);
   if(ma.team_ctl) return launch_team_mul<A, KSH>(ma);
   if(ma.logn > (uint32_t)kFusedMax) {

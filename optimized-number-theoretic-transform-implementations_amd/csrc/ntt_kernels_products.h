@@ -297,8 +297,21 @@ __device__ __forceinline__ void team_product_item(uint64_t *bblk, const uint64_t
  * intermediate of a's column pass, is taken through the twelve block stages first and waits in 32 VGPRs -- the registers
  * that hold the prefetched a^ words in the item above -- while b's block follows; a^ never exists in memory: 16N bytes
  * fewer across the fabric per product (no write-through store of a^, no read of it) and one launch less. */
-template <class A, int KSH, int LDAUX, int STAUX>
-__device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_t *ablk, uint64_t *cblk, uint32_t blk, uint32_t tid0,
+/* (a block of a separately held polynomial, its table entry read where the block is first touched -- a pointer read at the top of the
+ * item would sit in scalar registers through all 36 stages: two spilled VGPRs in the 128-VGPR kernels, whose scalar spills live in
+ * vector lanes) */
+struct TabBlock {
+  const void *    tab;
+  const uint64_t *limb;
+  uint32_t        poly;
+  uint32_t        off; /* words from the polynomial's start to the block */
+};
+__device__ __forceinline__ uint64_t *blk_ptr(uint64_t *p) { return p; }
+__device__ __forceinline__ const uint64_t *blk_ptr(const uint64_t *p) { return p; }
+__device__ __forceinline__ uint64_t *blk_ptr(const TabBlock &t) { return tab_poly<true>(t.tab, t.poly, t.limb) + t.off; }
+
+template <class A, int KSH, int LDAUX, int STAUX, class BB = uint64_t *, class AB = const uint64_t *, class CB = uint64_t *>
+__device__ __forceinline__ void team_product_item2(BB bblk, AB ablk, CB cblk, uint32_t blk, uint32_t tid0,
                                                    const Params<A> &pf, const Params<A> &pi, typename A::val *lds, typename A::ctw *tabl)
 {
   constexpr int LOGN = kTeamBlock;
@@ -313,7 +326,7 @@ __device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_
   asm volatile("" : "+v"(tl));
   const uint32_t tid = tl;
   uint64_t raw[kE];
-  prefetch_first<LOGN, LDAUX>(raw, tid, ablk);
+  prefetch_first<LOGN, LDAUX>(raw, tid, blk_ptr(ablk));
   typename A::ctw pre[4][kE / 2];
   preload_group_tw<A, LOGN, GL>(pre, tid, blk, pf);
   fill_lds_tables<A, LOGN, false, G>(tabl, pf, blk, tid); /* (published by the first exchange's barriers) */
@@ -333,7 +346,7 @@ __device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_
   };
   typename A::val xa[kE];
   convert_inputs<A, false>(xa, raw, false, pf.c);
-  prefetch_first<LOGN, LDAUX>(raw, tid, bblk); /* b's words travel during a's twelve stages */
+  prefetch_first<LOGN, LDAUX>(raw, tid, blk_ptr(bblk)); /* b's words travel during a's twelve stages */
   forward(xa);
   typename A::val x[kE];
   convert_inputs<A, false>(x, raw, false, pf.c);
@@ -351,7 +364,7 @@ __device__ __forceinline__ void team_product_item2(uint64_t *bblk, const uint64_
   });
   uint64_t out[kE];
   static_for<0, kE>([&](auto ee) { out[decltype(ee)::value] = A::store_inv(x[decltype(ee)::value], pf.c); });
-  buffer_store_first_raw<LOGN, STAUX>(out, tid, cblk);
+  buffer_store_first_raw<LOGN, STAUX>(out, tid, blk_ptr(cblk));
 }
 
 struct TeamProdCtl {
@@ -369,9 +382,11 @@ template <class A> struct KTeamProd {
   uint32_t     poly_major; /* as KTeam::poly_major */
 };
 
-template <class A, int LEAD, int KSH, bool FOUR = false, bool MULTI = false>
+/* PTRS (one limb per launch): kt.k.f.ptab / kt.k.ahat / kt.k.out are the device tables of b, a and c (tab_poly), kt.k.f.a = the limb's offset */
+template <class A, int LEAD, int KSH, bool FOUR = false, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A> kt)
 {
+  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, false, 3>;
@@ -452,6 +467,14 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       uint64_t *      bpoly = pf.a + poff;
       const uint64_t *apoly = pp.ahat + poff;
       uint64_t *      cpoly = pp.out + poff;
+      if constexpr(PTRS) {
+        /* (the column items' one pointer here; the block products read their entries where they touch the blocks: TabBlock) */
+        if(pass == 0) {
+          bpoly = tab_poly<true>(pf.ptab, pl, pf.a);
+          apoly = tab_poly<true>(pp.ahat, pl, pf.a);
+        }
+        if(pass == 2) cpoly = tab_poly<true>(pp.out, pl, pf.a);
+      }
       /* NTT_TEAMPROD_ONLY (diagnostic builds, like NTT_STAMPS; never in the shipped library): which item types do their work -- bit 0
        * b's column items, 3 a's column items, 1 the block products, 2 c's inverse column items; the others only run the queue protocol.
        * Wrong results; one --pmc pass per build gives an item type's FETCH / WRITE bytes by themselves (profiles/r06/config5_bytes_by_item.txt) */
@@ -472,8 +495,14 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
 #ifndef NTT_TEAMPROD_FAKEBLK
 #  define NTT_TEAMPROD_FAKEBLK 0
 #endif
-          team_product_item2<A, KSH, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
-                                                cpoly + ((uint64_t)item << LOGN), NTT_TEAMPROD_FAKEBLK ? 0u : item, tid, pf, pi, lds, tabl);
+          if constexpr(PTRS) {
+            const uint32_t ioff = item << LOGN;
+            team_product_item2<A, KSH, kAuxNt, 0>(TabBlock{pf.ptab, pf.a, pl, ioff}, TabBlock{pp.ahat, pf.a, pl, ioff}, TabBlock{pp.out, pf.a, pl, ioff}, item,
+                                                  tid, pf, pi, lds, tabl);
+          } else {
+            team_product_item2<A, KSH, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
+                                                  cpoly + ((uint64_t)item << LOGN), NTT_TEAMPROD_FAKEBLK ? 0u : item, tid, pf, pi, lds, tabl);
+          }
         } else {
           team_product_item<A, KSH, kAuxNt, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
                                                          cpoly + ((uint64_t)item << LOGN), item, tid, pf, pi, lds, tabl);
@@ -827,9 +856,11 @@ template <class A> struct KTeamDot {
 };
 
 /* row item: block `blk` of one polynomial; offa / offb = word offsets of the block inside the a-like operands (and c) / the b operands */
-template <class A, int KSH>
+/* PTRS: kd.a[i] / kd.b[i] (unless broadcast) are device tables; pl = the polynomial, offa = the block's offset inside it */
+template <class A, int KSH, bool PTRS = false>
 __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa, uint64_t offb, uint32_t blk, uint32_t tid0, const Params<A> &p,
-                                                  const KDot<A> &kd, uint64_t aoff, uint64_t boff, typename A::val *lds, typename A::ctw *tabl)
+                                                  const KDot<A> &kd, uint64_t aoff, uint64_t boff, typename A::val *lds, typename A::ctw *tabl,
+                                                  uint32_t pl = 0)
 {
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
@@ -857,8 +888,10 @@ __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa,
       constexpr int H = decltype(hh)::value;
       uint64_t      ra[kE], rb[kE];
       sched_fence();
-      load_last_raw<LOGN, 8 * H, 8 * H + 8, false>(ra, tid, kd.a[i] + aoff + offa);
-      load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, kd.b[i] + boff + offb);
+      const uint64_t *ai = PTRS ? tab_poly<true>(kd.a[i], pl, p.a) + offa : kd.a[i] + aoff + offa;
+      const uint64_t *bi = PTRS && kd.b_bcast == 0 ? tab_poly<true>(kd.b[i], pl, p.a) + offa : kd.b[i] + boff + offb;
+      load_last_raw<LOGN, 8 * H, 8 * H + 8, false>(ra, tid, ai);
+      load_last_raw<LOGN, 8 * H, 8 * H + 8>(rb, tid, bi);
       dot_tile<A, 8 * H, 8 * H + 8>(x, ra, rb, lazy, p.c);
     });
   }
@@ -885,9 +918,11 @@ __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa,
   buffer_store_first_raw<LOGN, 0>(out, tid, cblk);
 }
 
-template <class A, int LEAD, int KSH, bool MULTI = false>
+/* PTRS (one limb per launch): kt.d.k.ptab, kt.d.a[i], kt.d.b[i] (unless broadcast) are device tables, kt.d.k.a = the limb's offset */
+template <class A, int LEAD, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
 {
+  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, true, flavor_of<A>()>;
@@ -943,8 +978,8 @@ __global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
         aoff = (uint64_t)limb * kt.d.k.limb_stride;
         boff = (uint64_t)limb * kt.d.b_limb_stride;
       }
-      const uint64_t poff = (uint64_t)pl * p.pstride; /* the polynomial inside its limb: c and every operand laid out like it */
-      uint64_t *     poly = p.a + poff;
+      const uint64_t poff = PTRS ? 0 : (uint64_t)pl * p.pstride; /* the polynomial inside its limb: c and every operand laid out like it */
+      uint64_t *     poly = PTRS ? tab_poly<true>(p.ptab, pl, p.a) : p.a + poff;
       if(second) {
         if(tid == 0) {
           while(__hip_atomic_load(&ctl->done[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NROW) __builtin_amdgcn_s_sleep(8);
@@ -954,7 +989,7 @@ __global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
       } else {
         const uint64_t offa = poff + ((uint64_t)item << LOGN);
         const uint64_t offb = bc ? ((uint64_t)item << LOGN) : offa;
-        team_dot_row_item<A, KSH>(poly + ((uint64_t)item << LOGN), offa, offb, item, tid, p, kt.d, aoff, boff, lds, tabl);
+        team_dot_row_item<A, KSH, PTRS>(poly + ((uint64_t)item << LOGN), offa, offb, item, tid, p, kt.d, aoff, boff, lds, tabl, pl);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         sig = pidx;
@@ -1316,9 +1351,11 @@ __device__ __forceinline__ void team_mul_row_item(const uint64_t *ablk, const ui
   });
 }
 
-template <class A, int LEAD, int KSH, bool MULTI = false>
+/* PTRS (one limb per launch): kt.m.k.ptab, kt.m.b (unless broadcast) and kt.m.out are the device tables of a, b^ and c^, kt.m.k.a = the limb's offset */
+template <class A, int LEAD, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_mul_kernel(const KTeamMul<A> kt)
 {
+  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, false, flavor_of<A>()>;
@@ -1376,7 +1413,7 @@ __global__ void __launch_bounds__(256, 4) team_mul_kernel(const KTeamMul<A> kt)
         coff = (uint64_t)limb * kt.m.k.limb_stride;
       }
       const uint64_t poff = (uint64_t)pl * p.pstride; /* the polynomial inside its limb: a, c^ and a per-polynomial b^ alike */
-      uint64_t *     poly = p.a + poff;
+      uint64_t *     poly = PTRS ? tab_poly<true>(p.ptab, pl, p.a) : p.a + poff;
       if(!second) {
         /* inputs -> intermediate (kept dirty in the L2), as in team_kernel */
         team_column_item<A, LEAD, false, CMASK, kAuxSc0Sc1, 0>(poly, item * kTeamCols + tid, logn, p, MID_LAZY);
@@ -1389,8 +1426,9 @@ __global__ void __launch_bounds__(256, 4) team_mul_kernel(const KTeamMul<A> kt)
         }
         __syncthreads();
         const uint64_t ioff = (uint64_t)item << LOGN;
-        team_mul_row_item<A, KSH, kAuxNt>(poly + ioff, kt.m.b + boff + (bc ? ioff : poff + ioff), kt.m.out + coff + poff + ioff, item, tid, p, lazy,
-                                           acc, lds, tabl);
+        const uint64_t *bblk = bc ? kt.m.b + boff + ioff : (PTRS ? tab_poly<true>(kt.m.b, pl, p.a) + ioff : kt.m.b + boff + poff + ioff);
+        uint64_t *      cblk = PTRS ? tab_poly<true>(kt.m.out, pl, p.a) + ioff : kt.m.out + coff + poff + ioff;
+        team_mul_row_item<A, KSH, kAuxNt>(poly + ioff, bblk, cblk, item, tid, p, lazy, acc, lds, tabl);
       }
     }
   }

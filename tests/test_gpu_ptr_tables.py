@@ -358,7 +358,9 @@ def _tables(lib, oracle, rng, n, q, count, operands, seed, unit=None):
                                                  (12, 52, "auto", 1100), (13, 50, "auto", 23), (13, 52, "auto", 600), (14, 50, "auto", 300), (13, 57, "auto", 23),
                                                  (12, 59, "auto", 33), (14, 61, "auto", 9), (11, 60, "auto", 19), (15, 50, "auto", 12),
                                                  # 2^15: fwd(a) . b^ in ONE pass with the tables read at its output (batches that give every second CU a polynomial)
-                                                 (15, 50, "auto", 160), (15, 52, "auto", 131)])
+                                                 (15, 50, "auto", 160), (15, 52, "auto", 131),
+                                                 # 2^15..2^17 from 64 polynomials on: the one-launch (XCD-local) product kernels read the tables
+                                                 (15, 50, "auto", 70), (16, 50, "auto", 80), (17, 50, "auto", 66), (16, 52, "auto", 65), (16, 60, "auto", 72)])
 def test_products_over_pointer_tables(lib, oracle, m, bits, arith, count):
     """round 6: the NTT-domain products and the product chain over SEPARATELY HELD operands -- every operand a device table of
     pointers into a pool where all polynomials of all operands lie shuffled: c = inv(sum_i a_i^ . b_i^) for k = 1, 3 (canonical, lazy,
@@ -472,9 +474,11 @@ def test_products_over_pointer_tables(lib, oracle, m, bits, arith, count):
     key.free(), d.free(), plan.destroy()
 
 
-def test_rns_products_over_pointer_tables(lib, oracle):
-    """the RNS twins: every table entry points at limb 0 of an RNS polynomial ([limb][N] each), the limbs one after the other"""
-    m, nl, count = 13, 3, 10
+@pytest.mark.parametrize("m,count", [(13, 10), (16, 64)])
+def test_rns_products_over_pointer_tables(lib, oracle, m, count):
+    """the RNS twins: every table entry points at limb 0 of an RNS polynomial ([limb][N] each), the limbs one after the other
+    (2^13: the fused kernels' table forms, one launch per limb; 2^16 x 64: the XCD-local kernels')"""
+    nl = 3
     n = 1 << m
     qs = [lib.find_prime(50, n, i) for i in range(nl)]
     ws = [lib.min_root(q, n) for q in qs]
@@ -498,8 +502,16 @@ def test_rns_products_over_pointer_tables(lib, oracle):
         for l in range(nl):
             fa, fb = ctx[l].fwd(a[p][l].copy()), ctx[l].fwd(b[p][l].copy())
             assert np.array_equal(got[offs[2][p] + l * n:offs[2][p] + (l + 1) * n], ctx[l].inv(oracle.pointwise(fa, fb, qs[l]))), (p, l)
-            assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], a[p][l]), "the fused kernel leaves a as it was"
-            assert np.array_equal(got[offs[1][p] + l * n:offs[1][p] + (l + 1) * n], b[p][l]), "... and b"
+            if m <= 14:
+                assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], a[p][l]), "the fused kernel leaves a as it was"
+                assert np.array_equal(got[offs[1][p] + l * n:offs[1][p] + (l + 1) * n], b[p][l]), "... and b"
+    if m > 14:      # (the one-launch form above 2^14 uses a and b as scratch: put them back)
+        keep = d.download()
+        for p in range(count):
+            for l in range(nl):
+                keep[offs[0][p] + l * n:offs[0][p] + (l + 1) * n] = a[p][l]
+                keep[offs[1][p] + l * n:offs[1][p] + (l + 1) * n] = b[p][l]
+        d.upload(keep)
     # the operands into the NTT domain: c = inv(a^ . b^) again through the inner-product form, and c^ += fwd(c) . b^ on top of a^
     lib.rns_transform_dev_ptrs(plans, tabs[0].ptr, count, n)
     lib.rns_transform_dev_ptrs(plans, tabs[1].ptr, count, n)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/pointer_product_bench.py: products over SEPARATELY HELD operands (every operand a device table of pointers to randomly
 placed polynomials) against the same products over contiguous slabs.  Up to 2^14 the fused product kernels read their operands through
-the tables (one launch per call, the slab forms' bytes); --chain switches those forms off (NTT_OPT_DOT_FUSED 0, NTT_OPT_FUSED_PRODUCT 0)
+the tables (one launch per call, the slab forms' bytes), from 2^15 on the XCD-local one-launch kernels do; --chain switches those forms off (NTT_OPT_DOT_FUSED 0, NTT_OPT_FUSED_PRODUCT 0)
 and measures what the entry points did before: table-reading element-wise kernels plus transforms over the tables.
 Fractions are of 8 TB/s at the algorithmic bytes of the fused forms: 24N (c = a * b), (k + 1) 8N with a broadcast key / (2k + 1) 8N
 without (c = inv(sum a_i^ . b_i^)), 24N / 32N (c^ (+)= fwd(a) . b^)."""
@@ -15,7 +15,7 @@ Q = 0x7fffffffe0001
 print("# lib sha256 %s%s" % (__import__("hashlib").sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()[:16], "  (--chain: fused table forms off)" if chain else ""))
 print("%-5s %-6s %-44s %9s %9s %7s %7s" % ("logn", "count", "product", "slab ms", "tables ms", "frac", "vs slab"))
 K = 3
-for logn, count in ((14, 4096), (13, 8192), (12, 16384), (14, 512), (10, 65536), (15, 2048)):   # (2^15: only fwd(a) . b^ has a one-launch table form)
+for logn, count in ((14, 4096), (13, 8192), (12, 16384), (14, 512), (10, 65536), (15, 2048), (16, 1024), (17, 512)):   # (2^15..2^17: the XCD-local one-launch kernels)
     n = 1 << logn
     q = Q if (Q - 1) % (2 * n) == 0 else lib.find_prime(50, n, 0)
     plan = lib.Plan(n, q, lib.min_root(q, n))
@@ -23,6 +23,7 @@ for logn, count in ((14, 4096), (13, 8192), (12, 16384), (14, 512), (10, 65536),
     if chain:
         pt.set_option(lib.OPT_DOT_FUSED, 0)
         pt.set_option(lib.OPT_FUSED_PRODUCT, 0)
+        pt.set_option(lib.OPT_XCD_LOCAL, 0)
     rng = np.random.default_rng(logn)
     nops = 2 * K + 1
     total = nops * count
