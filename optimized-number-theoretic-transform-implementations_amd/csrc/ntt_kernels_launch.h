@@ -80,8 +80,9 @@ struct ProdArgs {
   int             team_lag, team_wpc;
   int             four; /* launch_team_product: ahat holds a's COEFFICIENTS; the launch transforms both operands */
   int             both; /* launch_product, N <= 2^14: the same for the fused product kernels */
-  int             ptrs; /* launch_product, N <= 2^14, both, one limb: b, ahat and out are DEVICE TABLES of polynomial addresses (the PTRS kernels) */
-  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
+  int             ptrs; /* launch_product, N <= 2^14, both: b, ahat and out are DEVICE TABLES of polynomial addresses (the PTRS kernels); nlimbs > 1: every
+                             * polynomial's limbs limb_stride words apart behind its entry (launch_team_product: one limb) */
+  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the (first) limb of this launch */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_product(const ProdArgs &pa);
@@ -105,8 +106,9 @@ struct DotArgs {
   int                    oversub; /* as PassArgs::oversub */
   void *                 team_ctl; /* N = 2^15..2^17: non-null = both passes as items of ONE launch (team_dot_kernel); TeamCtl + nlimbs * batch counters */
   int                    team_lag, team_wpc;
-  int                    ptrs; /* N <= 2^14, one limb: out, every a[i] and every b[i] that is not broadcast are DEVICE TABLES of polynomial addresses */
-  uint64_t               ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
+  int                    ptrs; /* out, every a[i] and every b[i] that is not broadcast are DEVICE TABLES of polynomial addresses; N <= 2^14 with nlimbs > 1: every
+                                    * polynomial's limbs limb_stride words apart behind its entry (team_dot_kernel: one limb) */
+  uint64_t               ptr_limb_off; /* ptrs: words from every table entry to the (first) limb of this launch */
   hipStream_t            stream;
 };
 template <class A, int KSH> hipError_t launch_dot(const DotArgs &da);
@@ -129,8 +131,9 @@ struct MulArgs {
   void *          team_ctl; /* N = 2^15..2^17: non-null = column items and row items with the product as ONE launch (team_mul_kernel); a = the caller's coefficients */
   int             team_lag, team_wpc;
   int             one_pass; /* N = 2^15, FP64 policies: the transform in one pass with the product at its output (onepass_mul_kernel) */
-  int             ptrs; /* N <= 2^14, one limb: a, out and b (unless broadcast) are DEVICE TABLES of polynomial addresses */
-  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the limb of this launch */
+  int             ptrs; /* a, out and b (unless broadcast) are DEVICE TABLES of polynomial addresses; N <= 2^14 with nlimbs > 1: every polynomial's limbs
+                             * limb_stride words apart behind its entry (onepass_mul_kernel, team_mul_kernel: one limb) */
+  uint64_t        ptr_limb_off; /* ptrs: words from every table entry to the (first) limb of this launch */
   hipStream_t     stream;
 };
 template <class A, int KSH> hipError_t launch_fwd_mul(const MulArgs &ma);
@@ -449,7 +452,9 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(pa.both && s0 != 0 && blog != 12 && blog != 14) return hipErrorInvalidValue;
     if(pa.ptrs) {
       /* separately held polynomials: the three operand pointers are tables (fused_product_kernel's PTRS form) */
-      if(!pa.both || s0 != 0 || nl != 1) return hipErrorNotSupported;
+      /* (several limbs: the limbs of every polynomial pa.limb_stride words apart behind its table entry -- the MULTI instances,
+       * whose limb_params add limb * limb_stride to the offset in pp.f.a) */
+      if(!pa.both || s0 != 0) return hipErrorNotSupported;
       pp.f.ptab = reinterpret_cast<const uint64_t *>(pa.b);
       pp.f.a    = reinterpret_cast<uint64_t *>((uintptr_t)pa.ptr_limb_off * 8u);
     }
@@ -466,7 +471,8 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     if(g > gcap) g = gcap;                                                                                          \
     pp.f.wgs_per_limb = (unsigned)g;                                                                                \
     if(pa.ptrs) {                                                                                                   \
-      hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
+      if(nl > 1) hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, true, true, true>), dim3((unsigned)g, (unsigned)nl), dim3(GS::WG), 0, pa.stream, pp); \
+      else hipLaunchKernelGGL((fused_product_small_kernel<A, LN, KSH, false, true, true>), dim3((unsigned)g), dim3(GS::WG), 0, pa.stream, pp); \
       return hipGetLastError();                                                                                     \
     }                                                                                                               \
     if(pa.both) {                                                                                                   \
@@ -499,7 +505,8 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       wgs = pp.f.nblocks < cap12 ? pp.f.nblocks : cap12;
       pp.f.wgs_per_limb = (uint32_t)wgs;
       if(pa.ptrs) {
-        hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G12::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 12, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G12::WG), 0, pa.stream, pp);
         return hipGetLastError();
       }
       if(pa.both) {
@@ -527,7 +534,8 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
       if(s0 != 0) return hipErrorNotSupported; /* (2^13-point blocks of a larger product: measured no faster than 2^14, not built) */
       pp.f.wgs_per_limb = (uint32_t)wgs;
       if(pa.ptrs) {
-        hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
+        if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G13::WG), 0, pa.stream, pp);
+        else hipLaunchKernelGGL((fused_product_kernel<A, 13, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(G13::WG), 0, pa.stream, pp);
         return hipGetLastError();
       }
       if(pa.both) {
@@ -541,7 +549,8 @@ template <class A, int KSH> hipError_t launch_product_impl(const ProdArgs &pa)
     }
     pp.f.wgs_per_limb = (uint32_t)wgs;
     if(pa.ptrs) {
-      hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
+      if(nl > 1) hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(1024), 0, pa.stream, pp);
+      else hipLaunchKernelGGL((fused_product_kernel<A, 14, KSH, true, true, false, true, true>), dim3((unsigned)wgs), dim3(1024), 0, pa.stream, pp);
       return hipGetLastError();
     }
     if(pa.both) {
@@ -686,9 +695,17 @@ template <class A, int LOGN, int KSH, bool LASTINV> hipError_t launch_dot_blocks
   kd.k.wgs_per_limb = (uint32_t)wgs;
   if(da.ptrs) {
     if constexpr(LASTINV) {
-      if(nl > 1) return hipErrorNotSupported;
       kd.k.ptab = reinterpret_cast<const uint64_t *>(da.out);
       kd.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)da.ptr_limb_off * 8u);
+      if(nl > 1) {
+        /* the limbs of an RNS set behind every table entry, da.limb_stride words apart: one launch over all of them */
+        if constexpr(multi_limb_built<A>()) {
+          hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, true, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, da.stream, kd);
+          return hipGetLastError();
+        } else {
+          return hipErrorNotSupported;
+        }
+      }
       hipLaunchKernelGGL((dot_inv_kernel<A, LOGN, KSH, true, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, da.stream, kd);
       return hipGetLastError();
     } else {
@@ -839,9 +856,18 @@ template <class A, int LOGN, int KSH> hipError_t launch_fwd_mul_blocks(const Mul
   if(wgs == 0) return hipSuccess;
   km.k.wgs_per_limb = (uint32_t)wgs;
   if(ma.ptrs) {
-    if(nl > 1 || km.k.s0 != 0) return hipErrorNotSupported;
+    if(km.k.s0 != 0) return hipErrorNotSupported;
     km.k.ptab = reinterpret_cast<const uint64_t *>(ma.a);
     km.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)ma.ptr_limb_off * 8u);
+    if(nl > 1) {
+      /* the limbs of an RNS set behind every table entry, ma.limb_stride words apart: one launch over all of them */
+      if constexpr(multi_limb_built<A>()) {
+        hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, true, true>), dim3((unsigned)wgs, (unsigned)nl), dim3(G::WG), 0, ma.stream, km);
+        return hipGetLastError();
+      } else {
+        return hipErrorNotSupported;
+      }
+    }
     hipLaunchKernelGGL((fwd_mul_kernel<A, LOGN, KSH, false, true>), dim3((unsigned)wgs), dim3(G::WG), 0, ma.stream, km);
     return hipGetLastError();
   }

@@ -40,23 +40,26 @@ template <class A> struct KProd {
   uint64_t *      out;
   uint32_t        a_lazy;
 };
-template <class A, bool MULTI> __device__ __forceinline__ ProdParams<A> limb_prod_params(const KProd<A> &k, uint32_t &bid, uint32_t &gdim)
+/* PTRS: k.ahat / k.out are device TABLES of polynomial addresses (tab_poly), the same for every limb; the limb's offset travels in
+ * pp.f.a (k.f.a + limb * k.f.limb_stride, k.f.a an offset from a null base) */
+template <class A, bool MULTI, bool PTRS = false> __device__ __forceinline__ ProdParams<A> limb_prod_params(const KProd<A> &k, uint32_t &bid, uint32_t &gdim)
 {
   uint32_t      limb;
   ProdParams<A> pp;
   pp.f = limb_params<A, false, MULTI>(k.f, bid, gdim, limb);
   pp.tw_i   = k.f.limbs[limb].tw_i;
   pp.tw8_i  = k.f.limbs[limb].tw8_i;
-  pp.ahat   = k.ahat + (uint64_t)limb * k.f.limb_stride;
-  pp.out    = k.out + (uint64_t)limb * k.f.limb_stride;
+  pp.ahat   = PTRS ? k.ahat : k.ahat + (uint64_t)limb * k.f.limb_stride;
+  pp.out    = PTRS ? k.out : k.out + (uint64_t)limb * k.f.limb_stride;
   pp.a_lazy = k.a_lazy;
   return pp;
 }
 
 /* PTRS forms of the product kernels (round 6): whole polynomials held SEPARATELY -- every operand pointer of the kernel arguments
- * is a DEVICE TABLE of polynomial addresses (a plain array of device pointers, as for the transforms: poly_offset), one limb per
- * launch; `limb` carries the words from every table entry to that limb as an offset from a null base, where the slab forms carry
- * an operand's base.  UNIFORM as in poly_offset: the polynomial's index is the same for the whole wave (one s_load_dwordx2). */
+ * is a DEVICE TABLE of polynomial addresses (a plain array of device pointers, as for the transforms: poly_offset); `limb` carries
+ * the words from every table entry to the workgroup's limb as an offset from a null base, where the slab forms carry an operand's
+ * base (up to 2^14 the MULTI instances serve the limbs of an RNS set in one launch -- limb_params adds limb * limb_stride to that
+ * offset; the XCD-local kernels and the one-pass product take one limb per launch).  UNIFORM as in poly_offset: the polynomial's index is the same for the whole wave (one s_load_dwordx2). */
 template <bool UNIFORM> __device__ __forceinline__ uint64_t *tab_poly(const void *tab, uint64_t poly, const uint64_t *limb)
 {
   return const_cast<uint64_t *>(limb) + poly_offset<UNIFORM>(poly, 0, reinterpret_cast<const uint64_t *>(tab));
@@ -71,15 +74,16 @@ template <bool UNIFORM> __device__ __forceinline__ uint64_t *tab_poly(const void
 /* BOTH: pp.ahat holds a's COEFFICIENTS (blocks of a larger product: a after its column passes) and the kernel takes them through the forward stages too -- a^
  * waits, as doubles, in the 32 VGPRs that hold the prefetched a^ words otherwise, so the register budget is the same; a^
  * never exists in memory (24N instead of 40N bytes per product, one launch instead of two) and a is left untouched. */
-/* PTRS (whole polynomials, BOTH, one limb): kp.ahat / kp.f.ptab / kp.out are the tables of a, b and c, kp.f.a = the limb's offset. */
+/* PTRS (whole polynomials, BOTH): kp.ahat / kp.f.ptab / kp.out are the tables of a, b and c, kp.f.a = the first limb's offset (MULTI:
+ * the limbs of an RNS set kp.f.limb_stride words apart behind every table entry). */
 template <class A, int LOGN, int KSH, bool ALAZY, bool WHOLE, bool MULTI = false, bool BOTH = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_kernel(const KProd<A> kp)
 {
-  static_assert(!PTRS || (WHOLE && BOTH && !MULTI), "pointer tables: coefficient-domain products of whole polynomials, one limb per launch");
+  static_assert(!PTRS || (WHOLE && BOTH), "pointer tables: coefficient-domain products of whole polynomials");
   /* (!WHOLE && BOTH: the blocks of a larger product; pp.ahat then holds what a's column passes left, as pf.a does for b) */
   uint32_t            bid, gdim;
-  const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
+  const ProdParams<A> pp = limb_prod_params<A, MULTI, PTRS>(kp, bid, gdim);
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, 3>;
   static_assert(A::kCompact && G::BPW == 1 && (LOGN == 14 || LOGN == 12 || (LOGN == 13 && WHOLE)),
@@ -528,9 +532,9 @@ template <class A, int LOGN, int KSH, bool MULTI = false, bool BOTH = false, boo
 __global__ void __launch_bounds__((Geom<LOGN, false, 3>::WG), (Geom<LOGN, false, 3>::WPS))
   fused_product_small_kernel(const KProd<A> kp)
 {
-  static_assert(!PTRS || (BOTH && !MULTI), "pointer tables: coefficient-domain products, one limb per launch (see fused_product_kernel)");
+  static_assert(!PTRS || BOTH, "pointer tables: coefficient-domain products (see fused_product_kernel)");
   uint32_t            bid, gdim;
-  const ProdParams<A> pp = limb_prod_params<A, MULTI>(kp, bid, gdim);
+  const ProdParams<A> pp = limb_prod_params<A, MULTI, PTRS>(kp, bid, gdim);
   using P = Plan<LOGN>;
   using G = Geom<LOGN, false, 3>;
   static_assert(A::kCompact && G::BPW > 1 && LOGN >= 8 && LOGN <= 11, "whole polynomials of 2^8..2^11 points");
@@ -652,12 +656,13 @@ template <int LOGN> __device__ __forceinline__ void prefetch_last_b(uint64_t (&r
   prefetch_last<LOGN, kDotAuxB>(raw, t, blk, live);
 }
 
-/* PTRS (whole polynomials, one limb per launch): kd.a[i], kd.b[i] (unless broadcast: then the polynomial itself, as ever) and
- * kd.k.ptab are the tables of a_i^, b_i^ and c; kd.k.a = the limb's offset (tab_poly). */
+/* PTRS (whole polynomials): kd.a[i], kd.b[i] (unless broadcast: then the polynomial itself, as ever) and kd.k.ptab are the tables of
+ * a_i^, b_i^ and c; kd.k.a = the first limb's offset (tab_poly), the limbs of an RNS set kd.k.limb_stride words apart behind every
+ * table entry (MULTI: limb_params adds them). */
 template <class A, int LOGN, int KSH, bool LASTINV, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, true, flavor_of<A>()>::WG), (Geom<LOGN, true, flavor_of<A>()>::WPS)) dot_inv_kernel(const KDot<A> kd)
 {
-  static_assert(!PTRS || (LASTINV && !MULTI), "pointer tables: whole polynomials, one limb per launch");
+  static_assert(!PTRS || LASTINV, "pointer tables: whole polynomials");
   uint32_t        bid, gdim, limb;
   const Params<A> p = limb_params<A, true, MULTI>(kd.k, bid, gdim, limb);
   using P = Plan<LOGN>;
@@ -1060,12 +1065,11 @@ __device__ __forceinline__ void buffer_store_last_range(const uint64_t (&u)[kE],
   });
 }
 
-/* PTRS (whole polynomials, one limb per launch): km.k.ptab, km.b (unless broadcast) and km.out are the tables of a, b^ and c^;
- * km.k.a = the limb's offset (tab_poly). */
+/* PTRS (whole polynomials): km.k.ptab, km.b (unless broadcast) and km.out are the tables of a, b^ and c^; km.k.a = the first limb's
+ * offset (tab_poly), the limbs of an RNS set km.k.limb_stride words apart behind every table entry (MULTI: limb_params adds them). */
 template <class A, int LOGN, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__((Geom<LOGN, false, flavor_of<A>()>::WG), (Geom<LOGN, false, flavor_of<A>()>::WPS)) fwd_mul_kernel(const KMul<A> km)
 {
-  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   uint32_t        bid, gdim, limb;
   const Params<A> p = limb_params<A, false, MULTI>(km.k, bid, gdim, limb);
   using P = Plan<LOGN>;

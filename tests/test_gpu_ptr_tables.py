@@ -532,3 +532,113 @@ def test_rns_products_over_pointer_tables(lib, oracle, m, count):
     d.free()
     for p in plans:
         p.destroy()
+
+
+@pytest.mark.parametrize("m,bits,count,pad", [(8, [50] * 5, 3, 0), (11, [50] * 4, 2, 24), (12, [50] * 17, 1, 0), (13, [50, 50, 49, 48], 3, 8),
+                                              (14, [50] * 6, 2, 0), (14, [52] * 3, 3, 40), (12, [60, 50, 50, 52, 52, 58, 58], 2, 16),
+                                              (10, [59] * 5, 4, 0), (14, [57] * 3, 2, 0), (6, [40] * 4, 5, 8)])
+def test_rns_products_over_pointer_tables_in_one_launch_over_the_limbs(lib, oracle, m, bits, count, pad):
+    """round 6, DESIGN 9.2: a few separately held RNS polynomials x many primes -- the share of one limb cannot fill the chip, so the
+    RNS twins of the products over device tables serve a run of compatible limbs with ONE launch of the fused kernels' table-reading
+    MULTI instances (the limb an index of the grid, every polynomial's limbs limb_stride words apart behind its table entry) where
+    they looped over the limbs before.  Forced both ways (NTT_OPT_RNS_LAUNCH 0 / 1) and left to the library: all three equal the
+    oracle, limb by limb; mixed chains split into runs (a 60-bit prime in front of 50-bit ones, 52-bit ones, 17 limbs = 16 + 1);
+    padded limb strides: the words between the limbs stay untouched; k = 1 and 3, canonical and lazy operands, a broadcast key
+    ([limb][N]), accumulate, c on a table of its own and on a's."""
+    nl = len(bits)
+    n = 1 << m
+    seen = {}
+    qs = []
+    for b in bits:
+        qs.append(lib.find_prime(b, n, seen.get(b, 0)))
+        seen[b] = seen.get(b, 0) + 1
+    ws = [lib.min_root(q, n) for q in qs]
+    plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    ctx = [oracle.ctx(n, q, w) for q, w in zip(qs, ws)]
+    ls = n + pad                       # limb stride (words)
+    span = (nl - 1) * ls + n
+    K = 3
+    rng = np.random.default_rng(m * 1000 + nl)
+    offs_all, words = _scatter(rng, (2 * K + 1) * count, span, 40)
+    offs = [offs_all[o * count:(o + 1) * count] for o in range(2 * K + 1)]     # 0..K-1: a_i, K..2K-1: b_i, 2K: c
+    blank = np.full(words, GUARD, dtype=np.uint64)
+    A = [[[oracle.fill_uniform(n, q, 7 + 100 * i + 10 * p + l) for l, q in enumerate(qs)] for p in range(count)] for i in range(K)]
+    B = [[[oracle.fill_uniform(n, q, 5000 + 100 * i + 10 * p + l) for l, q in enumerate(qs)] for p in range(count)] for i in range(K)]
+    Ah = [[[ctx[l].fwd(A[i][p][l].copy()) for l in range(nl)] for p in range(count)] for i in range(K)]
+    Bh = [[[ctx[l].fwd(B[i][p][l].copy()) for l in range(nl)] for p in range(count)] for i in range(K)]
+
+    def image(sets):
+        im = blank.copy()
+        for o, data in sets.items():
+            for p in range(count):
+                for l in range(nl):
+                    im[offs[o][p] + l * ls:offs[o][p] + l * ls + n] = data[p][l]
+        return im
+
+    def limbs_of(got, o, p):
+        return [got[offs[o][p] + l * ls:offs[o][p] + l * ls + n] for l in range(nl)]
+
+    def untouched(got, sets):
+        mk = np.ones(words, dtype=bool)
+        for o in sets:
+            for p in range(count):
+                for l in range(nl):
+                    mk[offs[o][p] + l * ls:offs[o][p] + l * ls + n] = False
+        return (got[mk] == GUARD).all()
+
+    d = lib.DeviceBuffer(words)
+    tabs = [lib.DeviceBuffer(count).upload(np.array([d.ptr + 8 * o for o in offs[i]], dtype=np.uint64)) for i in range(2 * K + 1)]
+    key = lib.DeviceBuffer(nl * n).upload(np.concatenate([Bh[0][0][l] for l in range(nl)]))      # a broadcast operand is [limb][N]
+    for mode in ("0", "1", None):
+        lib.set_rns_launch(plans, mode)
+        # c = inv(sum_i a_i^ . b_i^)
+        for k in (1, K):
+            for lazy in (False, True):
+                mult = [np.uint64(q) * np.uint64(3 if (lazy and q < (1 << 60)) else 0) for q in qs]
+                sets = {**{i: [[Ah[i][p][l] + mult[l] for l in range(nl)] for p in range(count)] for i in range(k)},
+                        **{K + i: [[Bh[i][p][l] + mult[l] for l in range(nl)] for p in range(count)] for i in range(k)}}
+                d.upload(image(sets))
+                lib.rns_inv_dot_dev_ptrs(plans, tabs[2 * K].ptr, [tabs[i].ptr for i in range(k)], [tabs[K + i].ptr for i in range(k)], count, ls,
+                                         lib.MUL_LAZY_IN if lazy else 0)
+                got = d.download()
+                for p in range(count):
+                    for l, x in enumerate(limbs_of(got, 2 * K, p)):
+                        acc = np.zeros(n, dtype=np.uint64)
+                        for i in range(k):
+                            acc = (acc + oracle.pointwise(Ah[i][p][l].copy(), Bh[i][p][l].copy(), qs[l])) % np.uint64(qs[l])
+                        assert np.array_equal(x, ctx[l].inv(acc)), (mode, k, lazy, p, l)
+                assert untouched(got, list(sets) + [2 * K]), (mode, k, lazy)
+        # a broadcast key, c on a's own table
+        d.upload(image({0: Ah[0]}))
+        lib.rns_inv_dot_dev_ptrs(plans, tabs[0].ptr, [tabs[0].ptr], [key.ptr], count, ls, lib.MUL_B_BROADCAST)
+        got = d.download()
+        for p in range(count):
+            for l, x in enumerate(limbs_of(got, 0, p)):
+                assert np.array_equal(x, ctx[l].inv(oracle.pointwise(Ah[0][p][l].copy(), Bh[0][0][l].copy(), qs[l]))), (mode, p, l)
+        assert untouched(got, [0]), mode
+        # c^ = fwd(a) . b^, then c^ += fwd(a') . key^
+        d.upload(image({0: A[0], 1: A[1], K: Bh[0]}))
+        lib.rns_fwd_mul_dev_ptrs(plans, tabs[2 * K].ptr, tabs[0].ptr, tabs[K].ptr, count, ls)
+        lib.rns_fwd_mul_dev_ptrs(plans, tabs[2 * K].ptr, tabs[1].ptr, key.ptr, count, ls, lib.MUL_ACCUMULATE | lib.MUL_B_BROADCAST)
+        got = d.download()
+        for p in range(count):
+            for l, x in enumerate(limbs_of(got, 2 * K, p)):
+                exp = (oracle.pointwise(Ah[0][p][l].copy(), Bh[0][p][l].copy(), qs[l]) +
+                       oracle.pointwise(Ah[1][p][l].copy(), Bh[0][0][l].copy(), qs[l])) % np.uint64(qs[l])
+                assert np.array_equal(x, exp), (mode, p, l)
+        assert untouched(got, [0, 1, K, 2 * K]), mode
+        # c = a * b: a table of its own, then a's
+        for form in ("own", "on_a"):
+            d.upload(image({0: A[0], K: B[0]}))
+            co = 2 * K if form == "own" else 0
+            lib.rns_negacyclic_mul_dev_ptrs(plans, tabs[co].ptr, tabs[0].ptr, tabs[K].ptr, count, ls)
+            got = d.download()
+            for p in range(count):
+                for l, x in enumerate(limbs_of(got, co, p)):
+                    assert np.array_equal(x, ctx[l].inv(oracle.pointwise(Ah[0][p][l].copy(), Bh[0][p][l].copy(), qs[l]))), (mode, form, p, l)
+            assert untouched(got, [0, K, co]), (mode, form)
+    for t in tabs:
+        t.free()
+    key.free(), d.free()
+    for p in plans:
+        p.destroy()

@@ -64,6 +64,7 @@ timeout 600 python3 tools/sweep.py --logn 10 12 13 14 15 16 17 --ops fwd inv mul
 (for lm in "" "--batch-major"; do timeout 300 python3 tools/pipeline_bench.py $lm; timeout 300 python3 tools/pipeline_bench.py --logn 16 --batch 1024 $lm; timeout 300 python3 tools/pipeline_bench.py --logn 15 --batch 2048 $lm; timeout 300 python3 tools/pipeline_bench.py --logn 14 --batch 4096 $lm; done) > $out/pipeline_rns.txt 2>&1
 timeout 600 python3 tools/pointer_batch_bench.py > $out/pointer_batches.txt 2>&1
 timeout 600 python3 tools/pointer_product_bench.py > $out/pointer_products.txt 2>&1
+timeout 300 python3 tools/rns_pointer_small_batch.py > $out/rns_pointer_small_batch.txt 2>&1
 timeout 1500 bash tools/folded_8_shards.sh $out/folded_8_shards.txt > /dev/null 2>&1
 if [ -x oracle/_ref/ntt-variants-bench-dropin ]; then timeout 600 oracle/_ref/ntt-variants-bench-dropin > $out/reference_bench_driver_dropin.txt 2>&1; fi
 timeout 900 python3 tools/soak.py --seconds 300 > $out/soak.txt 2>&1

@@ -377,6 +377,22 @@ while time.time() < t_end:
                 da.upload(place(f)), db.upload(place(f))
                 lib.rns_inv_dot(plans, dc.ptr, [da.ptr, db.ptr], [db.ptr, da.ptr], rb, layout=lay)   # inv(2 a^ (.) a^)
                 dt = gather(dc.download())
+                # the same set through the twins over DEVICE POINTER TABLES: a [batch][limb][N] image is `rb` separately held RNS polynomials
+                # whose limbs are N words apart -- shuffled tables into the three buffers; small batches: one launch over a run's limbs
+                tp = tp_dt = tp_fm = None
+                if bm:
+                    perm = rng.permutation(rb)
+                    tabs = [lib.DeviceBuffer(rb).upload(np.array([buf.ptr + 8 * int(pp) * nl * n for pp in perm], dtype=np.uint64)) for buf in (da, db, dc)]
+                    lib.rns_inv_dot_dev_ptrs(plans, tabs[2].ptr, [tabs[0].ptr, tabs[1].ptr], [tabs[1].ptr, tabs[0].ptr], rb, n)
+                    tp_dt = gather(dc.download())
+                    da.upload(place(ra))
+                    lib.rns_fwd_mul_dev_ptrs(plans, tabs[2].ptr, tabs[0].ptr, tabs[1].ptr, rb, n)        # fwd(a) (.) a^
+                    tp_fm = gather(dc.download())
+                    da.upload(place(ra)), db.upload(place(rbv))
+                    lib.rns_negacyclic_mul_dev_ptrs(plans, tabs[2].ptr, tabs[0].ptr, tabs[1].ptr, rb, n)
+                    tp = gather(dc.download())
+                    for t_ in tabs:
+                        t_.free()
                 for l, (x, y) in enumerate(zip(qs, ws)):
                     c2 = orc.ctx(n, x, y)
                     sl = slice(l * rb * n, (l + 1) * rb * n)
@@ -386,11 +402,14 @@ while time.time() < t_end:
                        not np.array_equal(sq[sl], c2.inv(orc.pointwise(fa, fa, x))) or \
                        not np.array_equal(dt[sl], c2.inv(orc.dot([fa, fa], [fa, fa], x))):
                         fail("rns", m=m, limbs=nl, batch=rb, limb=l, loop=rloop, batch_major=bm, q=hex(x))
+                    if bm and (not np.array_equal(tp[sl], pr[sl]) or not np.array_equal(tp_dt[sl], dt[sl]) or
+                               not np.array_equal(tp_fm[sl], orc.pointwise(fa, fa, x))):
+                        fail("rns over pointer tables", m=m, limbs=nl, batch=rb, limb=l, loop=rloop, q=hex(x))
                 for d in (da, db, dc):
                     d.free()
                 for pl in plans:
                     pl.destroy()
-                checks += 5 * nl
+                checks += (8 if bm else 5) * nl
                 stats_rns = stats.setdefault(("rns", 0, 0), 0)
                 stats[("rns", 0, 0)] = stats_rns + 1
     rounds += 1
