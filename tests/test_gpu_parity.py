@@ -1392,6 +1392,21 @@ def test_c_example_pointer_batch_runs():
     assert out.stdout.count("equal to the slab") == 2 and "schoolbook" in out.stdout
 
 
+def test_c_example_rns_ciphertext_tensor_runs():
+    """examples/rns_ciphertext_tensor.c: the tensor step of a ciphertext multiplication over four SEPARATELY ALLOCATED RNS polynomials
+    (eight 50-bit primes, N = 2^14) from plain C -- ntt_rns_transform_dev_ptrs, ntt_rns_inv_dot_dev_ptrs (k = 1 over two pairs, k = 2),
+    ntt_rns_negacyclic_mul_dev_ptrs, every call one launch over all limbs; one coefficient of every limb of e0, e1, e2 against the
+    schoolbook value"""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    exe = os.path.join(ROOT, "build", "rns_ciphertext_tensor")
+    libdir = os.path.join(ROOT, "optimized-number-theoretic-transform-implementations_amd")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "rns_ciphertext_tensor.c"), "-L" + libdir, "-lntt_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("equal to the schoolbook value") == 3 and "word for word" in out.stdout
+
+
 def test_c_example_rns_modulus_chain_runs():
     """examples/rns_chain_product.c: the RNS entry points from plain C over a chain of a 60-bit, three 50-bit and two 57-bit
     primes (runs of compatible limbs), every limb's product coefficient against the schoolbook value"""
