@@ -534,19 +534,25 @@ def test_rns_products_over_pointer_tables(lib, oracle, m, count):
         p.destroy()
 
 
-@pytest.mark.parametrize("m,bits,count,pad", [(8, [50] * 5, 3, 0), (11, [50] * 4, 2, 24), (12, [50] * 17, 1, 0), (13, [50, 50, 49, 48], 3, 8),
-                                              (14, [50] * 6, 2, 0), (14, [52] * 3, 3, 40), (12, [60, 50, 50, 52, 52, 58, 58], 2, 16),
-                                              (10, [59] * 5, 4, 0), (14, [57] * 3, 2, 0), (6, [40] * 4, 5, 8),
-                                              # above 2^14 (fewer than 64 polynomials): the chain -- element-wise launch and transforms over the tables -- per RUN
-                                              (15, [50] * 3, 2, 0), (16, [50] * 4, 3, 8), (16, [52, 52, 60, 60], 2, 0), (17, [50] * 2, 1, 0), (15, [58] * 3, 5, 24)])
-def test_rns_products_over_pointer_tables_in_one_launch_over_the_limbs(lib, oracle, m, bits, count, pad):
+RNS_TABLE_CASES = [(8, [50] * 5, 3, 0), (11, [50] * 4, 2, 24), (12, [50] * 17, 1, 0), (13, [50, 50, 49, 48], 3, 8),
+                   (14, [50] * 6, 2, 0), (14, [52] * 3, 3, 40), (12, [60, 50, 50, 52, 52, 58, 58], 2, 16),
+                   (10, [59] * 5, 4, 0), (14, [57] * 3, 2, 0), (6, [40] * 4, 5, 8),
+                   # above 2^14 (fewer than 64 polynomials): the chain -- element-wise launch and transforms over the tables -- per RUN
+                   (15, [50] * 3, 2, 0), (16, [50] * 4, 3, 8), (16, [52, 52, 60, 60], 2, 0), (17, [50] * 2, 1, 0), (15, [58] * 3, 5, 24)]
+
+
+@pytest.mark.parametrize("m,bits,count,pad,unfused", [c + (False,) for c in RNS_TABLE_CASES] +
+                         # the fused kernels switched off: the chain's launches over the run at sizes the fused kernels serve otherwise
+                         [c + (True,) for c in RNS_TABLE_CASES if c[0] in (12, 14) and len(c[1]) <= 7])
+def test_rns_products_over_pointer_tables_in_one_launch_over_the_limbs(lib, oracle, m, bits, count, pad, unfused):
     """round 6, DESIGN 9.2: a few separately held RNS polynomials x many primes -- the share of one limb cannot fill the chip, so the
     RNS twins of the products over device tables serve a run of compatible limbs with ONE launch of the fused kernels' table-reading
     MULTI instances (the limb an index of the grid, every polynomial's limbs limb_stride words apart behind its table entry) where
     they looped over the limbs before; above 2^14 the chain's launches (element-wise kernel, transforms over the tables) each over the run.  Forced both ways (NTT_OPT_RNS_LAUNCH 0 / 1) and left to the library: all three equal the
     oracle, limb by limb; mixed chains split into runs (a 60-bit prime in front of 50-bit ones, 52-bit ones, 17 limbs = 16 + 1);
     padded limb strides: the words between the limbs stay untouched; k = 1 and 3, canonical and lazy operands, a broadcast key
-    ([limb][N]), accumulate, c on a table of its own and on a's."""
+    ([limb][N]), accumulate, c on a table of its own and on a's.  unfused: the fused kernels switched off on every plan
+    (NTT_OPT_FUSED_PRODUCT 0, NTT_OPT_DOT_FUSED 0) -- the chain's launches over the run at the sizes the fused kernels serve otherwise."""
     nl = len(bits)
     n = 1 << m
     seen = {}
@@ -556,6 +562,10 @@ def test_rns_products_over_pointer_tables_in_one_launch_over_the_limbs(lib, orac
         seen[b] = seen.get(b, 0) + 1
     ws = [lib.min_root(q, n) for q in qs]
     plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+    if unfused:
+        for p in plans:
+            p.set_option(lib.OPT_FUSED_PRODUCT, 0)
+            p.set_option(lib.OPT_DOT_FUSED, 0)
     ctx = [oracle.ctx(n, q, w) for q, w in zip(qs, ws)]
     ls = n + pad                       # limb stride (words)
     span = (nl - 1) * ls + n
