@@ -279,6 +279,76 @@ print("graph ok")
     assert out.returncode == 0 and "graph ok" in out.stdout, out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("m", [14, 16])
+def test_rns_products_over_device_tables_captured_in_a_hip_graph(m):
+    """the RNS twins on a few polynomials x several primes -- one launch (2^14: the fused kernels' MULTI table forms) or one chain (2^16:
+    element-wise kernel and transforms over the tables) over the whole run of limbs -- allocate and copy nothing: both operands into the
+    NTT domain, e = inv(a^ . b^ + b^ . a^) and c = a' * b' over shuffled device tables captured into ONE HIP graph, replayed on fresh data"""
+    import subprocess
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import numpy as np
+import ontt
+from oracle_binding import Oracle
+lib, orc = ontt.load(), Oracle()
+m, nl, count, ops = %d, 6, 2, 5          # operands: a, b (transformed in place), e, a', b' (c lands on a')
+n = 1 << m
+qs = [lib.find_prime(50, n, i) for i in range(nl)]
+ws = [lib.min_root(q, n) for q in qs]
+plans = [lib.Plan(n, q, w) for q, w in zip(qs, ws)]
+ctx = [orc.ctx(n, q, w) for q, w in zip(qs, ws)]
+rng = np.random.default_rng(5)
+span, total = nl * n, ops * count
+gaps = rng.integers(1, 64, size=total) + np.arange(total) %% 7
+starts = np.cumsum(gaps + span) - span
+order = rng.permutation(total)
+offs = [[int(starts[i]) for i in order[o * count:(o + 1) * count]] for o in range(ops)]
+words = int(starts[-1] + span + 8)
+GUARD = np.uint64(0xA5A5A5A5A5A5A5A5)
+buf = torch.zeros(words, dtype=torch.int64, device="cuda:0")
+tabs = [torch.from_numpy(np.array([buf.data_ptr() + 8 * o for o in offs[k]], dtype=np.uint64).view(np.int64)).to("cuda:0") for k in range(ops)]
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=0)
+s.wait_stream(torch.cuda.current_stream())
+ta, tb, te, ta2, tb2 = (t.data_ptr() for t in tabs)
+with torch.cuda.graph(g, stream=s):
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rns_transform_dev_ptrs(plans, ta, count, n, 0, stream=st)
+    lib.rns_transform_dev_ptrs(plans, tb, count, n, 0, stream=st)
+    lib.rns_inv_dot_dev_ptrs(plans, te, [ta, tb], [tb, ta], count, n, 0, stream=st)        # e = inv(2 a^ . b^)
+    lib.rns_negacyclic_mul_dev_ptrs(plans, ta2, ta2, tb2, count, n, stream=st)              # c = a' * b' on a''s table
+for seed in (1, 2):
+    A = [[orc.fill_uniform(n, q, 10 * seed + 100 * p + l) for l, q in enumerate(qs)] for p in range(count)]
+    B = [[orc.fill_uniform(n, q, 7000 + 10 * seed + 100 * p + l) for l, q in enumerate(qs)] for p in range(count)]
+    img = np.full(words, GUARD, dtype=np.uint64)
+    mask = np.ones(words, dtype=bool)
+    for k in range(ops):
+        for o in offs[k]:
+            mask[o:o + span] = False
+    for p in range(count):
+        for l in range(nl):
+            for k, src in ((0, A), (1, B), (3, A), (4, B)):
+                img[offs[k][p] + l * n:offs[k][p] + (l + 1) * n] = src[p][l]
+    buf.copy_(torch.from_numpy(img.view(np.int64)))
+    g.replay()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().view(np.uint64)
+    assert (got[mask] == GUARD).all()
+    for p in range(count):
+        for l in range(nl):
+            fa, fb = ctx[l].fwd(A[p][l].copy()), ctx[l].fwd(B[p][l].copy())
+            prod = orc.pointwise(fa, fb, qs[l])
+            assert np.array_equal(got[offs[0][p] + l * n:offs[0][p] + (l + 1) * n], fa), (seed, p, l, "a^")
+            assert np.array_equal(got[offs[2][p] + l * n:offs[2][p] + (l + 1) * n], ctx[l].inv((prod + prod) %% np.uint64(qs[l]))), (seed, p, l, "e")
+            assert np.array_equal(got[offs[3][p] + l * n:offs[3][p] + (l + 1) * n], ctx[l].inv(prod)), (seed, p, l, "c")
+print("graph ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), m)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "graph ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_pointer_batch_arguments(lib, oracle):
     n = 1 << 12
     q = lib.find_prime(50, n, 0)
