@@ -351,7 +351,8 @@ NTT_API int ntt_rns_transform_dev_ptrs(int nlimbs, ntt_plan *const *plans, const
  * chains per call whatever the batch.  The ntt_rns_* twins: a run of compatible limbs (as for the slab forms: same policy and size
  * class; up to 16) whose per-limb share cannot fill the chip -- a few ciphertext polynomials x many primes -- goes out as ONE launch of
  * the fused kernels over all of its limbs up to N = 2^14 (the limb an index of the grid; NTT_OPT_RNS_LAUNCH 0 / 1 forces the
- * one-launch / the per-limb form); large batches and the sizes above 2^14 take one launch (chain) per limb.  Semantics, flags and operand ranges
+ * one-launch / the per-limb form; large batches up to 2^14 take one launch per limb); above 2^14 a run is ONE XCD-local launch from 64
+ * polynomials x limbs on (the limb part of the queue entry) and one chain over all of its limbs below that.  Semantics, flags and operand ranges
  * are those of the slab forms:
  *   ntt_inv_dot_dev_ptrs         c_p = inv( sum_{i<k} a_{i,p}^ (.) b_{i,p}^ ); h_ahat / h_bhat: HOST arrays of k device tables;
  *                                NTT_MUL_B_BROADCAST: h_bhat[i] is a device pointer to ONE polynomial (RNS: [limb][N]); k = 1: c's table

@@ -618,14 +618,21 @@ template <class A, int KSH> hipError_t launch_team_product_impl(const ProdArgs &
   } while(0)
     if(pa.ptrs) {
       /* separately held polynomials: b, ahat (a's coefficients) and out are device tables (team_product_kernel's PTRS form) */
-      if(!pa.four || nl != 1) return hipErrorNotSupported;
+      /* (several limbs: every polynomial's limbs pa.limb_stride words apart behind its table entry -- the MULTI instances) */
+      if(!pa.four) return hipErrorNotSupported;
       kt.k.f.ptab = reinterpret_cast<const uint64_t *>(pa.b);
       kt.k.f.a    = reinterpret_cast<uint64_t *>((uintptr_t)pa.ptr_limb_off * 8u);
+#define NTT_TEAM_PROD_PTRS(LEADV)                                                                                  \
+  do {                                                                                                             \
+    if(nl > 1) hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, true, true, true>), g, t, 0, pa.stream, kt); \
+    else hipLaunchKernelGGL((team_product_kernel<A, LEADV, KSH, true, false, true>), g, t, 0, pa.stream, kt);      \
+  } while(0)
       switch(pa.logn - kTeamBlock) {
-        case 3: hipLaunchKernelGGL((team_product_kernel<A, 3, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
-        case 4: hipLaunchKernelGGL((team_product_kernel<A, 4, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
-        default: hipLaunchKernelGGL((team_product_kernel<A, 5, KSH, true, false, true>), g, t, 0, pa.stream, kt); break;
+        case 3: NTT_TEAM_PROD_PTRS(3); break;
+        case 4: NTT_TEAM_PROD_PTRS(4); break;
+        default: NTT_TEAM_PROD_PTRS(5); break;
       }
+#undef NTT_TEAM_PROD_PTRS
       return hipGetLastError();
     }
     if(pa.four) {
@@ -767,14 +774,19 @@ template <class A, int KSH> hipError_t launch_team_dot(const DotArgs &da)
     kt.d.k.wgs_per_limb = (uint32_t)wgs;
     const dim3 g((unsigned)wgs), t(256);
     if(da.ptrs) {
-      if(nl != 1) return hipErrorNotSupported;
       kt.d.k.ptab = reinterpret_cast<const uint64_t *>(da.out);
       kt.d.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)da.ptr_limb_off * 8u);
+#define NTT_TEAM_DOT_PTRS(LEADV)                                                                             \
+  do {                                                                                                       \
+    if(nl > 1) hipLaunchKernelGGL((team_dot_kernel<A, LEADV, KSH, true, true>), g, t, 0, da.stream, kt);     \
+    else hipLaunchKernelGGL((team_dot_kernel<A, LEADV, KSH, false, true>), g, t, 0, da.stream, kt);          \
+  } while(0)
       switch(da.logn - kTeamBlock) {
-        case 3: hipLaunchKernelGGL((team_dot_kernel<A, 3, KSH, false, true>), g, t, 0, da.stream, kt); break;
-        case 4: hipLaunchKernelGGL((team_dot_kernel<A, 4, KSH, false, true>), g, t, 0, da.stream, kt); break;
-        default: hipLaunchKernelGGL((team_dot_kernel<A, 5, KSH, false, true>), g, t, 0, da.stream, kt); break;
+        case 3: NTT_TEAM_DOT_PTRS(3); break;
+        case 4: NTT_TEAM_DOT_PTRS(4); break;
+        default: NTT_TEAM_DOT_PTRS(5); break;
       }
+#undef NTT_TEAM_DOT_PTRS
       return hipGetLastError();
     }
 #define NTT_TEAM_DOT(LEADV)                                                                                  \
@@ -922,14 +934,19 @@ template <class A, int KSH> hipError_t launch_team_mul(const MulArgs &ma)
     kt.m.k.wgs_per_limb = (uint32_t)wgs;
     const dim3 g((unsigned)wgs), t(256);
     if(ma.ptrs) {
-      if(nl != 1) return hipErrorNotSupported;
       kt.m.k.ptab = reinterpret_cast<const uint64_t *>(ma.a);
       kt.m.k.a    = reinterpret_cast<uint64_t *>((uintptr_t)ma.ptr_limb_off * 8u);
+#define NTT_TEAM_MUL_PTRS(LEADV)                                                                             \
+  do {                                                                                                       \
+    if(nl > 1) hipLaunchKernelGGL((team_mul_kernel<A, LEADV, KSH, true, true>), g, t, 0, ma.stream, kt);     \
+    else hipLaunchKernelGGL((team_mul_kernel<A, LEADV, KSH, false, true>), g, t, 0, ma.stream, kt);          \
+  } while(0)
       switch(ma.logn - kTeamBlock) {
-        case 3: hipLaunchKernelGGL((team_mul_kernel<A, 3, KSH, false, true>), g, t, 0, ma.stream, kt); break;
-        case 4: hipLaunchKernelGGL((team_mul_kernel<A, 4, KSH, false, true>), g, t, 0, ma.stream, kt); break;
-        default: hipLaunchKernelGGL((team_mul_kernel<A, 5, KSH, false, true>), g, t, 0, ma.stream, kt); break;
+        case 3: NTT_TEAM_MUL_PTRS(3); break;
+        case 4: NTT_TEAM_MUL_PTRS(4); break;
+        default: NTT_TEAM_MUL_PTRS(5); break;
       }
+#undef NTT_TEAM_MUL_PTRS
       return hipGetLastError();
     }
 #define NTT_TEAM_MUL(LEADV)                                                                                  \

@@ -58,8 +58,8 @@ template <class A, bool MULTI, bool PTRS = false> __device__ __forceinline__ Pro
 /* PTRS forms of the product kernels (round 6): whole polynomials held SEPARATELY -- every operand pointer of the kernel arguments
  * is a DEVICE TABLE of polynomial addresses (a plain array of device pointers, as for the transforms: poly_offset); `limb` carries
  * the words from every table entry to the workgroup's limb as an offset from a null base, where the slab forms carry an operand's
- * base (up to 2^14 the MULTI instances serve the limbs of an RNS set in one launch -- limb_params adds limb * limb_stride to that
- * offset; the XCD-local kernels and the one-pass product take one limb per launch).  UNIFORM as in poly_offset: the polynomial's index is the same for the whole wave (one s_load_dwordx2). */
+ * base (the MULTI instances serve the limbs of an RNS set in one launch -- limb_params / team_limb add limb * limb_stride to that
+ * offset; the one-pass product at 2^15 takes one limb per launch).  UNIFORM as in poly_offset: the polynomial's index is the same for the whole wave (one s_load_dwordx2). */
 template <bool UNIFORM> __device__ __forceinline__ uint64_t *tab_poly(const void *tab, uint64_t poly, const uint64_t *limb)
 {
   return const_cast<uint64_t *>(limb) + poly_offset<UNIFORM>(poly, 0, reinterpret_cast<const uint64_t *>(tab));
@@ -386,11 +386,11 @@ template <class A> struct KTeamProd {
   uint32_t     poly_major; /* as KTeam::poly_major */
 };
 
-/* PTRS (one limb per launch): kt.k.f.ptab / kt.k.ahat / kt.k.out are the device tables of b, a and c (tab_poly), kt.k.f.a = the limb's offset */
+/* PTRS: kt.k.f.ptab / kt.k.ahat / kt.k.out are the device tables of b, a and c (tab_poly), kt.k.f.a = the first limb's offset; MULTI: the
+ * item's limb kt.k.f.limb_stride words further behind every table entry (loff) */
 template <class A, int LEAD, int KSH, bool FOUR = false, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A> kt)
 {
-  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, false, 3>;
@@ -471,13 +471,14 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
       uint64_t *      bpoly = pf.a + poff;
       const uint64_t *apoly = pp.ahat + poff;
       uint64_t *      cpoly = pp.out + poff;
+      const uint64_t *const plimb = pf.a + loff; /* PTRS: the item's limb as an offset from the null base (MULTI off: loff == 0) */
       if constexpr(PTRS) {
         /* (the column items' one pointer here; the block products read their entries where they touch the blocks: TabBlock) */
         if(pass == 0) {
-          bpoly = tab_poly<true>(pf.ptab, pl, pf.a);
-          apoly = tab_poly<true>(pp.ahat, pl, pf.a);
+          bpoly = tab_poly<true>(pf.ptab, pl, plimb);
+          apoly = tab_poly<true>(pp.ahat, pl, plimb);
         }
-        if(pass == 2) cpoly = tab_poly<true>(pp.out, pl, pf.a);
+        if(pass == 2) cpoly = tab_poly<true>(pp.out, pl, plimb);
       }
       /* NTT_TEAMPROD_ONLY (diagnostic builds, like NTT_STAMPS; never in the shipped library): which item types do their work -- bit 0
        * b's column items, 3 a's column items, 1 the block products, 2 c's inverse column items; the others only run the queue protocol.
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(256, 4) team_product_kernel(const KTeamProd<A>
 #endif
           if constexpr(PTRS) {
             const uint32_t ioff = item << LOGN;
-            team_product_item2<A, KSH, kAuxNt, 0>(TabBlock{pf.ptab, pf.a, pl, ioff}, TabBlock{pp.ahat, pf.a, pl, ioff}, TabBlock{pp.out, pf.a, pl, ioff}, item,
+            team_product_item2<A, KSH, kAuxNt, 0>(TabBlock{pf.ptab, plimb, pl, ioff}, TabBlock{pp.ahat, plimb, pl, ioff}, TabBlock{pp.out, plimb, pl, ioff}, item,
                                                   tid, pf, pi, lds, tabl);
           } else {
             team_product_item2<A, KSH, kAuxNt, 0>(bpoly + ((uint64_t)item << LOGN), apoly + ((uint64_t)item << LOGN),
@@ -923,11 +924,11 @@ __device__ __forceinline__ void team_dot_row_item(uint64_t *cblk, uint64_t offa,
   buffer_store_first_raw<LOGN, 0>(out, tid, cblk);
 }
 
-/* PTRS (one limb per launch): kt.d.k.ptab, kt.d.a[i], kt.d.b[i] (unless broadcast) are device tables, kt.d.k.a = the limb's offset */
+/* PTRS: kt.d.k.ptab, kt.d.a[i], kt.d.b[i] (unless broadcast) are device tables, kt.d.k.a = the first limb's offset (MULTI: team_limb adds the
+ * item's limb to it, so tab_poly(.., p.a) lands in that limb) */
 template <class A, int LEAD, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_dot_kernel(const KTeamDot<A> kt)
 {
-  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, true, flavor_of<A>()>;
@@ -1355,11 +1356,12 @@ __device__ __forceinline__ void team_mul_row_item(const uint64_t *ablk, const ui
   });
 }
 
-/* PTRS (one limb per launch): kt.m.k.ptab, kt.m.b (unless broadcast) and kt.m.out are the device tables of a, b^ and c^, kt.m.k.a = the limb's offset */
+/* PTRS: kt.m.k.ptab, kt.m.b (unless broadcast) and kt.m.out are the device tables of a, b^ and c^, kt.m.k.a = the first limb's offset (MULTI:
+ * team_limb adds the item's limb to it) */
 template <class A, int LEAD, int KSH, bool MULTI = false, bool PTRS = false>
 __global__ void __launch_bounds__(256, 4) team_mul_kernel(const KTeamMul<A> kt)
 {
-  static_assert(!PTRS || !MULTI, "pointer tables: one limb per launch");
+  
   constexpr int LOGN = kTeamBlock;
   using P            = Plan<LOGN>;
   using G            = Geom<LOGN, false, flavor_of<A>()>;

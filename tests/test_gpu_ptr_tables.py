@@ -608,7 +608,9 @@ RNS_TABLE_CASES = [(8, [50] * 5, 3, 0), (11, [50] * 4, 2, 24), (12, [50] * 17, 1
                    (14, [50] * 6, 2, 0), (14, [52] * 3, 3, 40), (12, [60, 50, 50, 52, 52, 58, 58], 2, 16),
                    (10, [59] * 5, 4, 0), (14, [57] * 3, 2, 0), (6, [40] * 4, 5, 8),
                    # above 2^14 (fewer than 64 polynomials): the chain -- element-wise launch and transforms over the tables -- per RUN
-                   (15, [50] * 3, 2, 0), (16, [50] * 4, 3, 8), (16, [52, 52, 60, 60], 2, 0), (17, [50] * 2, 1, 0), (15, [58] * 3, 5, 24)]
+                   (15, [50] * 3, 2, 0), (16, [50] * 4, 3, 8), (16, [52, 52, 60, 60], 2, 0), (17, [50] * 2, 1, 0), (15, [58] * 3, 5, 24),
+                   # ... from 64 polynomials x limbs on: the XCD-local one-launch kernels over the whole run (the limb in the queue entry)
+                   (16, [50] * 4, 20, 0), (15, [50] * 3, 70, 8), (17, [50] * 2, 40, 0), (16, [52, 52, 60, 60], 33, 0), (15, [50] * 5, 13, 0)]
 
 
 @pytest.mark.parametrize("m,bits,count,pad,unfused", [c + (False,) for c in RNS_TABLE_CASES] +

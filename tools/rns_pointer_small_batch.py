@@ -11,7 +11,7 @@ lib = ontt.load()
 print("# lib sha256 %s" % __import__("hashlib").sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()[:16])
 print("%-5s %-6s %-6s %-34s %12s %12s %12s %8s" % ("logn", "limbs", "count", "product", "per limb ms", "one launch", "automatic", "speedup"))
 K = 3
-for logn, nl, count in ((14, 16, 1), (14, 16, 2), (14, 16, 4), (14, 4, 2), (13, 16, 2), (12, 16, 2), (12, 16, 8), (14, 16, 64), (14, 16, 256), (15, 16, 2), (16, 16, 2), (16, 8, 4), (17, 4, 2)):
+for logn, nl, count in ((14, 16, 1), (14, 16, 2), (14, 16, 4), (14, 4, 2), (13, 16, 2), (12, 16, 2), (12, 16, 8), (14, 16, 64), (14, 16, 256), (15, 16, 2), (16, 16, 2), (16, 8, 4), (17, 4, 2), (16, 16, 4), (16, 16, 8), (17, 8, 8), (16, 4, 64), (16, 4, 512), (15, 4, 512)):
     n = 1 << logn
     qs = [lib.find_prime(50, n, i) for i in range(nl)]
     plans = [lib.Plan(n, q, lib.min_root(q, n)) for q in qs]
