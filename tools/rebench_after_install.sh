@@ -16,5 +16,5 @@ done
 timeout 600 python3 bench.py --config 2 --steps 20 --warmup 3 --no-also --no-cpu-baseline > $out/bench_config2_cold_20_steps_3_warmups.json 2>/dev/null
 grep -o '"traffic_from_this_binary": [a-z]*' $out/bench_*.json
 if [ "$soak" -gt 0 ]; then
-  timeout $((soak + 300)) python3 tools/soak.py --seconds $soak --seed 11 > $out/soak_seed11.txt 2>&1; echo "soak rc=$?"; tail -3 $out/soak_seed11.txt | cut -c1-250
+  timeout $((soak + 300)) python3 tools/soak.py --seconds $soak --seed 13 > $out/soak_seed13.txt 2>&1; echo "soak rc=$?"; tail -3 $out/soak_seed13.txt | cut -c1-250
 fi
