@@ -169,15 +169,16 @@ def test_reference_drivers_compile_unchanged_against_our_headers(lib):
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", exe))
 
 
-def test_c_example_builds_against_the_public_header(lib):
-    """examples/batched_product.c: a plain-C caller (gcc, no HIP headers) compiles and links against
-    include/ntt_mi355x.h + libntt_mi355x.so; the GPU suite runs it (test_c_example_runs)"""
+@pytest.mark.parametrize("example", ["batched_product", "rns_chain_product", "pointer_batch", "rns_ciphertext_tensor"])
+def test_c_example_builds_against_the_public_header(lib, example):
+    """examples/*.c that need nothing but the public header: plain-C callers (gcc, no HIP headers) compile and link against
+    include/ntt_mi355x.h + libntt_mi355x.so; the GPU suite runs them (test_c_example_*_runs)"""
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "batched_product.c"), "-L" + os.path.dirname(lib.LIB_PATH),
+                           os.path.join(ROOT, "examples", example + ".c"), "-L" + os.path.dirname(lib.LIB_PATH),
                            "-lntt_mi355x", "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH),
-                           "-o", os.path.join(ROOT, "build", "batched_product")])
-    assert os.path.exists(os.path.join(ROOT, "build", "batched_product"))
+                           "-o", os.path.join(ROOT, "build", example)])
+    assert os.path.exists(os.path.join(ROOT, "build", example))
 
 
 def _last_template_bool_is_multi(name):
