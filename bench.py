@@ -790,6 +790,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="default run: skip the also_config2/3/5 blocks")
     ap.add_argument("--layout", choices=("limb-major", "batch-major"), default="limb-major",
                     help="config 5: RNS operands as [limb][batch][N] (default) or as SURVEY 8(d) lays them out, [batch][prime][N]")
+    ap.add_argument("--q", default=None,
+                    help="another modulus for the chosen configuration's transforms (hex or decimal, prime with 2N | q - 1; single-prime "
+                         "configs 2, 3, 4: the reference's bench walks its (q, N) cases the same way, tests/bench.c:58-140); the metric string says so")
     ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each also_configN block (warm-ups covering >= 60 ms of work in front)")
     args = ap.parse_args()
 
@@ -820,7 +823,13 @@ def main():
     import ontt
     lib = ontt.load()
 
-    w = workload_for(args.config, args.logn or None).resolve(lib)
+    w = workload_for(args.config, args.logn or None)
+    if args.q:
+        if w.limbs != 1:
+            sys.exit("bench.py: --q applies to the single-prime configurations (2, 3, 4)")
+        w.q, w.root = int(args.q, 0), None
+        w.metric += " [--q %s: not BASELINE's modulus]" % hex(w.q)
+    w = w.resolve(lib)
     n = w.n
     batch = args.batch or w.per_gpu_batch(args.scaling, n_gpus)
     if w.kind == "rns_product" and args.steps + min(args.warmup, 2) > 24 and not args.batch:
@@ -902,7 +911,7 @@ def main():
             if w.config == 3:
                 out["also_reference_case_17"] = side_forward(lib, s0, Q, max(args.steps // 2, 2),
                                                              "forward only, 51-bit q of reference test case 17")
-            if w.config == 4 and n == N and not args.no_also and not args.batch and args.scaling == "weak":
+            if w.config == 4 and n == N and not args.no_also and not args.batch and args.scaling == "weak" and not args.q:
                 # BASELINE's other GPU configurations, one GPU's share each, after the headline's timed region (untouched
                 # above): the driver only runs this default command, so their numbers ride on its line.  At N > 1 they run on
                 # rank 0's GPU (shard 0's device) while the other ranks wait at the closing barrier: one GPU's share is what they

@@ -758,6 +758,23 @@ def test_bench_refuses_more_gpus_than_devices():
     assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)
 
 
+@pytest.mark.parametrize("q,config", [("0xfff88001", 4), ("0xffffffffffc0001", 4), ("0x80000001c0001", 2)])
+def test_bench_with_another_modulus(q, config):
+    """bench.py --q: the chosen configuration's transforms over another of the reference's moduli (tests/test_cases.h: a 32-bit,
+    a 60-bit and the 51-bit one of cases 13-15), small batch -- the line's parity check (first and last polynomial against the oracle)
+    runs on that modulus, the metric string says it is not BASELINE's"""
+    import json
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--q", q, "--steps", "2", "--warmup", "1", "--batch", "96",
+           "--no-cpu-baseline", "--headline-only"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "--q " + hex(int(q, 0)) in line["metric"] and line["parity"]["shards_checked"] == 1 and line["value"] > 0
+
+
 def test_squaring_aliases_both_operands(lib, oracle):
     """negacyclic_mul with d_a == d_b is a*a (the shared buffer used to be transformed twice)"""
     n, batch = 1 << 10, 3
